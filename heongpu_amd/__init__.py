@@ -1,0 +1,15 @@
+"""heongpu_amd -- MI355X-native RNS-polynomial backend behind HEonGPU's operator API.
+
+The product is heongpu_amd/lib/libhegpu.so (hand-written HIP for gfx950 plus
+a C ABI, see include/hegpu.h).  This package is the ctypes plumbing used by
+tests/ and bench.py; importing it without the built library fails loudly.
+"""
+from . import _lib
+from .api import (BFV, CKKS, SEC_NONE, SEC_128, TABLES_QP, TABLES_Q_BSK, OP_CKKS_RELIN, OP_CKKS_RESCALE,
+                  OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS, E_INVALID, E_LOGIC, E_RUNTIME,
+                  E_NODEVICE, Context, HEError, steps_to_galois_elt, to_device, to_host)
+
+_lib.load()
+
+__all__ = ["BFV", "CKKS", "SEC_NONE", "SEC_128", "TABLES_QP", "TABLES_Q_BSK", "Context", "HEError",
+           "steps_to_galois_elt", "to_device", "to_host"]

@@ -1,0 +1,77 @@
+"""ctypes binding of libhegpu.so (the C ABI declared in include/hegpu.h).
+
+This is plumbing only: every function here forwards to a C entry point; there
+is no Python/CPU fallback.  If the HIP library is missing the import fails
+loudly, and any device call without a GPU returns HEGPU_E_NODEVICE.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhegpu.so")
+
+u64 = ctypes.c_uint64
+u64p = ctypes.c_void_p  # device or host address passed as integer
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+voidp = ctypes.c_void_p
+
+# (name, restype, argtypes) -- must list EVERY symbol of include/hegpu.h
+SIGNATURES = [
+    ("hegpu_last_error", ctypes.c_char_p, []),
+    ("hegpu_version", ctypes.c_char_p, []),
+    ("hegpu_context_create", c_int,
+     [c_int, c_int, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_int, u64, c_int,
+      ctypes.POINTER(voidp)]),
+    ("hegpu_context_create_default", c_int, [c_int, c_int, c_int, u64, c_int, ctypes.POINTER(voidp)]),
+    ("hegpu_context_create_from_primes", c_int,
+     [c_int, c_int, ctypes.POINTER(u64), c_int, c_int, u64, ctypes.POINTER(voidp)]),
+    ("hegpu_context_destroy", None, [voidp]),
+    ("hegpu_context_upload", c_int, [voidp]),
+    ("hegpu_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),
+    ("hegpu_context_get", ctypes.c_long, [voidp, ctypes.c_char_p, voidp, ctypes.c_long]),
+    ("hegpu_context_device_ptr", voidp, [voidp, ctypes.c_char_p]),
+    ("hegpu_steps_to_galois_elt", c_int, [c_int, c_int, c_int]),
+    ("hegpu_ntt", c_int, [voidp, c_int, u64p, u64p, c_int, c_int, c_int, c_int, voidp, voidp, voidp]),
+    ("hegpu_addition", c_int, [voidp, u64p, u64p, u64p, c_int, c_int, c_int, c_int, voidp]),
+    ("hegpu_cross_multiplication", c_int,
+     [voidp, c_int, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
+    ("hegpu_cipher_broadcast", c_int, [voidp, u64p, u64, u64p, u64, c_int, c_int, c_int, c_int, c_int, voidp]),
+    ("hegpu_keyswitch_multiply_accumulate", c_int,
+     [voidp, u64p, u64, u64p, u64p, u64, c_int, c_int, c_int, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq_permute", c_int,
+     [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),
+    ("hegpu_fast_convertion", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, voidp]),
+    ("hegpu_fast_floor", c_int, [voidp, u64p, u64, u64p, u64, c_int, voidp]),
+    ("hegpu_workspace_bytes", c_size_t, [voidp, c_int, c_int, c_int]),
+    ("hegpu_ckks_multiply", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
+    ("hegpu_ckks_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_rescale_inplace", c_int, [voidp, u64p, u64, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_apply_galois", c_int,
+     [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_bfv_multiply", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_bfv_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_bfv_apply_galois", c_int,
+     [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libhegpu.so and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C heongpu_amd/csrc`.  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,237 @@
+"""Thin Python handle over the C ABI (include/hegpu.h) for tests and bench.
+
+PyTorch is used only for device memory and streams; all arithmetic happens in
+libhegpu.so.  Polynomial data is held in torch.int64 tensors that carry the
+uint64 bit patterns (torch has no full uint64 support); `to_device`/`to_host`
+convert from/to numpy uint64.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+BFV, CKKS = 1, 2
+SEC_NONE, SEC_128 = 0, 128
+TABLES_QP, TABLES_Q_BSK = 0, 1
+OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
+
+E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
+
+
+class HEError(RuntimeError):
+    """Error returned by the C ABI.  `code` distinguishes the reference's
+    exception classes: E_INVALID = std::invalid_argument, E_LOGIC =
+    std::logic_error, E_RUNTIME = std::runtime_error; other = hipError_t."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise HEError(rc, _lib.load().hegpu_last_error().decode())
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_device(arr, device="cuda"):
+    import torch
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Context:
+    """HEContext<BFV|CKKS>: parameter set + device tables."""
+
+    def __init__(self, handle):
+        self._lib = _lib.load()
+        self._h = handle
+
+    # -- constructors (mirror set_coeff_modulus_* of the reference) --
+    @classmethod
+    def from_bit_sizes(cls, scheme, n, log_q, log_p, plain_modulus=0, sec=SEC_128):
+        lib = _lib.load()
+        q = (ctypes.c_int * len(log_q))(*log_q)
+        p = (ctypes.c_int * max(len(log_p), 1))(*log_p)
+        h = ctypes.c_void_p()
+        _check(lib.hegpu_context_create(scheme, n, q, len(log_q), p, len(log_p), plain_modulus, sec,
+                                        ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_default(cls, scheme, n, p_count=1, plain_modulus=0, sec=SEC_128):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _check(lib.hegpu_context_create_default(scheme, n, p_count, plain_modulus, sec, ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_primes(cls, scheme, n, primes, q_count, p_count, plain_modulus=0):
+        lib = _lib.load()
+        arr = (ctypes.c_uint64 * len(primes))(*[int(x) for x in primes])
+        h = ctypes.c_void_p()
+        _check(lib.hegpu_context_create_from_primes(scheme, n, arr, q_count, p_count, plain_modulus,
+                                                    ctypes.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            self._lib.hegpu_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- properties --
+    def int(self, name):
+        return int(self._lib.hegpu_context_int(self._h, name.encode()))
+
+    @property
+    def n_power(self):
+        return self.int("n_power")
+
+    @property
+    def n(self):
+        return 1 << self.n_power
+
+    @property
+    def Q_size(self):
+        return self.int("Q_size")
+
+    @property
+    def P_size(self):
+        return self.int("P_size")
+
+    @property
+    def Q_prime_size(self):
+        return self.int("Q_prime_size")
+
+    @property
+    def bsk_modulus(self):
+        return self.int("bsk_modulus")
+
+    def table(self, name):
+        cnt = self._lib.hegpu_context_get(self._h, name.encode(), None, 0)
+        if cnt < 0:
+            raise KeyError(name)
+        out = np.zeros(cnt, dtype=np.uint64)
+        got = self._lib.hegpu_context_get(self._h, name.encode(), out.ctypes.data, cnt)
+        assert got == cnt
+        return out
+
+    def upload(self):
+        _check(self._lib.hegpu_context_upload(self._h))
+
+    def device_ptr(self, name):
+        return self._lib.hegpu_context_device_ptr(self._h, name.encode())
+
+    def workspace_bytes(self, op, depth, batch):
+        return int(self._lib.hegpu_workspace_bytes(self._h, op, depth, batch))
+
+    def workspace(self, op, depth, batch, device="cuda"):
+        import torch
+        nbytes = self.workspace_bytes(op, depth, batch)
+        return torch.empty(max(nbytes // 8, 1), dtype=torch.int64, device=device)
+
+    # -- NTT seam --
+    def ntt(self, src, dst, inverse, batch, mod_count, mod_offset=0, mod_order=None, poly_order=None,
+            table_set=TABLES_QP, stream=None):
+        _check(self._lib.hegpu_ntt(self._h, table_set, _ptr(src), _ptr(dst), int(inverse), batch, mod_count,
+                                   mod_offset, _ptr(mod_order), _ptr(poly_order),
+                                   stream if stream is not None else _stream()))
+
+    # -- kernels --
+    def addition(self, a, b, out, limbs, parts, batch=1, op=0, stream=None):
+        _check(self._lib.hegpu_addition(self._h, _ptr(a), _ptr(b), _ptr(out), limbs, parts, batch, op,
+                                        stream if stream is not None else _stream()))
+
+    def cross_multiplication(self, in1, s1, in2, s2, out, so, decomp_size, batch=1, table_set=TABLES_QP,
+                             stream=None):
+        _check(self._lib.hegpu_cross_multiplication(self._h, table_set, _ptr(in1), s1, _ptr(in2), s2, _ptr(out),
+                                                    so, decomp_size, batch,
+                                                    stream if stream is not None else _stream()))
+
+    def cipher_broadcast(self, src, s_in, out, s_out, digits, nmods, split, level, batch=1, stream=None):
+        _check(self._lib.hegpu_cipher_broadcast(self._h, _ptr(src), s_in, _ptr(out), s_out, digits, nmods, split,
+                                                level, batch, stream if stream is not None else _stream()))
+
+    def keyswitch_multiply_accumulate(self, src, s_in, key, out, s_out, digits, nmods, key_limbs, p_row, batch=1,
+                                      stream=None):
+        _check(self._lib.hegpu_keyswitch_multiply_accumulate(self._h, _ptr(src), s_in, _ptr(key), _ptr(out), s_out,
+                                                             digits, nmods, key_limbs, p_row, batch,
+                                                             stream if stream is not None else _stream()))
+
+    def divide_round_lastq(self, src, s_in, ct, s_ct, out, s_out, switchkey=0, batch=1, stream=None):
+        _check(self._lib.hegpu_divide_round_lastq(self._h, _ptr(src), s_in, _ptr(ct), s_ct, _ptr(out), s_out,
+                                                  switchkey, batch, stream if stream is not None else _stream()))
+
+    def divide_round_lastq_permute(self, src, s_in, in2, s_in2, out, s_out, galois_elt, depth=0, batch=1,
+                                   stream=None):
+        _check(self._lib.hegpu_divide_round_lastq_permute(self._h, _ptr(src), s_in, _ptr(in2), s_in2, _ptr(out),
+                                                          s_out, galois_elt, depth, batch,
+                                                          stream if stream is not None else _stream()))
+
+    def fast_convertion(self, in1, s1, in2, s2, out, so, batch=1, stream=None):
+        _check(self._lib.hegpu_fast_convertion(self._h, _ptr(in1), s1, _ptr(in2), s2, _ptr(out), so, batch,
+                                               stream if stream is not None else _stream()))
+
+    def fast_floor(self, src, si, out, so, batch=1, stream=None):
+        _check(self._lib.hegpu_fast_floor(self._h, _ptr(src), si, _ptr(out), so, batch,
+                                          stream if stream is not None else _stream()))
+
+    # -- operators (HEArithmeticOperator) --
+    def ckks_multiply(self, ct1, s1, ct2, s2, out, so, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_ckks_multiply(self._h, _ptr(ct1), s1, _ptr(ct2), s2, _ptr(out), so, depth, batch,
+                                             stream if stream is not None else _stream()))
+
+    def ckks_relinearize_inplace(self, ct, cs, key, depth, batch, ws, stream=None):
+        _check(self._lib.hegpu_ckks_relinearize_inplace(self._h, _ptr(ct), cs, _ptr(key), depth, batch, _ptr(ws),
+                                                        ws.numel() * 8,
+                                                        stream if stream is not None else _stream()))
+
+    def ckks_rescale_inplace(self, ct, cs, depth, batch, ws, stream=None):
+        _check(self._lib.hegpu_ckks_rescale_inplace(self._h, _ptr(ct), cs, depth, batch, _ptr(ws), ws.numel() * 8,
+                                                    stream if stream is not None else _stream()))
+
+    def ckks_apply_galois(self, ct, cs, out, so, key, galois_elt, depth, batch, ws, stream=None):
+        _check(self._lib.hegpu_ckks_apply_galois(self._h, _ptr(ct), cs, _ptr(out), so, _ptr(key), galois_elt, depth,
+                                                 batch, _ptr(ws), ws.numel() * 8,
+                                                 stream if stream is not None else _stream()))
+
+    def bfv_multiply(self, ct1, s1, ct2, s2, out, so, batch, ws, stream=None):
+        _check(self._lib.hegpu_bfv_multiply(self._h, _ptr(ct1), s1, _ptr(ct2), s2, _ptr(out), so, batch, _ptr(ws),
+                                            ws.numel() * 8, stream if stream is not None else _stream()))
+
+    def bfv_relinearize_inplace(self, ct, cs, key, batch, ws, stream=None):
+        _check(self._lib.hegpu_bfv_relinearize_inplace(self._h, _ptr(ct), cs, _ptr(key), batch, _ptr(ws),
+                                                       ws.numel() * 8,
+                                                       stream if stream is not None else _stream()))
+
+    def bfv_apply_galois(self, ct, cs, out, so, key, galois_elt, batch, ws, stream=None):
+        _check(self._lib.hegpu_bfv_apply_galois(self._h, _ptr(ct), cs, _ptr(out), so, _ptr(key), galois_elt, batch,
+                                                _ptr(ws), ws.numel() * 8,
+                                                stream if stream is not None else _stream()))
+
+
+def steps_to_galois_elt(steps, n, group_order):
+    return int(_lib.load().hegpu_steps_to_galois_elt(steps, n, group_order))

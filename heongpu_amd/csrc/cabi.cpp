@@ -1,0 +1,450 @@
+// cabi.cpp -- extern "C" entry points declared in include/hegpu.h.
+#include "../../include/hegpu.h"
+#include "context.hpp"
+#include "host_params.hpp"
+#include "ops.hpp"
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+using namespace hegpu;
+
+struct hegpu_context {
+    Context c;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+static int hip_ret(hipError_t e, const char* where)
+{
+    if (e == hipSuccess) return 0;
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (int) e;
+}
+
+template <typename F>
+static int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const std::invalid_argument& e) {
+        return fail(HEGPU_E_INVALID, e.what());
+    } catch (const std::logic_error& e) {
+        return fail(HEGPU_E_LOGIC, e.what());
+    } catch (const std::runtime_error& e) {
+        return fail(HEGPU_E_RUNTIME, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(HEGPU_E_RUNTIME, "out of host memory");
+    }
+}
+
+extern "C" {
+
+const char* hegpu_last_error(void) { return g_err.c_str(); }
+const char* hegpu_version(void) { return "hegpu-mi355x 0.1 (gfx950)"; }
+
+// reference util.cu:11-56 coefficient_validator
+static bool coefficient_validator(const int* q, int qn, const int* p, int pn)
+{
+    int total_p = 0;
+    for (int i = 0; i < pn; i++) total_p += p[i];
+    int idx = 0;
+    for (int g = 0; g < qn / pn; g++) {
+        int s = 0;
+        for (int j = 0; j < pn; j++) s += q[idx++];
+        if (s > total_p) return false;
+    }
+    int s = 0;
+    for (int j = 0; j < qn % pn; j++) s += q[idx++];
+    return s <= total_p;
+}
+
+static void check_degree(int n, int& n_power)
+{
+    if (n <= 0 || (n & (n - 1))) throw std::logic_error("Poly modulus degree have to be power of two");
+    if (n > 65536 || n < 4096) throw std::logic_error("Poly modulus degree is not supported");
+    n_power = 31 - __builtin_clz((unsigned) n);
+}
+
+static int finish_create(hegpu_context* h, int scheme, int n_power, uint64_t plain_modulus, int q_count,
+                         int p_count, hegpu_context** out)
+{
+    Context& c = h->c;
+    c.scheme = scheme;
+    c.n_power = n_power;
+    c.Q_size = q_count;
+    c.P_size = p_count;
+    c.plain_modulus = plain_modulus;
+    if (scheme == SCHEME_BFV && plain_modulus < 2) throw std::logic_error("plain modulus is not specified");
+    c.build_host();
+    *out = h;
+    return 0;
+}
+
+int hegpu_context_create(int scheme, int n, const int* qb, int qn, const int* pb, int pn, uint64_t plain_modulus,
+                         int sec_level, hegpu_context** out)
+{
+    return guarded([&]() -> int {
+        if (!out) throw std::invalid_argument("null output");
+        if (scheme != SCHEME_BFV && scheme != SCHEME_CKKS) throw std::invalid_argument("unknown scheme");
+        int n_power;
+        check_degree(n, n_power);
+        if (pn <= 0 || !pb) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
+        if (qn <= 0 || !qb) throw std::logic_error("log_Q_bases_bit_sizes cannot be empty!");
+        if (!coefficient_validator(qb, qn, pb, pn)) throw std::logic_error("P should be bigger than Q pairs!");
+        std::vector<int> bits(qb, qb + qn);
+        bits.insert(bits.end(), pb, pb + pn);
+        int total = 0;
+        for (int b : bits) total += b;
+        if (sec_level == HEGPU_SEC_128) {
+            if (host::max_logq_128(n) < total)
+                throw std::runtime_error("Parameters do not align with the security recommendations "
+                                         "provided by the lattice-estimator");
+        } else if (sec_level != HEGPU_SEC_NONE) {
+            throw std::runtime_error("Invalid security level");
+        }
+        hegpu_context* h = new hegpu_context();
+        try {
+            h->c.primes = host::find_primes((u64) n, bits);
+            return finish_create(h, scheme, n_power, plain_modulus, qn, pn, out);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+    });
+}
+
+int hegpu_context_create_default(int scheme, int n, int p_count, uint64_t plain_modulus, int sec_level,
+                                 hegpu_context** out)
+{
+    return guarded([&]() -> int {
+        if (!out) throw std::invalid_argument("null output");
+        if (scheme != SCHEME_BFV && scheme != SCHEME_CKKS) throw std::invalid_argument("unknown scheme");
+        int n_power;
+        check_degree(n, n_power);
+        if (p_count < 1) throw std::logic_error("P_modulus_size cannot be lower than 1!");
+        if (sec_level != HEGPU_SEC_128) throw std::runtime_error("Invalid security level");
+        std::vector<u64> chain = host::default_chain_128((u64) n);
+        if (chain.empty() || (int) chain.size() <= p_count) throw std::logic_error("no default chain");
+        hegpu_context* h = new hegpu_context();
+        try {
+            h->c.primes = chain;
+            return finish_create(h, scheme, n_power, plain_modulus, (int) chain.size() - p_count, p_count, out);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+    });
+}
+
+int hegpu_context_create_from_primes(int scheme, int n, const uint64_t* primes, int qn, int pn,
+                                     uint64_t plain_modulus, hegpu_context** out)
+{
+    return guarded([&]() -> int {
+        if (!out || !primes) throw std::invalid_argument("null argument");
+        if (scheme != SCHEME_BFV && scheme != SCHEME_CKKS) throw std::invalid_argument("unknown scheme");
+        int n_power;
+        check_degree(n, n_power);
+        if (pn <= 0 || qn <= 0) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
+        for (int i = 0; i < qn + pn; i++) {
+            if (primes[i] >> 61) throw std::logic_error("invalid modulus bit size");
+            if ((primes[i] - 1) % (2 * (u64) n)) throw std::logic_error("no sufficient root unity");
+        }
+        hegpu_context* h = new hegpu_context();
+        try {
+            h->c.primes.assign(primes, primes + qn + pn);
+            return finish_create(h, scheme, n_power, plain_modulus, qn, pn, out);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+    });
+}
+
+void hegpu_context_destroy(hegpu_context* ctx) { delete ctx; }
+
+int hegpu_context_upload(hegpu_context* ctx)
+{
+    if (!ctx) return fail(HEGPU_E_INVALID, "null context");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        (void) hipGetLastError();
+        return fail(HEGPU_E_NODEVICE, "no HIP device available: the HIP backend cannot run (no CPU fallback)");
+    }
+    return hip_ret(ctx->c.upload(), "context upload");
+}
+
+long hegpu_context_int(const hegpu_context* ctx, const char* name)
+{
+    if (!ctx || !name) return -1;
+    const Context& c = ctx->c;
+    if (!strcmp(name, "n_power")) return c.n_power;
+    if (!strcmp(name, "n")) return (long) c.n;
+    if (!strcmp(name, "Q_size")) return c.Q_size;
+    if (!strcmp(name, "P_size")) return c.P_size;
+    if (!strcmp(name, "Q_prime_size")) return c.Qp_size;
+    if (!strcmp(name, "bsk_modulus")) return c.bsk_size;
+    if (!strcmp(name, "scheme")) return c.scheme;
+    return -1;
+}
+
+long hegpu_context_get(const hegpu_context* ctx, const char* name, uint64_t* out, long cap)
+{
+    if (!ctx || !name) return -1;
+    auto it = ctx->c.host.find(name);
+    if (it == ctx->c.host.end()) return -1;
+    const long cnt = (long) it->second.size();
+    if (!out) return cnt;
+    if (cnt > cap) return -2;
+    memcpy(out, it->second.data(), cnt * sizeof(uint64_t));
+    return cnt;
+}
+
+const void* hegpu_context_device_ptr(const hegpu_context* ctx, const char* name)
+{
+    if (!ctx || !name) return nullptr;
+    auto it = ctx->c.dev.find(name);
+    return it == ctx->c.dev.end() ? nullptr : it->second;
+}
+
+int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order)
+{
+    return host::steps_to_galois_elt(steps, coeff_count, group_order);
+}
+
+#define NEED_CTX(ctx)                                                                      \
+    do {                                                                                   \
+        if (!(ctx)) return fail(HEGPU_E_INVALID, "null context");                          \
+        if (!(ctx)->c.uploaded) {                                                          \
+            int r__ = hegpu_context_upload(ctx);                                           \
+            if (r__) return r__;                                                           \
+        }                                                                                  \
+    } while (0)
+
+static const Mod* mods_of(const Context& c, int table_set)
+{
+    return table_set == HEGPU_TABLES_Q_BSK ? c.plan_merge.mods : c.plan_qp.mods;
+}
+
+int hegpu_ntt(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int inverse, int batch,
+              int mod_count, int mod_offset, const int* mod_order, const int* poly_order, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (table_set == HEGPU_TABLES_Q_BSK && c.scheme != SCHEME_BFV)
+        return fail(HEGPU_E_INVALID, "q|Bsk tables exist only in a BFV context");
+    NttArgs a = c.ntt_args(table_set);
+    const int avail = a.mod_count;
+    if (mod_count <= 0 || mod_offset < 0 || (!mod_order && mod_offset + mod_count > avail))
+        return fail(HEGPU_E_INVALID, "modulus range outside the table set");
+    a.in = (const u64*) in;
+    a.out = (u64*) out;
+    a.mod_count = mod_count;
+    a.mod_offset = mod_offset;
+    a.mod_order = mod_order;
+    a.poly_order = poly_order;
+    return hip_ret(ntt_launch(a, batch, inverse != 0, (hipStream_t) stream), "hegpu_ntt");
+}
+
+int hegpu_addition(hegpu_context* ctx, const uint64_t* in1, const uint64_t* in2, uint64_t* out, int limbs,
+                   int parts, int batch, int op, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (limbs <= 0 || limbs > c.Qp_size || op < 0 || op > 2) return fail(HEGPU_E_INVALID, "bad limbs/op");
+    return hip_ret(rns_addition((const u64*) in1, (const u64*) in2, (u64*) out, c.plan_qp.mods, c.n_power, limbs,
+                                parts, batch, op, (hipStream_t) stream),
+                   "hegpu_addition");
+}
+
+int hegpu_cross_multiplication(hegpu_context* ctx, int table_set, const uint64_t* in1, uint64_t s1,
+                               const uint64_t* in2, uint64_t s2, uint64_t* out, uint64_t so, int decomp_size,
+                               int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    const Mod* m = mods_of(c, table_set);
+    if (!m) return fail(HEGPU_E_INVALID, "table set not available");
+    return hip_ret(rns_cross_multiplication((const u64*) in1, s1, (const u64*) in2, s2, (u64*) out, so, m, c.n_power,
+                                            decomp_size, batch, (hipStream_t) stream),
+                   "hegpu_cross_multiplication");
+}
+
+int hegpu_cipher_broadcast(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                           uint64_t out_stride, int digits, int nmods, int split, int level, int batch,
+                           hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    return hip_ret(rns_decompose((const u64*) in, in_stride, (u64*) out, out_stride, c.plan_qp.mods, c.n_power,
+                                 digits, nmods, split, level, batch, (hipStream_t) stream),
+                   "hegpu_cipher_broadcast");
+}
+
+int hegpu_keyswitch_multiply_accumulate(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
+                                        const uint64_t* key, uint64_t* out, uint64_t out_stride, int digits,
+                                        int nmods, int key_limbs, int p_row, int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    return hip_ret(rns_keyswitch_mac((const u64*) in, in_stride, (const u64*) key, (u64*) out, out_stride,
+                                     c.plan_qp.mods, c.n_power, digits, nmods, key_limbs, p_row, batch,
+                                     (hipStream_t) stream),
+                   "hegpu_keyswitch_multiply_accumulate");
+}
+
+int hegpu_divide_round_lastq(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                             uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int switchkey, int batch,
+                             hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (c.P_size != 1) return fail(HEGPU_E_LOGIC, "divide_round_lastq needs a single special prime (method I)");
+    return hip_ret(rns_divide_round_lastq((const u64*) in, in_stride, (const u64*) ct, ct_stride, (u64*) out,
+                                          out_stride, c.plan_qp.mods, c.d64("half"), c.d64("half_mod"),
+                                          c.d64("last_q_modinv"), c.n_power, c.Q_size, switchkey, batch,
+                                          (hipStream_t) stream),
+                   "hegpu_divide_round_lastq");
+}
+
+int hegpu_divide_round_lastq_permute(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
+                                     const uint64_t* in2, uint64_t in2_stride, uint64_t* out,
+                                     uint64_t out_stride, int galois_elt, int depth, int batch,
+                                     hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (c.scheme == SCHEME_BFV && depth != 0) return fail(HEGPU_E_INVALID, "BFV ciphertexts have no depth");
+    return hip_ret(rns_moddown_permute((const u64*) in, in_stride, (const u64*) in2, in2_stride, (u64*) out,
+                                       out_stride, c.plan_qp.mods, c.d64("half"), c.d64("half_mod"),
+                                       c.d64("last_q_modinv"), galois_elt, c.n_power, c.Qp_size - depth,
+                                       c.Q_size - depth, c.Qp_size, c.Q_size, c.P_size, batch,
+                                       (hipStream_t) stream),
+                   "hegpu_divide_round_lastq_permute");
+}
+
+int hegpu_fast_convertion(hegpu_context* ctx, const uint64_t* in1, uint64_t s1, const uint64_t* in2, uint64_t s2,
+                          uint64_t* out, uint64_t so, int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "BFV context required");
+    return hip_ret(rns_fast_convertion((const u64*) in1, s1, (const u64*) in2, s2, (u64*) out, so, c.behz,
+                                       c.n_power, batch, (hipStream_t) stream),
+                   "hegpu_fast_convertion");
+}
+
+int hegpu_fast_floor(hegpu_context* ctx, const uint64_t* in, uint64_t si, uint64_t* out, uint64_t so, int batch,
+                     hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "BFV context required");
+    return hip_ret(rns_fast_floor((const u64*) in, si, (u64*) out, so, c.behz, c.n_power, batch,
+                                  (hipStream_t) stream),
+                   "hegpu_fast_floor");
+}
+
+size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch)
+{
+    if (!ctx || batch <= 0) return 0;
+    return ops_workspace_elems(ctx->c, op, depth, batch) * sizeof(u64);
+}
+
+#define CHECK_OP(ctx, want_scheme, op, depth, batch, ws, ws_bytes)                                            \
+    do {                                                                                                      \
+        if ((ctx)->c.scheme != (want_scheme)) return fail(HEGPU_E_INVALID, "context scheme mismatch");        \
+        if ((ctx)->c.P_size != 1)                                                                             \
+            return fail(HEGPU_E_LOGIC, "key-switching method II (P_size > 1) is not implemented yet");        \
+        if ((batch) <= 0) return fail(HEGPU_E_INVALID, "batch must be positive");                             \
+        if ((depth) < 0 || (depth) >= (ctx)->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");         \
+        if ((op) && (!(ws) || (ws_bytes) < hegpu_workspace_bytes(ctx, op, depth, batch)))                     \
+            return fail(HEGPU_E_INVALID, "workspace too small");                                              \
+    } while (0)
+
+int hegpu_ckks_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t s1, const uint64_t* ct2, uint64_t s2,
+                        uint64_t* out, uint64_t so, int depth, int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (depth < 0 || depth >= ctx->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");
+    return hip_ret(op_ckks_multiply(ctx->c, (const u64*) ct1, s1, (const u64*) ct2, s2, (u64*) out, so, depth, batch,
+                                    (hipStream_t) stream),
+                   "hegpu_ckks_multiply");
+}
+
+int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, const uint64_t* key, int depth,
+                                   int batch, void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_RELIN, depth, batch, ws, ws_bytes);
+    return hip_ret(op_ckks_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, depth, batch, (u64*) ws,
+                                       (hipStream_t) stream),
+                   "hegpu_ckks_relinearize_inplace");
+}
+
+int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, int depth, int batch, void* ws,
+                               size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_RESCALE, depth, batch, ws, ws_bytes);
+    if (depth >= ctx->c.Q_size - 1) return fail(HEGPU_E_LOGIC, "no modulus left to rescale by");
+    return hip_ret(op_ckks_rescale(ctx->c, (u64*) ct, cs, depth, batch, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_ckks_rescale_inplace");
+}
+
+int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, uint64_t* out, uint64_t so,
+                            const uint64_t* key, int galois_elt, int depth, int batch, void* ws, size_t ws_bytes,
+                            hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
+    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
+    return hip_ret(op_ckks_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key, galois_elt,
+                                        depth, batch, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_ckks_apply_galois");
+}
+
+int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t s1, const uint64_t* ct2, uint64_t s2,
+                       uint64_t* out, uint64_t so, int batch, void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (batch <= 0) return fail(HEGPU_E_INVALID, "batch must be positive");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_BFV_MULTIPLY, 0, batch))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return hip_ret(op_bfv_multiply(ctx->c, (const u64*) ct1, s1, (const u64*) ct2, s2, (u64*) out, so, batch,
+                                   (u64*) ws, (hipStream_t) stream),
+                   "hegpu_bfv_multiply");
+}
+
+int hegpu_bfv_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, const uint64_t* key, int batch,
+                                  void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_BFV, OP_BFV_RELIN, 0, batch, ws, ws_bytes);
+    return hip_ret(op_bfv_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, batch, (u64*) ws,
+                                      (hipStream_t) stream),
+                   "hegpu_bfv_relinearize_inplace");
+}
+
+int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, uint64_t* out, uint64_t so,
+                           const uint64_t* key, int galois_elt, int batch, void* ws, size_t ws_bytes,
+                           hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_BFV, OP_BFV_GALOIS, 0, batch, ws, ws_bytes);
+    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
+    return hip_ret(op_bfv_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key, galois_elt,
+                                       batch, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_bfv_apply_galois");
+}
+
+} // extern "C"

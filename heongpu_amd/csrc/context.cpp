@@ -1,0 +1,341 @@
+// context.cpp -- see context.hpp.
+#include "context.hpp"
+#include "host_params.hpp"
+#include <cstring>
+#include <stdexcept>
+
+namespace hegpu {
+
+using host::inv_mod_prime;
+using host::mul_mod;
+
+typedef std::vector<u64> vec;
+
+static void append(vec& dst, const vec& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+
+void Context::build_host()
+{
+    n = ((u64) 1) << n_power;
+    Qp_size = Q_size + P_size;
+    const int Q = Q_size, P = P_size, Qp = Qp_size;
+    if ((int) primes.size() != Qp) throw std::logic_error("prime chain size mismatch");
+    host.clear();
+    host["modulus"] = primes;
+
+    vec psi, ninv, fwd, inv;
+    for (int i = 0; i < Qp; i++) {
+        const u64 q = primes[i];
+        const u64 r = host::minimal_primitive_root(2 * n, q);
+        psi.push_back(r);
+        append(fwd, host::power_table_bitrev(r, q, n_power));
+        append(inv, host::power_table_bitrev(inv_mod_prime(r, q), q, n_power));
+        ninv.push_back(inv_mod_prime(n % q, q));
+    }
+    host["psi"] = psi;
+    host["n_inverse"] = ninv;
+    host["ntt_table"] = fwd;
+    host["intt_table"] = inv;
+
+    // mod-down by the special primes, last P prime first (util.cu:701-767)
+    vec lqm, half, half_mod, factor;
+    for (int i = 0; i < P; i++) {
+        const u64 p = primes[Qp - 1 - i];
+        half.push_back(p >> 1);
+        for (int j = 0; j < (Qp - 1) - i; j++) {
+            lqm.push_back(inv_mod_prime(p % primes[j], primes[j]));
+            half_mod.push_back((p >> 1) % primes[j]);
+        }
+        for (int j = 0; j < Q; j++) factor.push_back(p % primes[j]);
+    }
+    host["last_q_modinv"] = lqm;
+    host["half"] = half;
+    host["half_mod"] = half_mod;
+    host["factor"] = factor;
+
+    if (scheme == SCHEME_CKKS) {
+        // per-depth rescale constants (ckks/context.cu:342-368)
+        vec r_inv, r_half_mod, r_half;
+        for (int d = 0; d < Q - 1; d++) {
+            const int last = (Q - 1) - d;
+            const u64 ql = primes[last];
+            r_half.push_back(ql >> 1);
+            for (int i = 0; i < last; i++) {
+                r_inv.push_back(inv_mod_prime(ql % primes[i], primes[i]));
+                r_half_mod.push_back((ql >> 1) % primes[i]);
+            }
+        }
+        host["rescaled_last_q_modinv"] = r_inv;
+        host["rescaled_half_mod"] = r_half_mod;
+        host["rescaled_half"] = r_half;
+        // modulus-order / polynomial-order tables (ckks/operator.cu:24-56)
+        vec ploc, iloc;
+        for (int d = 0; d < Q; d++) {
+            for (int j = 0; j < Q - d; j++) ploc.push_back(j);
+            for (int j = 0; j < P; j++) ploc.push_back(Q + j);
+        }
+        for (int i = 0; i < Qp - 1; i++) {
+            const int c = Qp - i;
+            iloc.push_back(c - 1);
+            iloc.push_back(2 * c - 1);
+        }
+        host["new_prime_locations"] = ploc;
+        host["new_input_locations"] = iloc;
+    }
+
+    if (scheme == SCHEME_BFV) {
+        const u64 t = plain_modulus;
+        const u64 mt = ((u64) 1) << 32; // m_tilde (bfv/context.cu:510)
+        int total_bits = 0;
+        for (u64 q : primes) total_bits += 64 - __builtin_clzll(q);
+        const int t_bits = 64 - __builtin_clzll(t);
+        int bsk = Qp;
+        if (t_bits + total_bits + 32 >= 61 * Q + 61) bsk++; // bfv/context.cu:518-525
+        bsk_size = bsk;
+        vec ip = host::internal_primes(n, bsk + 1);
+        vec B(ip.begin(), ip.begin() + bsk);
+        const u64 gamma = ip[bsk];
+        const u64 msk = B[bsk - 1];
+        host["base_Bsk"] = B;
+        host["gamma"] = vec{gamma};
+        vec Bpsi;
+        for (u64 b : B) Bpsi.push_back(host::minimal_primitive_root(2 * n, b));
+        host["base_Bsk_psi"] = Bpsi;
+
+        vec m_q_Bsk, inv_punct, m_mt, inv_mt_B, prod_q_B, inv_prod_q_B, m_B_q, m_msk, inv_punct_B, prod_B_q;
+        for (int k = 0; k < bsk; k++)
+            for (int i = 0; i < Q; i++) {
+                u64 acc = 1;
+                for (int j = 0; j < Q; j++)
+                    if (j != i) acc = mul_mod(acc, primes[j], B[k]);
+                m_q_Bsk.push_back(acc);
+            }
+        for (int i = 0; i < Q; i++) {
+            u64 acc = 1, acc_mt = 1;
+            for (int j = 0; j < Q; j++)
+                if (j != i) {
+                    acc = mul_mod(acc, primes[j] % primes[i], primes[i]);
+                    acc_mt = mul_mod(acc_mt, primes[j] % mt, mt);
+                }
+            inv_punct.push_back(inv_mod_prime(acc, primes[i]));
+            m_mt.push_back(acc_mt);
+        }
+        u64 prod_q_mt = 1;
+        for (int i = 0; i < Q; i++) prod_q_mt = mul_mod(prod_q_mt, primes[i] % mt, mt);
+        const u64 inv_prod_q_mt = host::inv_mod_pow2_32(prod_q_mt);
+        for (int i = 0; i < bsk; i++) {
+            inv_mt_B.push_back(inv_mod_prime(mt % B[i], B[i]));
+            u64 acc = 1;
+            for (int j = 0; j < Q; j++) acc = mul_mod(acc, primes[j], B[i]);
+            prod_q_B.push_back(acc);
+            inv_prod_q_B.push_back(inv_mod_prime(acc, B[i]));
+        }
+        for (int k = 0; k < Q; k++)
+            for (int i = 0; i < bsk - 1; i++) {
+                u64 acc = 1;
+                for (int j = 0; j < bsk - 1; j++)
+                    if (j != i) acc = mul_mod(acc, B[j] % primes[k], primes[k]);
+                m_B_q.push_back(acc);
+            }
+        for (int i = 0; i < bsk - 1; i++) {
+            u64 a1 = 1, a2 = 1;
+            for (int j = 0; j < bsk - 1; j++)
+                if (j != i) {
+                    a1 = mul_mod(a1, B[j], msk);
+                    a2 = mul_mod(a2, B[j], B[i]);
+                }
+            m_msk.push_back(a1);
+            inv_punct_B.push_back(inv_mod_prime(a2, B[i]));
+        }
+        u64 prod_B_msk = 1;
+        for (int i = 0; i < bsk - 1; i++) prod_B_msk = mul_mod(prod_B_msk, B[i], msk);
+        for (int i = 0; i < Q; i++) {
+            u64 acc = 1;
+            for (int j = 0; j < bsk - 1; j++) acc = mul_mod(acc, B[j] % primes[i], primes[i]);
+            prod_B_q.push_back(acc);
+        }
+        host["base_change_matrix_Bsk"] = m_q_Bsk;
+        host["inv_punctured_prod_mod_base_array"] = inv_punct;
+        host["base_change_matrix_m_tilde"] = m_mt;
+        host["inv_prod_q_mod_m_tilde"] = vec{inv_prod_q_mt};
+        host["inv_m_tilde_mod_Bsk"] = inv_mt_B;
+        host["prod_q_mod_Bsk"] = prod_q_B;
+        host["inv_prod_q_mod_Bsk"] = inv_prod_q_B;
+        host["base_change_matrix_q"] = m_B_q;
+        host["base_change_matrix_msk"] = m_msk;
+        host["inv_punctured_prod_mod_B_array"] = inv_punct_B;
+        host["inv_prod_B_mod_m_sk"] = vec{inv_mod_prime(prod_B_msk, msk)};
+        host["prod_B_mod_q"] = prod_B_q;
+
+        // merged base [q | Bsk] with its NTT tables (bfv/context.cu:1210-1241)
+        vec mm(primes.begin(), primes.begin() + Q), mpsi(psi.begin(), psi.begin() + Q), mfwd, minv, mninv;
+        append(mm, B);
+        append(mpsi, Bpsi);
+        for (size_t i = 0; i < mm.size(); i++) {
+            append(mfwd, host::power_table_bitrev(mpsi[i], mm[i], n_power));
+            append(minv, host::power_table_bitrev(inv_mod_prime(mpsi[i], mm[i]), mm[i], n_power));
+            mninv.push_back(inv_mod_prime(n % mm[i], mm[i]));
+        }
+        host["q_Bsk_merge_modulus"] = mm;
+        host["q_Bsk_merge_ntt_tables"] = mfwd;
+        host["q_Bsk_merge_intt_tables"] = minv;
+        host["q_Bsk_n_inverse"] = mninv;
+    }
+}
+
+// ------------------------------------------------------------------ device
+template <typename T>
+static hipError_t to_device(const std::vector<T>& h, T** d)
+{
+    *d = nullptr;
+    if (h.empty()) return hipSuccess;
+    hipError_t e = hipMalloc((void**) d, h.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const vec& inv, const vec& ninv,
+                             int n_power)
+{
+    const u64 n = ((u64) 1) << n_power;
+    const int cnt = (int) mods.size();
+    std::vector<Mod> hm(cnt);
+    std::vector<ulonglong2> htw((size_t) cnt * n), hitw((size_t) cnt * n), hn(cnt), hw(cnt);
+    for (int k = 0; k < cnt; k++) {
+        const u64 q = mods[k];
+        hm[k] = make_mod(q);
+        for (u64 j = 0; j < n; j++) {
+            const u64 w = fwd[k * n + j], iw = inv[k * n + j];
+            htw[k * n + j] = make_ulonglong2(w, shoup_companion(w, q));
+            hitw[k * n + j] = make_ulonglong2(iw, shoup_companion(iw, q));
+        }
+        hn[k] = make_ulonglong2(ninv[k], shoup_companion(ninv[k], q));
+        const u64 w1n = host::mul_mod(inv[k * n + 1], ninv[k], q);
+        hw[k] = make_ulonglong2(w1n, shoup_companion(w1n, q));
+    }
+    p.count = cnt;
+    hipError_t e;
+    if ((e = to_device(hm, &p.mods)) != hipSuccess) return e;
+    if ((e = to_device(htw, &p.tw)) != hipSuccess) return e;
+    if ((e = to_device(hitw, &p.itw)) != hipSuccess) return e;
+    if ((e = to_device(hn, &p.ninv)) != hipSuccess) return e;
+    return to_device(hw, &p.w1ninv);
+}
+
+static void free_plan(NttPlan& p)
+{
+    if (p.mods) (void) hipFree(p.mods);
+    if (p.tw) (void) hipFree(p.tw);
+    if (p.itw) (void) hipFree(p.itw);
+    if (p.ninv) (void) hipFree(p.ninv);
+    if (p.w1ninv) (void) hipFree(p.w1ninv);
+    p = NttPlan();
+}
+
+hipError_t Context::upload()
+{
+    if (uploaded) return hipSuccess;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if ((e = build_plan(plan_qp, host["modulus"], host["ntt_table"], host["intt_table"], host["n_inverse"],
+                        n_power)) != hipSuccess)
+        return e;
+    static const char* u64_tables[] = {"last_q_modinv",
+                                       "half",
+                                       "half_mod",
+                                       "factor",
+                                       "rescaled_last_q_modinv",
+                                       "rescaled_half_mod",
+                                       "rescaled_half",
+                                       "base_change_matrix_Bsk",
+                                       "inv_punctured_prod_mod_base_array",
+                                       "base_change_matrix_m_tilde",
+                                       "inv_m_tilde_mod_Bsk",
+                                       "prod_q_mod_Bsk",
+                                       "inv_prod_q_mod_Bsk",
+                                       "base_change_matrix_q",
+                                       "base_change_matrix_msk",
+                                       "inv_punctured_prod_mod_B_array",
+                                       "prod_B_mod_q"};
+    for (const char* nm : u64_tables) {
+        auto it = host.find(nm);
+        if (it == host.end()) continue;
+        u64* d = nullptr;
+        if ((e = to_device(it->second, &d)) != hipSuccess) return e;
+        dev[nm] = d;
+    }
+    for (const char* nm : {"new_prime_locations", "new_input_locations"}) {
+        auto it = host.find(nm);
+        if (it == host.end()) continue;
+        std::vector<int> v(it->second.begin(), it->second.end());
+        int* d = nullptr;
+        if ((e = to_device(v, &d)) != hipSuccess) return e;
+        dev[nm] = d;
+    }
+    if (scheme == SCHEME_BFV) {
+        if ((e = build_plan(plan_merge, host["q_Bsk_merge_modulus"], host["q_Bsk_merge_ntt_tables"],
+                            host["q_Bsk_merge_intt_tables"], host["q_Bsk_n_inverse"], n_power)) != hipSuccess)
+            return e;
+        behz.ibase = plan_merge.mods;
+        behz.obase = plan_merge.mods + Q_size;
+        behz.m_tilde = make_mod(((u64) 1) << 32);
+        behz.plain = make_mod(plain_modulus);
+        behz.inv_prod_q_mod_m_tilde = host["inv_prod_q_mod_m_tilde"][0];
+        behz.inv_prod_B_mod_m_sk = host["inv_prod_B_mod_m_sk"][0];
+        behz.inv_m_tilde_mod_Bsk = d64("inv_m_tilde_mod_Bsk");
+        behz.prod_q_mod_Bsk = d64("prod_q_mod_Bsk");
+        behz.base_change_matrix_Bsk = d64("base_change_matrix_Bsk");
+        behz.base_change_matrix_m_tilde = d64("base_change_matrix_m_tilde");
+        behz.inv_punctured_prod_mod_base_array = d64("inv_punctured_prod_mod_base_array");
+        behz.inv_prod_q_mod_Bsk = d64("inv_prod_q_mod_Bsk");
+        behz.inv_punctured_prod_mod_B_array = d64("inv_punctured_prod_mod_B_array");
+        behz.base_change_matrix_q = d64("base_change_matrix_q");
+        behz.base_change_matrix_msk = d64("base_change_matrix_msk");
+        behz.prod_B_mod_q = d64("prod_B_mod_q");
+        behz.ibase_size = Q_size;
+        behz.obase_size = bsk_size;
+    }
+    uploaded = true;
+    return hipDeviceSynchronize();
+}
+
+void Context::release_device()
+{
+    free_plan(plan_qp);
+    free_plan(plan_merge);
+    for (auto& kv : dev)
+        if (kv.second) (void) hipFree(kv.second);
+    dev.clear();
+    uploaded = false;
+}
+
+Context::~Context()
+{
+    if (uploaded) release_device();
+}
+
+const u64* Context::d64(const char* name) const
+{
+    auto it = dev.find(name);
+    return it == dev.end() ? nullptr : (const u64*) it->second;
+}
+const int* Context::d32(const char* name) const
+{
+    auto it = dev.find(name);
+    return it == dev.end() ? nullptr : (const int*) it->second;
+}
+
+NttArgs Context::ntt_args(int table_set) const
+{
+    const NttPlan& p = table_set ? plan_merge : plan_qp;
+    NttArgs a{};
+    a.mods = p.mods;
+    a.tw = p.tw;
+    a.itw = p.itw;
+    a.ninv = p.ninv;
+    a.w1ninv = p.w1ninv;
+    a.n_power = n_power;
+    a.mod_count = p.count;
+    return a;
+}
+
+} // namespace hegpu

@@ -1,0 +1,60 @@
+// context.hpp -- parameter set + device-resident tables of one HE context.
+//
+// Host-side counterpart of the reference's HEContextImpl<BFV|CKKS>::generate()
+// (reference src/lib/host/ckks/context.cu:272-440, bfv/context.cu:396-705):
+// prime chain, psi, NTT tables, mod-down / rescale constants, the CKKS order
+// tables (ckks/operator.cu:24-56) and the BFV BEHZ constants
+// (bfv/context.cu:939-1347).  Host tables are kept under the reference's
+// member names so tests can compare them one by one.
+#pragma once
+#include "modarith.cuh"
+#include "ntt.hpp"
+#include "rns.hpp"
+#include <map>
+#include <string>
+#include <vector>
+
+namespace hegpu {
+
+enum Scheme { SCHEME_BFV = 1, SCHEME_CKKS = 2 };
+
+struct NttPlan {
+    // device arrays, one entry / table per modulus
+    Mod* mods = nullptr;
+    ulonglong2* tw = nullptr;
+    ulonglong2* itw = nullptr;
+    ulonglong2* ninv = nullptr;
+    ulonglong2* w1ninv = nullptr;
+    int count = 0;
+};
+
+struct Context {
+    int scheme = 0;
+    int n_power = 0;
+    u64 n = 0;
+    int Q_size = 0, P_size = 0, Qp_size = 0;
+    int bsk_size = 0;
+    u64 plain_modulus = 0;
+    std::vector<u64> primes; // Q then P
+    std::map<std::string, std::vector<u64>> host; // named host tables
+
+    // ---- device state (valid after upload())
+    bool uploaded = false;
+    int device = -1;
+    NttPlan plan_qp;    // tables for the Q' chain
+    NttPlan plan_merge; // BFV: [q_0..q_{Q-1}, Bsk...]
+    std::map<std::string, void*> dev; // named device arrays (u64 / int)
+    Mod* bsk_mods = nullptr;
+    BehzDev behz{};
+
+    ~Context();
+    void build_host();           // derive every host table from `primes`
+    hipError_t upload();         // allocate + copy device tables (current device)
+    void release_device();
+
+    const u64* d64(const char* name) const;
+    const int* d32(const char* name) const;
+    NttArgs ntt_args(int table_set) const; // 0 = Q' chain, 1 = merged q|Bsk
+};
+
+} // namespace hegpu

@@ -1,0 +1,229 @@
+// ops.cpp -- operator sequences (the reference's host orchestration), batched
+// over independent ciphertexts and free of allocation: all temporaries live in
+// a caller-provided workspace so the sequences can be captured in a hipGraph.
+#include "ops.hpp"
+
+namespace hegpu {
+
+#define TRY(x)                           \
+    do {                                 \
+        hipError_t e__ = (x);            \
+        if (e__ != hipSuccess) return e__; \
+    } while (0)
+
+static int prime_loc_offset(const Context& c, int depth)
+{
+    int counter = c.Qp_size, location = 0; // reference ckks/operator.cu:949-955
+    for (int i = 0; i < depth; i++) { location += counter; counter--; }
+    return location;
+}
+
+size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
+{
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const int L = Q + c.bsk_size;
+    u64 per = 0;
+    switch (op) {
+        case OP_CKKS_RELIN: per = ((u64) l * rc + 2 * rc) * n; break;
+        case OP_CKKS_RESCALE: per = ((u64) 2 * (l - 1) + 2 * l) * n; break;
+        case OP_CKKS_GALOIS: per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n; break;
+        case OP_BFV_MULTIPLY: per = (u64) 7 * L * n; break;
+        case OP_BFV_RELIN: per = ((u64) Q * Qp + 2 * Qp) * n; break;
+        case OP_BFV_GALOIS: per = ((u64) Q * Qp + 2 * Qp) * n; break;
+        default: return 0;
+    }
+    return per * (u64) batch;
+}
+
+hipError_t op_ckks_multiply(const Context& c, const u64* ct1, u64 s1, const u64* ct2, u64 s2, u64* out, u64 so,
+                            int depth, int batch, hipStream_t st)
+{
+    return rns_cross_multiplication(ct1, s1, ct2, s2, out, so, c.plan_qp.mods, c.n_power, c.Q_size - depth, batch,
+                                    st);
+}
+
+// reference ckks/operator.cu:899-1023
+hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
+                               hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const u64 per = ((u64) l * rc + 2 * rc) * n;
+    u64* temp1 = ws;                      // [l][rc][N] per item, later [2][l][N]
+    u64* temp2 = ws + (u64) l * rc * n;   // [2][rc][N] per item
+    u64* c2 = ct + ((u64) l << (np + 1));
+    const Mod* mods = c.plan_qp.mods;
+
+    NttArgs a = c.ntt_args(0);
+    // INTT(c2), batch l per item                                     (:919)
+    a.in = c2; a.out = c2; a.mod_count = l; a.polys_per_item = l;
+    a.in_item_stride = a.out_item_stride = cs;
+    TRY(ntt_launch(a, l * batch, true, st));
+    // digit decomposition c2 -> [l][rc][N]                           (:932)
+    TRY(rns_decompose(c2, cs, temp1, per, mods, np, l, rc, l, Qp - rc, batch, st));
+    // forward NTT, modulus order skips dropped primes               (:956)
+    a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc;
+    a.in_item_stride = a.out_item_stride = per;
+    a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    TRY(ntt_launch(a, l * rc * batch, false, st));
+    // inner product with the key                                     (:967)
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, l, rc, Qp, l, batch, st));
+    // INTT of the two P-limb polynomials only                        (:996)
+    a = c.ntt_args(0);
+    a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
+    a.in_item_stride = a.out_item_stride = per;
+    a.poly_order = c.d32("new_input_locations") + 2 * depth;
+    TRY(ntt_launch(a, 2 * batch, true, st));
+    // stage one: P limb (+half) reduced into every q_j               (:1003)
+    TRY(rns_moddown_stage_one(temp2, per, temp1, per, mods, c.d64("half"), c.d64("half_mod"), np, Q, l, batch, st));
+    // forward NTT of that                                            (:1011)
+    a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * l * batch, false, st));
+    // stage two: (x - last) * P^-1 + ct, written over ct parts 0,1   (:1015)
+    return rns_moddown_stage_two(temp1, per, temp2, per, l + 1, ct, cs, ct, cs, mods, c.d64("last_q_modinv"), np, l,
+                                 1, batch, st);
+}
+
+// reference ckks/operator.cu:1156-1244
+hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, P = c.P_size;
+    const int l = Q - depth;
+    int counter = Q - 1, location = 0;
+    for (int i = 0; i < depth; i++) { location += counter; counter--; }
+    const u64 per = ((u64) 2 * (l - 1) + 2 * l) * n;
+    u64* temp1 = ws;                         // [2][l-1][N]
+    u64* temp2 = ws + (u64) 2 * (l - 1) * n; // copy of ct, part stride l
+    const Mod* mods = c.plan_qp.mods;
+
+    NttArgs a = c.ntt_args(0);
+    a.in = ct; a.out = ct; a.mod_count = 1; a.mod_offset = l - 1; a.polys_per_item = 2;
+    a.in_item_stride = a.out_item_stride = cs;
+    a.poly_order = c.d32("new_input_locations") + (depth + P) * 2;
+    TRY(ntt_launch(a, 2 * batch, true, st));                                               // :1197
+    TRY(rns_moddown_stage_one(ct, cs, temp1, per, mods, c.d64("rescaled_half") + depth,
+                              c.d64("rescaled_half_mod") + location, np, l - 1, l - 1, batch, st)); // :1205
+    a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = l - 1; a.polys_per_item = 2 * (l - 1);
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * (l - 1) * batch, false, st));                                    // :1214
+    TRY(rns_copy_limbs(ct, (u64) l * n, cs, temp2, (u64) l * n, per, np, l - 1, 2, batch, st)); // :1219
+    return rns_moddown_stage_two(temp1, per, temp2, per, l, nullptr, 0, ct, cs, mods,
+                                 c.d64("rescaled_last_q_modinv") + location, np, l - 1, 0, batch, st); // :1225
+}
+
+// reference ckks/operator.cu:1422-1559
+hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                                int galois_elt, int depth, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const u64 per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n;
+    u64* temp0 = ws;                       // [2][l][N] coefficient-domain copy of ct
+    u64* temp2 = temp0 + (u64) 2 * l * n;  // [l][rc][N]
+    u64* temp3 = temp2 + (u64) l * rc * n; // [2][rc][N]
+    const Mod* mods = c.plan_qp.mods;
+    const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+
+    NttArgs a = c.ntt_args(0);
+    a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = cs; a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * l * batch, true, st));                                           // :1461
+    TRY(rns_decompose(temp0 + (u64) l * n, per, temp2, per, mods, np, l, rc, l, Qp - rc, batch, st)); // :1467
+    a = c.ntt_args(0);
+    a.in = temp2; a.out = temp2; a.mod_count = rc; a.polys_per_item = l * rc;
+    a.in_item_stride = a.out_item_stride = per;
+    a.mod_order = order;
+    TRY(ntt_launch(a, l * rc * batch, false, st));                                         // :1490
+    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, batch, st)); // :1501
+    a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
+    TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1524
+    TRY(rns_moddown_permute(temp3, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
+                            c.d64("last_q_modinv"), galois_elt, np, rc, l, Qp, Q, c.P_size, batch, st)); // :1530
+    a = c.ntt_args(0);
+    a.in = out; a.out = out; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = a.out_item_stride = so;
+    return ntt_launch(a, 2 * l * batch, false, st);                                        // :1541
+}
+
+// reference bfv/operator.cu:336-430
+hipError_t op_bfv_multiply(const Context& c, const u64* ct1, u64 s1, const u64* ct2, u64 s2, u64* out, u64 so,
+                           int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int L = c.Q_size + c.bsk_size;
+    const u64 per = (u64) 7 * L * n;
+    u64* temp1 = ws;                   // [4][L][N]
+    u64* temp2 = ws + (u64) 4 * L * n; // [3][L][N]
+    TRY(rns_fast_convertion(ct1, s1, ct2, s2, temp1, per, c.behz, np, batch, st));         // :364
+    NttArgs a = c.ntt_args(1);
+    a.in = temp1; a.out = temp1; a.mod_count = L; a.polys_per_item = 4 * L;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, 4 * L * batch, false, st));                                          // :393
+    TRY(rns_cross_multiplication(temp1, per, temp1 + (u64) 2 * L * n, per, temp2, per, c.plan_merge.mods, np, L,
+                                 batch, st));                                              // :399
+    a.in = temp2; a.out = temp2; a.polys_per_item = 3 * L;
+    TRY(ntt_launch(a, 3 * L * batch, true, st));                                           // :410
+    return rns_fast_floor(temp2, per, out, so, c.behz, np, batch, st);                     // :416
+}
+
+// reference bfv/operator.cu:505-583
+hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
+                              hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const u64 per = ((u64) Q * Qp + 2 * Qp) * n;
+    u64* temp1 = ws;
+    u64* temp2 = ws + (u64) Q * Qp * n;
+    const Mod* mods = c.plan_qp.mods;
+    TRY(rns_decompose(ct + ((u64) Q << (np + 1)), cs, temp1, per, mods, np, Q, Qp, Qp, 0, batch, st)); // :515
+    NttArgs a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, Q * Qp * batch, false, st));                                         // :531
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :540
+    a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
+    TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
+    return rns_divide_round_lastq(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
+                                  c.d64("last_q_modinv"), np, Q, 0, batch, st);            // :576
+}
+
+// reference bfv/operator.cu:771-864 (c0 is read straight from the input
+// ciphertext instead of being copied aside: out must not alias ct)
+hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                               int galois_elt, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const u64 per = ((u64) Q * Qp + 2 * Qp) * n;
+    u64* temp1 = ws;
+    u64* temp2 = ws + (u64) Q * Qp * n;
+    const Mod* mods = c.plan_qp.mods;
+    TRY(rns_decompose(ct + (u64) Q * n, cs, temp1, per, mods, np, Q, Qp, Qp, 0, batch, st)); // :789
+    NttArgs a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, Q * Qp * batch, false, st));                                         // :805
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :814
+    a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
+    TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846
+    return rns_moddown_permute(temp2, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
+                               c.d64("last_q_modinv"), galois_elt, np, Qp, Q, Qp, Q, c.P_size, batch, st); // :853
+}
+
+} // namespace hegpu

@@ -1,0 +1,520 @@
+// rns.hip -- RNS element-wise kernels for gfx950 (see rns.hpp for the
+// reference kernels each one replaces).
+//
+// All of these are streaming kernels bounded by HBM: every thread owns two
+// adjacent coefficients and moves them with 16-byte loads/stores (dwordx4),
+// a workgroup covers 512 contiguous coefficients of one limb, and the grid is
+// (N/512, limb-ish, batch-ish) so that thousands of workgroups are in flight.
+// Arithmetic that the reference does with repeated canonical add/mult is done
+// lazily where it is exact (128-bit accumulation in the key-switch MAC), so
+// outputs are the same canonical residues.
+#include "rns.hpp"
+
+namespace hegpu {
+
+#define RNS_THREADS 256
+#define RNS_PER_BLOCK 512
+
+__device__ __forceinline__ ulonglong2 ld2(const u64* p) { return *reinterpret_cast<const ulonglong2*>(p); }
+__device__ __forceinline__ void st2(u64* p, ulonglong2 v) { *reinterpret_cast<ulonglong2*>(p) = v; }
+__device__ __forceinline__ u64 coeff0() { return ((u64) blockIdx.x * RNS_THREADS + threadIdx.x) * 2; }
+
+static inline dim3 grid3(int n_power, int y, int z) { return dim3((1u << n_power) / RNS_PER_BLOCK, y, z); }
+
+// ---------------------------------------------------------------- add/sub/neg
+template <int OP>
+__global__ __launch_bounds__(RNS_THREADS) void k_addition(const u64* __restrict__ a, const u64* __restrict__ b,
+                                                          u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                          int n_power, int limbs)
+{
+    const u64 q = mods[blockIdx.y].q;
+    // blockIdx.z runs over batch*parts; all of them have `limbs` limbs
+    const u64 loc = coeff0() + ((u64) blockIdx.y << n_power) + (((u64) limbs * blockIdx.z) << n_power);
+    ulonglong2 r;
+    if (OP == 0) {
+        ulonglong2 x = ld2(a + loc), y = ld2(b + loc);
+        r.x = add_mod(x.x, y.x, q);
+        r.y = add_mod(x.y, y.y, q);
+    } else if (OP == 1) {
+        ulonglong2 x = ld2(a + loc), y = ld2(b + loc);
+        r.x = sub_mod(x.x, y.x, q);
+        r.y = sub_mod(x.y, y.y, q);
+    } else {
+        ulonglong2 x = ld2(a + loc);
+        r.x = sub_mod(0, x.x, q);
+        r.y = sub_mod(0, x.y, q);
+    }
+    st2(out + loc, r);
+}
+
+hipError_t rns_addition(const u64* a, const u64* b, u64* out, const Mod* mods, int n_power, int limbs,
+                        int parts, int batch, int op, hipStream_t st)
+{
+    dim3 g = grid3(n_power, limbs, parts * batch);
+    if (op == 0) hipLaunchKernelGGL(k_addition<0>, g, dim3(RNS_THREADS), 0, st, a, b, out, mods, n_power, limbs);
+    else if (op == 1) hipLaunchKernelGGL(k_addition<1>, g, dim3(RNS_THREADS), 0, st, a, b, out, mods, n_power, limbs);
+    else hipLaunchKernelGGL(k_addition<2>, g, dim3(RNS_THREADS), 0, st, a, b, out, mods, n_power, limbs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- tensor product
+__global__ __launch_bounds__(RNS_THREADS) void k_cross_multiplication(const u64* __restrict__ in1, u64 s1,
+                                                                      const u64* __restrict__ in2, u64 s2,
+                                                                      u64* __restrict__ out, u64 so,
+                                                                      const Mod* __restrict__ mods, int n_power,
+                                                                      int decomp_size)
+{
+    const Mod m = mods[blockIdx.y];
+    const u64 loc = coeff0() + ((u64) blockIdx.y << n_power);
+    const u64 part = (u64) decomp_size << n_power;
+    const u64* p1 = in1 + s1 * blockIdx.z;
+    const u64* p2 = in2 + s2 * blockIdx.z;
+    u64* po = out + so * blockIdx.z;
+    ulonglong2 a0 = ld2(p1 + loc), a1 = ld2(p1 + loc + part);
+    ulonglong2 b0 = ld2(p2 + loc), b1 = ld2(p2 + loc + part);
+    ulonglong2 o0, o1, o2;
+    o0.x = mul_barrett(a0.x, b0.x, m);
+    o0.y = mul_barrett(a0.y, b0.y, m);
+    o2.x = mul_barrett(a1.x, b1.x, m);
+    o2.y = mul_barrett(a1.y, b1.y, m);
+    // a0*b1 + a1*b0: one 128-bit sum, one reduction (same canonical value)
+    {
+        u64 h1, l1, h2, l2;
+        mul64wide(a0.x, b1.x, h1, l1);
+        mul64wide(a1.x, b0.x, h2, l2);
+        u64 lo = l1 + l2;
+        u64 hi = h1 + h2 + (lo < l1);
+        o1.x = reduce128(hi, lo, m);
+        mul64wide(a0.y, b1.y, h1, l1);
+        mul64wide(a1.y, b0.y, h2, l2);
+        lo = l1 + l2;
+        hi = h1 + h2 + (lo < l1);
+        o1.y = reduce128(hi, lo, m);
+    }
+    st2(po + loc, o0);
+    st2(po + loc + part, o1);
+    st2(po + loc + 2 * part, o2);
+}
+
+hipError_t rns_cross_multiplication(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
+                                    const Mod* mods, int n_power, int decomp_size, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cross_multiplication, grid3(n_power, decomp_size, batch), dim3(RNS_THREADS), 0, st, in1,
+                       s1, in2, s2, out, so, mods, n_power, decomp_size);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- digit decomposition
+__global__ __launch_bounds__(RNS_THREADS) void k_decompose(const u64* __restrict__ in, u64 in_stride,
+                                                           u64* __restrict__ out, u64 out_stride,
+                                                           const Mod* __restrict__ mods, int n_power, int nmods,
+                                                           int split, int level)
+{
+    const u64 c = coeff0();
+    const ulonglong2 x = ld2(in + in_stride * blockIdx.z + ((u64) blockIdx.y << n_power) + c);
+    u64* po = out + out_stride * blockIdx.z + (((u64) nmods * blockIdx.y) << n_power) + c;
+    for (int i = 0; i < nmods; i++) {
+        const Mod m = mods[(i < split) ? i : i + level];
+        ulonglong2 r;
+        r.x = reduce64(x.x, m);
+        r.y = reduce64(x.y, m);
+        st2(po + ((u64) i << n_power), r);
+    }
+}
+
+hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods, int n_power,
+                         int digits, int nmods, int split, int level, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decompose, grid3(n_power, digits, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
+                       out_stride, mods, n_power, nmods, split, level);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- key-switch inner product
+__device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
+{
+    u64 h, l;
+    mul64wide(a, b, h, l);
+    lo += l;
+    hi += h + (lo < l);
+}
+
+__global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __restrict__ in, u64 in_stride,
+                                                               const u64* __restrict__ key,
+                                                               u64* __restrict__ out, u64 out_stride,
+                                                               const Mod* __restrict__ mods, int n_power,
+                                                               int digits, int nmods, int key_limbs, int p_row)
+{
+    const int y = blockIdx.y;
+    const int kidx = (y == p_row) ? (key_limbs - 1) : y;
+    const Mod m = mods[kidx];
+    const u64 c = coeff0();
+    const u64* pin = in + in_stride * blockIdx.z + ((u64) y << n_power) + c;
+    const u64* pk = key + ((u64) kidx << n_power) + c;
+    const u64 key_off1 = (u64) key_limbs << n_power;
+    const u64 key_off2 = (u64) key_limbs << (n_power + 1);
+    const u64 dig_off = (u64) nmods << n_power;
+    u64 h00 = 0, l00 = 0, h01 = 0, l01 = 0, h10 = 0, l10 = 0, h11 = 0, l11 = 0;
+#pragma unroll 2
+    for (int i = 0; i < digits; i++) {
+        ulonglong2 d = ld2(pin + dig_off * i);
+        ulonglong2 k0 = ld2(pk + key_off2 * i);
+        ulonglong2 k1 = ld2(pk + key_off2 * i + key_off1);
+        acc_mad(h00, l00, d.x, k0.x);
+        acc_mad(h01, l01, d.y, k0.y);
+        acc_mad(h10, l10, d.x, k1.x);
+        acc_mad(h11, l11, d.y, k1.y);
+    }
+    ulonglong2 r0, r1;
+    r0.x = reduce128(h00, l00, m);
+    r0.y = reduce128(h01, l01, m);
+    r1.x = reduce128(h10, l10, m);
+    r1.y = reduce128(h11, l11, m);
+    u64* po = out + out_stride * blockIdx.z + ((u64) y << n_power) + c;
+    st2(po, r0);
+    st2(po + dig_off, r1);
+}
+
+hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
+                             const Mod* mods, int n_power, int digits, int nmods, int key_limbs, int p_row,
+                             int batch, hipStream_t st)
+{
+    if (digits > 64) return hipErrorInvalidValue; // 128-bit accumulator bound
+    hipLaunchKernelGGL(k_keyswitch_mac, grid3(n_power, nmods, batch), dim3(RNS_THREADS), 0, st, in, in_stride, key,
+                       out, out_stride, mods, n_power, digits, nmods, key_limbs, p_row);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- mod-down (BFV, single kernel)
+__global__ __launch_bounds__(RNS_THREADS) void k_divide_round_lastq(
+    const u64* __restrict__ in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out, u64 out_stride,
+    const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
+    const u64* __restrict__ last_q_modinv, int n_power, int D, int switchkey)
+{
+    const int y = blockIdx.y;
+    const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const Mod m = mods[y];
+    const u64 qP = mods[D].q;
+    const u64 c = coeff0();
+    const u64* pin = in + in_stride * b + (((u64) (D + 1) << n_power) * z) + c;
+    ulonglong2 last = ld2(pin + ((u64) D << n_power));
+    ulonglong2 x = ld2(pin + ((u64) y << n_power));
+    const u64 h = half[0], hm = half_mod[y], inv = last_q_modinv[y];
+    const u64 loc = (((u64) D << n_power) * z) + ((u64) y << n_power) + c;
+    ulonglong2 cin = make_ulonglong2(0, 0);
+    if (!(switchkey && z != 0)) cin = ld2(ct + ct_stride * b + loc);
+    ulonglong2 r;
+    {
+        u64 l = add_mod(last.x, h, qP);
+        l = reduce64(l, m);
+        l = sub_mod(l, hm, m.q);
+        u64 v = sub_mod(x.x, l, m.q);
+        v = mul_barrett(v, inv, m);
+        r.x = add_mod(cin.x, v, m.q);
+    }
+    {
+        u64 l = add_mod(last.y, h, qP);
+        l = reduce64(l, m);
+        l = sub_mod(l, hm, m.q);
+        u64 v = sub_mod(x.y, l, m.q);
+        v = mul_barrett(v, inv, m);
+        r.y = add_mod(cin.y, v, m.q);
+    }
+    st2(out + out_stride * b + loc, r);
+}
+
+hipError_t rns_divide_round_lastq(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
+                                  u64 out_stride, const Mod* mods, const u64* half, const u64* half_mod,
+                                  const u64* last_q_modinv, int n_power, int decomp, int switchkey, int batch,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(k_divide_round_lastq, grid3(n_power, decomp, 2 * batch), dim3(RNS_THREADS), 0, st, in,
+                       in_stride, ct, ct_stride, out, out_stride, mods, half, half_mod, last_q_modinv, n_power,
+                       decomp, switchkey);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- mod-down stage one (CKKS / rescale)
+__global__ __launch_bounds__(RNS_THREADS) void k_moddown_stage_one(
+    const u64* __restrict__ in, u64 in_stride, u64* __restrict__ out, u64 out_stride,
+    const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod, int n_power,
+    int first_decomp, int C)
+{
+    const int y = blockIdx.y; // cipher part
+    const u64 c = coeff0();
+    const u64 qP = mods[first_decomp].q;
+    ulonglong2 last =
+        ld2(in + in_stride * blockIdx.z + ((u64) C << n_power) + (((u64) (C + 1) << n_power) * y) + c);
+    const u64 h = half[0];
+    last.x = add_mod(last.x, h, qP);
+    last.y = add_mod(last.y, h, qP);
+    u64* po = out + out_stride * blockIdx.z + (((u64) C << n_power) * y) + c;
+    for (int i = 0; i < C; i++) {
+        const Mod m = mods[i];
+        const u64 hm = half_mod[i];
+        ulonglong2 r;
+        r.x = sub_mod(reduce64(last.x, m), hm, m.q);
+        r.y = sub_mod(reduce64(last.y, m), hm, m.q);
+        st2(po + ((u64) i << n_power), r);
+    }
+}
+
+hipError_t rns_moddown_stage_one(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                                 const u64* half, const u64* half_mod, int n_power, int first_decomp,
+                                 int cur_decomp, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_moddown_stage_one, grid3(n_power, 2, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
+                       out_stride, mods, half, half_mod, n_power, first_decomp, cur_decomp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- mod-down stage two / rescale
+__global__ __launch_bounds__(RNS_THREADS) void k_moddown_stage_two(
+    const u64* __restrict__ in_last, u64 last_stride, const u64* in, u64 in_stride, int in_limbs, const u64* ct,
+    u64 ct_stride, u64* out, u64 out_stride, const Mod* __restrict__ mods,
+    const u64* __restrict__ last_q_modinv, int n_power, int C, int with_ct)
+{
+    const int y = blockIdx.y;
+    const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const Mod m = mods[y];
+    const u64 c = coeff0();
+    const u64 loc = ((u64) y << n_power) + (((u64) C << n_power) * z) + c;
+    ulonglong2 last = ld2(in_last + last_stride * b + loc);
+    ulonglong2 x = ld2(in + in_stride * b + ((u64) y << n_power) + (((u64) in_limbs << n_power) * z) + c);
+    const u64 inv = last_q_modinv[y];
+    ulonglong2 r;
+    r.x = mul_barrett(sub_mod(x.x, last.x, m.q), inv, m);
+    r.y = mul_barrett(sub_mod(x.y, last.y, m.q), inv, m);
+    if (with_ct == 1 || (with_ct == 2 && z == 0)) {
+        ulonglong2 cin = ld2(ct + ct_stride * b + loc);
+        r.x = add_mod(cin.x, r.x, m.q);
+        r.y = add_mod(cin.y, r.y, m.q);
+    } else if (with_ct == 2) {
+        r.x = add_mod(0, r.x, m.q);
+        r.y = add_mod(0, r.y, m.q);
+    }
+    st2(out + out_stride * b + loc, r);
+}
+
+hipError_t rns_moddown_stage_two(const u64* in_last, u64 last_stride, const u64* in, u64 in_stride, int in_limbs,
+                                 const u64* ct, u64 ct_stride, u64* out, u64 out_stride, const Mod* mods,
+                                 const u64* last_q_modinv, int n_power, int cur_decomp, int with_ct, int batch,
+                                 hipStream_t st)
+{
+    hipLaunchKernelGGL(k_moddown_stage_two, grid3(n_power, cur_decomp, 2 * batch), dim3(RNS_THREADS), 0, st,
+                       in_last, last_stride, in, in_stride, in_limbs, ct, ct_stride, out, out_stride, mods,
+                       last_q_modinv, n_power, cur_decomp, with_ct);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- mod-down + Galois permutation
+// One coefficient per thread: the destination index i*g mod N scatters.
+template <bool SINGLE_P>
+__global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
+    const u64* __restrict__ in, u64 in_stride, const u64* __restrict__ in2, u64 in2_stride, u64* __restrict__ out,
+    u64 out_stride, const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
+    const u64* __restrict__ last_q_modinv, int galois_elt, int n_power, int Qp_cur, int Q_cur, int first_Qp,
+    int first_Q, int P_size)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const Mod m = mods[y];
+    const u64* pin = in + in_stride * b + (((u64) Qp_cur << n_power) * z) + idx;
+    u64 x = pin[(u64) y << n_power];
+    if (SINGLE_P) {
+        u64 l = pin[(u64) Q_cur << n_power];
+        l = add_mod(l, half[0], mods[first_Qp - 1].q);
+        l = reduce64(l, m);
+        l = sub_mod(l, half_mod[y], m.q);
+        l = sub_mod(x, l, m.q);
+        x = mul_barrett(l, last_q_modinv[y], m);
+    } else {
+        u64 last_ct[15];
+        for (int i = 0; i < P_size; i++) last_ct[i] = pin[(u64) (Q_cur + i) << n_power];
+        int location_ = 0;
+        for (int i = 0; i < P_size; i++) {
+            u64 lh = last_ct[P_size - 1 - i];
+            lh = add_mod(lh, half[i], mods[first_Qp - 1 - i].q);
+            for (int j = 0; j < (P_size - 1 - i); j++) {
+                const Mod mj = mods[first_Q + j];
+                u64 t1 = reduce64(lh, mj);
+                t1 = sub_mod(t1, half_mod[location_ + first_Q + j], mj.q);
+                t1 = sub_mod(last_ct[j], t1, mj.q);
+                last_ct[j] = mul_barrett(t1, last_q_modinv[location_ + first_Q + j], mj);
+            }
+            u64 t1 = reduce64(lh, m);
+            t1 = sub_mod(t1, half_mod[location_ + y], m.q);
+            t1 = sub_mod(x, t1, m.q);
+            x = mul_barrett(t1, last_q_modinv[location_ + y], m);
+            location_ += (first_Qp - 1 - i);
+        }
+    }
+    if (z == 0) x = add_mod(in2[in2_stride * b + ((u64) y << n_power) + idx], x, m.q);
+    const u32 raw = idx * (u32) galois_elt;
+    const u32 dst = raw & ((1u << n_power) - 1);
+    if ((raw >> n_power) & 1) x = m.q - x; // no zero test: reference switchkey.cu:1694,1711
+    out[out_stride * b + (((u64) Q_cur << n_power) * z) + ((u64) y << n_power) + dst] = x;
+}
+
+hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64 in2_stride, u64* out,
+                               u64 out_stride, const Mod* mods, const u64* half, const u64* half_mod,
+                               const u64* last_q_modinv, int galois_elt, int n_power, int Qp_cur, int Q_cur,
+                               int first_Qp, int first_Q, int P_size, int batch, hipStream_t st)
+{
+    dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
+    if (P_size > 15) return hipErrorInvalidValue;
+    if (P_size == 1)
+        hipLaunchKernelGGL(k_moddown_permute<true>, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride, out,
+                           out_stride, mods, half, half_mod, last_q_modinv, galois_elt, n_power, Qp_cur, Q_cur,
+                           first_Qp, first_Q, P_size);
+    else
+        hipLaunchKernelGGL(k_moddown_permute<false>, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride,
+                           out, out_stride, mods, half, half_mod, last_q_modinv, galois_elt, n_power, Qp_cur, Q_cur,
+                           first_Qp, first_Q, P_size);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- strided limb copy
+__global__ __launch_bounds__(RNS_THREADS) void k_copy_limbs(const u64* __restrict__ in, u64 in_part_stride,
+                                                            u64 in_stride, u64* __restrict__ out,
+                                                            u64 out_part_stride, u64 out_stride, int n_power,
+                                                            int parts)
+{
+    const int z = blockIdx.z % parts, b = blockIdx.z / parts;
+    const u64 c = coeff0() + ((u64) blockIdx.y << n_power);
+    st2(out + out_stride * b + out_part_stride * z + c, ld2(in + in_stride * b + in_part_stride * z + c));
+}
+
+hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64* out, u64 out_part_stride,
+                          u64 out_stride, int n_power, int limbs, int parts, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_limbs, grid3(n_power, limbs, parts * batch), dim3(RNS_THREADS), 0, st, in,
+                       in_part_stride, in_stride, out, out_part_stride, out_stride, n_power, parts);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- BFV BEHZ kernels
+#define BEHZ_MAX 40
+
+__global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __restrict__ in1, u64 s1,
+                                                                 const u64* __restrict__ in2, u64 s2,
+                                                                 u64* __restrict__ out1, u64 so, BehzDev b,
+                                                                 int n_power)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int idy = blockIdx.y;
+    const int ib = b.ibase_size, ob = b.obase_size;
+    const u64* input = ((idy >> 1) == 0) ? (in1 + s1 * blockIdx.z) : (in2 + s2 * blockIdx.z);
+    const u64 location = idx + ((u64) ((idy & 1) * ib) << n_power);
+    u64 temp[BEHZ_MAX];
+    u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * (ob + ib)) << n_power);
+    for (int i = 0; i < ib; i++) {
+        const Mod mi = b.ibase[i];
+        u64 v = input[location + ((u64) i << n_power)];
+        po[(u64) i << n_power] = v;
+        v = mul_barrett(v, b.m_tilde.q, mi);
+        temp[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+    }
+    // m_tilde channel
+    u64 acc_mt = 0;
+    for (int j = 0; j < ib; j++) {
+        u64 ti = reduce64(temp[j], b.m_tilde);
+        u64 mu = mul_barrett(ti, b.base_change_matrix_m_tilde[j], b.m_tilde);
+        acc_mt = add_mod(acc_mt, mu, b.m_tilde.q);
+    }
+    const u64 mt = b.m_tilde.q;
+    u64 r_mt = mul_barrett(acc_mt, b.inv_prod_q_mod_m_tilde, b.m_tilde);
+    r_mt = mt - r_mt;
+    for (int i = 0; i < ob; i++) {
+        const Mod mo = b.obase[i];
+        u64 hi = 0, lo = 0;
+        for (int j = 0; j < ib; j++) acc_mad(hi, lo, temp[j], b.base_change_matrix_Bsk[j + i * ib]);
+        u64 t2 = reduce128(hi, lo, mo);
+        u64 t3 = r_mt;
+        if (t3 >= (mt >> 1)) {
+            t3 = mo.q - mt;
+            t3 = add_mod(t3, r_mt, mo.q);
+        }
+        t3 = mul_barrett(t3, b.prod_q_mod_Bsk[i], mo);
+        t3 = add_mod(t2, t3, mo.q);
+        po[(u64) (i + ib) << n_power] = mul_barrett(t3, b.inv_m_tilde_mod_Bsk[i], mo);
+    }
+}
+
+hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
+                               const BehzDev& b, int n_power, int batch, hipStream_t st)
+{
+    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
+    dim3 g((1u << n_power) / RNS_THREADS, 4, batch);
+    hipLaunchKernelGGL(k_fast_convertion, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restrict__ in, u64 si,
+                                                            u64* __restrict__ out1, u64 so, BehzDev b, int n_power)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int idy = blockIdx.y;
+    const int ib = b.ibase_size, ob = b.obase_size;
+    const u64 t = b.plain.q;
+    const u64* pq = in + si * blockIdx.z + idx + ((u64) (idy * (ib + ob)) << n_power);
+    const u64* pB = pq + ((u64) ib << n_power);
+    u64 reg_q[BEHZ_MAX], temp3[BEHZ_MAX];
+    for (int i = 0; i < ib; i++) {
+        const Mod mi = b.ibase[i];
+        u64 v = mul_barrett(pq[(u64) i << n_power], t, mi);
+        reg_q[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+    }
+    u64 reg_Bsk_last = 0;
+    for (int i = 0; i < ob; i++) {
+        const Mod mo = b.obase[i];
+        u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
+        u64 hi = 0, lo = 0;
+        for (int j = 0; j < ib; j++) acc_mad(hi, lo, reg_q[j], b.base_change_matrix_Bsk[j + i * ib]);
+        u64 tmp = reduce128(hi, lo, mo);
+        u64 t2 = sub_mod(mo.q, tmp, mo.q);
+        t2 = add_mod(t2, rb, mo.q);
+        rb = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
+        if (i < ob - 1) temp3[i] = mul_barrett(rb, b.inv_punctured_prod_mod_B_array[i], mo);
+        else reg_Bsk_last = rb;
+    }
+    const Mod msk = b.obase[ob - 1];
+    u64 hi = 0, lo = 0;
+    for (int j = 0; j < ob - 1; j++) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j]);
+    u64 t4sk = reduce128(hi, lo, msk);
+    u64 alpha_sk = sub_mod(msk.q, reg_Bsk_last, msk.q);
+    alpha_sk = add_mod(alpha_sk, t4sk, msk.q);
+    alpha_sk = mul_barrett(alpha_sk, b.inv_prod_B_mod_m_sk, msk);
+    const bool neg = alpha_sk > (msk.q >> 1);
+    u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * ib) << n_power);
+    for (int i = 0; i < ib; i++) {
+        const Mod mi = b.ibase[i];
+        u64 h2 = 0, l2 = 0;
+        for (int j = 0; j < ob - 1; j++)
+            acc_mad(h2, l2, reduce64(temp3[j], mi), b.base_change_matrix_q[j + i * (ob - 1)]);
+        u64 t4 = reduce128(h2, l2, mi);
+        u64 obase_ = reduce64(msk.q, mi);
+        u64 alpha_ = reduce64(alpha_sk, mi);
+        u64 inner;
+        if (neg) {
+            inner = sub_mod(obase_, alpha_, mi.q);
+            inner = mul_barrett(inner, b.prod_B_mod_q[i], mi);
+        } else {
+            inner = sub_mod(mi.q, b.prod_B_mod_q[i], mi.q);
+            inner = mul_barrett(inner, alpha_, mi);
+        }
+        po[(u64) i << n_power] = add_mod(t4, inner, mi.q);
+    }
+}
+
+hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev& b, int n_power, int batch,
+                          hipStream_t st)
+{
+    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
+    dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
+    hipLaunchKernelGGL(k_fast_floor, g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power);
+    return hipGetLastError();
+}
+
+} // namespace hegpu

@@ -1,0 +1,91 @@
+// rns.hpp -- launchers for the RNS element-wise kernels (internal C++).
+// Each launcher cites the reference kernel it replaces; layouts are the
+// reference's limb-major planar layout: [part][limb][coeff] per ciphertext,
+// ciphertexts of a batch `*_stride` elements apart.
+#pragma once
+#include "modarith.cuh"
+
+namespace hegpu {
+
+// reference src/lib/kernel/addition.cu:10-47
+hipError_t rns_addition(const u64* a, const u64* b, u64* out, const Mod* mods, int n_power,
+                        int limbs, int parts, int batch, int op /*0 add,1 sub,2 neg*/,
+                        hipStream_t st);
+
+// reference multiplication.cu:102-126
+hipError_t rns_cross_multiplication(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out,
+                                    u64 so, const Mod* mods, int n_power, int decomp_size,
+                                    int batch, hipStream_t st);
+
+// reference switchkey.cu:11-59, 1558-1590, 1592-1619 (digit decomposition):
+// out[y][i][n] = in[y][n] mod q_{map(i)},  map(i) = i < split ? i : i+level.
+hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                         int n_power, int digits, int nmods, int split, int level, int batch,
+                         hipStream_t st);
+
+// reference switchkey.cu:61-285: out[c][y][n] = sum_i in[i][y][n]*key[i][c][kidx(y)][n].
+// key strides use key_limbs (= Q' at depth 0); kidx(y) = (y==p_row) ? key_limbs-1 : y.
+hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
+                             const Mod* mods, int n_power, int digits, int nmods, int key_limbs,
+                             int p_row, int batch, hipStream_t st);
+
+// reference switchkey.cu:400-478 (switchkey != 0: ct added to part 0 only)
+hipError_t rns_divide_round_lastq(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride,
+                                  u64* out, u64 out_stride, const Mod* mods, const u64* half,
+                                  const u64* half_mod, const u64* last_q_modinv, int n_power,
+                                  int decomp, int switchkey, int batch, hipStream_t st);
+
+// reference switchkey.cu:678-705
+hipError_t rns_moddown_stage_one(const u64* in, u64 in_stride, u64* out, u64 out_stride,
+                                 const Mod* mods, const u64* half, const u64* half_mod, int n_power,
+                                 int first_decomp, int cur_decomp, int batch, hipStream_t st);
+
+// reference switchkey.cu:707-771 (ct may alias out); with_ct: 0 none (rescale,
+// switchkey.cu:792-815), 1 both parts, 2 part 0 only (switchkey variant)
+hipError_t rns_moddown_stage_two(const u64* in_last, u64 last_stride, const u64* in, u64 in_stride,
+                                 int in_limbs, const u64* ct, u64 ct_stride, u64* out,
+                                 u64 out_stride, const Mod* mods, const u64* last_q_modinv,
+                                 int n_power, int cur_decomp, int with_ct, int batch,
+                                 hipStream_t st);
+
+// reference switchkey.cu:1621-1813 (mod-down by P_size primes + Galois permute)
+hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64 in2_stride,
+                               u64* out, u64 out_stride, const Mod* mods, const u64* half,
+                               const u64* half_mod, const u64* last_q_modinv, int galois_elt,
+                               int n_power, int Qp_cur, int Q_cur, int first_Qp, int first_Q,
+                               int P_size, int batch, hipStream_t st);
+
+// plain strided copy of `limbs` limbs x `parts` parts (switchkey.cu:776-790,
+// bfv_duplicate's c0 copy)
+hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64* out,
+                          u64 out_part_stride, u64 out_stride, int n_power, int limbs, int parts,
+                          int batch, hipStream_t st);
+
+struct BehzDev {
+    const Mod* ibase;       // q_0..q_{Q-1}
+    const Mod* obase;       // Bsk
+    Mod m_tilde;
+    Mod plain;
+    u64 inv_prod_q_mod_m_tilde;
+    u64 inv_prod_B_mod_m_sk;
+    const u64* inv_m_tilde_mod_Bsk;
+    const u64* prod_q_mod_Bsk;
+    const u64* base_change_matrix_Bsk;
+    const u64* base_change_matrix_m_tilde;
+    const u64* inv_punctured_prod_mod_base_array;
+    const u64* inv_prod_q_mod_Bsk;
+    const u64* inv_punctured_prod_mod_B_array;
+    const u64* base_change_matrix_q;
+    const u64* base_change_matrix_msk;
+    const u64* prod_B_mod_q;
+    int ibase_size, obase_size;
+};
+
+// reference multiplication.cu:10-100
+hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
+                               const BehzDev& b, int n_power, int batch, hipStream_t st);
+// reference multiplication.cu:128-272
+hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev& b, int n_power,
+                          int batch, hipStream_t st);
+
+} // namespace hegpu

@@ -1,0 +1,172 @@
+/*
+ * hegpu.h -- C ABI of the MI355X-native RNS-polynomial backend (libhegpu.so).
+ *
+ * The reference (Alisah-Ozcan/HEonGPU) has no FFI seam: its boundary is the
+ * C++ class API plus, one level down, the gpuntt:: free functions and the
+ * __global__ kernels of src/lib/kernel.  This header is that lower seam as a
+ * plain C ABI: raw device pointers, sizes and a hipStream_t (as void*); no
+ * torch or C++ types.  Every entry point cites the reference interface it
+ * replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - all data is uint64 residues in the reference's limb-major planar layout:
+ *    element [part][limb][coeff] of a ciphertext at
+ *    coeff + (limb << n_power) + part * (limbs << n_power);
+ *  - batched calls take `batch` ciphertexts `*_stride` ELEMENTS apart;
+ *  - every call is asynchronous on `stream`; return value 0 = success,
+ *    otherwise a hipError_t code (or HEGPU_E_* below); hegpu_last_error()
+ *    returns a message for the calling thread;
+ *  - device pointers must live on the device the context was uploaded to.
+ */
+#ifndef HEGPU_H
+#define HEGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hegpu_context hegpu_context; /* opaque */
+typedef void* hegpu_stream;                 /* hipStream_t */
+
+enum { HEGPU_BFV = 1, HEGPU_CKKS = 2 };
+enum { HEGPU_SEC_NONE = 0, HEGPU_SEC_128 = 128 };
+enum { HEGPU_TABLES_QP = 0, HEGPU_TABLES_Q_BSK = 1 };
+enum {
+    HEGPU_E_INVALID = 10001, /* std::invalid_argument in the reference */
+    HEGPU_E_LOGIC = 10002,   /* std::logic_error */
+    HEGPU_E_RUNTIME = 10003, /* std::runtime_error */
+    HEGPU_E_NODEVICE = 10004
+};
+
+const char* hegpu_last_error(void);
+const char* hegpu_version(void);
+
+/* ------------------------------------------------------------------ context
+ * HEContextImpl<S>: set_poly_modulus_degree + set_coeff_modulus_bit_sizes +
+ * [set_plain_modulus] + generate  (src/lib/host/ckks/context.cu:33-147,272-440;
+ * src/lib/host/bfv/context.cu:33-147,396-705).  Creation is host-only (works
+ * without a GPU); hegpu_context_upload() puts the tables on the current
+ * device.  Errors mirror the reference's exceptions. */
+int hegpu_context_create(int scheme, int poly_modulus_degree, const int* log_q_bits, int q_count,
+                         const int* log_p_bits, int p_count, uint64_t plain_modulus, int sec_level,
+                         hegpu_context** out);
+/* set_coeff_modulus_default_values(P_modulus_size) (bfv/context.cu:267-374) */
+int hegpu_context_create_default(int scheme, int poly_modulus_degree, int p_count, uint64_t plain_modulus,
+                                 int sec_level, hegpu_context** out);
+/* set_coeff_modulus_values(Q, P) (bfv/context.cu:149-265): explicit primes */
+int hegpu_context_create_from_primes(int scheme, int poly_modulus_degree, const uint64_t* primes, int q_count,
+                                     int p_count, uint64_t plain_modulus, hegpu_context** out);
+void hegpu_context_destroy(hegpu_context* ctx);
+int hegpu_context_upload(hegpu_context* ctx);
+/* integer properties: "n_power","Q_size","P_size","Q_prime_size","bsk_modulus" */
+long hegpu_context_int(const hegpu_context* ctx, const char* name);
+/* copy the named HOST table (reference member name without trailing '_',
+ * e.g. "modulus","ntt_table","last_q_modinv","base_change_matrix_Bsk")
+ * into out[cap]; returns the element count, <0 if unknown / too small */
+long hegpu_context_get(const hegpu_context* ctx, const char* name, uint64_t* out, long cap);
+/* device address of a named device table ("new_prime_locations", ...) */
+const void* hegpu_context_device_ptr(const hegpu_context* ctx, const char* name);
+/* keygeneration.cu:684-728 steps_to_galois_elt */
+int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order);
+
+/* ------------------------------------------------------------------ NTT seam
+ * gpuntt::GPU_NTT / GPU_NTT_Inplace / GPU_INTT / GPU_INTT_Inplace
+ *   (call sites src/lib/host/bfv/operator.cu:393,410; ckks/operator.cu:919,1011)
+ * gpuntt::GPU_NTT_Modulus_Ordered_Inplace  (ckks/operator.cu:956,1524)
+ * gpuntt::GPU_NTT_Poly_Ordered_Inplace     (ckks/operator.cu:996,1197)
+ * `batch` polynomials of N coefficients; polynomial i uses modulus
+ * mod_offset + (mod_order ? mod_order[i % mod_count] : i % mod_count) of the
+ * chosen table set and lives at slot (poly_order ? poly_order[i] : i).
+ * mod_order / poly_order are DEVICE int arrays or NULL.  in == out allowed. */
+int hegpu_ntt(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int inverse, int batch,
+              int mod_count, int mod_offset, const int* mod_order, const int* poly_order, hegpu_stream stream);
+
+/* ------------------------------------------------------------------ kernels
+ * 1:1 replacements of the reference __global__ kernels (grid dims become
+ * arguments).  `table_set` selects the modulus array (Q' chain or q|Bsk). */
+/* src/lib/kernel/addition.cu:10-47 ; op 0=addition 1=substraction 2=negation */
+int hegpu_addition(hegpu_context* ctx, const uint64_t* in1, const uint64_t* in2, uint64_t* out, int limbs,
+                   int parts, int batch, int op, hegpu_stream stream);
+/* src/lib/kernel/multiplication.cu:102-126 */
+int hegpu_cross_multiplication(hegpu_context* ctx, int table_set, const uint64_t* in1, uint64_t in1_stride,
+                               const uint64_t* in2, uint64_t in2_stride, uint64_t* out, uint64_t out_stride,
+                               int decomp_size, int batch, hegpu_stream stream);
+/* src/lib/kernel/switchkey.cu:11-59,1558-1619: out[d][i][n] = in[d][n] mod
+ * q_{i < split ? i : i+level} for d < digits, i < nmods */
+int hegpu_cipher_broadcast(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                           uint64_t out_stride, int digits, int nmods, int split, int level, int batch,
+                           hegpu_stream stream);
+/* src/lib/kernel/switchkey.cu:61-285 (p_row < 0: non-leveled variant) */
+int hegpu_keyswitch_multiply_accumulate(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
+                                        const uint64_t* key, uint64_t* out, uint64_t out_stride, int digits,
+                                        int nmods, int key_limbs, int p_row, int batch, hegpu_stream stream);
+/* src/lib/kernel/switchkey.cu:400-478 */
+int hegpu_divide_round_lastq(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                             uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int switchkey, int batch,
+                             hegpu_stream stream);
+/* src/lib/kernel/switchkey.cu:1621-1813 (scheme of ctx picks bfv/ckks form) */
+int hegpu_divide_round_lastq_permute(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
+                                     const uint64_t* in2, uint64_t in2_stride, uint64_t* out,
+                                     uint64_t out_stride, int galois_elt, int depth, int batch,
+                                     hegpu_stream stream);
+/* src/lib/kernel/multiplication.cu:10-100 / 128-272 (BFV BEHZ) */
+int hegpu_fast_convertion(hegpu_context* ctx, const uint64_t* in1, uint64_t in1_stride, const uint64_t* in2,
+                          uint64_t in2_stride, uint64_t* out, uint64_t out_stride, int batch,
+                          hegpu_stream stream);
+int hegpu_fast_floor(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                     uint64_t out_stride, int batch, hegpu_stream stream);
+
+/* ------------------------------------------------------------------ operators
+ * HEArithmeticOperator<S> sequences, batched over independent ciphertexts.
+ * `ws` is a caller-provided device workspace of at least
+ * hegpu_workspace_bytes(ctx, op, depth, batch) bytes (no allocation happens
+ * inside, so the calls are hipGraph-capturable). */
+enum {
+    HEGPU_OP_CKKS_RELIN = 1,
+    HEGPU_OP_CKKS_RESCALE = 2,
+    HEGPU_OP_CKKS_GALOIS = 3,
+    HEGPU_OP_BFV_MULTIPLY = 4,
+    HEGPU_OP_BFV_RELIN = 5,
+    HEGPU_OP_BFV_GALOIS = 6
+};
+size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
+
+/* HEOperator<CKKS>::multiply_ckks (src/lib/host/ckks/operator.cu:796-837):
+ * ct [2][l][N] x [2][l][N] -> out [3][l][N], l = Q - depth */
+int hegpu_ckks_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_stride, const uint64_t* ct2,
+                        uint64_t ct2_stride, uint64_t* out, uint64_t out_stride, int depth, int batch,
+                        hegpu_stream stream);
+/* relinearize_seal_method_inplace_ckks (ckks/operator.cu:899-1023):
+ * ct [3][l][N] -> first two parts, in place; relin_key [Q][2][Q'][N] */
+int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
+                                   const uint64_t* relin_key, int depth, int batch, void* ws, size_t ws_bytes,
+                                   hegpu_stream stream);
+/* rescale_inplace_ckks_leveled (ckks/operator.cu:1156-1244):
+ * ct [2][l][N] -> [2][l-1][N] in place (caller then uses depth+1) */
+int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride, int depth, int batch,
+                               void* ws, size_t ws_bytes, hegpu_stream stream);
+/* apply_galois_ckks_method_I (ckks/operator.cu:1422-1559); out != ct */
+int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
+                            uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int depth,
+                            int batch, void* ws, size_t ws_bytes, hegpu_stream stream);
+/* multiply_bfv (src/lib/host/bfv/operator.cu:336-430): coefficient domain,
+ * ct [2][Q][N] x [2][Q][N] -> out [3][Q][N] */
+int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_stride, const uint64_t* ct2,
+                       uint64_t ct2_stride, uint64_t* out, uint64_t out_stride, int batch, void* ws,
+                       size_t ws_bytes, hegpu_stream stream);
+/* relinearize_seal_method_inplace (bfv/operator.cu:505-583) */
+int hegpu_bfv_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
+                                  const uint64_t* relin_key, int batch, void* ws, size_t ws_bytes,
+                                  hegpu_stream stream);
+/* apply_galois_method_I (bfv/operator.cu:771-864); out != ct */
+int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
+                           uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int batch, void* ws,
+                           size_t ws_bytes, hegpu_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEGPU_H */

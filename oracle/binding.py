@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from heongpu_amd/.  See hegpu_oracle.h
+("parity unpinned" notice).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+u64 = ctypes.c_uint64
+P64 = ctypes.POINTER(u64)
+PI = ctypes.POINTER(ctypes.c_int)
+BFV, CKKS = 1, 2
+
+
+class OMod(ctypes.Structure):
+    _fields_ = [("value", u64), ("bit", u64), ("mu", u64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = ctypes.CDLL(LIB_PATH)
+    L.o_mod.restype = OMod
+    L.o_mod.argtypes = [u64]
+    for nm in ("o_add", "o_sub", "o_mult"):
+        getattr(L, nm).restype = u64
+        getattr(L, nm).argtypes = [u64, u64, ctypes.POINTER(OMod)]
+    L.o_reduce_forced.restype = u64
+    L.o_reduce_forced.argtypes = [u64, ctypes.POINTER(OMod)]
+    L.o_min_primitive_root.restype = u64
+    L.o_min_primitive_root.argtypes = [u64, u64]
+    L.o_is_prime.argtypes = [u64]
+    L.o_generate_primes.argtypes = [u64, PI, ctypes.c_int, P64]
+    L.o_generate_internal_primes.argtypes = [u64, ctypes.c_int, P64]
+    L.o_default_modulus_128.argtypes = [u64, P64]
+    L.o_steps_to_galois_elt.argtypes = [ctypes.c_int] * 3
+    L.o_fill_poly.argtypes = [ctypes.c_void_p, u64, ctypes.c_int, u64, u64]
+    L.o_ctx_create.restype = ctypes.c_void_p
+    L.o_ctx_create.argtypes = [ctypes.c_int, ctypes.c_int, P64, ctypes.c_int, ctypes.c_int, u64]
+    L.o_ctx_free.argtypes = [ctypes.c_void_p]
+    L.o_ctx_get.restype = ctypes.c_long
+    L.o_ctx_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long]
+    vp = ctypes.c_void_p
+    ci = ctypes.c_int
+    L.o_gpu_ntt.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_gpu_intt.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci]
+    L.o_gpu_ntt_modulus_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.o_gpu_ntt_poly_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.o_addition.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_substraction.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_negation.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.o_cross_multiplication.argtypes = [vp, vp, vp, vp, ci, ci]
+    L.o_ckks_multiply.argtypes = [vp, vp, vp, vp, ci]
+    L.o_ckks_relinearize.argtypes = [vp, vp, vp, ci]
+    L.o_ckks_rescale.argtypes = [vp, vp, ci]
+    L.o_ckks_apply_galois.argtypes = [vp, vp, vp, vp, ci, ci]
+    L.o_bfv_multiply.argtypes = [vp, vp, vp, vp]
+    L.o_bfv_relinearize.argtypes = [vp, vp, vp]
+    L.o_bfv_apply_galois.argtypes = [vp, vp, vp, vp, ci]
+    L.o_ckks_mul_relin_batch.argtypes = [vp, vp, vp, vp, vp, ci, ci]
+    L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
+    L.o_fast_floor.argtypes = [vp, vp, vp]
+    L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.o_keyswitch_mac.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_divide_round_lastq.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def splitmix64(x):
+    """numpy-vectorised splitmix64 (same as o_splitmix64)."""
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def fill_poly(seed, limb, n, q):
+    """splitmix64(seed + limb*2^32 + idx) mod q  (SURVEY.md 8d synthetic data)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) + np.uint64(seed) + (np.uint64(limb) << np.uint64(32))
+        return splitmix64(idx) % np.uint64(q)
+
+
+class OracleContext:
+    def __init__(self, scheme, n_power, primes, q_count, p_count, plain_modulus=0):
+        L = lib()
+        arr = (u64 * len(primes))(*[int(x) for x in primes])
+        self.h = L.o_ctx_create(scheme, n_power, arr, q_count, p_count, plain_modulus)
+        self.L = L
+        self.scheme, self.n_power, self.n = scheme, n_power, 1 << n_power
+        self.Q, self.P, self.Qp = q_count, p_count, q_count + p_count
+        self.primes = [int(x) for x in primes]
+        self._mods = None
+
+    def close(self):
+        if self.h:
+            self.L.o_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self, name, cap=None):
+        cap = cap or (self.n * (self.Qp + 70) + 4096)
+        out = np.zeros(cap, dtype=np.uint64)
+        cnt = self.L.o_ctx_get(self.h, name.encode(), _p(out), cap)
+        if cnt < 0:
+            raise KeyError(name)
+        return out[:cnt].copy()
+
+    def mods(self, values):
+        arr = (OMod * len(values))()
+        for i, v in enumerate(values):
+            arr[i] = self.L.o_mod(int(v))
+        return arr
+
+    @property
+    def qp_mods(self):
+        if self._mods is None:
+            self._mods = self.mods(self.primes)
+        return self._mods
+
+    # NTT family on the Q' chain tables (offsets as the reference passes them)
+    def ntt(self, data, batch, mod_count, mod_offset=0, inverse=False, out=None):
+        tab = self.table("intt_table" if inverse else "ntt_table")
+        ninv = self.table("n_inverse")
+        mods = self.qp_mods
+        out = data if out is None else out
+        moff = ctypes.byref(mods, mod_offset * ctypes.sizeof(OMod))
+        tp = tab.ctypes.data + mod_offset * self.n * 8
+        if inverse:
+            self.L.o_gpu_intt(_p(data), _p(out), tp, ctypes.cast(moff, ctypes.c_void_p),
+                              ninv.ctypes.data + mod_offset * 8, self.n_power, batch, mod_count)
+        else:
+            self.L.o_gpu_ntt(_p(data), _p(out), tp, ctypes.cast(moff, ctypes.c_void_p), self.n_power, batch,
+                             mod_count)
+        return out
+
+    def ckks_multiply(self, ct1, ct2, depth=0):
+        l = self.Q - depth
+        out = np.zeros(3 * l * self.n, dtype=np.uint64)
+        self.L.o_ckks_multiply(self.h, _p(ct1), _p(ct2), _p(out), depth)
+        return out
+
+    def ckks_relinearize(self, ct3, key, depth=0):
+        self.L.o_ckks_relinearize(self.h, _p(ct3), _p(key), depth)
+        return ct3
+
+    def ckks_rescale(self, ct, depth=0):
+        self.L.o_ckks_rescale(self.h, _p(ct), depth)
+        return ct
+
+    def ckks_apply_galois(self, ct, key, galois_elt, depth=0):
+        l = self.Q - depth
+        out = np.zeros(2 * l * self.n, dtype=np.uint64)
+        self.L.o_ckks_apply_galois(self.h, _p(ct), _p(out), _p(key), galois_elt, depth)
+        return out
+
+    def bfv_multiply(self, ct1, ct2):
+        out = np.zeros(3 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_multiply(self.h, _p(ct1), _p(ct2), _p(out))
+        return out
+
+    def bfv_relinearize(self, ct3, key):
+        self.L.o_bfv_relinearize(self.h, _p(ct3), _p(key))
+        return ct3
+
+    def bfv_apply_galois(self, ct, key, galois_elt):
+        out = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_apply_galois(self.h, _p(ct), _p(out), _p(key), galois_elt)
+        return out

@@ -1,0 +1,191 @@
+/*
+ * o_ops.c -- the reference's host orchestration restated (kernel sequences,
+ * temporary layouts, order tables).  TEST INFRASTRUCTURE ONLY
+ * (see hegpu_oracle.h).
+ */
+#include "hegpu_oracle.h"
+#include "o_kernels.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static u64* alloc64(size_t n) { return (u64*) malloc((n ? n : 1) * sizeof(u64)); }
+
+/* ckks/operator.cu:796-837 multiply_ckks */
+void o_ckks_multiply(const octx_t* c, const u64* ct1, const u64* ct2,
+                     u64* out3, int depth)
+{
+    int l = c->Q_size - depth;
+    o_cross_multiplication(ct1, ct2, out3, c->mod, c->n_power, l);
+}
+
+static int prime_loc_offset(const octx_t* c, int depth)
+{
+    /* ckks/operator.cu:949-955 */
+    int counter = c->Qp_size, location = 0;
+    for (int i = 0; i < depth; i++) { location += counter; counter--; }
+    return location;
+}
+
+/* ckks/operator.cu:899-1023 relinearize_seal_method_inplace_ckks */
+void o_ckks_relinearize(const octx_t* c, u64* ct3, const u64* relin_key,
+                        int depth)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int Q = c->Q_size, Qp = c->Qp_size;
+    int l = Q - depth, rns_cur = Qp - depth;
+    u64* c2 = ct3 + ((u64) l << (np + 1));
+    o_gpu_intt(c2, c2, c->intt_table, c->mod, c->n_inv, np, l, l); /* :919 */
+    u64* temp1 = alloc64(n * Q * Qp + 2 * n * Qp);                 /* :924 */
+    u64* temp2 = temp1 + n * Q * Qp;
+    o_cipher_broadcast_leveled(c2, temp1, c->mod, Qp, rns_cur, np, l);
+    o_gpu_ntt_modulus_ordered(temp1, c->ntt_table, c->mod, c->n_inv, 0, np,
+                              l * rns_cur, rns_cur,
+                              c->new_prime_locations +
+                                  prime_loc_offset(c, depth));       /* :956 */
+    o_keyswitch_mac_leveled(temp1, relin_key, temp2, c->mod, Qp, l, np);
+    o_gpu_ntt_poly_ordered(temp2, c->intt_table + (u64) Q * n, c->mod + Q,
+                           c->n_inv + Q, 1, np, 2, 1,
+                           c->new_input_locations + 2 * depth);      /* :996 */
+    o_divide_round_lastq_leveled_stage_one(temp2, temp1, c->mod, c->half,
+                                           c->half_mod, np, Q, l);
+    o_gpu_ntt(temp1, temp1, c->ntt_table, c->mod, np, 2 * l, l);   /* :1011 */
+    o_divide_round_lastq_leveled_stage_two(temp1, temp2, ct3, ct3, c->mod,
+                                           c->last_q_modinv, np, l, 0);
+    free(temp1);
+}
+
+/* ckks/operator.cu:1156-1244 rescale_inplace_ckks_leveled */
+void o_ckks_rescale(const octx_t* c, u64* ct, int depth)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int Q = c->Q_size, Qp = c->Qp_size, P = c->P_size;
+    int l = Q - depth;
+    int counter = Q - 1, location = 0;
+    for (int i = 0; i < depth; i++) { location += counter; counter--; }
+    u64* temp1 = alloc64(4 * n * Qp);
+    u64* temp2 = temp1 + 2 * n * Qp;
+    o_gpu_ntt_poly_ordered(ct, c->intt_table + (u64) (l - 1) * n,
+                           c->mod + (l - 1), c->n_inv + (l - 1), 1, np, 2, 1,
+                           c->new_input_locations + (depth + P) * 2);
+    o_divide_round_lastq_leveled_stage_one(
+        ct, temp1, c->mod, c->rescaled_half + depth,
+        c->rescaled_half_mod + location, np, l - 1, l - 1);
+    o_gpu_ntt(temp1, temp1, c->ntt_table, c->mod, np, 2 * (l - 1), l - 1);
+    o_move_cipher_leveled(ct, temp2, np, l - 1);
+    o_divide_round_lastq_rescale(temp1, temp2, ct, c->mod,
+                                 c->rescaled_last_q_modinv + location, np,
+                                 l - 1);
+    free(temp1);
+}
+
+/* ckks/operator.cu:1422-1559 apply_galois_ckks_method_I */
+void o_ckks_apply_galois(const octx_t* c, const u64* ct, u64* out,
+                         const u64* galois_key, int galois_elt, int depth)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int Q = c->Q_size, Qp = c->Qp_size;
+    int l = Q - depth, rns_cur = Qp - depth;
+    u64* temp0 = alloc64(4 * n * Q + n * Q * Qp + 2 * n * Qp);
+    u64* temp2 = temp0 + 4 * n * Q;
+    u64* temp3 = temp2 + n * Q * Qp;
+    const int* order = c->new_prime_locations + prime_loc_offset(c, depth);
+    o_gpu_intt(ct, temp0, c->intt_table, c->mod, c->n_inv, np, 2 * l, l);
+    o_ckks_duplicate(temp0, temp2, c->mod, np, Qp, rns_cur, l);
+    o_gpu_ntt_modulus_ordered(temp2, c->ntt_table, c->mod, c->n_inv, 0, np,
+                              l * rns_cur, rns_cur, order);
+    o_keyswitch_mac_leveled(temp2, galois_key, temp3, c->mod, Qp, l, np);
+    o_gpu_ntt_modulus_ordered(temp3, c->intt_table, c->mod, c->n_inv, 1, np,
+                              2 * rns_cur, rns_cur, order);
+    o_divide_round_lastq_permute(temp3, temp0, out, c->mod, c->half,
+                                 c->half_mod, c->last_q_modinv, galois_elt, np,
+                                 rns_cur, l, Qp, Q, c->P_size);
+    o_gpu_ntt(out, out, c->ntt_table, c->mod, np, 2 * l, l);
+    free(temp0);
+}
+
+/* bfv/operator.cu:336-430 multiply_bfv */
+void o_bfv_multiply(const octx_t* c, const u64* ct1, const u64* ct2,
+                    u64* out3)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int L = c->Q_size + c->bsk_size;
+    u64* temp1 = alloc64(7 * n * L);
+    u64* temp2 = temp1 + 4 * n * L;
+    o_fast_convertion(c, ct1, ct2, temp1);
+    o_gpu_ntt(temp1, temp1, c->merge_ntt_table, c->merge_mod, np, 4 * L, L);
+    o_cross_multiplication(temp1, temp1 + 2 * (u64) L * n, temp2,
+                           c->merge_mod, np, L);
+    o_gpu_intt(temp2, temp2, c->merge_intt_table, c->merge_mod,
+               c->merge_n_inv, np, 3 * L, L);
+    o_fast_floor(c, temp2, out3);
+    free(temp1);
+}
+
+/* bfv/operator.cu:505-583 relinearize_seal_method_inplace */
+void o_bfv_relinearize(const octx_t* c, u64* ct3, const u64* relin_key)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int Q = c->Q_size, Qp = c->Qp_size;
+    u64* temp1 = alloc64(n * Q * Qp + 2 * n * Qp);
+    u64* temp2 = temp1 + n * Q * Qp;
+    o_cipher_broadcast(ct3 + ((u64) Q << (np + 1)), temp1, c->mod, np, Q, Qp);
+    o_gpu_ntt(temp1, temp1, c->ntt_table, c->mod, np, Q * Qp, Qp);
+    o_keyswitch_mac(temp1, relin_key, temp2, c->mod, np, Qp, Q);
+    o_gpu_intt(temp2, temp2, c->intt_table, c->mod, c->n_inv, np, 2 * Qp, Qp);
+    o_divide_round_lastq(temp2, ct3, ct3, c->mod, c->half, c->half_mod,
+                         c->last_q_modinv, np, Q, 0);
+    free(temp1);
+}
+
+/* bfv/operator.cu:771-864 apply_galois_method_I */
+void o_bfv_apply_galois(const octx_t* c, const u64* ct, u64* out,
+                        const u64* galois_key, int galois_elt)
+{
+    int np = c->n_power;
+    u64 n = c->n;
+    int Q = c->Q_size, Qp = c->Qp_size;
+    u64* temp0 = alloc64(2 * n * Q + n * Q * Qp + 2 * n * Qp);
+    u64* temp1 = temp0 + 2 * n * Q;
+    u64* temp2 = temp1 + n * Q * Qp;
+    o_bfv_duplicate(ct, temp0, temp1, c->mod, np, Q, Qp);
+    o_gpu_ntt(temp1, temp1, c->ntt_table, c->mod, np, Q * Qp, Qp);
+    o_keyswitch_mac(temp1, galois_key, temp2, c->mod, np, Qp, Q);
+    o_gpu_intt(temp2, temp2, c->intt_table, c->mod, c->n_inv, np, 2 * Qp, Qp);
+    o_divide_round_lastq_permute(temp2, temp0, out, c->mod, c->half,
+                                 c->half_mod, c->last_q_modinv, galois_elt, np,
+                                 Qp, Q, Qp, Q, c->P_size);
+    free(temp0);
+}
+
+int o_omp_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* CPU baseline: `batch` independent multiply+relinearize, OpenMP over the
+ * ciphertext pairs (inner NTT loops then run serially per thread). */
+void o_ckks_mul_relin_batch(const octx_t* c, const u64* ct1, const u64* ct2,
+                            u64* out3, const u64* relin_key, int depth,
+                            int batch)
+{
+    int l = c->Q_size - depth;
+    u64 ctsz = 2 * (u64) l * c->n, osz = 3 * (u64) l * c->n;
+#pragma omp parallel for schedule(dynamic)
+    for (int b = 0; b < batch; b++) {
+        o_ckks_multiply(c, ct1 + b * ctsz, ct2 + b * ctsz, out3 + b * osz,
+                        depth);
+        o_ckks_relinearize(c, out3 + b * osz, relin_key, depth);
+    }
+}
