@@ -152,15 +152,17 @@ class OracleContext:
         ninv = self.table("n_inverse")
         mods = self.qp_mods
         out = data if out is None else out
-        moff = ctypes.byref(mods, mod_offset * ctypes.sizeof(OMod))
+        moff = ctypes.addressof(mods) + mod_offset * ctypes.sizeof(OMod)
         tp = tab.ctypes.data + mod_offset * self.n * 8
         if inverse:
-            self.L.o_gpu_intt(_p(data), _p(out), tp, ctypes.cast(moff, ctypes.c_void_p),
-                              ninv.ctypes.data + mod_offset * 8, self.n_power, batch, mod_count)
+            self.L.o_gpu_intt(_p(data), _p(out), tp, moff, ninv.ctypes.data + mod_offset * 8, self.n_power, batch,
+                              mod_count)
         else:
-            self.L.o_gpu_ntt(_p(data), _p(out), tp, ctypes.cast(moff, ctypes.c_void_p), self.n_power, batch,
-                             mod_count)
+            self.L.o_gpu_ntt(_p(data), _p(out), tp, moff, self.n_power, batch, mod_count)
         return out
+
+    def mods_addr(self, offset=0):
+        return ctypes.addressof(self.qp_mods) + offset * ctypes.sizeof(OMod)
 
     def ckks_multiply(self, ct1, ct2, depth=0):
         l = self.Q - depth

@@ -1,0 +1,248 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Shapes follow BASELINE.json configs C1 (BFV N=2^12 default chain) and C2
+(CKKS N=2^14, Q=8, P=1); the NTT is covered for every supported N.
+"""
+import numpy as np
+import pytest
+
+from helpers import synth_ct, synth_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _ckks_pair(hg, oracle, n, log_q, log_p):
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, log_p)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, c.n_power, primes, len(log_q), len(log_p))
+    c.upload()
+    return c, o, primes
+
+
+def _bfv_pair(hg, oracle, n, t):
+    c = hg.Context.from_default(hg.BFV, n, 1, t)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, c.Q_size, c.P_size, t)
+    c.upload()
+    return c, o, primes
+
+
+@pytest.mark.parametrize("n_power", [12, 13, 14, 15, 16])
+def test_ntt_forward_inverse(hg, oracle, torch, n_power):
+    n = 1 << n_power
+    # 60/30/45-bit primes exercise the extreme modulus sizes
+    c, o, primes = _ckks_pair(hg, oracle, n, [60, 30, 45], [60])
+    Qp = 4
+    batch = 2 * Qp + 4  # wraps around the modulus list
+    x = np.concatenate([oracle.fill_poly(7 + i, i % Qp, n, primes[i % Qp]) for i in range(batch)])
+    want = o.ntt(x.copy(), batch, Qp)
+    d = hg.to_device(x)
+    out = torch.empty_like(d)
+    c.ntt(d, out, False, batch, Qp)            # GPU_NTT (out of place)
+    torch.cuda.synchronize()
+    got = hg.to_host(out)
+    assert np.array_equal(got, want)
+    c.ntt(out, out, True, batch, Qp)           # GPU_INTT_Inplace
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), x)
+    # inverse vs oracle on arbitrary canonical input
+    want_i = o.ntt(x.copy(), batch, Qp, inverse=True)
+    c.ntt(d, d, True, batch, Qp)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want_i)
+
+
+def test_ntt_bsk_61bit_and_offsets(hg, oracle, torch):
+    """61-bit Bsk primes (merged q|Bsk tables) and caller-offset tables."""
+    c, o, primes = _bfv_pair(hg, oracle, 4096, 1032193)
+    n = 4096
+    mm = [int(v) for v in c.table("q_Bsk_merge_modulus")]
+    L = len(mm)
+    x = np.concatenate([oracle.fill_poly(3 + i, i, n, mm[i % L]) for i in range(2 * L)])
+    tab = o.table("q_Bsk_merge_ntt_tables")
+    mods = o.mods(mm)
+    want = x.copy()
+    o.L.o_gpu_ntt(want.ctypes.data, want.ctypes.data, tab.ctypes.data, mods, 12, 2 * L, L)
+    d = hg.to_device(x)
+    c.ntt(d, d, False, 2 * L, L, table_set=hg.TABLES_Q_BSK)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+    c.ntt(d, d, True, 2 * L, L, table_set=hg.TABLES_Q_BSK)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), x)
+    # mod_offset: transform 2 polys with the P prime only (index Q)
+    y = np.concatenate([oracle.fill_poly(50 + i, 2, n, primes[2]) for i in range(2)])
+    want = o.ntt(y.copy(), 2, 1, mod_offset=2)
+    d = hg.to_device(y)
+    c.ntt(d, d, False, 2, 1, mod_offset=2)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+
+
+def test_ntt_ordered_variants(hg, oracle, torch):
+    c, o, primes = _ckks_pair(hg, oracle, 8192, [40, 35, 35, 35], [40])
+    n, Q, Qp = 8192, 4, 5
+    depth = 1
+    rc = Qp - depth
+    order_host = [int(v) for v in o.table("new_prime_locations")]
+    off = Qp  # slice for depth 1 starts at sum_{j<1}(Q'-j)
+    order = order_host[off:off + rc]
+    batch = 3 * rc
+    x = np.concatenate([oracle.fill_poly(11 + i, 0, n, primes[order[i % rc]]) for i in range(batch)])
+    tab = o.table("ntt_table")
+    ninv = o.table("n_inverse")
+    want = x.copy()
+    ord_arr = np.array(order, dtype=np.int32)
+    o.L.o_gpu_ntt_modulus_ordered(want.ctypes.data, tab.ctypes.data, o.qp_mods, ninv.ctypes.data, 0, 13, batch, rc,
+                                  ord_arr.ctypes.data)
+    d = hg.to_device(x)
+    dev_order = c.device_ptr("new_prime_locations") + 4 * off
+    c.ntt(d, d, False, batch, rc, mod_order=dev_order)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+    # inverse, modulus ordered (apply_galois path, ckks/operator.cu:1524)
+    itab = o.table("intt_table")
+    o.L.o_gpu_ntt_modulus_ordered(want.ctypes.data, itab.ctypes.data, o.qp_mods, ninv.ctypes.data, 1, 13, batch, rc,
+                                  ord_arr.ctypes.data)
+    c.ntt(d, d, True, batch, rc, mod_order=dev_order)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+    assert np.array_equal(want, x)
+    # poly ordered: INTT only slots {rc-1, 2rc-1} with the P prime (relin path)
+    slots = np.array([rc - 1, 2 * rc - 1], dtype=np.int32)
+    z = np.concatenate([oracle.fill_poly(90 + i, 0, n, primes[Qp - 1]) for i in range(2 * rc)])
+    want = z.copy()
+    o.L.o_gpu_ntt_poly_ordered(want.ctypes.data, itab.ctypes.data + Q * n * 8, o.mods_addr(Q),
+                               ninv.ctypes.data + Q * 8, 1, 13, 2, 1, slots.ctypes.data)
+    d = hg.to_device(z)
+    dev_slots = c.device_ptr("new_input_locations") + 4 * 2 * depth
+    c.ntt(d, d, True, 2, 1, mod_offset=Q, poly_order=dev_slots)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+
+
+def test_add_sub_neg(hg, oracle, torch):
+    c, o, primes = _bfv_pair(hg, oracle, 4096, 1032193)
+    n, Q = 4096, 2
+    batch = 3
+    a = np.concatenate([synth_ct(primes, range(Q), 2, n, 1 + b) for b in range(batch)])
+    b_ = np.concatenate([synth_ct(primes, range(Q), 2, n, 40 + b) for b in range(batch)])
+    a[5] = 0  # negation of zero
+    da, db = hg.to_device(a), hg.to_device(b_)
+    out = torch.empty_like(da)
+    for op, fn in ((0, o.L.o_addition), (1, o.L.o_substraction)):
+        want = np.zeros_like(a)
+        per = 2 * Q * n
+        for i in range(batch):
+            fn(a[i * per:].ctypes.data, b_[i * per:].ctypes.data, want[i * per:].ctypes.data, o.qp_mods, 12, Q, 2)
+        c.addition(da, db, out, Q, 2, batch, op)
+        torch.cuda.synchronize()
+        assert np.array_equal(hg.to_host(out), want)
+    want = np.zeros_like(a)
+    per = 2 * Q * n
+    for i in range(batch):
+        o.L.o_negation(a[i * per:].ctypes.data, want[i * per:].ctypes.data, o.qp_mods, 12, Q, 2)
+    c.addition(da, None, out, Q, 2, batch, 2)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), want)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_ckks_mul_relin_rescale(hg, oracle, torch, depth):
+    """Config C2: CKKS N=2^14, Q{50,40x7} P{50}: multiply -> relinearize -> rescale."""
+    n = 16384
+    c, o, primes = _ckks_pair(hg, oracle, n, [50] + [40] * 7, [50])
+    Q, Qp = 8, 9
+    l = Q - depth
+    batch = 2
+    key = synth_key(primes, Q, Qp, n, 3)
+    dkey = hg.to_device(key)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * l * n, d2, 2 * l * n, out, 3 * l * n, depth, batch)
+    torch.cuda.synchronize()
+    want_mul = [o.ckks_multiply(ct1[b], ct2[b], depth) for b in range(batch)]
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], want_mul[b]), "multiply"
+    ws = c.workspace(hg.OP_CKKS_RELIN, depth, batch)
+    c.ckks_relinearize_inplace(out, 3 * l * n, dkey, depth, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    want_rel = [o.ckks_relinearize(want_mul[b].copy(), key, depth) for b in range(batch)]
+    for b in range(batch):
+        assert np.array_equal(got[b][:2 * l * n], want_rel[b][:2 * l * n]), "relinearize"
+    if l >= 2:
+        ws2 = c.workspace(hg.OP_CKKS_RESCALE, depth, batch)
+        c.ckks_rescale_inplace(out, 3 * l * n, depth, batch, ws2)
+        torch.cuda.synchronize()
+        got = hg.to_host(out).reshape(batch, -1)
+        for b in range(batch):
+            w = o.ckks_rescale(want_rel[b][:2 * l * n].copy(), depth)
+            assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
+
+
+@pytest.mark.parametrize("depth", [0, 2])
+def test_ckks_apply_galois(hg, oracle, torch, depth):
+    n = 8192
+    c, o, primes = _ckks_pair(hg, oracle, n, [40, 35, 35, 35], [40])
+    Q, Qp = 4, 5
+    l = Q - depth
+    batch = 2
+    gk = synth_key(primes, Q, Qp, n, 9)
+    for steps in (1, -3):
+        g = hg.steps_to_galois_elt(steps, n, 5)
+        assert g == oracle.lib().o_steps_to_galois_elt(steps, n, 5)
+        cts = [synth_ct(primes, range(l), 2, n, 5 + b) for b in range(batch)]
+        d = hg.to_device(np.concatenate(cts))
+        out = torch.empty_like(d)
+        ws = c.workspace(hg.OP_CKKS_GALOIS, depth, batch)
+        c.ckks_apply_galois(d, 2 * l * n, out, 2 * l * n, hg.to_device(gk), g, depth, batch, ws)
+        torch.cuda.synchronize()
+        got = hg.to_host(out).reshape(batch, -1)
+        for b in range(batch):
+            assert np.array_equal(got[b], o.ckks_apply_galois(cts[b], gk, g, depth))
+
+
+def test_bfv_multiply_relin_rotate(hg, oracle, torch):
+    """Config C1 shapes on the GPU: BFV N=2^12 default chain, t=1032193."""
+    n, t = 4096, 1032193
+    c, o, primes = _bfv_pair(hg, oracle, n, t)
+    Q, Qp = 2, 3
+    batch = 3
+    key = synth_key(primes, Q, Qp, n, 3)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    ws = c.workspace(hg.OP_BFV_MULTIPLY, 0, batch)
+    c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    want_mul = [o.bfv_multiply(ct1[b], ct2[b]) for b in range(batch)]
+    for b in range(batch):
+        assert np.array_equal(got[b], want_mul[b]), "bfv multiply"
+    ws = c.workspace(hg.OP_BFV_RELIN, 0, batch)
+    c.bfv_relinearize_inplace(out, 3 * Q * n, hg.to_device(key), batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        w = o.bfv_relinearize(want_mul[b].copy(), key)
+        assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), "bfv relinearize"
+    g = hg.steps_to_galois_elt(1, n, 3)
+    rot = torch.empty(batch * 2 * Q * n, dtype=torch.int64, device="cuda")
+    ws = c.workspace(hg.OP_BFV_GALOIS, 0, batch)
+    c.bfv_apply_galois(d1, 2 * Q * n, rot, 2 * Q * n, hg.to_device(key), g, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.bfv_apply_galois(ct1[b], key, g)), "bfv rotate"
