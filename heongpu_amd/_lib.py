@@ -68,6 +68,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C heongpu_amd/csrc`.  There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must
+    # be the copy already in the process when libhegpu.so is loaded, otherwise
+    # two HIP runtimes coexist and neither sees the other's device state.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

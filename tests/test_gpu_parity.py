@@ -18,8 +18,8 @@ def torch():
     return torch
 
 
-def _ckks_pair(hg, oracle, n, log_q, log_p):
-    c = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, log_p)
+def _ckks_pair(hg, oracle, n, log_q, log_p, sec=None):
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, log_p, sec=hg.SEC_128 if sec is None else sec)
     primes = [int(x) for x in c.table("modulus")]
     o = oracle.OracleContext(oracle.CKKS, c.n_power, primes, len(log_q), len(log_p))
     c.upload()
@@ -38,7 +38,7 @@ def _bfv_pair(hg, oracle, n, t):
 def test_ntt_forward_inverse(hg, oracle, torch, n_power):
     n = 1 << n_power
     # 60/30/45-bit primes exercise the extreme modulus sizes
-    c, o, primes = _ckks_pair(hg, oracle, n, [60, 30, 45], [60])
+    c, o, primes = _ckks_pair(hg, oracle, n, [60, 30, 45], [60], sec=hg.SEC_NONE)
     Qp = 4
     batch = 2 * Qp + 4  # wraps around the modulus list
     x = np.concatenate([oracle.fill_poly(7 + i, i % Qp, n, primes[i % Qp]) for i in range(batch)])
