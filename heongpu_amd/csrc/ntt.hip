@@ -131,7 +131,8 @@ __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
     if (a.mod_order) k = a.mod_order[k];
     s.mod = a.mod_offset + k;
     u64 slot = a.poly_order ? (u64) a.poly_order[j] : (u64) j;
-    s.in_off = (u64) item * a.in_item_stride + (slot << a.n_power);
+    u64 in_slot = a.decomp_mods ? (u64) (j / a.decomp_mods) : slot;
+    s.in_off = (u64) item * a.in_item_stride + (in_slot << a.n_power);
     s.out_off = (u64) item * a.out_item_stride + (slot << a.n_power);
     return s;
 }
@@ -148,7 +149,7 @@ __device__ __forceinline__ int row_phys(int e) { return e + ((e >> 4) << 1); }
 
 // ------------------------------------------------------------------ forward
 // Column pass: stages 0..S1-1 (row stride 256).  grid = (256/CT, batch).
-template <int S1>
+template <int S1, bool DECOMP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
 {
     constexpr int R = 1 << S1;
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
             u64 y[RA];
 #pragma unroll
             for (int k = 0; k < RA; k++) y[k] = src[(u64) (rb + 16 * k) * 256 + c];
+            if (DECOMP) {
+#pragma unroll
+                for (int k = 0; k < RA; k++) y[k] = reduce64(y[k], md);
+            }
             ct_radix<NSA>(y, tw, 1u, q, q2);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = y[k];
@@ -187,6 +192,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = src[(u64) k * 256 + col];
+        if (DECOMP) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
+        }
     }
     ct_radix<4>(x, tw, (u32) (RA + r1), q, q2);
 #pragma unroll
@@ -335,10 +344,14 @@ template <int S1>
 static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
-    hipLaunchKernelGGL(ntt_fwd_col<S1>, dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
+    if (a.decomp_mods)
+        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((ntt_fwd_col<S1, false>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
     NttArgs b = a;
     b.in = a.out;
     b.in_item_stride = a.out_item_stride;
+    b.decomp_mods = 0;
     hipLaunchKernelGGL(ntt_fwd_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, b);
 }
 
@@ -357,6 +370,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
     if (a.n_power < 12 || a.n_power > 16) return hipErrorInvalidValue;
+    if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
     if (batch > 65535) {
         // gridDim.y limit: split (poly_order / mod_order semantics need the
         // absolute polynomial index, so only plain batches are split)

@@ -28,6 +28,12 @@ struct NttArgs {
     int polys_per_item;
     u64 in_item_stride;
     u64 out_item_stride;
+    // Fused RNS digit decomposition (forward only): when decomp_mods > 0,
+    // polynomial j of an item is digit d = j / decomp_mods re-reduced into its
+    // modulus; it is READ from input slot d (not j) and every coefficient goes
+    // through reduce64 first.  Replaces cipher_broadcast*_kernel + NTT
+    // (reference switchkey.cu:11-59 followed by ckks/operator.cu:956).
+    int decomp_mods;
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

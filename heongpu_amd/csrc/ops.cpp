@@ -63,12 +63,11 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.in = c2; a.out = c2; a.mod_count = l; a.polys_per_item = l;
     a.in_item_stride = a.out_item_stride = cs;
     TRY(ntt_launch(a, l * batch, true, st));
-    // digit decomposition c2 -> [l][rc][N]                           (:932)
-    TRY(rns_decompose(c2, cs, temp1, per, mods, np, l, rc, l, Qp - rc, batch, st));
-    // forward NTT, modulus order skips dropped primes               (:956)
+    // digit decomposition c2 -> [l][rc][N] fused into the forward NTT's
+    // first load; modulus order skips dropped primes                (:932-960)
     a = c.ntt_args(0);
-    a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc;
-    a.in_item_stride = a.out_item_stride = per;
+    a.in = c2; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
+    a.in_item_stride = cs; a.out_item_stride = per;
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     TRY(ntt_launch(a, l * rc * batch, false, st));
     // inner product with the key                                     (:967)
@@ -140,12 +139,12 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, 2 * l * batch, true, st));                                           // :1461
-    TRY(rns_decompose(temp0 + (u64) l * n, per, temp2, per, mods, np, l, rc, l, Qp - rc, batch, st)); // :1467
-    a = c.ntt_args(0);
-    a.in = temp2; a.out = temp2; a.mod_count = rc; a.polys_per_item = l * rc;
+    a = c.ntt_args(0); // ckks_duplicate_kernel fused into the NTT load          :1467-1494
+    a.in = temp0 + (u64) l * n; a.out = temp2; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
     a.in_item_stride = a.out_item_stride = per;
     a.mod_order = order;
-    TRY(ntt_launch(a, l * rc * batch, false, st));                                         // :1490
+    TRY(ntt_launch(a, l * rc * batch, false, st));
+    a.decomp_mods = 0;
     TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, batch, st)); // :1501
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1524
@@ -190,11 +189,12 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
     u64* temp1 = ws;
     u64* temp2 = ws + (u64) Q * Qp * n;
     const Mod* mods = c.plan_qp.mods;
-    TRY(rns_decompose(ct + ((u64) Q << (np + 1)), cs, temp1, per, mods, np, Q, Qp, Qp, 0, batch, st)); // :515
-    NttArgs a = c.ntt_args(0);
-    a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
-    a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, Q * Qp * batch, false, st));                                         // :531
+    NttArgs a = c.ntt_args(0); // cipher_broadcast_kernel fused into the NTT load    :515-534
+    a.in = ct + ((u64) Q << (np + 1)); a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
+    a.decomp_mods = Qp;
+    a.in_item_stride = cs; a.out_item_stride = per;
+    TRY(ntt_launch(a, Q * Qp * batch, false, st));
+    a.decomp_mods = 0; a.in_item_stride = per;
     TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :540
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
@@ -214,11 +214,12 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
     u64* temp1 = ws;
     u64* temp2 = ws + (u64) Q * Qp * n;
     const Mod* mods = c.plan_qp.mods;
-    TRY(rns_decompose(ct + (u64) Q * n, cs, temp1, per, mods, np, Q, Qp, Qp, 0, batch, st)); // :789
-    NttArgs a = c.ntt_args(0);
-    a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
-    a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, Q * Qp * batch, false, st));                                         // :805
+    NttArgs a = c.ntt_args(0); // bfv_duplicate_kernel fused into the NTT load       :789-808
+    a.in = ct + (u64) Q * n; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
+    a.decomp_mods = Qp;
+    a.in_item_stride = cs; a.out_item_stride = per;
+    TRY(ntt_launch(a, Q * Qp * batch, false, st));
+    a.decomp_mods = 0; a.in_item_stride = per;
     TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :814
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846

@@ -139,17 +139,22 @@ __device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
     hi += h + (lo < l);
 }
 
+// Workgroups are ordered batch-fastest (blockIdx.x = ciphertext): the `batch`
+// workgroups that read the same key tile (same limb, same 512 coefficients)
+// are dispatched back to back, so the evaluation key streams from HBM once
+// per tile instead of once per ciphertext (it is reused out of L2 / MALL).
 __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __restrict__ in, u64 in_stride,
                                                                const u64* __restrict__ key,
                                                                u64* __restrict__ out, u64 out_stride,
                                                                const Mod* __restrict__ mods, int n_power,
                                                                int digits, int nmods, int key_limbs, int p_row)
 {
-    const int y = blockIdx.y;
+    const int item = blockIdx.x;
+    const int y = blockIdx.z;
     const int kidx = (y == p_row) ? (key_limbs - 1) : y;
     const Mod m = mods[kidx];
-    const u64 c = coeff0();
-    const u64* pin = in + in_stride * blockIdx.z + ((u64) y << n_power) + c;
+    const u64 c = ((u64) blockIdx.y * RNS_THREADS + threadIdx.x) * 2;
+    const u64* pin = in + in_stride * item + ((u64) y << n_power) + c;
     const u64* pk = key + ((u64) kidx << n_power) + c;
     const u64 key_off1 = (u64) key_limbs << n_power;
     const u64 key_off2 = (u64) key_limbs << (n_power + 1);
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __rest
     r0.y = reduce128(h01, l01, m);
     r1.x = reduce128(h10, l10, m);
     r1.y = reduce128(h11, l11, m);
-    u64* po = out + out_stride * blockIdx.z + ((u64) y << n_power) + c;
+    u64* po = out + out_stride * item + ((u64) y << n_power) + c;
     st2(po, r0);
     st2(po + dig_off, r1);
 }
@@ -180,8 +185,9 @@ hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* 
                              int batch, hipStream_t st)
 {
     if (digits > 64) return hipErrorInvalidValue; // 128-bit accumulator bound
-    hipLaunchKernelGGL(k_keyswitch_mac, grid3(n_power, nmods, batch), dim3(RNS_THREADS), 0, st, in, in_stride, key,
-                       out, out_stride, mods, n_power, digits, nmods, key_limbs, p_row);
+    dim3 g(batch, (1u << n_power) / RNS_PER_BLOCK, nmods);
+    hipLaunchKernelGGL(k_keyswitch_mac, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride, mods,
+                       n_power, digits, nmods, key_limbs, p_row);
     return hipGetLastError();
 }
 
