@@ -200,6 +200,8 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     const int cnt = (int) mods.size();
     std::vector<Mod> hm(cnt);
     std::vector<ulonglong2> htw((size_t) cnt * n), hitw((size_t) cnt * n), hn(cnt), hw(cnt);
+    const u64 rows = n / 256, perB = rows * 15 * 16; // re-laid entries per modulus
+    std::vector<ulonglong2> htwB((size_t) cnt * perB), hitwB((size_t) cnt * perB);
     for (int k = 0; k < cnt; k++) {
         const u64 q = mods[k];
         hm[k] = make_mod(q);
@@ -208,6 +210,15 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
             htw[k * n + j] = make_ulonglong2(w, shoup_companion(w, q));
             hitw[k * n + j] = make_ulonglong2(iw, shoup_companion(iw, q));
         }
+        for (u64 c = 0; c < rows; c++)
+            for (int st = 0; st < 4; st++)
+                for (int b = 0; b < (1 << st); b++)
+                    for (int j = 0; j < 16; j++) {
+                        const u64 src = ((((rows + c) * 16 + j) << st) + b);
+                        const u64 dst = k * perB + (c * 15 + ((1 << st) - 1 + b)) * 16 + j;
+                        htwB[dst] = htw[k * n + src];
+                        hitwB[dst] = hitw[k * n + src];
+                    }
         hn[k] = make_ulonglong2(ninv[k], shoup_companion(ninv[k], q));
         const u64 w1n = host::mul_mod(inv[k * n + 1], ninv[k], q);
         hw[k] = make_ulonglong2(w1n, shoup_companion(w1n, q));
@@ -217,6 +228,8 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     if ((e = to_device(hm, &p.mods)) != hipSuccess) return e;
     if ((e = to_device(htw, &p.tw)) != hipSuccess) return e;
     if ((e = to_device(hitw, &p.itw)) != hipSuccess) return e;
+    if ((e = to_device(htwB, &p.twB)) != hipSuccess) return e;
+    if ((e = to_device(hitwB, &p.itwB)) != hipSuccess) return e;
     if ((e = to_device(hn, &p.ninv)) != hipSuccess) return e;
     return to_device(hw, &p.w1ninv);
 }
@@ -226,6 +239,8 @@ static void free_plan(NttPlan& p)
     if (p.mods) (void) hipFree(p.mods);
     if (p.tw) (void) hipFree(p.tw);
     if (p.itw) (void) hipFree(p.itw);
+    if (p.twB) (void) hipFree(p.twB);
+    if (p.itwB) (void) hipFree(p.itwB);
     if (p.ninv) (void) hipFree(p.ninv);
     if (p.w1ninv) (void) hipFree(p.w1ninv);
     p = NttPlan();
@@ -331,6 +346,8 @@ NttArgs Context::ntt_args(int table_set) const
     a.mods = p.mods;
     a.tw = p.tw;
     a.itw = p.itw;
+    a.twB = p.twB;
+    a.itwB = p.itwB;
     a.ninv = p.ninv;
     a.w1ninv = p.w1ninv;
     a.n_power = n_power;

@@ -23,6 +23,8 @@ struct NttPlan {
     Mod* mods = nullptr;
     ulonglong2* tw = nullptr;
     ulonglong2* itw = nullptr;
+    ulonglong2* twB = nullptr;  // row-pass last-four-stages layout (see ntt.hpp)
+    ulonglong2* itwB = nullptr;
     ulonglong2* ninv = nullptr;
     ulonglong2* w1ninv = nullptr;
     int count = 0;

@@ -17,10 +17,11 @@
 //  * 256 threads x 16 coefficients per workgroup: radix-16 butterflies run
 //    entirely in VGPRs (4 stages per LDS exchange), LDS (34-36 KiB per
 //    workgroup, padded against bank conflicts) is only the transpose medium.
-//  * Shoup/Harvey lazy butterflies: one mulhi64 + two mullo64 per butterfly
-//    (10 v_mad_u64_u32/v_mul_lo_u32), values kept in [0,4q) (forward) /
-//    [0,2q) (inverse) with a single exact correction at the end, so results
-//    are canonical residues -- bit-identical to any exact NTT.
+//  * Shoup/Harvey lazy butterflies with a 3-multiply quotient estimate and a
+//    multiply-accumulate chain against -q: 9 32-bit multiplies per butterfly,
+//    values kept in [0,8q) (forward) / [0,4q) (inverse) with a single exact
+//    correction at the end, so results are canonical residues --
+//    bit-identical to any exact NTT (q < 2^61 keeps 8q inside 64 bits).
 //  * wave-uniform twiddles (column pass, first round) are fetched through
 //    the scalar cache; the rest are 16-byte (w, w') pairs read as dwordx4.
 #include "ntt.hpp"
@@ -29,41 +30,142 @@ namespace hegpu {
 
 #define NTT_THREADS 256
 
-__device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
-
-// Harvey CT butterfly, x,y in [0,4q) -> [0,4q)
-__device__ __forceinline__ void ct_bfly(u64& x, u64& y, ulonglong2 w, u64 q, u64 q2)
+// Ablation hooks for tools/exp/ntt_exp.hip (0 in the product build):
+// 1 = memory traffic only (butterflies skipped), 2 = arithmetic only,
+// 3 = data traffic only (no butterflies, no twiddle loads).
+#ifndef NTT_EXP_MODE
+#define NTT_EXP_MODE 0
+#endif
+__device__ __forceinline__ u64 gld(const u64* p)
 {
-    u64 u = csub(x, q2);
-    u64 t = mul_shoup_lazy(y, w.x, w.y, q);
-    x = u + t;
-    y = u - t + q2;
+#if NTT_EXP_MODE == 2
+    return (u64) (size_t) p * 0x9E3779B97F4A7C15ull >> 4;
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void gst(u64* p, u64 v)
+{
+#if NTT_EXP_MODE == 2
+    if (v == 0x123456789abcdefull) *p = v;
+#else
+    *p = v;
+#endif
 }
 
-// GS butterfly, x,y in [0,2q) -> [0,2q)
-__device__ __forceinline__ void gs_bfly(u64& x, u64& y, ulonglong2 w, u64 q, u64 q2)
+__device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
+
+// Per-modulus constants of the lazy butterflies.
+struct QC {
+    u64 q;   // modulus
+    u64 q4;  // 4q  (lazy range bound, 8q < 2^64 because q < 2^61)
+    u32 nq0, nq1; // -q mod 2^64, split
+};
+__device__ __forceinline__ QC make_qc(u64 q)
 {
+    QC c;
+    c.q = q;
+    c.q4 = 4 * q;
+    u64 nq = 0 - q;
+    c.nq0 = (u32) nq;
+    c.nq1 = (u32) (nq >> 32);
+    return c;
+}
+
+// Shoup multiplication by the constant w.x with companion w.y = floor(w.x*2^64/q).
+// The quotient estimate drops only the lo*lo partial product of mulhi64 (3
+// multiplies instead of 4), so it can be short by at most 1:
+// result = y*w mod q + {0,1,2}q, inside [0,4q) for ANY 64-bit y.  All nine
+// 32-bit multiplies are v_mad_u64_u32 / v_mul_lo_u32 (v_mul_hi_u32 issues at
+// roughly half their rate on gfx950 -- profiles/r1a_first/ubench_intmul.txt),
+// and y*w - qh*q is one multiply-accumulate chain against -q.
+__device__ __forceinline__ u64 shoup_lazy(u64 y, ulonglong2 w, const QC& c)
+{
+    const u32 y0 = (u32) y, y1 = (u32) (y >> 32);
+    const u32 w0 = (u32) w.x, w1 = (u32) (w.x >> 32), p0 = (u32) w.y, p1 = (u32) (w.y >> 32);
+    const u64 A = (u64) y0 * p1;
+    const u64 B = (u64) y1 * p0 + (u32) A;
+    const u64 qh = (u64) y1 * p1 + (A >> 32) + (B >> 32);
+    const u32 h0 = (u32) qh, h1 = (u32) (qh >> 32);
+    u64 acc = (u64) y0 * w0;
+    acc += (u64) h0 * c.nq0;
+    const u32 hi = y0 * w1 + y1 * w0 + h0 * c.nq1 + h1 * c.nq0;
+    return acc + ((u64) hi << 32);
+}
+
+// exact product: canonical residue of y*w for any 64-bit y
+__device__ __forceinline__ u64 shoup_full(u64 y, ulonglong2 w, const QC& c)
+{
+    u64 r = shoup_lazy(y, w, c);
+    r = csub(r, 2 * c.q);
+    return csub(r, c.q);
+}
+
+// Harvey-style CT butterfly.  LAZY == false: x,y in [0,8q) -> [0,8q) (one
+// conditional subtraction per butterfly; needs only q < 2^61).  LAZY == true
+// (q < 2^57): no correction at all -- every stage adds at most 4q to the bound,
+// so 16 stages stay below 65q < 2^64; one exact reduction ends the transform.
+template <bool LAZY>
+__device__ __forceinline__ void ct_bfly(u64& x, u64& y, ulonglong2 w, const QC& c)
+{
+#if NTT_EXP_MODE == 1 || NTT_EXP_MODE == 3
+    x ^= w.x; y ^= w.y; return;
+#endif
+    u64 u = LAZY ? x : csub(x, c.q4);
+    u64 t = shoup_lazy(y, w, c);
+    x = u + t;
+    y = u + c.q4 - t;
+}
+
+// GS butterfly, x,y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void gs_bfly(u64& x, u64& y, ulonglong2 w, const QC& c)
+{
+#if NTT_EXP_MODE == 1 || NTT_EXP_MODE == 3
+    x ^= w.x; y ^= w.y; return;
+#endif
     u64 s = x + y;
-    u64 d = x - y + q2;
-    x = csub(s, q2);
-    y = mul_shoup_lazy(d, w.x, w.y, q);
+    u64 d = x + c.q4 - y;
+    x = csub(s, c.q4);
+    y = shoup_lazy(d, w, c);
 }
 
 // LOGR Cooley-Tukey stages on 2^LOGR register-resident values.  Local stage
 // s, block b uses root index (root0 << s) + b.
-template <int LOGR>
+template <int LOGR, bool LAZY>
 __device__ __forceinline__ void ct_radix(u64 (&x)[1 << LOGR], const ulonglong2* __restrict__ tw,
-                                         u32 root0, u64 q, u64 q2)
+                                         u32 root0, const QC& c)
 {
 #pragma unroll
     for (int s = 0; s < LOGR; s++) {
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
+#if NTT_EXP_MODE == 3
+            ulonglong2 w = make_ulonglong2(root0, s);
+#else
             ulonglong2 w = tw[(root0 << s) + b];
+#endif
 #pragma unroll
             for (int j = 0; j < half; j++)
-                ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, q, q2);
+                ct_bfly<LAZY>(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+}
+
+// The last four CT stages of the row pass with the re-laid table: slot k of
+// this thread is tb[k * 16] (tb already points at [mod][row][0][lane]).
+template <bool LAZY>
+__device__ __forceinline__ void ct_radix16_tb(u64 (&x)[16], const ulonglong2* __restrict__ tb, const QC& c)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+#pragma unroll
+            for (int j = 0; j < half; j++)
+                ct_bfly<LAZY>(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
 }
@@ -71,17 +173,37 @@ __device__ __forceinline__ void ct_radix(u64 (&x)[1 << LOGR], const ulonglong2* 
 // LOGR Gentleman-Sande stages (reverse order of ct_radix).
 template <int LOGR>
 __device__ __forceinline__ void gs_radix(u64 (&x)[1 << LOGR], const ulonglong2* __restrict__ tw,
-                                         u32 root0, u64 q, u64 q2)
+                                         u32 root0, const QC& c)
 {
 #pragma unroll
     for (int s = LOGR - 1; s >= 0; s--) {
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
+#if NTT_EXP_MODE == 3
+            ulonglong2 w = make_ulonglong2(root0, s);
+#else
             ulonglong2 w = tw[(root0 << s) + b];
+#endif
 #pragma unroll
             for (int j = 0; j < half; j++)
-                gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, q, q2);
+                gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+}
+
+// The first four GS stages of the inverse row pass with the re-laid table.
+__device__ __forceinline__ void gs_radix16_tb(u64 (&x)[16], const ulonglong2* __restrict__ tb, const QC& c)
+{
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+#pragma unroll
+            for (int j = 0; j < half; j++)
+                gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
 }
@@ -90,27 +212,30 @@ __device__ __forceinline__ void gs_radix(u64 (&x)[1 << LOGR], const ulonglong2* 
 // fully reduces: x' = (x+y)*ninv, y' = (x-y)*(w1*ninv).
 template <int LOGR>
 __device__ __forceinline__ void gs_radix_last(u64 (&x)[1 << LOGR], const ulonglong2* __restrict__ tw,
-                                              u32 root0, ulonglong2 ninv, ulonglong2 w1ninv,
-                                              u64 q, u64 q2)
+                                              u32 root0, ulonglong2 ninv, ulonglong2 w1ninv, const QC& c)
 {
 #pragma unroll
     for (int s = LOGR - 1; s >= 1; s--) {
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
+#if NTT_EXP_MODE == 3
+            ulonglong2 w = make_ulonglong2(root0, s);
+#else
             ulonglong2 w = tw[(root0 << s) + b];
+#endif
 #pragma unroll
             for (int j = 0; j < half; j++)
-                gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, q, q2);
+                gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
     const int half = (1 << LOGR) >> 1;
 #pragma unroll
     for (int j = 0; j < half; j++) {
         u64 s = x[j] + x[j + half];
-        u64 d = x[j] - x[j + half] + q2;
-        x[j] = mul_shoup(s, ninv.x, ninv.y, q);
-        x[j + half] = mul_shoup(d, w1ninv.x, w1ninv.y, q);
+        u64 d = x[j] + c.q4 - x[j + half];
+        x[j] = shoup_full(s, ninv, c);
+        x[j + half] = shoup_full(d, w1ninv, c);
     }
 }
 
@@ -122,6 +247,18 @@ struct PolySel {
 __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
 {
     PolySel s;
+    if (a.group_span) {
+        // modulus-major walk: grid index = k * span + r  ->  r-th polynomial
+        // (in item-major order) among those with modulus slot k
+        const int k = poly / a.group_span, r = poly - k * a.group_span;
+        if (a.polys_per_item) {
+            const int per_item = a.polys_per_item / a.mod_count; // digits per item
+            const int it = r / per_item, d = r - it * per_item;
+            poly = it * a.polys_per_item + d * a.mod_count + k;
+        } else {
+            poly = r * a.mod_count + k;
+        }
+    }
     int item = 0, j = poly;
     if (a.polys_per_item) {
         item = poly / a.polys_per_item;
@@ -137,32 +274,44 @@ __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
     return s;
 }
 
-// column-tile LDS index (pad 16 elements per 256 against the 2-way conflict
-// of the 16-column tile)
-__device__ __forceinline__ int col_phys(int e) { return e + ((e >> 8) << 4); }
-// row-tile LDS index (pad 2 elements per 16 so 128-byte-strided b128 reads
-// spread over all banks)
-__device__ __forceinline__ int row_phys(int e) { return e + ((e >> 4) << 1); }
+// LDS tiles are exactly 4096 elements (32 KiB -> 5 workgroups per CU); bank
+// conflicts are removed by XOR swizzles instead of padding.
+// column tile: rows 16 apart (256 elements) would share banks in the 16-column
+// tile -> flip the 128-byte half on odd 256-element blocks.
+__device__ __forceinline__ int col_phys(int e) { return e ^ (((e >> 8) & 1) << 4); }
+// row tile: a thread's 16 contiguous elements are read as 16-byte pairs at a
+// 128-byte lane stride -> XOR the pair index (bits 3:1) with bits 7:5 so the
+// 16 lanes of a b128 group hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int row_phys(int e) { return e ^ (((e >> 5) & 7) << 1); }
 
-#define COL_LDS_ELEMS (4096 + 256)
-#define ROW_LDS_ELEMS (4096 + 512)
+// The row-pass exchanges stay inside the 16 lanes that own one row, i.e. inside
+// one wavefront, and a wave's LDS operations execute in order: only the
+// compiler has to be kept from reordering them, no s_barrier is needed.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define COL_LDS_ELEMS 4096
+#define ROW_LDS_ELEMS 4096
 
 // ------------------------------------------------------------------ forward
+// Moduli below 2^57 take the correction-free butterflies (see ct_bfly).
+#define NTT_LAZY_BITS 57
+
 // Column pass: stages 0..S1-1 (row stride 256).  grid = (256/CT, batch).
-template <int S1, bool DECOMP>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
+template <int S1, bool DECOMP, bool LAZY>
+__device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
 {
     constexpr int R = 1 << S1;
     constexpr int CT = 4096 / R;
     constexpr int NSA = S1 - 4;
     constexpr int RA = 1 << NSA;
     constexpr int G = 16 / RA;
-    __shared__ u64 lds[(NSA > 0) ? COL_LDS_ELEMS : 1];
-
     const int t = threadIdx.x;
-    const PolySel ps = select_poly(a, blockIdx.y);
-    const Mod md = a.mods[ps.mod];
-    const u64 q = md.q, q2 = 2 * md.q;
+    const QC qc = make_qc(md.q);
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + blockIdx.x * CT;
     u64* __restrict__ dst = a.out + ps.out_off + blockIdx.x * CT;
@@ -177,12 +326,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
             const int c = L % CT, rb = L / CT;
             u64 y[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = src[(u64) (rb + 16 * k) * 256 + c];
+            for (int k = 0; k < RA; k++) y[k] = gld(&src[(u64) (rb + 16 * k) * 256 + c]);
             if (DECOMP) {
 #pragma unroll
                 for (int k = 0; k < RA; k++) y[k] = reduce64(y[k], md);
             }
-            ct_radix<NSA>(y, tw, 1u, q, q2);
+            ct_radix<NSA, LAZY>(y, tw, 1u, qc);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = y[k];
         }
@@ -191,27 +340,35 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
         for (int k = 0; k < 16; k++) x[k] = lds[col_phys((16 * r1 + k) * CT + col)];
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = src[(u64) k * 256 + col];
+        for (int k = 0; k < 16; k++) x[k] = gld(&src[(u64) k * 256 + col]);
         if (DECOMP) {
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
         }
     }
-    ct_radix<4>(x, tw, (u32) (RA + r1), q, q2);
+    ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(u64) (16 * r1 + k) * 256 + col] = x[k];
+    for (int k = 0; k < 16; k++) gst(&dst[(u64) (16 * r1 + k) * 256 + col], x[k]);
+}
+
+template <int S1, bool DECOMP>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
+{
+    __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
+    const PolySel ps = select_poly(a, blockIdx.y);
+    const Mod md = a.mods[ps.mod];
+    if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
+    else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
 
 // Row pass: stages S1..S1+7 on contiguous rows of 256, 16 rows per block.
-// Values arrive in [0,4q) from the column pass; the result is fully reduced.
+// Values arrive lazily reduced from the column pass; the result is canonical.
 // grid = (N/4096, batch); in place on a.out.
-__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
+template <bool LAZY>
+__device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const PolySel ps = select_poly(a, blockIdx.y);
-    const Mod md = a.mods[ps.mod];
-    const u64 q = md.q, q2 = 2 * md.q;
+    const QC qc = make_qc(md.q);
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     u64* __restrict__ p = a.out + ps.out_off + (u64) blockIdx.x * 4096;
@@ -220,32 +377,43 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
     const u32 crow = blockIdx.x * 16 + row; // global row index
     u64 x[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = p[row * 256 + i0 + 16 * k];
-    ct_radix<4>(x, tw, (1u << s1) + crow, q, q2);
+    for (int k = 0; k < 16; k++) x[k] = gld(&p[row * 256 + i0 + 16 * k]);
+    ct_radix<4, LAZY>(x, tw, (1u << s1) + crow, qc);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = x[k];
-    __syncthreads();
-    {
-        const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0)]);
+    wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            ulonglong2 v = l2[k];
-            x[2 * k] = v.x;
-            x[2 * k + 1] = v.y;
-        }
+    for (int k = 0; k < 8; k++) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+        x[2 * k] = v.x;
+        x[2 * k + 1] = v.y;
     }
-    ct_radix<4>(x, tw, (((1u << s1) + crow) << 4) + (u32) i0, q, q2);
+    ct_radix16_tb<LAZY>(x, a.twB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), qc);
+    if (LAZY) {
+        // x < 65q: one exact reduction (floor(2^64/q) quotient estimate)
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = csub(csub(x[k], q2), q);
-    __syncthreads();
-    {
-        ulonglong2* l2 = reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0)]);
+        for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
+    } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) l2[k] = make_ulonglong2(x[2 * k], x[2 * k + 1]);
+        for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
     }
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 16; k++) p[row * 256 + i0 + 16 * k] = lds[row_phys(row * 256 + i0 + 16 * k)];
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+            make_ulonglong2(x[2 * k], x[2 * k + 1]);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) gst(&p[row * 256 + i0 + 16 * k], lds[row_phys(row * 256 + i0 + 16 * k)]);
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    const PolySel ps = select_poly(a, blockIdx.y);
+    const Mod md = a.mods[ps.mod];
+    if (md.bit <= NTT_LAZY_BITS) fwd_row_body<true>(a, ps, md, lds);
+    else fwd_row_body<false>(a, ps, md, lds);
 }
 
 // ------------------------------------------------------------------ inverse
@@ -256,7 +424,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
     const int t = threadIdx.x;
     const PolySel ps = select_poly(a, blockIdx.y);
     const Mod md = a.mods[ps.mod];
-    const u64 q = md.q, q2 = 2 * md.q;
+    const QC qc = make_qc(md.q);
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.itw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
@@ -265,31 +433,31 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
     const int row = t >> 4, i0 = t & 15;
     const u32 crow = blockIdx.x * 16 + row;
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = src[row * 256 + i0 + 16 * k];
-    __syncthreads();
+    for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = gld(&src[row * 256 + i0 + 16 * k]);
+    wave_lds_fence();
     u64 x[16];
     {
-        const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0)]);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            ulonglong2 v = l2[k];
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
             x[2 * k] = v.x;
             x[2 * k + 1] = v.y;
         }
     }
-    gs_radix<4>(x, tw, (((1u << s1) + crow) << 4) + (u32) i0, q, q2);
-    __syncthreads();
+    gs_radix16_tb(x, a.itwB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), qc);
+    wave_lds_fence();
     {
-        ulonglong2* l2 = reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0)]);
 #pragma unroll
-        for (int k = 0; k < 8; k++) l2[k] = make_ulonglong2(x[2 * k], x[2 * k + 1]);
+        for (int k = 0; k < 8; k++)
+            *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+                make_ulonglong2(x[2 * k], x[2 * k + 1]);
     }
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = lds[row_phys(row * 256 + i0 + 16 * k)];
-    gs_radix<4>(x, tw, (1u << s1) + crow, q, q2);
+    gs_radix<4>(x, tw, (1u << s1) + crow, qc);
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[row * 256 + i0 + 16 * k] = x[k];
+    for (int k = 0; k < 16; k++) gst(&dst[row * 256 + i0 + 16 * k], x[k]);
 }
 
 // Column pass last: GS stages S1-1..0, N^-1 folded into the final stage.
@@ -307,7 +475,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
     const int t = threadIdx.x;
     const PolySel ps = select_poly(a, blockIdx.y);
     const Mod md = a.mods[ps.mod];
-    const u64 q = md.q, q2 = 2 * md.q;
+    const QC qc = make_qc(md.q);
     const ulonglong2* __restrict__ tw = a.itw + ((u64) ps.mod << a.n_power);
     const ulonglong2 ninv = a.ninv[ps.mod], w1ninv = a.w1ninv[ps.mod];
     u64* __restrict__ p = a.out + ps.out_off + blockIdx.x * CT;
@@ -315,9 +483,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
     const int col = t % CT, r1 = t / CT;
     u64 x[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = p[(u64) (16 * r1 + k) * 256 + col];
+    for (int k = 0; k < 16; k++) x[k] = gld(&p[(u64) (16 * r1 + k) * 256 + col]);
     if constexpr (NSA > 0) {
-        gs_radix<4>(x, tw, (u32) (RA + r1), q, q2);
+        gs_radix<4>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[col_phys((16 * r1 + k) * CT + col)] = x[k];
         __syncthreads();
@@ -328,14 +496,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
             u64 y[RA];
 #pragma unroll
             for (int k = 0; k < RA; k++) y[k] = lds[col_phys((rb + 16 * k) * CT + c)];
-            gs_radix_last<NSA>(y, tw, 1u, ninv, w1ninv, q, q2);
+            gs_radix_last<NSA>(y, tw, 1u, ninv, w1ninv, qc);
 #pragma unroll
-            for (int k = 0; k < RA; k++) p[(u64) (rb + 16 * k) * 256 + c] = y[k];
+            for (int k = 0; k < RA; k++) gst(&p[(u64) (rb + 16 * k) * 256 + c], y[k]);
         }
     } else {
-        gs_radix_last<4>(x, tw, 1u, ninv, w1ninv, q, q2);
+        gs_radix_last<4>(x, tw, 1u, ninv, w1ninv, qc);
 #pragma unroll
-        for (int k = 0; k < 16; k++) p[(u64) k * 256 + col] = x[k];
+        for (int k = 0; k < 16; k++) gst(&p[(u64) k * 256 + col], x[k]);
     }
 }
 
@@ -396,11 +564,16 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
         }
         return hipSuccess;
     }
+    NttArgs g = a;
+    g.group_span = 0;
+    if (!a.poly_order && a.mod_count > 1 && batch % a.mod_count == 0 &&
+        (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
+        g.group_span = batch / a.mod_count;
     switch (a.n_power - 8) {
 #define CASE(S)                                   \
     case S:                                       \
-        if (inverse) launch_inv<S>(a, batch, st); \
-        else launch_fwd<S>(a, batch, st);         \
+        if (inverse) launch_inv<S>(g, batch, st); \
+        else launch_fwd<S>(g, batch, st);         \
         break;
         CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE

@@ -14,6 +14,13 @@ struct NttArgs {
     const Mod* mods;          // plan: per-modulus records
     const ulonglong2* tw;     // plan: forward (psi^br(j), shoup companion) [mod][N]
     const ulonglong2* itw;    // plan: inverse (psi^-br(j), companion)     [mod][N]
+    // plan: the same twiddles re-laid for the last four (contiguous) stages of
+    // the row pass: [mod][row c][slot k = 0..14][lane j = 0..15], slot k =
+    // (1<<s)-1+b of local stage s, so that the 16 lanes of a row read 256
+    // contiguous bytes per slot (the natural table would be a 128-byte lane
+    // stride there).  Entry = tw[(((N/256 + c)*16 + j) << s) + b].
+    const ulonglong2* twB;
+    const ulonglong2* itwB;
     const ulonglong2* ninv;   // plan: (N^-1, companion)                    [mod]
     const ulonglong2* w1ninv; // plan: (itw[1]*N^-1, companion)             [mod]
     const int* mod_order;     // optional: modulus index = mod_order[i % mod_count]
@@ -34,6 +41,10 @@ struct NttArgs {
     // through reduce64 first.  Replaces cipher_broadcast*_kernel + NTT
     // (reference switchkey.cu:11-59 followed by ckks/operator.cu:956).
     int decomp_mods;
+    // Set by ntt_launch: when > 0 the grid walks polynomials modulus-major
+    // (all polynomials of one modulus back to back) so that concurrently
+    // running workgroups share one modulus' twiddle table in L2.
+    int group_span; // polynomials per modulus class = batch / mod_count
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

@@ -8,7 +8,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define ITERS 4096
-#define CH 8
+#define CH 16
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(u64* out, u32 a0, u32 b0)
@@ -26,8 +26,14 @@ __global__ __launch_bounds__(256) void k(u64* out, u32 a0, u32 b0)
                 acc[c] = (u32) acc[c] * x + 1;
             } else if (KIND == 2) { // v_mul_hi_u32
                 acc[c] = __umulhi((u32) acc[c], x) + y;
-            } else if (KIND == 3) { // 64-bit add (v_add_co + v_addc)
-                acc[c] = acc[c] + (((u64) y << 32) | x);
+            } else if (KIND == 3) { // 64-bit add, operand varies per iteration
+                acc[c] = acc[c] + acc[(c + 1) % CH];
+            } else if (KIND == 7) { // 32-bit add
+                acc[c] = (u32) acc[c] + (u32) acc[(c + 1) % CH];
+            } else if (KIND == 8) { // compare + select (v_cmp_u64 + 2 cndmask)
+                acc[c] = (acc[c] >= acc[(c + 1) % CH]) ? acc[c] - 7 : acc[(c + 2) % CH];
+            } else if (KIND == 9) { // xor 32
+                acc[c] = (u32) acc[c] ^ ((u32) acc[(c + 1) % CH] >> 1);
             } else if (KIND == 4) { // v_fma_f64
                 double d = __longlong_as_double(acc[c]);
                 d = fma(d, 1.0000001, 0.5);
@@ -74,5 +80,8 @@ int main()
     run<4>("v_fma_f64", d);
     run<5>("v_fma_f32", d);
     run<6>("v_mul_u32_u24", d);
+    run<7>("add_u32", d);
+    run<8>("cmp64+sel+sub", d);
+    run<9>("xor+shift32", d);
     return 0;
 }
