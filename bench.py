@@ -50,16 +50,12 @@ def main():
     import torch.distributed as dist
 
     import heongpu_amd as hg
+    from heongpu_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    rank, world, local_rank = sharding.init_distributed("nccl")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     ctx = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
@@ -82,7 +78,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(key, src=0)
+        sharding.broadcast_eval_key(key, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 

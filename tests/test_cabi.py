@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads and exports every symbol declared in
+include/hegpu.h; host-only entry points behave like the reference's
+exceptions (no compute calls here -- there is no GPU on this box)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "hegpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hegpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(hg):
+    from heongpu_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    bound = {s[0] for s in _lib.SIGNATURES}
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in hegpu.h but not exported by libhegpu.so"
+        assert name in bound, f"{name} has no ctypes signature"
+    assert bound <= set(names), "ctypes binds a symbol the header does not declare"
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C, no torch/C++ types."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write('#include "hegpu.h"\nint main(void){return 0;}\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", c,
+                               "-o", os.path.join(d, "t.o")])
+
+
+def test_context_errors_mirror_reference_exceptions(hg):
+    # std::logic_error cases (reference ckks/context.cu:33-44, util.cu:11-56)
+    for n in (1000, 2048, 131072):
+        with pytest.raises(hg.HEError) as e:
+            hg.Context.from_bit_sizes(hg.CKKS, n, [40, 30], [40], sec=hg.SEC_NONE)
+        assert e.value.code == hg.E_LOGIC
+    with pytest.raises(hg.HEError) as e:
+        hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [], sec=hg.SEC_NONE)
+    assert e.value.code == hg.E_LOGIC and "cannot be empty" in str(e.value)
+    with pytest.raises(hg.HEError) as e:  # P must cover every group of |P| Q primes
+        hg.Context.from_bit_sizes(hg.CKKS, 8192, [50, 50], [40], sec=hg.SEC_NONE)
+    assert e.value.code == hg.E_LOGIC and "bigger than Q" in str(e.value)
+    with pytest.raises(hg.HEError) as e:  # invalid modulus bit size (util.cu:252-256)
+        hg.Context.from_bit_sizes(hg.CKKS, 8192, [29, 29], [40], sec=hg.SEC_NONE)
+    assert e.value.code == hg.E_LOGIC
+    # std::runtime_error: security check (ckks/context.cu:94-119, secstdparams.h:25-41)
+    with pytest.raises(hg.HEError) as e:
+        hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30, 30], [40], sec=hg.SEC_128)
+    assert e.value.code == hg.E_RUNTIME and "security" in str(e.value)
+    hg.Context.from_bit_sizes(hg.CKKS, 4096, [36, 36], [37], sec=hg.SEC_128)  # 109 bits: allowed
+    with pytest.raises(hg.HEError):  # BFV needs a plain modulus
+        hg.Context.from_default(hg.BFV, 4096, 1, 0)
+
+
+def test_default_chain_and_properties(hg):
+    c = hg.Context.from_default(hg.BFV, 32768, 1, 786433)  # config C3 parameters
+    assert (c.n_power, c.Q_size, c.P_size, c.Q_prime_size) == (15, 14, 1, 15)
+    assert c.bsk_modulus in (15, 16)
+    assert int(c.table("modulus")[0]) == 0x2000000002b0001
+    assert c.workspace_bytes(hg.OP_BFV_GALOIS, 0, 64) == 64 * (14 * 15 + 2 * 15) * 32768 * 8
+
+
+def test_galois_elements(hg, oracle):
+    for n in (4096, 65536):
+        for steps in (0, 1, 2, -1, -7, 100):
+            for order in (3, 5):
+                assert hg.steps_to_galois_elt(steps, n, order) == oracle.lib().o_steps_to_galois_elt(steps, n, order)
+
+
+def test_no_device_means_loud_failure(hg):
+    """without a GPU every device entry point must fail loudly (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    c = hg.Context.from_bit_sizes(hg.CKKS, 4096, [36, 36], [37])
+    with pytest.raises(hg.HEError) as e:
+        c.upload()
+    assert e.value.code == hg.E_NODEVICE
+    with pytest.raises(hg.HEError) as e:
+        c.ntt(0, 0, False, 1, 1, stream=0)
+    assert e.value.code == hg.E_NODEVICE

@@ -1,0 +1,102 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py -- batch sharding +
+evaluation-key broadcast -- with the oracle standing in for the GPU compute
+(the sharding code is identical; only the backend name differs on MI355X)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import synth_ct, synth_key
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from heongpu_amd import sharding
+    from oracle import binding as ob
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = sharding.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    import ctypes
+    n, Q, Qp, total = 4096, 3, 4, 5
+    bits = (ctypes.c_int * 4)(40, 30, 30, 40)
+    out = (ctypes.c_uint64 * 4)()
+    ob.lib().o_generate_primes(n, bits, 4, out)
+    primes = [int(v) for v in out]
+    o = ob.OracleContext(ob.CKKS, 12, primes, Q, 1)
+    key = torch.zeros(2 * Q * Qp * n, dtype=torch.int64)
+    if rank == 0:  # only rank 0 owns the key before the broadcast
+        key.copy_(torch.from_numpy(synth_key(primes, Q, Qp, n, 3).view(np.int64)))
+    sharding.broadcast_eval_key(key, src=0, chunk_elems=50000)  # several chunks
+    key_np = key.numpy().view(np.uint64)
+    start, count = sharding.shard_range(total, world, rank)
+    res = []
+    for b in range(start, start + count):
+        ct1 = synth_ct(primes, range(Q), 2, n, 1 + 10 * b)
+        ct2 = synth_ct(primes, range(Q), 2, n, 2 + 10 * b)
+        m = o.ckks_multiply(ct1, ct2, 0)
+        o.ckks_relinearize(m, key_np, 0)
+        res.append(m[:2 * Q * n].copy())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (start, count, [r_.tobytes() for r_ in res]))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from heongpu_amd import sharding
+    for total in (0, 1, 5, 64, 513):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                s, c = sharding.shard_range(total, world, r)
+                seen += list(range(s, s + c))
+            assert seen == list(range(total))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_mul_relin_matches_single_process(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference for all 5 ciphertext pairs
+    import ctypes
+    n, Q, Qp, total = 4096, 3, 4, 5
+    bits = (ctypes.c_int * 4)(40, 30, 30, 40)
+    out = (ctypes.c_uint64 * 4)()
+    oracle.lib().o_generate_primes(n, bits, 4, out)
+    primes = [int(v) for v in out]
+    o = oracle.OracleContext(oracle.CKKS, 12, primes, Q, 1)
+    key = synth_key(primes, Q, Qp, n, 3)
+    covered = []
+    for start, count, blobs in gathered:
+        assert len(blobs) == count
+        for i, blob in enumerate(blobs):
+            b = start + i
+            m = o.ckks_multiply(synth_ct(primes, range(Q), 2, n, 1 + 10 * b),
+                                synth_ct(primes, range(Q), 2, n, 2 + 10 * b), 0)
+            o.ckks_relinearize(m, key, 0)
+            assert m[:2 * Q * n].tobytes() == blob, f"ciphertext {b} differs"
+            covered.append(b)
+    assert sorted(covered) == list(range(total))

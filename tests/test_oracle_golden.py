@@ -1,0 +1,148 @@
+"""CPU: the C oracle and the product's host-side parameter derivation against
+the committed golden vectors (tests/golden/*.json, produced by the independent
+pure-Python big-int restatement oracle/pyref.py -- the reference's own tests
+hold no golden vectors)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import synth_ct, synth_key
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def summ(arr):
+    a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+    return {"sha256": hashlib.sha256(a.tobytes()).hexdigest(), "head": [int(v) for v in a[:4]], "count": int(a.size)}
+
+
+def check(arr, want, what):
+    got = summ(arr)
+    assert got["count"] == want["count"], what
+    assert got["head"] == want["head"], what
+    assert got["sha256"] == want["sha256"], what
+
+
+@pytest.fixture(scope="module")
+def c1(oracle):
+    g = load("c1_bfv_4096.json")
+    o = oracle.OracleContext(oracle.BFV, 12, g["primes"], 2, 1, 1032193)
+    return g, o
+
+
+def test_reference_hardcoded_constants(oracle):
+    """constants that ARE in the reference tree: default chain (defaultmodulus.cpp:18-20),
+    psi probe values, TFHE prime/psi (tfhe/context.cu:23-24)."""
+    import ctypes
+    out = (ctypes.c_uint64 * 8)()
+    assert oracle.lib().o_default_modulus_128(4096, out) == 3
+    assert [int(out[i]) for i in range(3)] == [0x800004001, 0x800008001, 0x1000002001]
+    for q, psi in ((0x800004001, 6071469), (0x800008001, 18291550), (0x1000002001, 28979647)):
+        assert oracle.lib().o_min_primitive_root(8192, q) == psi
+    # TFHE: psi hard-coded in the reference must be the minimal primitive 2N-th root
+    assert oracle.lib().o_min_primitive_root(2048, 1152921504606877697) == 1689264667710614
+
+
+def test_c1_parameters(c1, hg):
+    g, o = c1
+    for name in ("psi", "n_inverse", "last_q_modinv", "half", "half_mod", "factor", "base_Bsk"):
+        assert [int(v) for v in o.table(name)] == g[name], name
+    assert int(o.table("gamma")[0]) == g["gamma"]
+    prod = hg.Context.from_default(hg.BFV, 4096, 1, 1032193)
+    assert prod.bsk_modulus == g["bsk_modulus"]
+    for name, want in g["tables"].items():
+        for src, tab in (("oracle", o.table(name)), ("product", prod.table(name))):
+            if isinstance(want, dict):
+                check(tab, want, f"{src}:{name}")
+            else:
+                assert [int(v) for v in tab] == want, f"{src}:{name}"
+
+
+def test_c1_ntt(c1, oracle):
+    g, o = c1
+    n, q = 4096, g["primes"][0]
+    x = oracle.fill_poly(7, 0, n, q)
+    check(o.ntt(x.copy(), 1, 1), g["ntt"]["forward"], "forward NTT")
+    check(o.ntt(x.copy(), 1, 1, inverse=True), g["ntt"]["inverse_of_input"], "inverse NTT")
+
+
+def test_c1_ops(c1, oracle):
+    """config C1: BFV add + multiply(+relinearize) + rotate on the CPU path."""
+    g, o = c1
+    n, Q = 4096, 2
+    primes = g["primes"]
+    ct1 = synth_ct(primes, range(Q), 2, n, 1)
+    ct2 = synth_ct(primes, range(Q), 2, n, 2)
+    key = synth_key(primes, Q, 3, n, 3)
+    out = np.zeros_like(ct1)
+    o.L.o_addition(ct1.ctypes.data, ct2.ctypes.data, out.ctypes.data, o.qp_mods, 12, Q, 2)
+    check(out, g["ops"]["add"], "add")
+    o.L.o_substraction(ct1.ctypes.data, ct2.ctypes.data, out.ctypes.data, o.qp_mods, 12, Q, 2)
+    check(out, g["ops"]["sub"], "sub")
+    mul = o.bfv_multiply(ct1, ct2)
+    check(mul, g["ops"]["multiply"], "multiply")
+    rel = o.bfv_relinearize(mul.copy(), key)
+    check(rel[:2 * Q * n], g["ops"]["multiply_relinearize"], "multiply+relinearize")
+    assert oracle.lib().o_steps_to_galois_elt(1, n, 3) == g["ops"]["galois_elt"]
+    check(o.bfv_apply_galois(ct1, key, g["ops"]["galois_elt"]), g["ops"]["rotate_rows_1"], "rotate")
+
+
+def test_ckks_small(oracle, hg):
+    g = load("ckks_4096.json")
+    n, Q, Qp = 4096, 3, 4
+    prod = hg.Context.from_bit_sizes(hg.CKKS, n, [40, 30, 30], [40], sec=hg.SEC_NONE)
+    assert [int(v) for v in prod.table("modulus")] == g["primes"]
+    o = oracle.OracleContext(oracle.CKKS, 12, g["primes"], Q, 1)
+    for name in ("psi", "n_inverse", "last_q_modinv", "half", "half_mod", "factor", "rescaled_half",
+                 "rescaled_half_mod", "rescaled_last_q_modinv", "new_prime_locations", "new_input_locations"):
+        assert [int(v) for v in o.table(name)] == g[name], "oracle:" + name
+        assert [int(v) for v in prod.table(name)] == g[name], "product:" + name
+    for name in ("ntt_table", "intt_table"):
+        check(o.table(name), g["tables"][name], "oracle:" + name)
+        check(prod.table(name), g["tables"][name], "product:" + name)
+    key = synth_key(g["primes"], Q, Qp, n, 3)
+    for depth in (0, 1):
+        want = g["ops"]["depth%d" % depth]
+        l = Q - depth
+        ct1 = synth_ct(g["primes"], range(l), 2, n, 1)
+        ct2 = synth_ct(g["primes"], range(l), 2, n, 2)
+        mul = o.ckks_multiply(ct1, ct2, depth)
+        check(mul, want["multiply"], "multiply")
+        rel = o.ckks_relinearize(mul.copy(), key, depth)[:2 * l * n].copy()
+        check(rel, want["relinearize"], "relinearize")
+        res = o.ckks_rescale(rel.copy(), depth)[:2 * (l - 1) * n]
+        check(res, want["rescale"], "rescale")
+        assert oracle.lib().o_steps_to_galois_elt(1, n, 5) == want["galois_elt"]
+        check(o.ckks_apply_galois(ct1, key, want["galois_elt"], depth), want["rotate_1"], "rotate")
+
+
+def test_benchmark_chains(oracle, hg):
+    """prime chains of the C2 / C4 benchmark configs (deterministic SEAL-style search)."""
+    g = load("params.json")
+    for name, item in g.items():
+        nq = len(item["bits"]) - 1
+        prod = hg.Context.from_bit_sizes(hg.CKKS, item["n"], item["bits"][:nq], item["bits"][nq:])
+        assert [int(v) for v in prod.table("modulus")] == item["primes"], name
+        import ctypes
+        bits = (ctypes.c_int * len(item["bits"]))(*item["bits"])
+        out = (ctypes.c_uint64 * len(item["bits"]))()
+        assert oracle.lib().o_generate_primes(item["n"], bits, len(item["bits"]), out) == 0
+        assert [int(v) for v in out] == item["primes"], name
+        psi = [int(v) for v in prod.table("psi")][:2]
+        assert psi == item["psi"][:2]
+
+
+def test_no_barrett_domain_violation(oracle):
+    """every o_mult call of the suites above stayed inside Barrett's exact domain
+    (a*b < 2^(2*bit)): outside it the reference's behaviour would be unpinned."""
+    import ctypes
+    v = ctypes.c_uint64.in_dll(oracle.lib(), "o_barrett_domain_violations").value
+    assert v == 0
