@@ -186,6 +186,15 @@ def main():
         "ntt": {"forward_GBps": fwd_gbps, "inverse_GBps": inv_gbps, "n": N, "limbs": polys},
         "hbm_fraction_end_to_end": ((6 * l * l + 32 * l + 8) * W * value / world) / 1e9 / HBM_PEAK_GBPS,
     }
+    # HBM traffic of the same launch from the PMC counters (separate rocprofv3
+    # --pmc passes, tools/profile.sh): committed next to the kernel stats.
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("limb_ntts_per_launch") == polys:
+            line["roofline"]["traffic"] = tj["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
     if bcast_ms is not None:
         line["key_broadcast_ms"] = bcast_ms
 
