@@ -246,3 +246,31 @@ def test_bfv_multiply_relin_rotate(hg, oracle, torch):
     got = hg.to_host(rot).reshape(batch, -1)
     for b in range(batch):
         assert np.array_equal(got[b], o.bfv_apply_galois(ct1[b], key, g)), "bfv rotate"
+
+
+def test_c3_bfv_rotate_batch64_full_size(hg, oracle, torch):
+    """Config C3 at full size: BFV N=2^15, default chain (Q=14, P=1), rotate_rows
+    by one step (Galois element 3, key-switch method I), batch 64; a sample of the
+    batch is compared bit-for-bit with the oracle, the rest through the
+    batch-consistency property (identical inputs -> identical outputs)."""
+    n, t = 32768, 786433
+    c, o, primes = _bfv_pair(hg, oracle, n, t)
+    Q, Qp = c.Q_size, c.Q_prime_size
+    assert (Q, Qp) == (14, 15)
+    batch, uniq = 64, 4
+    key = synth_key(primes, Q, Qp, n, 100)
+    cts = [synth_ct(primes, range(Q), 2, n, 1 + b) for b in range(uniq)]
+    per = 2 * Q * n
+    d = torch.empty(batch * per, dtype=torch.int64, device="cuda")
+    for b in range(batch):
+        d[b * per:(b + 1) * per].copy_(torch.from_numpy(cts[b % uniq].view(np.int64)))
+    out = torch.empty_like(d)
+    g = hg.steps_to_galois_elt(1, n, 3)
+    ws = c.workspace(hg.OP_BFV_GALOIS, 0, batch)
+    c.bfv_apply_galois(d, per, out, per, hg.to_device(key), g, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, per)
+    for b in range(uniq):
+        assert np.array_equal(got[b], o.bfv_apply_galois(cts[b], key, g)), f"ciphertext {b}"
+    for b in range(uniq, batch):
+        assert np.array_equal(got[b], got[b % uniq]), f"batch item {b} differs from its twin"
