@@ -54,6 +54,16 @@ SIGNATURES = [
     ("hegpu_bfv_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, voidp, c_size_t, voidp]),
     ("hegpu_bfv_apply_galois", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_tfhe_context_create", c_int, [ctypes.POINTER(voidp)]),
+    ("hegpu_tfhe_context_destroy", None, [voidp]),
+    ("hegpu_tfhe_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),
+    ("hegpu_tfhe_prime", u64, [voidp]),
+    ("hegpu_tfhe_prepare_bootkey", c_int, [voidp, u64p, u64p, voidp]),
+    ("hegpu_tfhe_gate_precompute", c_int, [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
+    ("hegpu_tfhe_bootstrapping", c_int, [voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp]),
+    ("hegpu_tfhe_key_switching", c_int, [voidp, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
+    ("hegpu_tfhe_gate", c_int,
+     [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp, c_size_t, voidp]),
 ]
 
 _lib = None

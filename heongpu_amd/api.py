@@ -233,5 +233,63 @@ class Context:
                                                 stream if stream is not None else _stream()))
 
 
+GATE_NAND, GATE_AND, GATE_AND_FIRST_NOT, GATE_NOR, GATE_OR, GATE_XNOR, GATE_XOR, GATE_NOT = range(8)
+
+
+class TfheContext:
+    """HEContext<TFHE> + HELogicOperator<TFHE> over the C ABI (fixed STD128 set)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _check(self._lib.hegpu_tfhe_context_create(ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.hegpu_tfhe_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def int(self, name):
+        return int(self._lib.hegpu_tfhe_context_int(self._h, name.encode()))
+
+    @property
+    def prime(self):
+        return int(self._lib.hegpu_tfhe_prime(self._h))
+
+    def prepare_bootkey(self, boot_key, stream=None):
+        import torch
+        out = torch.empty_like(boot_key)
+        _check(self._lib.hegpu_tfhe_prepare_bootkey(self._h, _ptr(boot_key), _ptr(out),
+                                                    stream if stream is not None else _stream()))
+        return out
+
+    def gate_precompute(self, gate, out_a, out_b, a1, b1, a2, b2, shape, stream=None):
+        _check(self._lib.hegpu_tfhe_gate_precompute(self._h, gate, _ptr(out_a), _ptr(out_b), _ptr(a1), _ptr(b1),
+                                                    _ptr(a2), _ptr(b2), shape,
+                                                    stream if stream is not None else _stream()))
+
+    def bootstrapping(self, in_a, in_b, prepared_bk, out_a, out_b, shape, stream=None):
+        _check(self._lib.hegpu_tfhe_bootstrapping(self._h, _ptr(in_a), _ptr(in_b), _ptr(prepared_bk), _ptr(out_a),
+                                                  _ptr(out_b), shape, stream if stream is not None else _stream()))
+
+    def key_switching(self, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, stream=None):
+        _check(self._lib.hegpu_tfhe_key_switching(self._h, _ptr(in_a), _ptr(in_b), _ptr(out_a), _ptr(out_b),
+                                                  _ptr(ks_a), _ptr(ks_b), shape,
+                                                  stream if stream is not None else _stream()))
+
+    def gate(self, gate, a1, b1, a2, b2, out_a, out_b, prepared_bk, ks_a, ks_b, shape, ws, stream=None):
+        _check(self._lib.hegpu_tfhe_gate(self._h, gate, _ptr(a1), _ptr(b1), _ptr(a2), _ptr(b2), _ptr(out_a),
+                                         _ptr(out_b), _ptr(prepared_bk), _ptr(ks_a), _ptr(ks_b), shape, _ptr(ws),
+                                         ws.numel() * ws.element_size(),
+                                         stream if stream is not None else _stream()))
+
+
 def steps_to_galois_elt(steps, n, group_order):
     return int(_lib.load().hegpu_steps_to_galois_elt(steps, n, group_order))

@@ -3,6 +3,7 @@
 #include "context.hpp"
 #include "host_params.hpp"
 #include "ops.hpp"
+#include "tfhe.hpp"
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -445,6 +446,179 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, 
     return hip_ret(op_bfv_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key, galois_elt,
                                        batch, (u64*) ws, (hipStream_t) stream),
                    "hegpu_bfv_apply_galois");
+}
+
+// ------------------------------------------------------------------ TFHE
+struct hegpu_tfhe_context {
+    TfheDev p{};
+    std::vector<ulonglong2> htw, hitw;
+    ulonglong2* dtw = nullptr;
+    ulonglong2* ditw = nullptr;
+    bool uploaded = false;
+};
+
+int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
+{
+    return guarded([&]() -> int {
+        if (!out) throw std::invalid_argument("null output");
+        hegpu_tfhe_context* h = new hegpu_tfhe_context();
+        const u64 q = 1152921504606877697ULL, psi = 1689264667710614ULL; // tfhe/context.cu:23-24
+        const int np = 10;
+        TfheDev& p = h->p;
+        p.mod = make_mod(q);
+        std::vector<u64> fwd = host::power_table_bitrev(psi, q, np);
+        std::vector<u64> inv = host::power_table_bitrev(host::inv_mod_prime(psi, q), q, np);
+        h->htw.resize(1024);
+        h->hitw.resize(1024);
+        for (int j = 0; j < 1024; j++) {
+            h->htw[j] = make_ulonglong2(fwd[j], shoup_companion(fwd[j], q));
+            h->hitw[j] = make_ulonglong2(inv[j], shoup_companion(inv[j], q));
+        }
+        const u64 ninv = host::inv_mod_prime(1024, q), w1n = host::mul_mod(inv[1], ninv, q);
+        p.ninv = make_ulonglong2(ninv, shoup_companion(ninv, q));
+        p.w1ninv = make_ulonglong2(w1n, shoup_companion(w1n, q));
+        p.n = 512; p.N = 1024; p.k = 1; p.bk_l = 2; p.bk_bg_bit = 10;
+        p.half_bg = (1 << p.bk_bg_bit) >> 1;
+        p.mask_mod = (1 << p.bk_bg_bit) - 1;
+        long long sum = 0; // compute_offset, tfhe/context.cu:70-81
+        for (int i = 1; i <= p.bk_l; i++) sum += 1LL << (32 - i * p.bk_bg_bit);
+        p.offset = (int) (sum * p.half_bg);
+        p.ks_base_bit = 2; p.ks_length = 8;
+        *out = h;
+        return 0;
+    });
+}
+
+void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx)
+{
+    if (!ctx) return;
+    if (ctx->dtw) (void) hipFree(ctx->dtw);
+    if (ctx->ditw) (void) hipFree(ctx->ditw);
+    delete ctx;
+}
+
+long hegpu_tfhe_context_int(const hegpu_tfhe_context* ctx, const char* name)
+{
+    if (!ctx || !name) return -1;
+    const TfheDev& p = ctx->p;
+    if (!strcmp(name, "n")) return p.n;
+    if (!strcmp(name, "N")) return p.N;
+    if (!strcmp(name, "k")) return p.k;
+    if (!strcmp(name, "bk_l")) return p.bk_l;
+    if (!strcmp(name, "bk_bg_bit")) return p.bk_bg_bit;
+    if (!strcmp(name, "ks_base_bit")) return p.ks_base_bit;
+    if (!strcmp(name, "ks_length")) return p.ks_length;
+    if (!strcmp(name, "offset")) return p.offset;
+    if (!strcmp(name, "bootkey_elems")) return (long) p.n * (p.k + 1) * p.bk_l * (p.k + 1) * p.N;
+    if (!strcmp(name, "kskey_b_elems")) return (long) p.N * p.k * p.ks_length * ((1 << p.ks_base_bit) - 1);
+    if (!strcmp(name, "kskey_a_elems")) return (long) p.N * p.k * p.ks_length * ((1 << p.ks_base_bit) - 1) * p.n;
+    return -1;
+}
+
+uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx) { return ctx ? ctx->p.mod.q : 0; }
+
+static int tfhe_need(hegpu_tfhe_context* ctx)
+{
+    if (!ctx) return fail(HEGPU_E_INVALID, "null context");
+    if (ctx->uploaded) return 0;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        (void) hipGetLastError();
+        return fail(HEGPU_E_NODEVICE, "no HIP device available: the HIP backend cannot run (no CPU fallback)");
+    }
+    hipError_t e;
+    if ((e = hipMalloc((void**) &ctx->dtw, 1024 * sizeof(ulonglong2))) != hipSuccess) return hip_ret(e, "tfhe upload");
+    if ((e = hipMalloc((void**) &ctx->ditw, 1024 * sizeof(ulonglong2))) != hipSuccess) return hip_ret(e, "tfhe upload");
+    (void) hipMemcpy(ctx->dtw, ctx->htw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    (void) hipMemcpy(ctx->ditw, ctx->hitw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    ctx->p.tw = ctx->dtw;
+    ctx->p.itw = ctx->ditw;
+    ctx->uploaded = true;
+    return 0;
+}
+
+// tfhe/operator.cu:317-323
+static int32_t encode_to_torus32(uint32_t mu, uint32_t m_size)
+{
+    uint64_t interval = ((1ULL << 63) / m_size) * 2;
+    uint64_t phase64 = mu * interval;
+    return (int32_t) (phase64 >> 32);
+}
+
+int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
+                               hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    const TfheDev& p = ctx->p;
+    const u64 polys = (u64) p.n * (p.k + 1) * p.bk_l * (p.k + 1);
+    return hip_ret(tfhe_prepare_bootkey((const u64*) boot_key, (u64*) prepared, polys, (hipStream_t) stream),
+                   "hegpu_tfhe_prepare_bootkey");
+}
+
+int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a, int32_t* out_b,
+                               const int32_t* a1, const int32_t* b1, const int32_t* a2, const int32_t* b2,
+                               int shape, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    int enc, s1, s2, m = 1;
+    const int e8 = encode_to_torus32(1, 8), e4 = encode_to_torus32(1, 4);
+    switch (gate) { // tfhe/operator.cu:24-198
+        case HEGPU_GATE_NAND: enc = e8; s1 = -1; s2 = -1; break;
+        case HEGPU_GATE_AND: enc = -e8; s1 = 1; s2 = 1; break;
+        case HEGPU_GATE_AND_FIRST_NOT: enc = -e8; s1 = -1; s2 = 1; break;
+        case HEGPU_GATE_NOR: enc = -e8; s1 = -1; s2 = -1; break;
+        case HEGPU_GATE_OR: enc = e8; s1 = 1; s2 = 1; break;
+        case HEGPU_GATE_XNOR: enc = -e4; s1 = -1; s2 = -1; m = 2; break;
+        case HEGPU_GATE_XOR: enc = e4; s1 = 1; s2 = 1; m = 2; break;
+        case HEGPU_GATE_NOT: enc = 0; s1 = -1; s2 = 1; a2 = nullptr; b2 = nullptr; break;
+        default: return fail(HEGPU_E_INVALID, "unknown gate");
+    }
+    return hip_ret(tfhe_gate_pre(out_a, out_b, a1, b1, a2, b2, enc, s1, s2, m, ctx->p.n, shape, (hipStream_t) stream),
+                   "hegpu_tfhe_gate_precompute");
+}
+
+int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
+                             const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
+                             hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
+                                     encode_to_torus32(1, 8), shape, (hipStream_t) stream),
+                   "hegpu_tfhe_bootstrapping");
+}
+
+int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
+                             int32_t* out_b, const int32_t* ks_a, const int32_t* ks_b, int shape,
+                             hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, (hipStream_t) stream),
+                   "hegpu_tfhe_key_switching");
+}
+
+int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, const int32_t* in1_b,
+                    const int32_t* in2_a, const int32_t* in2_b, int32_t* out_a, int32_t* out_b,
+                    const uint64_t* prepared_boot_key, const int32_t* ks_a, const int32_t* ks_b, int shape, void* ws,
+                    size_t ws_bytes, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    const TfheDev& p = ctx->p;
+    if (gate == HEGPU_GATE_NOT) // NOT needs no bootstrapping (tfhe/operator.cuh:640-686)
+        return hegpu_tfhe_gate_precompute(ctx, gate, out_a, out_b, in1_a, in1_b, nullptr, nullptr, shape, stream);
+    const size_t need = ((size_t) p.n + (size_t) p.k * p.N + 2) * shape * sizeof(int32_t);
+    if (!ws || ws_bytes < need) return fail(HEGPU_E_INVALID, "workspace too small");
+    int32_t* t_a = (int32_t*) ws;
+    int32_t* t_b = t_a + (size_t) p.n * shape;
+    int32_t* e_a = t_b + shape;
+    int32_t* e_b = e_a + (size_t) p.k * p.N * shape;
+    if ((r = hegpu_tfhe_gate_precompute(ctx, gate, t_a, t_b, in1_a, in1_b, in2_a, in2_b, shape, stream))) return r;
+    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e_a, e_b, shape, stream))) return r;
+    return hegpu_tfhe_key_switching(ctx, e_a, e_b, out_a, out_b, ks_a, ks_b, shape, stream);
 }
 
 } // extern "C"

@@ -1,0 +1,418 @@
+// tfhe.hip -- TFHE gate bootstrapping (config C5) for gfx950.
+//
+// Replaces the reference's tfhe_*_pre_comp_kernel, the 2 x n = 1024 launches of
+// tfhe_bootstrapping_kernel_{unique,regular}_step{1,2}, tfhe_sample_extraction_kernel
+// and tfhe_key_switching_kernel (reference src/lib/kernel/bootstrapping.cu:378-1436,
+// host loop src/lib/host/tfhe/operator.cu:200-294) and SmallForwardNTT /
+// SmallInverseNTT (src/lib/kernel/small_ntt.cu:10-126).
+//
+// MI355X design: ONE persistent workgroup per gate runs all n = 512 blind-rotate
+// iterations.  The accumulator (2 x 1024 int32 = 8 KiB) never leaves LDS, where
+// the reference round-trips a 64 KiB product buffer and the accumulator through
+// HBM 512 times per gate.  A workgroup is 4 wavefronts; wavefront (y,z) owns
+// the gadget digit z of accumulator polynomial y and runs its 1024-point
+// negacyclic NTT alone: 16 coefficients per lane, radix-16 / radix-16 / radix-4
+// rounds with wave-local LDS exchanges (no s_barrier inside a transform).  The
+// external product is reduced across the four wavefronts through the same
+// 32 KiB of LDS, wavefronts 0/1 run the two inverse transforms and update the
+// accumulator.  All arithmetic is exact (60-bit NTT prime), so the int32 torus
+// results are identical to the reference's.
+#include "tfhe.hpp"
+
+namespace hegpu {
+
+#define TF_N 1024
+#define TF_THREADS 256
+
+__device__ __forceinline__ u64 tcsub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
+
+struct TQ {
+    u64 q, q4;
+    u32 nq0, nq1;
+};
+
+// 9-multiply lazy Shoup product, result in [0,4q) (see ntt.hip:shoup_lazy)
+__device__ __forceinline__ u64 tshoup(u64 y, ulonglong2 w, const TQ& c)
+{
+    const u32 y0 = (u32) y, y1 = (u32) (y >> 32);
+    const u32 w0 = (u32) w.x, w1 = (u32) (w.x >> 32), p0 = (u32) w.y, p1 = (u32) (w.y >> 32);
+    const u64 A = (u64) y0 * p1;
+    const u64 B = (u64) y1 * p0 + (u32) A;
+    const u64 qh = (u64) y1 * p1 + (A >> 32) + (B >> 32);
+    const u32 h0 = (u32) qh, h1 = (u32) (qh >> 32);
+    u64 acc = (u64) y0 * w0;
+    acc += (u64) h0 * c.nq0;
+    const u32 hi = y0 * w1 + y1 * w0 + h0 * c.nq1 + h1 * c.nq0;
+    return acc + ((u64) hi << 32);
+}
+
+__device__ __forceinline__ void t_ct(u64& x, u64& y, ulonglong2 w, const TQ& c)
+{
+    u64 u = tcsub(x, c.q4);
+    u64 t = tshoup(y, w, c);
+    x = u + t;
+    y = u + c.q4 - t;
+}
+
+__device__ __forceinline__ void t_gs(u64& x, u64& y, ulonglong2 w, const TQ& c)
+{
+    u64 s = x + y;
+    u64 d = x + c.q4 - y;
+    x = tcsub(s, c.q4);
+    y = tshoup(d, w, c);
+}
+
+// LDS staging index: one pad element per 16 so that the 16-contiguous-per-lane
+// and the 64-element-block access patterns are both bank-conflict free.
+#define TF_BUF (TF_N + TF_N / 16)
+__device__ __forceinline__ int bi(int e) { return e + (e >> 4); }
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Forward 1024-point NTT by one wavefront.  In: x[k] = element lane + 64k
+// (any value < 8q).  Out: x[k] = slot 16*lane + k, canonical.  `buf` = this
+// wave's 1024-element LDS area.
+__device__ __forceinline__ void wave_ntt1024(u64 (&x)[16], u64* buf, const ulonglong2* __restrict__ tw,
+                                             const TQ& c, int lane)
+{
+    // stages 0-3 (strides 512..64): roots 1 | 2,3 | 4..7 | 8..15, wave-uniform
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = tw[(1 << s) + b];
+#pragma unroll
+            for (int j = 0; j < half; j++) t_ct(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(lane + 64 * k)] = x[k];
+    wave_fence();
+    // stages 4-7 inside 64-element blocks: lane = (block b, c0), elements 64b + c0 + 4m
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[bi(64 * b + c0 + 4 * m)];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = tw[((16 + b) << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) t_ct(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = x[m];
+    wave_fence();
+    // stages 8,9 on 16 contiguous elements per lane
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = buf[bi(16 * lane + k)];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const ulonglong2 w8 = tw[256 + 4 * lane + g];
+        t_ct(x[4 * g + 0], x[4 * g + 2], w8, c);
+        t_ct(x[4 * g + 1], x[4 * g + 3], w8, c);
+        const ulonglong2 w9a = tw[512 + 8 * lane + 2 * g], w9b = tw[512 + 8 * lane + 2 * g + 1];
+        t_ct(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        t_ct(x[4 * g + 2], x[4 * g + 3], w9b, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = tcsub(tcsub(tcsub(x[k], c.q4), 2 * c.q), c.q);
+    wave_fence();
+}
+
+// Inverse 1024-point NTT by one wavefront.  In: x[k] = slot 16*lane + k
+// (canonical).  Out: x[k] = coefficient lane + 64k, canonical, N^-1 applied.
+__device__ __forceinline__ void wave_intt1024(u64 (&x)[16], u64* buf, const ulonglong2* __restrict__ itw,
+                                              ulonglong2 ninv, ulonglong2 w1ninv, const TQ& c, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const ulonglong2 w9a = itw[512 + 8 * lane + 2 * g], w9b = itw[512 + 8 * lane + 2 * g + 1];
+        t_gs(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        t_gs(x[4 * g + 2], x[4 * g + 3], w9b, c);
+        const ulonglong2 w8 = itw[256 + 4 * lane + g];
+        t_gs(x[4 * g + 0], x[4 * g + 2], w8, c);
+        t_gs(x[4 * g + 1], x[4 * g + 3], w8, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(16 * lane + k)] = x[k];
+    wave_fence();
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[bi(64 * b + c0 + 4 * m)];
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = itw[((16 + b) << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) t_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = x[m];
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = buf[bi(lane + 64 * k)];
+#pragma unroll
+    for (int s = 3; s >= 1; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = itw[(1 << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) t_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { // last stage with N^-1 folded in, exact
+        u64 s = x[j] + x[j + 8];
+        u64 d = x[j] + c.q4 - x[j + 8];
+        u64 r0 = tshoup(s, ninv, c), r1 = tshoup(d, w1ninv, c);
+        x[j] = tcsub(tcsub(r0, 2 * c.q), c.q);
+        x[j + 8] = tcsub(tcsub(r1, 2 * c.q), c.q);
+    }
+    wave_fence();
+}
+
+// reference bootstrapping.cu:662-674
+__device__ __forceinline__ int modswitch(int input, int modulus_log)
+{
+    const u64 range_log = 63 - modulus_log;
+    const u64 half_range = 1ULL << (range_log - 1);
+    const u64 r = (((u64) (u32) input) << 32) + half_range;
+    return (int) (r >> range_log);
+}
+
+// Boot key re-layout: reference order [i][y][z][c][N] (slot s) -> [i][y][z][c][k][lane]
+// with s = 16*lane + k, so that a wavefront reads its 16 slots per lane with
+// fully coalesced 512-byte loads.
+__global__ __launch_bounds__(256) void k_tfhe_prepare_bootkey(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                              u64 polys)
+{
+    const u64 p = blockIdx.x;
+    if (p >= polys) return;
+    for (int t = threadIdx.x; t < TF_N; t += 256) {
+        const int k = t >> 6, lane = t & 63;
+        dst[p * TF_N + t] = src[p * TF_N + 16 * lane + k];
+    }
+}
+
+// Blind rotation + sample extraction for one gate per workgroup.
+// in_a [shape][n], in_b [shape]; bk = prepared boot key; out_a [shape][N], out_b [shape].
+__global__ __launch_bounds__(TF_THREADS) void k_tfhe_blind_rotate(const int* __restrict__ in_a,
+                                                                  const int* __restrict__ in_b,
+                                                                  const u64* __restrict__ bk, int* __restrict__ out_a,
+                                                                  int* __restrict__ out_b, TfheDev p, int encoded)
+{
+    __shared__ int acc[2][TF_N];
+    __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int y = wv >> 1, z = wv & 1;
+    const int g = blockIdx.x;
+    const int n = p.n;
+    TQ c;
+    c.q = p.mod.q;
+    c.q4 = 4 * c.q;
+    {
+        u64 nq = 0 - c.q;
+        c.nq0 = (u32) nq;
+        c.nq1 = (u32) (nq >> 32);
+    }
+    const u64 threshold = c.q >> 1;
+
+    // acc_0 = (0, X^(2N - b~) * mu)   (bootstrapping.cu:905-933)
+    {
+        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
+        for (int j = t; j < TF_N; j += TF_THREADS) {
+            acc[0][j] = 0;
+            acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
+        }
+    }
+    __syncthreads();
+
+    const int shift = 32 - 10 * (z + 1);
+    for (int i = 0; i < n; i++) {
+        const int aN = modswitch(in_a[(u64) g * n + i], 10);
+        // (X^a~ * acc_y - acc_y), gadget digit z, lifted to Z_q  (bootstrapping.cu:1063-1119)
+        u64 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = lane + 64 * k;
+            int r;
+            if (aN < TF_N) r = (j < aN) ? -acc[y][TF_N - aN + j] : acc[y][j - aN];
+            else {
+                const int m = aN - TF_N;
+                r = (j < m) ? acc[y][TF_N - m + j] : -acc[y][j - m];
+            }
+            const u32 diff = (u32) r - (u32) acc[y][j];
+            const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
+            x[k] = (d < 0) ? (u64) (c.q + (long long) d) : (u64) d;
+        }
+        wave_ntt1024(x, buf[wv], p.tw, c, lane);
+        // external product terms with BK_i[y][z][c], c = 0,1
+        const u64* bkp = bk + ((((u64) i * 2 + y) * 2 + z) * 2) * TF_N + lane;
+        u64 p0[16], p1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            p0[k] = mul_barrett(x[k], bkp[64 * k], p.mod);
+            p1[k] = mul_barrett(x[k], bkp[TF_N + 64 * k], p.mod);
+        }
+        __syncthreads(); // every wave is done with its NTT staging area
+        // reduction over the four (y,z) waves through LDS
+        if (wv >= 2) {
+            u64* d0 = buf[2 * (wv - 2)];
+            u64* d1 = buf[2 * (wv - 2) + 1];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                d0[bi(lane + 64 * k)] = p0[k];
+                d1[bi(lane + 64 * k)] = p1[k];
+            }
+        }
+        __syncthreads();
+        if (wv < 2) {
+            const u64* s0 = buf[2 * wv];
+            const u64* s1 = buf[2 * wv + 1];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                p0[k] = add_mod(p0[k], s0[bi(lane + 64 * k)], c.q);
+                p1[k] = add_mod(p1[k], s1[bi(lane + 64 * k)], c.q);
+            }
+        }
+        __syncthreads();
+        if (wv < 2) {
+            // wave 0 keeps c=0 and hands c=1 to wave 1; wave 1 keeps c=1, hands c=0
+            u64* give = buf[wv];
+#pragma unroll
+            for (int k = 0; k < 16; k++) give[bi(lane + 64 * k)] = (wv == 0) ? p1[k] : p0[k];
+        }
+        __syncthreads();
+        if (wv < 2) {
+            const u64* take = buf[1 - wv];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64 mine = (wv == 0) ? p0[k] : p1[k];
+                x[k] = add_mod(mine, take[bi(lane + 64 * k)], c.q);
+            }
+        }
+        __syncthreads();
+        if (wv < 2) {
+            wave_intt1024(x, buf[wv], p.itw, p.ninv, p.w1ninv, c, lane);
+            // centred lift to int32 and accumulate (bootstrapping.cu:1294-1311)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int post = (x[k] >= threshold) ? (int) (long long) (x[k] - c.q) : (int) (long long) x[k];
+                const int j = lane + 64 * k;
+                acc[wv][j] = (int) ((u32) acc[wv][j] + (u32) post);
+            }
+        }
+        __syncthreads();
+    }
+    // sample extraction at index 0 (bootstrapping.cu:1314-1347), k = 1
+    for (int j = t; j < TF_N; j += TF_THREADS)
+        out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
+    if (t == 0) out_b[g] = acc[1][0];
+}
+
+// out = enc + m*(s1*in1 + s2*in2) on the 32-bit torus (bootstrapping.cu:378-660)
+__global__ __launch_bounds__(256) void k_tfhe_gate_pre(int* __restrict__ out_a, int* __restrict__ out_b,
+                                                       const int* __restrict__ a1, const int* __restrict__ b1,
+                                                       const int* __restrict__ a2, const int* __restrict__ b2,
+                                                       int encoded, int s1, int s2, int m, int n)
+{
+    const int g = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        u32 v = 0;
+        const u32 x1 = (u32) a1[(u64) g * n + i];
+        const u32 x2 = a2 ? (u32) a2[(u64) g * n + i] : 0u;
+        v = (s1 > 0) ? v + x1 : v - x1;
+        v = (s2 > 0) ? v + x2 : v - x2;
+        out_a[(u64) g * n + i] = (int) ((u32) m * v);
+    }
+    if (threadIdx.x == 0) {
+        u32 v = (u32) encoded;
+        const u32 y1 = (u32) m * (u32) b1[g];
+        const u32 y2 = b2 ? (u32) m * (u32) b2[g] : 0u;
+        v = (s1 > 0) ? v + y1 : v - y1;
+        v = (s2 > 0) ? v + y2 : v - y2;
+        out_b[g] = (int) v;
+    }
+}
+
+// tfhe_key_switching_kernel (bootstrapping.cu:1349-1436): one workgroup per
+// gate, 256 threads x 2 output coefficients (n = 512); the digit of each input
+// coefficient is wave-uniform, key rows are 2 KiB coalesced reads.
+__global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restrict__ in_a,
+                                                            const int* __restrict__ in_b, int* __restrict__ out_a,
+                                                            int* __restrict__ out_b, const int* __restrict__ ks_a,
+                                                            const int* __restrict__ ks_b, int bb, int len, int n,
+                                                            int Nk)
+{
+    const int g = blockIdx.x, t = threadIdx.x;
+    const int mask = (1 << bb) - 1;
+    const u32 precision_offset = 1u << (32 - (1 + bb * len));
+    u32 acc0 = 0, acc1 = 0, accb = (t == 0) ? (u32) in_b[g] : 0u;
+    const int* pa = in_a + (u64) g * Nk;
+    for (int i = 0; i < Nk; i++) {
+        const u32 a = (u32) pa[i] + precision_offset;
+#pragma unroll
+        for (int i2 = 0; i2 < 8; i2++) {
+            if (i2 >= len) break;
+            const int d = (int) ((a >> (32 - (i2 + 1) * bb)) & (u32) mask);
+            if (d != 0) {
+                const u64 row = ((u64) i * len + i2) * mask + (d - 1);
+                const int* ka = ks_a + row * n;
+                acc0 -= (u32) ka[t];
+                if (t + 256 < n) acc1 -= (u32) ka[t + 256];
+                if (t == 0) accb -= (u32) ks_b[row];
+            }
+        }
+    }
+    out_a[(u64) g * n + t] = (int) acc0;
+    if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1;
+    if (t == 0) out_b[g] = (int) accb;
+}
+
+hipError_t tfhe_prepare_bootkey(const u64* src, u64* dst, u64 polys, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tfhe_prepare_bootkey, dim3((unsigned) polys), dim3(256), 0, st, src, dst, polys);
+    return hipGetLastError();
+}
+
+hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
+                             int* out_b, int encoded, int shape, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
+                       out_b, p, encoded);
+    return hipGetLastError();
+}
+
+hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
+                         int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tfhe_gate_pre, dim3(shape), dim3(256), 0, st, out_a, out_b, a1, b1, a2, b2, encoded, s1, s2,
+                       m, n);
+    return hipGetLastError();
+}
+
+hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,
+                              const int* ks_a, const int* ks_b, int shape, hipStream_t st)
+{
+    if (p.n > 512 || p.ks_length > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tfhe_key_switching, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,
+                       p.ks_base_bit, p.ks_length, p.n, p.N * p.k);
+    return hipGetLastError();
+}
+
+} // namespace hegpu

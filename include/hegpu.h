@@ -166,6 +166,50 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_s
                            uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int batch, void* ws,
                            size_t ws_bytes, hegpu_stream stream);
 
+/* ------------------------------------------------------------------ TFHE
+ * Gate bootstrapping on the reference's fixed STD128 set
+ * (src/lib/host/tfhe/context.cu:15-57: n=512, N=1024, k=1, l=2, Bg=2^10,
+ * ks_base_bit=2, ks_length=8, NTT prime 1152921504606877697).
+ * LWE ciphertexts: a [shape][n] + b [shape], int32 torus
+ * (src/lib/host/tfhe/operator.cu:296-314).  Boot key: uint64 NTT domain,
+ * reference layout [n][k+1][l][k+1][N] (bootstrapping.cu:1037-1041);
+ * key-switch key a [N*k][ks_length][base-1][n], b [N*k][ks_length][base-1]
+ * (bootstrapping.cu:1385-1412). */
+typedef struct hegpu_tfhe_context hegpu_tfhe_context;
+enum {
+    HEGPU_GATE_NAND = 0, HEGPU_GATE_AND = 1, HEGPU_GATE_AND_FIRST_NOT = 2, HEGPU_GATE_NOR = 3,
+    HEGPU_GATE_OR = 4, HEGPU_GATE_XNOR = 5, HEGPU_GATE_XOR = 6, HEGPU_GATE_NOT = 7
+};
+/* HEContextImpl<TFHE>::HEContextImpl (tfhe/context.cu:15-57); host only */
+int hegpu_tfhe_context_create(hegpu_tfhe_context** out);
+void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
+/* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems","kskey_a_elems","kskey_b_elems" */
+long hegpu_tfhe_context_int(const hegpu_tfhe_context* ctx, const char* name);
+uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx);
+/* one-time device re-layout of a boot key (reference layout -> wave-coalesced layout) */
+int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
+                               hegpu_stream stream);
+/* tfhe_{nand,and,and_first_not,nor,or,xnor,xor}_pre_comp_kernel / tfhe_not_comp_kernel
+ * (src/lib/kernel/bootstrapping.cu:378-660); in2_* ignored for NOT */
+int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a, int32_t* out_b,
+                               const int32_t* in1_a, const int32_t* in1_b, const int32_t* in2_a,
+                               const int32_t* in2_b, int shape, hegpu_stream stream);
+/* HELogicOperator<TFHE>::bootstrapping (tfhe/operator.cu:200-270): blind rotate with
+ * test vector mu = encode_to_torus32(1,8) + sample extraction; out_a [shape][k*N] */
+int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
+                             const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
+                             hegpu_stream stream);
+/* HELogicOperator<TFHE>::key_switching (tfhe/operator.cu:272-294) */
+int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
+                             int32_t* out_b, const int32_t* ks_key_a, const int32_t* ks_key_b, int shape,
+                             hegpu_stream stream);
+/* HELogicOperator<TFHE>::{NAND,AND,NOR,OR,XNOR,XOR} (tfhe/operator.cuh:53-640):
+ * precompute -> bootstrapping -> key switching.  ws: (n + k*N + 2) * shape int32. */
+int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, const int32_t* in1_b,
+                    const int32_t* in2_a, const int32_t* in2_b, int32_t* out_a, int32_t* out_b,
+                    const uint64_t* prepared_boot_key, const int32_t* ks_key_a, const int32_t* ks_key_b, int shape,
+                    void* ws, size_t ws_bytes, hegpu_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,16 @@ def lib():
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_keyswitch_mac.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.o_divide_round_lastq.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    i32p = ctypes.c_void_p
+    L.o_tfhe_create.restype = ctypes.c_void_p
+    L.o_tfhe_free.argtypes = [vp]
+    L.o_tfhe_prime.restype = u64
+    L.o_tfhe_prime.argtypes = [vp]
+    L.o_tfhe_encode_to_torus32.restype = ctypes.c_int32
+    L.o_tfhe_encode_to_torus32.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    L.o_tfhe_gate_pre.argtypes = [i32p, i32p, i32p, i32p, i32p, i32p, ctypes.c_int32, ci, ci, ci, ci, ci]
+    L.o_tfhe_bootstrapping.argtypes = [vp, i32p, i32p, vp, i32p, i32p, ctypes.c_int32, ci]
+    L.o_tfhe_key_switching.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, ci]
     _lib = L
     return L
 
@@ -197,3 +207,54 @@ class OracleContext:
         out = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
         self.L.o_bfv_apply_galois(self.h, _p(ct), _p(out), _p(key), galois_elt)
         return out
+
+
+# gate id -> (encoded numerator/denominator sign, s1, s2, m)  (tfhe/operator.cu:24-198)
+TFHE_GATES = {0: (+1, 8, -1, -1, 1), 1: (-1, 8, 1, 1, 1), 2: (-1, 8, -1, 1, 1), 3: (-1, 8, -1, -1, 1),
+              4: (+1, 8, 1, 1, 1), 5: (-1, 4, -1, -1, 2), 6: (+1, 4, 1, 1, 2)}
+
+
+class OracleTfhe:
+    """CPU oracle of the TFHE gate path (o_tfhe.c)."""
+
+    n, N, k, l, ks_length, ks_base = 512, 1024, 1, 2, 8, 4
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.o_tfhe_create()
+        self.prime = int(self.L.o_tfhe_prime(self.h))
+        self.mu = int(self.L.o_tfhe_encode_to_torus32(1, 8))
+
+    def __del__(self):
+        try:
+            self.L.o_tfhe_free(self.h)
+        except Exception:
+            pass
+
+    def gate_pre(self, gate, a1, b1, a2, b2):
+        sign, den, s1, s2, m = TFHE_GATES[gate]
+        enc = sign * int(self.L.o_tfhe_encode_to_torus32(1, den))
+        shape = b1.shape[0]
+        oa = np.zeros(shape * self.n, dtype=np.int32)
+        ob = np.zeros(shape, dtype=np.int32)
+        self.L.o_tfhe_gate_pre(_p(oa), _p(ob), _p(a1), _p(b1), _p(a2), _p(b2), enc, s1, s2, m, self.n, shape)
+        return oa, ob
+
+    def bootstrapping(self, a, b, boot_key):
+        shape = b.shape[0]
+        oa = np.zeros(shape * self.k * self.N, dtype=np.int32)
+        ob = np.zeros(shape, dtype=np.int32)
+        self.L.o_tfhe_bootstrapping(self.h, _p(a), _p(b), _p(boot_key), _p(oa), _p(ob), self.mu, shape)
+        return oa, ob
+
+    def key_switching(self, a, b, ks_a, ks_b):
+        shape = b.shape[0]
+        oa = np.zeros(shape * self.n, dtype=np.int32)
+        ob = np.zeros(shape, dtype=np.int32)
+        self.L.o_tfhe_key_switching(self.h, _p(a), _p(b), _p(oa), _p(ob), _p(ks_a), _p(ks_b), shape)
+        return oa, ob
+
+    def gate(self, gate, a1, b1, a2, b2, boot_key, ks_a, ks_b):
+        ta, tb = self.gate_pre(gate, a1, b1, a2, b2)
+        ea, eb = self.bootstrapping(ta, tb, boot_key)
+        return self.key_switching(ea, eb, ks_a, ks_b)

@@ -166,6 +166,19 @@ void o_ckks_mul_relin_batch(const octx_t* c, const u64* ct1, const u64* ct2,
                             u64* out3, const u64* relin_key, int depth,
                             int batch);
 
+/* ---- TFHE gate bootstrapping (config C5; o_tfhe.c) ---- */
+typedef struct otfhe otfhe_t;
+otfhe_t* o_tfhe_create(void);
+void o_tfhe_free(otfhe_t* c);
+u64 o_tfhe_prime(const otfhe_t* c);
+int32_t o_tfhe_encode_to_torus32(uint32_t mu, uint32_t m_size);
+void o_tfhe_gate_pre(int32_t* out_a, int32_t* out_b, const int32_t* a1, const int32_t* b1, const int32_t* a2,
+                     const int32_t* b2, int32_t encoded, int s1, int s2, int m, int n, int shape);
+void o_tfhe_bootstrapping(const otfhe_t* c, const int32_t* in_a, const int32_t* in_b, const u64* boot_key,
+                          int32_t* out_a, int32_t* out_b, int32_t encoded, int shape);
+void o_tfhe_key_switching(const otfhe_t* c, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
+                          int32_t* out_b, const int32_t* ks_a, const int32_t* ks_b, int shape);
+
 #ifdef __cplusplus
 }
 #endif
