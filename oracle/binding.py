@@ -90,6 +90,8 @@ def lib():
     L.o_tfhe_gate_pre.argtypes = [i32p, i32p, i32p, i32p, i32p, i32p, ctypes.c_int32, ci, ci, ci, ci, ci]
     L.o_tfhe_bootstrapping.argtypes = [vp, i32p, i32p, vp, i32p, i32p, ctypes.c_int32, ci]
     L.o_tfhe_key_switching.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, ci]
+    L.o_tfhe_to_ntt.argtypes = [vp, i32p, vp]
+    L.o_tfhe_polymul.argtypes = [vp, i32p, i32p, i32p]
     _lib = L
     return L
 
@@ -230,6 +232,17 @@ class OracleTfhe:
             self.L.o_tfhe_free(self.h)
         except Exception:
             pass
+
+    def to_ntt(self, poly):
+        out = np.zeros(self.N, dtype=np.uint64)
+        self.L.o_tfhe_to_ntt(self.h, _p(np.ascontiguousarray(poly, dtype=np.int32)), _p(out))
+        return out
+
+    def polymul(self, a, s):
+        out = np.zeros(self.N, dtype=np.int32)
+        self.L.o_tfhe_polymul(self.h, _p(np.ascontiguousarray(a, dtype=np.int32)),
+                              _p(np.ascontiguousarray(s, dtype=np.int32)), _p(out))
+        return out
 
     def gate_pre(self, gate, a1, b1, a2, b2):
         sign, den, s1, s2, m = TFHE_GATES[gate]

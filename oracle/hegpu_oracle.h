@@ -176,6 +176,8 @@ void o_tfhe_gate_pre(int32_t* out_a, int32_t* out_b, const int32_t* a1, const in
                      const int32_t* b2, int32_t encoded, int s1, int s2, int m, int n, int shape);
 void o_tfhe_bootstrapping(const otfhe_t* c, const int32_t* in_a, const int32_t* in_b, const u64* boot_key,
                           int32_t* out_a, int32_t* out_b, int32_t encoded, int shape);
+void o_tfhe_to_ntt(const otfhe_t* c, const int32_t* poly, u64* out);
+void o_tfhe_polymul(const otfhe_t* c, const int32_t* a, const int32_t* s, int32_t* out);
 void o_tfhe_key_switching(const otfhe_t* c, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
                           int32_t* out_b, const int32_t* ks_a, const int32_t* ks_b, int shape);
 

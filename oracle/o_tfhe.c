@@ -185,3 +185,26 @@ void o_tfhe_key_switching(const otfhe_t* c, const int32_t* in_a, const int32_t* 
         out_b[g] = (int32_t) acc_b;
     }
 }
+
+/* ---- helpers for the semantic tests (key generation lives in tests/) ---- */
+/* int32 torus polynomial -> NTT domain residues mod the TFHE prime */
+void o_tfhe_to_ntt(const otfhe_t* c, const int32_t* poly, u64* out)
+{
+    for (int j = 0; j < T_N; j++)
+        out[j] = (poly[j] < 0) ? (u64) (c->prime.value + (long long) poly[j]) : (u64) poly[j];
+    o_ntt_limb(out, c->ntt, &c->prime, T_NP);
+}
+
+/* exact negacyclic product of an int32 torus polynomial with a small integer
+ * polynomial (|s_j| <= 1), result wrapped to int32 */
+void o_tfhe_polymul(const otfhe_t* c, const int32_t* a, const int32_t* s, int32_t* out)
+{
+    u64 x[T_N], y[T_N];
+    o_tfhe_to_ntt(c, a, x);
+    o_tfhe_to_ntt(c, s, y);
+    for (int j = 0; j < T_N; j++) x[j] = o_mult(x[j], y[j], &c->prime);
+    o_intt_limb(x, c->intt, &c->prime, c->n_inverse, T_NP);
+    const u64 th = c->prime.value >> 1;
+    for (int j = 0; j < T_N; j++)
+        out[j] = (x[j] >= th) ? (int32_t) (long long) (x[j] - c->prime.value) : (int32_t) (long long) x[j];
+}
