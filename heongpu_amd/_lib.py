@@ -38,7 +38,8 @@ SIGNATURES = [
      [voidp, c_int, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
     ("hegpu_cipher_broadcast", c_int, [voidp, u64p, u64, u64p, u64, c_int, c_int, c_int, c_int, c_int, voidp]),
     ("hegpu_keyswitch_multiply_accumulate", c_int,
-     [voidp, u64p, u64, u64p, u64p, u64, c_int, c_int, c_int, c_int, c_int, voidp]),
+     [voidp, u64p, u64, u64p, u64p, u64, c_int, c_int, c_int, c_int, c_int, c_int, voidp]),
+    ("hegpu_base_conversion_DtoQtilde", c_int, [voidp, u64p, u64, u64p, u64, c_int, c_int, voidp]),
     ("hegpu_divide_round_lastq", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
     ("hegpu_divide_round_lastq_permute", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),

@@ -175,11 +175,15 @@ class Context:
         _check(self._lib.hegpu_cipher_broadcast(self._h, _ptr(src), s_in, _ptr(out), s_out, digits, nmods, split,
                                                 level, batch, stream if stream is not None else _stream()))
 
-    def keyswitch_multiply_accumulate(self, src, s_in, key, out, s_out, digits, nmods, key_limbs, p_row, batch=1,
-                                      stream=None):
+    def keyswitch_multiply_accumulate(self, src, s_in, key, out, s_out, digits, nmods, key_limbs, split, level,
+                                      batch=1, stream=None):
         _check(self._lib.hegpu_keyswitch_multiply_accumulate(self._h, _ptr(src), s_in, _ptr(key), _ptr(out), s_out,
-                                                             digits, nmods, key_limbs, p_row, batch,
+                                                             digits, nmods, key_limbs, split, level, batch,
                                                              stream if stream is not None else _stream()))
+
+    def base_conversion_DtoQtilde(self, src, s_in, out, s_out, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_base_conversion_DtoQtilde(self._h, _ptr(src), s_in, _ptr(out), s_out, depth, batch,
+                                                         stream if stream is not None else _stream()))
 
     def divide_round_lastq(self, src, s_in, ct, s_ct, out, s_out, switchkey=0, batch=1, stream=None):
         _check(self._lib.hegpu_divide_round_lastq(self._h, _ptr(src), s_in, _ptr(ct), s_ct, _ptr(out), s_out,

@@ -291,14 +291,31 @@ int hegpu_cipher_broadcast(hegpu_context* ctx, const uint64_t* in, uint64_t in_s
 
 int hegpu_keyswitch_multiply_accumulate(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
                                         const uint64_t* key, uint64_t* out, uint64_t out_stride, int digits,
-                                        int nmods, int key_limbs, int p_row, int batch, hegpu_stream stream)
+                                        int nmods, int key_limbs, int split, int level, int batch,
+                                        hegpu_stream stream)
 {
     NEED_CTX(ctx);
     const Context& c = ctx->c;
     return hip_ret(rns_keyswitch_mac((const u64*) in, in_stride, (const u64*) key, (u64*) out, out_stride,
-                                     c.plan_qp.mods, c.n_power, digits, nmods, key_limbs, p_row, batch,
+                                     c.plan_qp.mods, c.n_power, digits, nmods, key_limbs, split, level, batch,
                                      (hipStream_t) stream),
                    "hegpu_keyswitch_multiply_accumulate");
+}
+
+int hegpu_base_conversion_DtoQtilde(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                                    uint64_t out_stride, int depth, int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (c.P_size < 2) return fail(HEGPU_E_LOGIC, "method II tables exist only when P_size > 1");
+    if (depth < 0 || depth >= (int) c.m2_levels.size()) return fail(HEGPU_E_INVALID, "invalid depth");
+    const Context::M2Level& L = c.m2_levels[depth];
+    return hip_ret(rns_base_conversion_DtoQtilde((const u64*) in, in_stride, (u64*) out, out_stride, c.plan_qp.mods,
+                                                 c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
+                                                 c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
+                                                 c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc,
+                                                 c.Q_size - depth, depth, batch, (hipStream_t) stream),
+                   "hegpu_base_conversion_DtoQtilde");
 }
 
 int hegpu_divide_round_lastq(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
@@ -362,8 +379,6 @@ size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int ba
 #define CHECK_OP(ctx, want_scheme, op, depth, batch, ws, ws_bytes)                                            \
     do {                                                                                                      \
         if ((ctx)->c.scheme != (want_scheme)) return fail(HEGPU_E_INVALID, "context scheme mismatch");        \
-        if ((ctx)->c.P_size != 1)                                                                             \
-            return fail(HEGPU_E_LOGIC, "key-switching method II (P_size > 1) is not implemented yet");        \
         if ((batch) <= 0) return fail(HEGPU_E_INVALID, "batch must be positive");                             \
         if ((depth) < 0 || (depth) >= (ctx)->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");         \
         if ((op) && (!(ws) || (ws_bytes) < hegpu_workspace_bytes(ctx, op, depth, batch)))                     \
@@ -386,8 +401,10 @@ int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs
 {
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_RELIN, depth, batch, ws, ws_bytes);
-    return hip_ret(op_ckks_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, depth, batch, (u64*) ws,
-                                       (hipStream_t) stream),
+    return hip_ret(ctx->c.P_size == 1 ? op_ckks_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, depth, batch,
+                                                            (u64*) ws, (hipStream_t) stream)
+                                      : op_ckks_relinearize_II(ctx->c, (u64*) ct, cs, (const u64*) key, depth, batch,
+                                                               (u64*) ws, (hipStream_t) stream),
                    "hegpu_ckks_relinearize_inplace");
 }
 
@@ -408,8 +425,11 @@ int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs,
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
     if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
-    return hip_ret(op_ckks_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key, galois_elt,
-                                        depth, batch, (u64*) ws, (hipStream_t) stream),
+    return hip_ret(ctx->c.P_size == 1
+                       ? op_ckks_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
+                                              galois_elt, depth, batch, (u64*) ws, (hipStream_t) stream)
+                       : op_ckks_apply_galois_II(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
+                                                 galois_elt, depth, batch, (u64*) ws, (hipStream_t) stream),
                    "hegpu_ckks_apply_galois");
 }
 
@@ -431,8 +451,10 @@ int hegpu_bfv_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs,
 {
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_BFV, OP_BFV_RELIN, 0, batch, ws, ws_bytes);
-    return hip_ret(op_bfv_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, batch, (u64*) ws,
-                                      (hipStream_t) stream),
+    return hip_ret(ctx->c.P_size == 1 ? op_bfv_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, batch, (u64*) ws,
+                                                           (hipStream_t) stream)
+                                      : op_bfv_relinearize_II(ctx->c, (u64*) ct, cs, (const u64*) key, batch,
+                                                              (u64*) ws, (hipStream_t) stream),
                    "hegpu_bfv_relinearize_inplace");
 }
 
@@ -443,8 +465,11 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, 
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_BFV, OP_BFV_GALOIS, 0, batch, ws, ws_bytes);
     if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
-    return hip_ret(op_bfv_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key, galois_elt,
-                                       batch, (u64*) ws, (hipStream_t) stream),
+    return hip_ret(ctx->c.P_size == 1
+                       ? op_bfv_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
+                                             galois_elt, batch, (u64*) ws, (hipStream_t) stream)
+                       : op_bfv_apply_galois_II(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
+                                                galois_elt, batch, (u64*) ws, (hipStream_t) stream),
                    "hegpu_bfv_apply_galois");
 }
 

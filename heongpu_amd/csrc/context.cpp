@@ -1,6 +1,7 @@
 // context.cpp -- see context.hpp.
 #include "context.hpp"
 #include "host_params.hpp"
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -80,6 +81,56 @@ void Context::build_host()
         }
         host["new_prime_locations"] = ploc;
         host["new_input_locations"] = iloc;
+    }
+
+    if (P > 1) {
+        // KeySwitchParameterGenerator (reference src/lib/kernel/contextpool.cpp:11-438):
+        // greedy digits of m primes (m = 2 for BFV, P_size for CKKS), per depth for CKKS
+        m2_width = (scheme == SCHEME_BFV) ? 2 : P;
+        const int levels = (scheme == SCHEME_BFV) ? 1 : Q;
+        vec Ij, Iloc, mi, matrix, prod;
+        m2_levels.clear();
+        for (int lvl = 0; lvl < levels; lvl++) {
+            const int l = Q - lvl, rc = Qp - lvl;
+            vec base(primes.begin(), primes.begin() + l);
+            base.insert(base.end(), primes.begin() + Q, primes.end());
+            M2Level L;
+            L.rc = rc;
+            L.off_digits = (int) Ij.size();
+            L.off_mi = (int) mi.size();
+            L.off_matrix = (int) matrix.size();
+            L.off_prod = (int) prod.size();
+            for (int s0 = 0; s0 < l; s0 += m2_width) {
+                const int cnt = std::min(m2_width, l - s0);
+                Ij.push_back(cnt);
+                Iloc.push_back(s0);
+                L.d++;
+                for (int k = 0; k < rc; k++)
+                    for (int i = 0; i < cnt; i++) {
+                        u64 acc = 1;
+                        for (int j = 0; j < cnt; j++)
+                            if (j != i) acc = mul_mod(acc, base[s0 + j] % base[k], base[k]);
+                        matrix.push_back(acc);
+                    }
+                for (int i = 0; i < cnt; i++) {
+                    u64 acc = 1;
+                    for (int j = 0; j < cnt; j++)
+                        if (j != i) acc = mul_mod(acc, base[s0 + j] % base[s0 + i], base[s0 + i]);
+                    mi.push_back(inv_mod_prime(acc, base[s0 + i]));
+                }
+                for (int k = 0; k < rc; k++) {
+                    u64 acc = 1;
+                    for (int j = 0; j < cnt; j++) acc = mul_mod(acc, base[s0 + j] % base[k], base[k]);
+                    prod.push_back(acc);
+                }
+            }
+            m2_levels.push_back(L);
+        }
+        host["m2_I_j"] = Ij;
+        host["m2_I_location"] = Iloc;
+        host["m2_Mi_inv"] = mi;
+        host["m2_matrix"] = matrix;
+        host["m2_prod"] = prod;
     }
 
     if (scheme == SCHEME_BFV) {
@@ -270,7 +321,10 @@ hipError_t Context::upload()
                                        "base_change_matrix_q",
                                        "base_change_matrix_msk",
                                        "inv_punctured_prod_mod_B_array",
-                                       "prod_B_mod_q"};
+                                       "prod_B_mod_q",
+                                       "m2_Mi_inv",
+                                       "m2_matrix",
+                                       "m2_prod"};
     for (const char* nm : u64_tables) {
         auto it = host.find(nm);
         if (it == host.end()) continue;
@@ -278,7 +332,7 @@ hipError_t Context::upload()
         if ((e = to_device(it->second, &d)) != hipSuccess) return e;
         dev[nm] = d;
     }
-    for (const char* nm : {"new_prime_locations", "new_input_locations"}) {
+    for (const char* nm : {"new_prime_locations", "new_input_locations", "m2_I_j", "m2_I_location"}) {
         auto it = host.find(nm);
         if (it == host.end()) continue;
         std::vector<int> v(it->second.begin(), it->second.end());

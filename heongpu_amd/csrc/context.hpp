@@ -39,6 +39,17 @@ struct Context {
     u64 plain_modulus = 0;
     std::vector<u64> primes; // Q then P
     std::map<std::string, std::vector<u64>> host; // named host tables
+    // key-switching method II (P_size > 1): per-depth digit partition + table
+    // offsets into the flattened host/device arrays "m2_*"
+    struct M2Level {
+        int d = 0, rc = 0;
+        int off_digits = 0; // into m2_I_j / m2_I_location
+        int off_mi = 0;     // into m2_Mi_inv
+        int off_matrix = 0; // into m2_matrix
+        int off_prod = 0;   // into m2_prod
+    };
+    std::vector<M2Level> m2_levels;
+    int m2_width = 0; // digit width m: 2 for BFV, P_size for CKKS
 
     // ---- device state (valid after upload())
     bool uploaded = false;

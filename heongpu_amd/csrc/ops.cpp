@@ -71,7 +71,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     TRY(ntt_launch(a, l * rc * batch, false, st));
     // inner product with the key                                     (:967)
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, l, rc, Qp, l, batch, st));
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, l, rc, Qp, l, depth, batch, st));
     // INTT of the two P-limb polynomials only                        (:996)
     a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
@@ -145,7 +145,7 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     a.mod_order = order;
     TRY(ntt_launch(a, l * rc * batch, false, st));
     a.decomp_mods = 0;
-    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, batch, st)); // :1501
+    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, depth, batch, st)); // :1501
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1524
     TRY(rns_moddown_permute(temp3, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
@@ -195,7 +195,7 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, Q * Qp * batch, false, st));
     a.decomp_mods = 0; a.in_item_stride = per;
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :540
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, Qp, 0, batch, st)); // :540
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
     return rns_divide_round_lastq(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
@@ -220,11 +220,143 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, Q * Qp * batch, false, st));
     a.decomp_mods = 0; a.in_item_stride = per;
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, -1, batch, st)); // :814
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, Qp, 0, batch, st)); // :814
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846
     return rns_moddown_permute(temp2, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
                                c.d64("last_q_modinv"), galois_elt, np, Qp, Q, Qp, Q, c.P_size, batch, st); // :853
+}
+
+// ------------------------------------------------------------------ method II (P_size > 1)
+static hipError_t dtoq(const Context& c, int lvl, const u64* in, u64 in_stride, u64* out, u64 out_stride, int l,
+                       int level, int batch, hipStream_t st)
+{
+    const Context::M2Level& L = c.m2_levels[lvl];
+    return rns_base_conversion_DtoQtilde(in, in_stride, out, out_stride, c.plan_qp.mods,
+                                         c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
+                                         c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
+                                         c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc, l, level,
+                                         batch, st);
+}
+
+// reference ckks/operator.cu:1025-1154
+hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
+                                  hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const int d = c.m2_levels[depth].d;
+    const u64 per = ((u64) l * rc + 2 * rc) * n;
+    u64* temp1 = ws;
+    u64* temp2 = ws + (u64) l * rc * n;
+    u64* c2 = ct + ((u64) l << (np + 1));
+    const Mod* mods = c.plan_qp.mods;
+    const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    NttArgs a = c.ntt_args(0);
+    a.in = c2; a.out = c2; a.mod_count = l; a.polys_per_item = l;
+    a.in_item_stride = a.out_item_stride = cs;
+    TRY(ntt_launch(a, l * batch, true, st));                                               // :1052
+    TRY(dtoq(c, depth, c2, cs, temp1, per, l, depth, batch, st));                          // :1065
+    a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, d * rc * batch, false, st));                                         // :1095
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, d, rc, Qp, l, depth, batch, st)); // :1110
+    a.in = temp2; a.out = temp2; a.polys_per_item = 2 * rc;
+    TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1131
+    TRY(rns_moddown_extended(temp2, per, nullptr, 0, temp1, per, mods, c.d64("half"), c.d64("half_mod"),
+                             c.d64("last_q_modinv"), np, rc, l, Qp, Q, c.P_size, 0, batch, st)); // :1136
+    a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * l * batch, false, st));                                          // :1145
+    // addition(temp1, ct, ct): per-item strides differ, so one launch per item batch via copy-free add
+    return rns_addition_strided(temp1, per, ct, cs, ct, cs, mods, np, l, 2, batch, st);     // :1149
+}
+
+// reference ckks/operator.cu:1561-1720
+hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                                   int galois_elt, int depth, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const int d = c.m2_levels[depth].d;
+    const u64 per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n;
+    u64* temp0 = ws;
+    u64* temp3 = temp0 + (u64) 2 * l * n;
+    u64* temp4 = temp3 + (u64) l * rc * n;
+    const Mod* mods = c.plan_qp.mods;
+    const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    NttArgs a = c.ntt_args(0);
+    a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = cs; a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * l * batch, true, st));
+    TRY(dtoq(c, depth, temp0 + (u64) l * n, per, temp3, per, l, depth, batch, st));
+    a = c.ntt_args(0);
+    a.in = temp3; a.out = temp3; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, d * rc * batch, false, st));
+    TRY(rns_keyswitch_mac(temp3, per, key, temp4, per, mods, np, d, rc, Qp, l, depth, batch, st));
+    a.in = temp4; a.out = temp4; a.polys_per_item = 2 * rc;
+    TRY(ntt_launch(a, 2 * rc * batch, true, st));
+    TRY(rns_moddown_permute(temp4, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
+                            c.d64("last_q_modinv"), galois_elt, np, rc, l, Qp, Q, c.P_size, batch, st));
+    a = c.ntt_args(0);
+    a.in = out; a.out = out; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = a.out_item_stride = so;
+    return ntt_launch(a, 2 * l * batch, false, st);
+}
+
+// reference bfv/operator.cu:585-672
+hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
+                                 hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int d = c.m2_levels[0].d;
+    const u64 per = ((u64) Q * Qp + 2 * Qp) * n;
+    u64* temp1 = ws;
+    u64* temp2 = ws + (u64) Q * Qp * n;
+    const Mod* mods = c.plan_qp.mods;
+    TRY(dtoq(c, 0, ct + ((u64) Q << (np + 1)), cs, temp1, per, Q, 0, batch, st));          // :599
+    NttArgs a = c.ntt_args(0);
+    a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = d * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, d * Qp * batch, false, st));                                         // :619
+    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, d, Qp, Qp, Qp, 0, batch, st)); // :629
+    a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
+    TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :657
+    return rns_moddown_extended(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
+                                c.d64("last_q_modinv"), np, Qp, Q, Qp, Q, c.P_size, 1, batch, st); // :662
+}
+
+// reference bfv/operator.cu:866-973
+hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                                  int galois_elt, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int d = c.m2_levels[0].d;
+    const u64 per = ((u64) Q * Qp + 2 * Qp) * n;
+    u64* temp2 = ws;
+    u64* temp3 = ws + (u64) Q * Qp * n;
+    const Mod* mods = c.plan_qp.mods;
+    TRY(dtoq(c, 0, ct + (u64) Q * n, cs, temp2, per, Q, 0, batch, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = temp2; a.out = temp2; a.mod_count = Qp; a.polys_per_item = d * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    TRY(ntt_launch(a, d * Qp * batch, false, st));
+    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, d, Qp, Qp, Qp, 0, batch, st));
+    a.in = temp3; a.out = temp3; a.polys_per_item = 2 * Qp;
+    TRY(ntt_launch(a, 2 * Qp * batch, true, st));
+    return rns_moddown_permute(temp3, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
+                               c.d64("last_q_modinv"), galois_elt, np, Qp, Q, Qp, Q, c.P_size, batch, st);
 }
 
 } // namespace hegpu

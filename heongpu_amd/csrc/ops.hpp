@@ -23,4 +23,14 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
 hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                int galois_elt, int batch, u64* ws, hipStream_t st);
 
+// key-switching method II (P_size > 1)
+hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
+                                  hipStream_t st);
+hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                                   int galois_elt, int depth, int batch, u64* ws, hipStream_t st);
+hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
+                                 hipStream_t st);
+hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
+                                  int galois_elt, int batch, u64* ws, hipStream_t st);
+
 } // namespace hegpu

@@ -57,6 +57,27 @@ hipError_t rns_addition(const u64* a, const u64* b, u64* out, const Mod* mods, i
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(RNS_THREADS) void k_addition_strided(const u64* a, u64 sa, const u64* b, u64 sb,
+                                                                  u64* out, u64 so, const Mod* __restrict__ mods,
+                                                                  int n_power, int limbs, int parts)
+{
+    const u64 q = mods[blockIdx.y].q;
+    const int z = blockIdx.z % parts, item = blockIdx.z / parts;
+    const u64 loc = coeff0() + ((u64) blockIdx.y << n_power) + (((u64) limbs * z) << n_power);
+    ulonglong2 x = ld2(a + sa * item + loc), y = ld2(b + sb * item + loc), r;
+    r.x = add_mod(x.x, y.x, q);
+    r.y = add_mod(x.y, y.y, q);
+    st2(out + so * item + loc, r);
+}
+
+hipError_t rns_addition_strided(const u64* a, u64 sa, const u64* b, u64 sb, u64* out, u64 so, const Mod* mods,
+                                int n_power, int limbs, int parts, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_addition_strided, grid3(n_power, limbs, parts * batch), dim3(RNS_THREADS), 0, st, a, sa, b,
+                       sb, out, so, mods, n_power, limbs, parts);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- tensor product
 __global__ __launch_bounds__(RNS_THREADS) void k_cross_multiplication(const u64* __restrict__ in1, u64 s1,
                                                                       const u64* __restrict__ in2, u64 s2,
@@ -147,11 +168,12 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __rest
                                                                const u64* __restrict__ key,
                                                                u64* __restrict__ out, u64 out_stride,
                                                                const Mod* __restrict__ mods, int n_power,
-                                                               int digits, int nmods, int key_limbs, int p_row)
+                                                               int digits, int nmods, int key_limbs, int split,
+                                                               int level)
 {
     const int item = blockIdx.x;
     const int y = blockIdx.z;
-    const int kidx = (y == p_row) ? (key_limbs - 1) : y;
+    const int kidx = (y < split) ? y : y + level;
     const Mod m = mods[kidx];
     const u64 c = ((u64) blockIdx.y * RNS_THREADS + threadIdx.x) * 2;
     const u64* pin = in + in_stride * item + ((u64) y << n_power) + c;
@@ -181,13 +203,13 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __rest
 }
 
 hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
-                             const Mod* mods, int n_power, int digits, int nmods, int key_limbs, int p_row,
-                             int batch, hipStream_t st)
+                             const Mod* mods, int n_power, int digits, int nmods, int key_limbs, int split,
+                             int level, int batch, hipStream_t st)
 {
     if (digits > 64) return hipErrorInvalidValue; // 128-bit accumulator bound
     dim3 g(batch, (1u << n_power) / RNS_PER_BLOCK, nmods);
     hipLaunchKernelGGL(k_keyswitch_mac, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride, mods,
-                       n_power, digits, nmods, key_limbs, p_row);
+                       n_power, digits, nmods, key_limbs, split, level);
     return hipGetLastError();
 }
 
@@ -313,6 +335,113 @@ hipError_t rns_moddown_stage_two(const u64* in_last, u64 last_stride, const u64*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- method II: digit -> Q~ base conversion
+// IEEE single-precision overflow estimate exactly as the reference computes it:
+// r = sum_i (float)y_i / (float)q_i in digit order, roundf.
+__global__ __launch_bounds__(RNS_THREADS) void k_base_conversion_DtoQtilde(
+    const u64* __restrict__ in, u64 in_stride, u64* __restrict__ out, u64 out_stride, const Mod* __restrict__ mods,
+    const u64* __restrict__ matrix, const u64* __restrict__ mi_inv, const u64* __restrict__ prod,
+    const int* __restrict__ I_j_, const int* __restrict__ I_location_, int n_power, int rc, int l, int level)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int g = blockIdx.y;
+    const int cnt = I_j_[g], s0 = I_location_[g];
+    const u64* pin = in + in_stride * blockIdx.z + idx + ((u64) s0 << n_power);
+    u64* po = out + out_stride * blockIdx.z + idx + (((u64) g * rc) << n_power);
+    u64 partial[20];
+    float r = 0.0f;
+    for (int i = 0; i < cnt; i++) {
+        const Mod m = mods[s0 + i];
+        partial[i] = mul_barrett(pin[(u64) i << n_power], mi_inv[s0 + i], m);
+        r = __fadd_rn(r, __fdiv_rn((float) partial[i], (float) m.q));
+    }
+    const u64 r_ = (u64) roundf(r);
+    for (int i = 0; i < rc; i++) {
+        const Mod m = mods[(i < l) ? i : i + level];
+        u64 hi = 0, lo = 0;
+        for (int j = 0; j < cnt; j++) {
+            u64 h2, l2;
+            mul64wide(reduce64(partial[j], m), matrix[j + i * cnt + s0 * rc], h2, l2);
+            lo += l2;
+            hi += h2 + (lo < l2);
+        }
+        const u64 temp = reduce128(hi, lo, m);
+        const u64 r_mul = mul_barrett(r_, prod[i + g * rc], m);
+        po[(u64) i << n_power] = sub_mod(temp, r_mul, m.q);
+    }
+}
+
+hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                                         const u64* matrix, const u64* mi_inv, const u64* prod, const int* I_j,
+                                         const int* I_location, int n_power, int d, int rc, int l, int level,
+                                         int batch, hipStream_t st)
+{
+    dim3 g((1u << n_power) / RNS_THREADS, d, batch);
+    hipLaunchKernelGGL(k_base_conversion_DtoQtilde, g, dim3(RNS_THREADS), 0, st, in, in_stride, out, out_stride,
+                       mods, matrix, mi_inv, prod, I_j, I_location, n_power, rc, l, level);
+    return hipGetLastError();
+}
+
+// mod-down of limb y by the P_size special primes, one at a time, last first
+// (the loop of switchkey.cu:497-534 / 1239-1276 / 1650-1683)
+__device__ __forceinline__ u64 moddown_multi(u64 x, const u64* pin, int y, const Mod& m, const Mod* __restrict__ mods,
+                                             const u64* __restrict__ half, const u64* __restrict__ half_mod,
+                                             const u64* __restrict__ last_q_modinv, int n_power, int Q_cur,
+                                             int first_Qp, int first_Q, int P_size)
+{
+    u64 last_ct[15];
+    for (int i = 0; i < P_size; i++) last_ct[i] = pin[(u64) (Q_cur + i) << n_power];
+    int location_ = 0;
+    for (int i = 0; i < P_size; i++) {
+        u64 lh = last_ct[P_size - 1 - i];
+        lh = add_mod(lh, half[i], mods[first_Qp - 1 - i].q);
+        for (int j = 0; j < (P_size - 1 - i); j++) {
+            const Mod mj = mods[first_Q + j];
+            u64 t1 = reduce64(lh, mj);
+            t1 = sub_mod(t1, half_mod[location_ + first_Q + j], mj.q);
+            t1 = sub_mod(last_ct[j], t1, mj.q);
+            last_ct[j] = mul_barrett(t1, last_q_modinv[location_ + first_Q + j], mj);
+        }
+        u64 t1 = reduce64(lh, m);
+        t1 = sub_mod(t1, half_mod[location_ + y], m.q);
+        t1 = sub_mod(x, t1, m.q);
+        x = mul_barrett(t1, last_q_modinv[location_ + y], m);
+        location_ += (first_Qp - 1 - i);
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
+    const u64* __restrict__ in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out, u64 out_stride,
+    const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
+    const u64* __restrict__ last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp, int first_Q,
+    int P_size, int with_ct)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const Mod m = mods[y];
+    const u64* pin = in + in_stride * b + (((u64) Qp_cur << n_power) * z) + idx;
+    u64 x = moddown_multi(pin[(u64) y << n_power], pin, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur,
+                          first_Qp, first_Q, P_size);
+    const u64 loc = ((u64) y << n_power) + (((u64) Q_cur << n_power) * z) + idx;
+    if (with_ct == 1 || (with_ct == 2 && z == 0)) x = add_mod(ct[ct_stride * b + loc], x, m.q);
+    out[out_stride * b + loc] = x;
+}
+
+hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
+                                u64 out_stride, const Mod* mods, const u64* half, const u64* half_mod,
+                                const u64* last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp,
+                                int first_Q, int P_size, int with_ct, int batch, hipStream_t st)
+{
+    if (P_size > 15) return hipErrorInvalidValue;
+    dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
+    hipLaunchKernelGGL(k_moddown_extended, g, dim3(RNS_THREADS), 0, st, in, in_stride, ct, ct_stride, out,
+                       out_stride, mods, half, half_mod, last_q_modinv, n_power, Qp_cur, Q_cur, first_Qp, first_Q,
+                       P_size, with_ct);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- mod-down + Galois permutation
 // One coefficient per thread: the destination index i*g mod N scatters.
 template <bool SINGLE_P>
@@ -336,25 +465,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
         l = sub_mod(x, l, m.q);
         x = mul_barrett(l, last_q_modinv[y], m);
     } else {
-        u64 last_ct[15];
-        for (int i = 0; i < P_size; i++) last_ct[i] = pin[(u64) (Q_cur + i) << n_power];
-        int location_ = 0;
-        for (int i = 0; i < P_size; i++) {
-            u64 lh = last_ct[P_size - 1 - i];
-            lh = add_mod(lh, half[i], mods[first_Qp - 1 - i].q);
-            for (int j = 0; j < (P_size - 1 - i); j++) {
-                const Mod mj = mods[first_Q + j];
-                u64 t1 = reduce64(lh, mj);
-                t1 = sub_mod(t1, half_mod[location_ + first_Q + j], mj.q);
-                t1 = sub_mod(last_ct[j], t1, mj.q);
-                last_ct[j] = mul_barrett(t1, last_q_modinv[location_ + first_Q + j], mj);
-            }
-            u64 t1 = reduce64(lh, m);
-            t1 = sub_mod(t1, half_mod[location_ + y], m.q);
-            t1 = sub_mod(x, t1, m.q);
-            x = mul_barrett(t1, last_q_modinv[location_ + y], m);
-            location_ += (first_Qp - 1 - i);
-        }
+        x = moddown_multi(x, pin, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur, first_Qp, first_Q,
+                          P_size);
     }
     if (z == 0) x = add_mod(in2[in2_stride * b + ((u64) y << n_power) + idx], x, m.q);
     const u32 raw = idx * (u32) galois_elt;

@@ -12,6 +12,11 @@ hipError_t rns_addition(const u64* a, const u64* b, u64* out, const Mod* mods, i
                         int limbs, int parts, int batch, int op /*0 add,1 sub,2 neg*/,
                         hipStream_t st);
 
+// addition with per-ciphertext strides: out[b] = a[b] + b_[b] over [parts][limbs][N]
+// (addition.cu:10-21 as used by ckks/operator.cu:1149)
+hipError_t rns_addition_strided(const u64* a, u64 sa, const u64* b, u64 sb, u64* out, u64 so, const Mod* mods,
+                                int n_power, int limbs, int parts, int batch, hipStream_t st);
+
 // reference multiplication.cu:102-126
 hipError_t rns_cross_multiplication(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out,
                                     u64 so, const Mod* mods, int n_power, int decomp_size,
@@ -24,10 +29,26 @@ hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride,
                          hipStream_t st);
 
 // reference switchkey.cu:61-285: out[c][y][n] = sum_i in[i][y][n]*key[i][c][kidx(y)][n].
-// key strides use key_limbs (= Q' at depth 0); kidx(y) = (y==p_row) ? key_limbs-1 : y.
+// key strides use key_limbs (= Q' at depth 0); kidx(y) = (y < split) ? y : y + level
+// (method I leveled: split = l, level = depth maps row l to the P limb; method II,
+// switchkey.cu:287-398: rows >= l are the P limbs).
 hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
                              const Mod* mods, int n_power, int digits, int nmods, int key_limbs,
-                             int p_row, int batch, hipStream_t st);
+                             int split, int level, int batch, hipStream_t st);
+
+// reference switchkey.cu:872-927 / 985-1046 (method II digit -> Q~ fast base
+// conversion with the float32 overflow estimate); out [d][rc][N]
+hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                                         const u64* matrix, const u64* mi_inv, const u64* prod, const int* I_j,
+                                         const int* I_location, int n_power, int d, int rc, int l, int level,
+                                         int batch, hipStream_t st);
+
+// reference switchkey.cu:480-611 / 1222-1282 (mod-down by P_size primes);
+// with_ct: 0 none, 1 both parts, 2 part 0 only
+hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
+                                u64 out_stride, const Mod* mods, const u64* half, const u64* half_mod,
+                                const u64* last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp,
+                                int first_Q, int P_size, int with_ct, int batch, hipStream_t st);
 
 // reference switchkey.cu:400-478 (switchkey != 0: ct added to part 0 only)
 hipError_t rns_divide_round_lastq(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride,

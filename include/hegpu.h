@@ -99,10 +99,16 @@ int hegpu_cross_multiplication(hegpu_context* ctx, int table_set, const uint64_t
 int hegpu_cipher_broadcast(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
                            uint64_t out_stride, int digits, int nmods, int split, int level, int batch,
                            hegpu_stream stream);
-/* src/lib/kernel/switchkey.cu:61-285 (p_row < 0: non-leveled variant) */
+/* src/lib/kernel/switchkey.cu:61-398: out[c][y][n] = sum_i in[i][y][n] * key[i][c][kidx(y)][n],
+ * kidx(y) = y < split ? y : y + level (non-leveled: split = nmods, level = 0;
+ * method I leveled: split = l, level = depth; method II leveled: same) */
 int hegpu_keyswitch_multiply_accumulate(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride,
                                         const uint64_t* key, uint64_t* out, uint64_t out_stride, int digits,
-                                        int nmods, int key_limbs, int p_row, int batch, hegpu_stream stream);
+                                        int nmods, int key_limbs, int split, int level, int batch,
+                                        hegpu_stream stream);
+/* src/lib/kernel/switchkey.cu:872-927,985-1046 (method II digit -> Q~ base conversion, P_size > 1) */
+int hegpu_base_conversion_DtoQtilde(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                                    uint64_t out_stride, int depth, int batch, hegpu_stream stream);
 /* src/lib/kernel/switchkey.cu:400-478 */
 int hegpu_divide_round_lastq(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
                              uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int switchkey, int batch,
@@ -139,8 +145,11 @@ size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int ba
 int hegpu_ckks_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_stride, const uint64_t* ct2,
                         uint64_t ct2_stride, uint64_t* out, uint64_t out_stride, int depth, int batch,
                         hegpu_stream stream);
-/* relinearize_seal_method_inplace_ckks (ckks/operator.cu:899-1023):
- * ct [3][l][N] -> first two parts, in place; relin_key [Q][2][Q'][N] */
+/* relinearize_inplace (host/ckks/operator.cuh:1053-1094): key-switch method I
+ * when P_size == 1 (relinearize_seal_method_inplace_ckks, ckks/operator.cu:899-1023,
+ * relin_key [Q][2][Q'][N]), method II when P_size > 1
+ * (relinearize_external_product_method2_inplace_ckks, ckks/operator.cu:1025-1154,
+ * relin_key [d][2][Q'][N]).  ct [3][l][N] -> first two parts, in place. */
 int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
                                    const uint64_t* relin_key, int depth, int batch, void* ws, size_t ws_bytes,
                                    hegpu_stream stream);

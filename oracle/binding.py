@@ -75,6 +75,10 @@ def lib():
     L.o_bfv_relinearize.argtypes = [vp, vp, vp]
     L.o_bfv_apply_galois.argtypes = [vp, vp, vp, vp, ci]
     L.o_ckks_mul_relin_batch.argtypes = [vp, vp, vp, vp, vp, ci, ci]
+    L.o_bfv_relinearize_II.argtypes = [vp, vp, vp]
+    L.o_bfv_apply_galois_II.argtypes = [vp, vp, vp, vp, ci]
+    L.o_ckks_relinearize_II.argtypes = [vp, vp, vp, ci]
+    L.o_ckks_apply_galois_II.argtypes = [vp, vp, vp, vp, ci, ci]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
@@ -194,6 +198,26 @@ class OracleContext:
         l = self.Q - depth
         out = np.zeros(2 * l * self.n, dtype=np.uint64)
         self.L.o_ckks_apply_galois(self.h, _p(ct), _p(out), _p(key), galois_elt, depth)
+        return out
+
+    # key-switching method II (P_size > 1)
+    def ckks_relinearize_II(self, ct3, key, depth=0):
+        self.L.o_ckks_relinearize_II(self.h, _p(ct3), _p(key), depth)
+        return ct3
+
+    def ckks_apply_galois_II(self, ct, key, galois_elt, depth=0):
+        l = self.Q - depth
+        out = np.zeros(2 * l * self.n, dtype=np.uint64)
+        self.L.o_ckks_apply_galois_II(self.h, _p(ct), _p(out), _p(key), galois_elt, depth)
+        return out
+
+    def bfv_relinearize_II(self, ct3, key):
+        self.L.o_bfv_relinearize_II(self.h, _p(ct3), _p(key))
+        return ct3
+
+    def bfv_apply_galois_II(self, ct, key, galois_elt):
+        out = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_apply_galois_II(self.h, _p(ct), _p(out), _p(key), galois_elt)
         return out
 
     def bfv_multiply(self, ct1, ct2):

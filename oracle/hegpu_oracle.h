@@ -118,7 +118,27 @@ typedef struct octx {
     u64 merge_psi[O_MAX_MOD + O_MAX_BSK];
     u64 merge_n_inv[O_MAX_MOD + O_MAX_BSK];
     u64 *merge_ntt_table, *merge_intt_table; /* [Q+bsk][N] */
+    /* key-switching method II tables (contextpool.cpp), NULL when P_size == 1 */
+    struct o_m2* m2;
 } octx_t;
+
+/* KeySwitchParameterGenerator output for one depth (contextpool.cpp:161-438) */
+typedef struct o_m2_level {
+    int d;            /* digits */
+    int rc;           /* current Q~ size = Q' - depth */
+    int *I_j, *I_location;
+    u64 *Mi_inv;      /* [sum I_j] */
+    u64 *matrix;      /* per digit l: [rc][I_j[l]] at offset I_location[l]*rc */
+    u64 *prod;        /* [d][rc] */
+    int n_matrix;
+} o_m2_level_t;
+typedef struct o_m2 {
+    int levels;       /* 1 for BFV, Q for CKKS */
+    int m;            /* digit width: 2 for BFV, P_size for CKKS */
+    o_m2_level_t* lv;
+} o_m2_t;
+void o_m2_build(octx_t* c);
+void o_m2_free(octx_t* c);
 
 /* primes given explicitly (Q then P); plain_modulus used for BFV only */
 octx_t* o_ctx_create(int scheme, int n_power, const u64* primes, int Q_size,
@@ -159,6 +179,14 @@ void o_bfv_relinearize(const octx_t* c, u64* ct3, const u64* relin_key);
 /* bfv/operator.cu:771-864 */
 void o_bfv_apply_galois(const octx_t* c, const u64* ct, u64* out,
                         const u64* galois_key, int galois_elt);
+
+/* key-switching method II (P_size > 1): bfv/operator.cu:585-672, 866-973;
+ * ckks/operator.cu:1025-1154, 1561-1720.  key layout [d][2][Q'][N]. */
+void o_bfv_relinearize_II(const octx_t* c, u64* ct3, const u64* relin_key);
+void o_bfv_apply_galois_II(const octx_t* c, const u64* ct, u64* out, const u64* galois_key, int galois_elt);
+void o_ckks_relinearize_II(const octx_t* c, u64* ct3, const u64* relin_key, int depth);
+void o_ckks_apply_galois_II(const octx_t* c, const u64* ct, u64* out, const u64* galois_key, int galois_elt,
+                            int depth);
 
 /* CPU-baseline helper: batch of independent mul+relin (OpenMP over cts) */
 int o_omp_threads(void);

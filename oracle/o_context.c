@@ -251,6 +251,7 @@ octx_t* o_ctx_create(int scheme, int n_power, const u64* primes, int Q_size,
     }
     if (scheme == O_CKKS) ckks_tables(c);
     if (scheme == O_BFV) bfv_tables(c, plain_modulus);
+    if (P_size > 1) o_m2_build(c);
     return c;
 }
 
@@ -268,6 +269,7 @@ void o_ctx_free(octx_t* c)
     free(c->base_change_matrix_q); free(c->base_change_matrix_msk);
     free(c->inv_punctured_prod_mod_B); free(c->prod_B_mod_q);
     free(c->merge_ntt_table); free(c->merge_intt_table);
+    o_m2_free(c);
     free(c);
 }
 
@@ -316,6 +318,32 @@ long o_ctx_get(const octx_t* c, const char* nm, u64* out, long cap)
         return put_int(c->new_prime_locations, c->n_prime_loc, out, cap);
     if (IS("new_input_locations"))
         return put_int(c->new_input_locations, c->n_input_loc, out, cap);
+    if (c->m2 && !strncmp(nm, "m2_", 3)) {
+        /* method II tables, all depths concatenated (same order as the product) */
+        long cnt = 0;
+        for (int lv = 0; lv < c->m2->levels; lv++) {
+            const o_m2_level_t* L = &c->m2->lv[lv];
+            long nl = 0;
+            for (int g = 0; g < L->d; g++) nl += L->I_j[g];
+            long k = 0;
+            const u64* src = NULL;
+            if (IS("m2_I_j") || IS("m2_I_location")) {
+                k = L->d;
+                if (cnt + k > cap) return -2;
+                for (long i = 0; i < k; i++)
+                    out[cnt + i] = (u64) (IS("m2_I_j") ? L->I_j[i] : L->I_location[i]);
+                cnt += k;
+                continue;
+            } else if (IS("m2_Mi_inv")) { k = nl; src = L->Mi_inv; }
+            else if (IS("m2_matrix")) { k = L->n_matrix; src = L->matrix; }
+            else if (IS("m2_prod")) { k = (long) L->d * L->rc; src = L->prod; }
+            else return -1;
+            if (cnt + k > cap) return -2;
+            memcpy(out + cnt, src, k * sizeof(u64));
+            cnt += k;
+        }
+        return cnt;
+    }
     if (c->scheme != O_BFV) return -1;
     if (IS("base_Bsk")) return put_mods(c->bsk, B, out, cap);
     if (IS("base_Bsk_psi")) return put(c->bsk_psi, B, out, cap);

@@ -72,6 +72,39 @@ class RLWE:
                 key[i, 1, j] = a[j]
         return key.reshape(-1)
 
+    def switch_key_II(self, target_ntt, m, secret_ntt=None):
+        """method II (hybrid) key: digit i covers limbs [i*m, min((i+1)*m, Q));
+        key[i][0][j] = -(a_i*secret + e_i) + [j in digit i] (P mod q_j) target with
+        P = product of ALL special primes (keygeneration.cu:584-629); layout [d][2][Q'][N]."""
+        if secret_ntt is None:
+            secret_ntt = self.s_ntt
+        Q, Qp, n = self.Q, self.Qp, self.n
+        P = 1
+        for j in range(Q, Qp):
+            P *= self.primes[j]
+        d = (Q + m - 1) // m
+        key = np.zeros((d, 2, Qp, n), dtype=np.uint64)
+        for i in range(d):
+            a = self.uniform_ntt(range(Qp))
+            e = self.to_ntt(self.error(), range(Qp))
+            for j in range(Qp):
+                q = self.primes[j]
+                k0 = self.negmod(self.addmod(self.mulmod(a[j], secret_ntt[j], q), e[j], q), q)
+                if j < Q and j // m == i:
+                    k0 = self.addmod(k0, self.mulmod(target_ntt[j], np.full(n, P % q, dtype=np.uint64), q), q)
+                key[i, 0, j] = k0
+                key[i, 1, j] = a[j]
+        return key.reshape(-1)
+
+    def relin_key_II(self, m):
+        s2 = np.stack([self.mulmod(self.s_ntt[j], self.s_ntt[j], self.primes[j]) for j in range(self.Qp)])
+        return self.switch_key_II(s2, m)
+
+    def galois_key_II(self, g, m):
+        g_inv = pow(g, -1, 2 * self.n)
+        sg = self.apply_galois_poly(self.s.astype(object), g_inv)
+        return self.switch_key_II(self.s_ntt, m, self.to_ntt(sg, range(self.Qp)))
+
     def relin_key(self):
         s2 = np.stack([self.mulmod(self.s_ntt[j], self.s_ntt[j], self.primes[j]) for j in range(self.Qp)])
         return self.switch_key(s2)

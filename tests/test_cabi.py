@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "hegpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(hegpu_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(hegpu_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported(hg):

@@ -274,3 +274,66 @@ def test_c3_bfv_rotate_batch64_full_size(hg, oracle, torch):
         assert np.array_equal(got[b], o.bfv_apply_galois(cts[b], key, g)), f"ciphertext {b}"
     for b in range(uniq, batch):
         assert np.array_equal(got[b], got[b % uniq]), f"batch item {b} differs from its twin"
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_ckks_method_II(hg, oracle, torch, depth):
+    """key-switching method II (P_size = 2): relinearize + rotate, leveled."""
+    n = 8192
+    c, o, primes = _ckks_pair(hg, oracle, n, [40, 35, 35, 35, 35], [40, 40], sec=hg.SEC_NONE)
+    Q, Qp = 5, 7
+    l = Q - depth
+    d0 = (Q + 1) // 2
+    batch = 2
+    key = synth_key(primes, d0, Qp, n, 3)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * l * n, d2, 2 * l * n, out, 3 * l * n, depth, batch)
+    ws = c.workspace(hg.OP_CKKS_RELIN, depth, batch)
+    c.ckks_relinearize_inplace(out, 3 * l * n, hg.to_device(key), depth, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        w = o.ckks_multiply(ct1[b], ct2[b], depth)
+        o.ckks_relinearize_II(w, key, depth)
+        assert np.array_equal(got[b][:2 * l * n], w[:2 * l * n]), "method II relinearize"
+    g = hg.steps_to_galois_elt(1, n, 5)
+    rot = torch.empty(batch * 2 * l * n, dtype=torch.int64, device="cuda")
+    ws = c.workspace(hg.OP_CKKS_GALOIS, depth, batch)
+    c.ckks_apply_galois(d1, 2 * l * n, rot, 2 * l * n, hg.to_device(key), g, depth, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.ckks_apply_galois_II(ct1[b], key, g, depth)), "method II rotate"
+
+
+def test_bfv_method_II(hg, oracle, torch):
+    n, t = 4096, 1032193
+    c = hg.Context.from_bit_sizes(hg.BFV, n, [36, 36, 36], [37, 37], plain_modulus=t, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, 12, primes, 3, 2, t)
+    c.upload()
+    Q, Qp, batch = 3, 5, 2
+    key = synth_key(primes, 2, Qp, n, 3)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+    c.bfv_relinearize_inplace(out, 3 * Q * n, hg.to_device(key), batch, c.workspace(hg.OP_BFV_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        w = o.bfv_multiply(ct1[b], ct2[b])
+        o.bfv_relinearize_II(w, key)
+        assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), "bfv method II relinearize"
+    g = hg.steps_to_galois_elt(2, n, 3)
+    rot = torch.empty(batch * 2 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_apply_galois(d1, 2 * Q * n, rot, 2 * Q * n, hg.to_device(key), g, batch,
+                       c.workspace(hg.OP_BFV_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.bfv_apply_galois_II(ct1[b], key, g)), "bfv method II rotate"

@@ -146,3 +146,16 @@ def test_no_barrett_domain_violation(oracle):
     import ctypes
     v = ctypes.c_uint64.in_dll(oracle.lib(), "o_barrett_domain_violations").value
     assert v == 0
+
+
+def test_method_II_tables_product_vs_oracle(oracle, hg):
+    """KeySwitchParameterGenerator output (contextpool.cpp): product host code vs oracle."""
+    for scheme, oscheme, bits_q, bits_p, t in ((hg.CKKS, oracle.CKKS, [40, 30, 30, 30, 30], [40, 40], 0),
+                                               (hg.CKKS, oracle.CKKS, [50, 40, 40, 40, 40, 40, 40], [50, 50, 50], 0),
+                                               (hg.BFV, oracle.BFV, [36, 36, 36], [37, 37], 1032193)):
+        n = 4096
+        prod = hg.Context.from_bit_sizes(scheme, n, bits_q, bits_p, plain_modulus=t, sec=hg.SEC_NONE)
+        primes = [int(v) for v in prod.table("modulus")]
+        o = oracle.OracleContext(oscheme, prod.n_power, primes, len(bits_q), len(bits_p), t)
+        for name in ("m2_I_j", "m2_I_location", "m2_Mi_inv", "m2_matrix", "m2_prod"):
+            assert np.array_equal(prod.table(name), o.table(name)), name

@@ -144,3 +144,70 @@ def test_ckks_rotate_decrypts(ckks, oracle, depth):
     want = he.apply_galois_poly(m.astype(object), g)
     err = max(abs(int(a) - int(b) * scale) for a, b in zip(x, want))
     assert err < scale // 2 ** 8
+
+
+# ---------------------------------------------------------------- key-switching method II (P_size > 1)
+@pytest.fixture(scope="module")
+def ckks2(oracle):
+    """reference test_ckks_relinearization.cpp:438 style: two special primes"""
+    import ctypes
+    bits = [40, 30, 30, 30, 30, 40, 40]
+    arr = (ctypes.c_int * len(bits))(*bits)
+    out = (ctypes.c_uint64 * len(bits))()
+    assert oracle.lib().o_generate_primes(4096, arr, len(bits), out) == 0
+    o = oracle.OracleContext(oracle.CKKS, 12, [int(v) for v in out], 5, 2)
+    return o, RLWE(o, seed=3)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_ckks_method_II_relin_and_rotate(ckks2, oracle, depth):
+    o, he = ckks2
+    n, Q = o.n, o.Q
+    l = Q - depth
+    sc = 1 << 25
+    rng = np.random.default_rng(20 + depth)
+    m1, m2 = rng.integers(-4, 5, n), rng.integers(-4, 5, n)
+    c1 = he.encrypt([int(v) * sc for v in m1], l, ntt_domain=True)
+    c2 = he.encrypt([int(v) * sc for v in m2], l, ntt_domain=True)
+    ct3 = o.ckks_multiply(c1, c2, depth)
+    o.ckks_relinearize_II(ct3, he.relin_key_II(o.P), depth)
+    x, M = he.decrypt(ct3[:2 * l * n], l, 2, ntt_domain=True)
+    pr = negacyclic_mul(m1, m2)
+    err = max(abs(int(a) - int(b) * sc * sc) for a, b in zip(x, pr))
+    assert err < sc * sc // 2 ** 6, "method II relinearization keeps the message"
+    g = oracle.lib().o_steps_to_galois_elt(2, n, 5)
+    out = o.ckks_apply_galois_II(c1, he.galois_key_II(g, o.P), g, depth)
+    x, M = he.decrypt(out, l, 2, ntt_domain=True)
+    want = he.apply_galois_poly(m1.astype(object), g)
+    err = max(abs(int(a) - int(b) * sc) for a, b in zip(x, want))
+    assert err < sc // 2 ** 6, "method II rotation"
+
+
+def test_bfv_method_II_relin_and_rotate(oracle):
+    """reference test_bfv_relinearization.cpp:434 style: Q={36,36,36} P={37,37}, digits of m=2"""
+    import ctypes
+    t = 1032193
+    bits = [36, 36, 36, 37, 37]
+    arr = (ctypes.c_int * len(bits))(*bits)
+    out = (ctypes.c_uint64 * len(bits))()
+    assert oracle.lib().o_generate_primes(4096, arr, len(bits), out) == 0
+    o = oracle.OracleContext(oracle.BFV, 12, [int(v) for v in out], 3, 2, t)
+    he = RLWE(o, seed=4)
+    n, Q = o.n, o.Q
+    M = 1
+    for j in range(Q):
+        M *= o.primes[j]
+    rng = np.random.default_rng(31)
+    m1, m2 = rng.integers(0, t, n), rng.integers(0, t, n)
+    ct1 = he.encrypt(_bfv_encode(m1, M, t), Q, ntt_domain=False)
+    ct2 = he.encrypt(_bfv_encode(m2, M, t), Q, ntt_domain=False)
+    ct3 = o.bfv_multiply(ct1, ct2)
+    o.bfv_relinearize_II(ct3, he.relin_key_II(2))
+    x, _ = he.decrypt(ct3[:2 * Q * n], Q, 2, ntt_domain=False)
+    want = np.array([int(v) % t for v in negacyclic_mul(m1, m2)], dtype=np.int64)
+    assert np.array_equal(_bfv_decode(x, M, t), want)
+    g = oracle.lib().o_steps_to_galois_elt(3, n, 3)
+    out_ct = o.bfv_apply_galois_II(ct1, he.galois_key_II(g, 2), g)
+    x, _ = he.decrypt(out_ct, Q, 2, ntt_domain=False)
+    want = np.array([int(v) % t for v in he.apply_galois_poly(m1.astype(object), g)], dtype=np.int64)
+    assert np.array_equal(_bfv_decode(x, M, t), want)
