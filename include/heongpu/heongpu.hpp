@@ -1,0 +1,536 @@
+// heongpu.hpp -- C++ class layer over the C ABI (include/hegpu.h), mirroring
+// the reference's public surface for the hot path so that consumer code reads
+// the same:
+//   heongpu::HEContext<S> ctx = heongpu::GenHEContext<S>(sec);
+//   ctx->set_poly_modulus_degree(n); ctx->set_coeff_modulus_bit_sizes(Q, P); ctx->generate();
+//   heongpu::Ciphertext<S> ct(ctx);  heongpu::Relinkey<S> rk(ctx);  heongpu::Galoiskey<S> gk(ctx, shifts);
+//   heongpu::HEArithmeticOperator<S> op(ctx);
+//   op.multiply(a, b, c); op.relinearize_inplace(c, rk); op.rescale_inplace(c); op.rotate_rows(c, d, gk, 1);
+// Reference: src/include/heongpu/heongpu.hpp:9-45, util/schemes.h:15-67,
+// util/storagemanager.cuh:23-97, util/devicevector.cuh:17-173,
+// host/{bfv,ckks}/{context,ciphertext,evaluationkey,operator}.cuh.
+//
+// What is NOT here yet: key generation, encryption /
+// decryption, encoders.  Until then keys and ciphertexts are filled through
+// the `load()` members with data produced elsewhere (tests: seeded synthetic
+// data / python big-int key generation in the reference's layouts).
+//
+// Header-only; link against heongpu_amd/lib/libhegpu.so and the HIP runtime.
+#pragma once
+#include "../hegpu.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace heongpu {
+
+typedef unsigned long long Data64;
+
+enum class Scheme { BFV = 1, CKKS = 2, TFHE = 3 };                           // util/schemes.h:15-20
+enum class sec_level_type { none = 0, sec128 = 128, sec192 = 192, sec256 = 256 };
+enum class storage_type : std::uint8_t { HOST = 0x1, DEVICE = 0x2 };        // util/storagemanager.cuh:23-27
+enum class keyswitching_type { NONE = 0, KEYSWITCHING_METHOD_I = 1, KEYSWITCHING_METHOD_II = 2 };
+
+// util/storagemanager.cuh:34-97
+struct ExecutionOptions {
+    hipStream_t stream_ = nullptr;
+    storage_type storage_ = storage_type::DEVICE;
+    bool keep_initial_condition_ = true;
+    ExecutionOptions& set_stream(hipStream_t s) { stream_ = s; return *this; }
+    ExecutionOptions& set_storage_type(storage_type s) { storage_ = s; return *this; }
+    ExecutionOptions& set_initial_location(bool k) { keep_initial_condition_ = k; return *this; }
+};
+
+class HipException : public std::runtime_error { // reference util/util.cuh:25-45 CudaException
+  public:
+    explicit HipException(const std::string& m) : std::runtime_error(m) {}
+};
+
+namespace detail {
+inline void check(int rc)
+{
+    if (rc == 0) return;
+    const std::string msg = hegpu_last_error();
+    switch (rc) {
+        case HEGPU_E_INVALID: throw std::invalid_argument(msg);
+        case HEGPU_E_LOGIC: throw std::logic_error(msg);
+        case HEGPU_E_RUNTIME: throw std::runtime_error(msg);
+        default: throw HipException(msg);
+    }
+}
+inline void hip(hipError_t e)
+{
+    if (e != hipSuccess) throw HipException(hipGetErrorString(e));
+}
+// one stream-ordered pool per device, never trimmed (the reference's RMM
+// pool_memory_resource, util/memorypool.cuh:56-117)
+inline void init_pool()
+{
+    static bool done = false;
+    if (done) return;
+    int dev = 0;
+    hip(hipGetDevice(&dev));
+    hipMemPool_t pool;
+    hip(hipDeviceGetDefaultMemPool(&pool, dev));
+    uint64_t keep = UINT64_MAX;
+    hip(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    done = true;
+}
+} // namespace detail
+
+// util/devicevector.cuh:17-173: stream-ordered device buffer
+template <typename T> class DeviceVector {
+  public:
+    DeviceVector() = default;
+    explicit DeviceVector(size_t n, hipStream_t s = nullptr) { resize(n, s); }
+    DeviceVector(const std::vector<T>& h, hipStream_t s = nullptr)
+    {
+        resize(h.size(), s);
+        if (!h.empty()) detail::hip(hipMemcpyAsync(p_, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    DeviceVector(const DeviceVector& o) { copy_from(o); }
+    DeviceVector& operator=(const DeviceVector& o)
+    {
+        if (this != &o) { release(); copy_from(o); }
+        return *this;
+    }
+    DeviceVector(DeviceVector&& o) noexcept : p_(o.p_), n_(o.n_), s_(o.s_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceVector& operator=(DeviceVector&& o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; s_ = o.s_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceVector() { release(); }
+    void resize(size_t n, hipStream_t s = nullptr)
+    {
+        release();
+        s_ = s;
+        n_ = n;
+        if (n) {
+            detail::init_pool();
+            detail::hip(hipMallocAsync((void**) &p_, n * sizeof(T), s));
+        }
+    }
+    T* data() const { return p_; }
+    size_t size() const { return n_; }
+    hipStream_t stream() const { return s_; }
+    void set_stream(hipStream_t s) { s_ = s; }
+
+  private:
+    void release()
+    {
+        if (p_) (void) hipFreeAsync(p_, s_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    void copy_from(const DeviceVector& o)
+    {
+        resize(o.n_, o.s_);
+        if (n_) detail::hip(hipMemcpyAsync(p_, o.p_, n_ * sizeof(T), hipMemcpyDeviceToDevice, s_));
+    }
+    T* p_ = nullptr;
+    size_t n_ = 0;
+    hipStream_t s_ = nullptr;
+};
+
+template <typename T> using HostVector = std::vector<T>; // util/hostvector.cuh:17-31 (pinned there)
+
+// ------------------------------------------------------------------ context
+template <Scheme S> class HEContextImpl {
+    static_assert(S == Scheme::BFV || S == Scheme::CKKS, "use the C ABI (hegpu_tfhe_*) for TFHE");
+
+  public:
+    explicit HEContextImpl(sec_level_type sec = sec_level_type::sec128) : sec_level_(sec) {}
+    ~HEContextImpl() { if (h_) hegpu_context_destroy(h_); }
+    HEContextImpl(const HEContextImpl&) = delete;
+
+    void set_poly_modulus_degree(size_t n) // ckks/context.cu:24-52
+    {
+        if (coeff_modulus_specified_ || poly_modulus_degree_specified_)
+            throw std::logic_error("Poly modulus degree cannot be changed after the coeff_modulus is specified!");
+        if (n == 0 || (n & (n - 1))) throw std::logic_error("Poly modulus degree have to be power of two");
+        if (n > 65536 || n < 4096) throw std::logic_error("Poly modulus degree is not supported");
+        n_ = n;
+        poly_modulus_degree_specified_ = true;
+    }
+    void set_coeff_modulus_bit_sizes(const std::vector<int>& q, const std::vector<int>& p) // :54-147
+    {
+        if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
+            throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
+        if (p.empty()) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
+        q_bits_ = q;
+        p_bits_ = p;
+        use_default_ = false;
+        coeff_modulus_specified_ = true;
+    }
+    void set_coeff_modulus_default_values(int p_count) // bfv/context.cu:267-374
+    {
+        if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
+            throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
+        if (p_count < 1) throw std::logic_error("P_modulus_size cannot be lower than 1!");
+        default_p_ = p_count;
+        use_default_ = true;
+        coeff_modulus_specified_ = true;
+    }
+    void set_plain_modulus(int t) { plain_modulus_ = (uint64_t) t; } // bfv/context.cu:376-389
+    void generate()
+    {
+        if (context_generated_ || !poly_modulus_degree_specified_ || !coeff_modulus_specified_)
+            throw std::logic_error("Context is already generated or parameters are missing!");
+        const int sec = (sec_level_ == sec_level_type::none) ? HEGPU_SEC_NONE : (int) sec_level_;
+        if (sec_level_ == sec_level_type::sec192 || sec_level_ == sec_level_type::sec256)
+            throw std::runtime_error("Invalid security level"); // only the 128-bit table is carried so far
+        if (use_default_)
+            detail::check(hegpu_context_create_default((int) S, (int) n_, default_p_, plain_modulus_, sec, &h_));
+        else
+            detail::check(hegpu_context_create((int) S, (int) n_, q_bits_.data(), (int) q_bits_.size(), p_bits_.data(),
+                                               (int) p_bits_.size(), plain_modulus_, sec, &h_));
+        detail::check(hegpu_context_upload(h_));
+        n_power = (int) hegpu_context_int(h_, "n_power");
+        Q_size = (int) hegpu_context_int(h_, "Q_size");
+        P_size = (int) hegpu_context_int(h_, "P_size");
+        Q_prime_size = (int) hegpu_context_int(h_, "Q_prime_size");
+        n = (int) n_;
+        keyswitching_type_ = P_size == 1 ? keyswitching_type::KEYSWITCHING_METHOD_I
+                                         : keyswitching_type::KEYSWITCHING_METHOD_II;
+        prime_vector_.resize(Q_prime_size);
+        hegpu_context_get(h_, "modulus", (uint64_t*) prime_vector_.data(), Q_prime_size);
+        context_generated_ = true;
+    }
+    inline int get_poly_modulus_degree() const noexcept { return n; }
+    inline int get_ciphertext_modulus_count() const noexcept { return Q_size; }
+    inline int get_key_modulus_count() const noexcept { return Q_prime_size; }
+    inline std::vector<Data64> get_key_modulus() const noexcept { return prime_vector_; }
+    inline int get_log_poly_modulus_degree() const noexcept { return n_power; }
+    hegpu_context* handle() const { return h_; }
+
+    int n = 0, n_power = 0, Q_size = 0, P_size = 0, Q_prime_size = 0;
+    bool context_generated_ = false;
+    keyswitching_type keyswitching_type_ = keyswitching_type::NONE;
+    std::vector<Data64> prime_vector_;
+
+  private:
+    hegpu_context* h_ = nullptr;
+    sec_level_type sec_level_;
+    size_t n_ = 0;
+    uint64_t plain_modulus_ = 0;
+    std::vector<int> q_bits_, p_bits_;
+    int default_p_ = 1;
+    bool use_default_ = false, poly_modulus_degree_specified_ = false, coeff_modulus_specified_ = false;
+};
+
+template <Scheme S> using HEContext = std::shared_ptr<HEContextImpl<S>>;
+template <Scheme S> HEContext<S> GenHEContext(sec_level_type sec = sec_level_type::sec128) // util/schemes.h:24-31
+{
+    return std::make_shared<HEContextImpl<S>>(sec);
+}
+
+// ------------------------------------------------------------------ ciphertext
+template <Scheme S> class HEArithmeticOperator;
+
+template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
+    friend class HEArithmeticOperator<S>;
+
+  public:
+    explicit Ciphertext(HEContext<S> context, const ExecutionOptions& options = ExecutionOptions())
+    {
+        if (!context || !context->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        ring_size_ = context->n;
+        coeff_modulus_count_ = context->Q_size;
+        cipher_size_ = 2;
+        in_ntt_domain_ = (S == Scheme::CKKS); // CKKS ciphertexts live in the NTT domain (ckks/ciphertext.cu)
+        storage_type_ = options.storage_;
+        device_locations_.set_stream(options.stream_);
+    }
+    Data64* data() { return device_locations_.data(); }
+    const Data64* data() const { return device_locations_.data(); }
+    size_t memory_size() const { return device_locations_.size(); }
+    void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    void switch_stream(hipStream_t s) { device_locations_.set_stream(s); }
+    hipStream_t stream() const noexcept { return device_locations_.stream(); }
+    bool is_on_device() const noexcept { return storage_type_ == storage_type::DEVICE; }
+    inline int ring_size() const noexcept { return ring_size_; }
+    inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
+    inline int size() const noexcept { return cipher_size_; }
+    inline int depth() const noexcept { return depth_; }
+    inline double scale() const noexcept { return scale_; }
+    inline bool in_ntt_domain() const noexcept { return in_ntt_domain_; }
+    inline bool rescale_required() const noexcept { return rescale_required_; }
+    inline bool relinearization_required() const noexcept { return relinearization_required_; }
+    void get_data(std::vector<Data64>& out, hipStream_t s = nullptr) const
+    {
+        out.resize(device_locations_.size());
+        detail::hip(hipMemcpyAsync(out.data(), device_locations_.data(), out.size() * sizeof(Data64),
+                                   hipMemcpyDeviceToHost, s));
+        detail::hip(hipStreamSynchronize(s));
+    }
+    // Until the encryptor exists: fill with residues laid out [size][Q - depth][N].
+    void load(const std::vector<Data64>& host, int cipher_size, int depth, double scale = 1.0, hipStream_t s = nullptr)
+    {
+        const size_t want = (size_t) cipher_size * (coeff_modulus_count_ - depth) * ring_size_;
+        if (host.size() != want) throw std::invalid_argument("Invalid Ciphertexts size!");
+        device_locations_ = DeviceVector<Data64>(host, s);
+        cipher_size_ = cipher_size;
+        depth_ = depth;
+        scale_ = scale;
+        ciphertext_generated_ = true;
+        relinearization_required_ = cipher_size == 3;
+    }
+
+  private:
+    int ring_size_ = 0, coeff_modulus_count_ = 0, cipher_size_ = 2, depth_ = 0;
+    double scale_ = 0;
+    bool in_ntt_domain_ = false, rescale_required_ = false, relinearization_required_ = false;
+    bool ciphertext_generated_ = false;
+    storage_type storage_type_ = storage_type::DEVICE;
+    DeviceVector<Data64> device_locations_;
+};
+
+// ------------------------------------------------------------------ keys
+template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N (evaluationkey.cu:30-36)
+  public:
+    explicit Relinkey(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
+        d_ = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
+        relinkey_size_ = (size_t) 2 * d_ * context_->Q_prime_size * context_->n;
+        key_type = context_->P_size == 1 ? 1 : 2;
+    }
+    Data64* data() { return device_location_.data(); }
+    size_t size() const { return relinkey_size_; }
+    void load(const std::vector<Data64>& host, hipStream_t s = nullptr) // until the key generator exists
+    {
+        if (host.size() != relinkey_size_) throw std::invalid_argument("Invalid relinkey size!");
+        device_location_ = DeviceVector<Data64>(host, s);
+    }
+    int key_type = 1;
+
+  private:
+    HEContext<S> context_;
+    int d_ = 0;
+    size_t relinkey_size_ = 0;
+    DeviceVector<Data64> device_location_;
+};
+
+template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration.cu:684-728
+  public:
+    Galoiskey(HEContext<S> context, const std::vector<int>& shifts) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        group_order_ = (S == Scheme::BFV) ? 3 : 5; // bfv/evaluationkey.cu:308, ckks/evaluationkey.cu:408
+        for (int sh : shifts) galois_elt[sh] = hegpu_steps_to_galois_elt(sh, context_->n, group_order_);
+        const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
+        const int d = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
+        galoiskey_size_ = (size_t) 2 * d * context_->Q_prime_size * context_->n;
+    }
+    size_t size() const { return galoiskey_size_; }
+    void load(int galois_element, const std::vector<Data64>& host, hipStream_t s = nullptr)
+    {
+        if (host.size() != galoiskey_size_) throw std::invalid_argument("Invalid galoiskey size!");
+        device_location_[galois_element] = DeviceVector<Data64>(host, s);
+    }
+    std::map<int, int> galois_elt;                           // shift -> Galois element
+    std::map<int, DeviceVector<Data64>> device_location_;    // Galois element -> key
+    int group_order_ = 5;
+
+  private:
+    HEContext<S> context_;
+    size_t galoiskey_size_ = 0;
+};
+
+// ------------------------------------------------------------------ operator
+template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
+  public:
+    explicit HEArithmeticOperator(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+    }
+
+    void add(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        binary(a, b, out, 0, o);
+    }
+    void sub(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        binary(a, b, out, 1, o);
+    }
+    void negate(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        const int l = limbs(a);
+        DeviceVector<Data64> m((size_t) a.cipher_size_ * l * context_->n, o.stream_);
+        detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), nullptr, (uint64_t*) m.data(), l,
+                                     a.cipher_size_, 1, 2, o.stream_));
+        copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+
+    // host/ckks/operator.cuh:632-689, host/bfv/operator.cuh:348-391
+    void multiply(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (a.relinearization_required_ || b.relinearization_required_)
+            throw std::invalid_argument("Ciphertexts can not be multiplied because of the non-linear part! Please "
+                                        "use relinearization operation!");
+        if (a.rescale_required_ || b.rescale_required_)
+            throw std::invalid_argument("Ciphertexts can not be multiplied because of the noise! Please use rescale "
+                                        "operation to get rid of additional noise!");
+        if (a.depth_ != b.depth_) throw std::logic_error("Ciphertexts leveled are not equal");
+        const int l = limbs(a);
+        const size_t n = context_->n;
+        if (a.memory_size() < 2 * n * l || b.memory_size() < 2 * n * l)
+            throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m(3 * n * l, o.stream_);
+        if (S == Scheme::CKKS) {
+            detail::check(hegpu_ckks_multiply(context_->handle(), (const uint64_t*) a.data(), 0,
+                                              (const uint64_t*) b.data(), 0, (uint64_t*) m.data(), 0, a.depth_, 1,
+                                              o.stream_));
+        } else {
+            const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_BFV_MULTIPLY, 0, 1);
+            DeviceVector<Data64> ws(wsb / 8, o.stream_);
+            detail::check(hegpu_bfv_multiply(context_->handle(), (const uint64_t*) a.data(), 0,
+                                             (const uint64_t*) b.data(), 0, (uint64_t*) m.data(), 0, 1, ws.data(), wsb,
+                                             o.stream_));
+        }
+        const double sc = a.scale_ * b.scale_;
+        copy_meta(a, out);
+        out.memory_set(std::move(m));
+        out.cipher_size_ = 3;
+        out.scale_ = sc;
+        out.relinearization_required_ = true;
+        out.rescale_required_ = (S == Scheme::CKKS);
+    }
+    void multiply_inplace(Ciphertext<S>& a, Ciphertext<S>& b, const ExecutionOptions& o = ExecutionOptions())
+    {
+        multiply(a, b, a, o);
+    }
+
+    // host/ckks/operator.cuh:1053-1094: method I or II by the context's P_size
+    void relinearize_inplace(Ciphertext<S>& a, Relinkey<S>& rk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!a.relinearization_required_)
+            throw std::invalid_argument("Ciphertexts can not use relinearization, since no non-linear part!");
+        const int l = limbs(a);
+        const int op = (S == Scheme::CKKS) ? HEGPU_OP_CKKS_RELIN : HEGPU_OP_BFV_RELIN;
+        const size_t wsb = hegpu_workspace_bytes(context_->handle(), op, a.depth_, 1);
+        DeviceVector<Data64> ws(wsb / 8, o.stream_);
+        if (S == Scheme::CKKS)
+            detail::check(hegpu_ckks_relinearize_inplace(context_->handle(), (uint64_t*) a.data(),
+                                                         (uint64_t) 3 * l * context_->n, (const uint64_t*) rk.data(),
+                                                         a.depth_, 1, ws.data(), wsb, o.stream_));
+        else
+            detail::check(hegpu_bfv_relinearize_inplace(context_->handle(), (uint64_t*) a.data(),
+                                                        (uint64_t) 3 * l * context_->n, (const uint64_t*) rk.data(), 1,
+                                                        ws.data(), wsb, o.stream_));
+        a.relinearization_required_ = false;
+        a.cipher_size_ = 2;
+    }
+
+    // host/ckks/operator.cuh:1423-1445 (CKKS only)
+    void rescale_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::CKKS, "rescale is a CKKS operation");
+        if (!a.rescale_required_ || a.relinearization_required_)
+            throw std::invalid_argument("Ciphertexts can not be rescaled because ciphertext rescaling is not required "
+                                        "or relinearization is required first!");
+        const int l = limbs(a);
+        if (l < 2) throw std::logic_error("Ciphertext modulus can not be reducible, since there is only one modulus");
+        const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_RESCALE, a.depth_, 1);
+        DeviceVector<Data64> ws(wsb / 8, o.stream_);
+        detail::check(hegpu_ckks_rescale_inplace(context_->handle(), (uint64_t*) a.data(),
+                                                 (uint64_t) 2 * l * context_->n, a.depth_, 1, ws.data(), wsb,
+                                                 o.stream_));
+        a.scale_ = a.scale_ / (double) context_->prime_vector_[l - 1]; // ckks/operator.cu:1235-1241
+        a.depth_++;
+        a.rescale_required_ = false;
+    }
+
+    // host/bfv/operator.cuh:576-660, ckks/operator.cu:1338-1378: direct key or power-of-two chain
+    void rotate_rows(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, int shift,
+                     const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (shift == 0) { out = in; return; }
+        const int g = hegpu_steps_to_galois_elt(shift, context_->n, gk.group_order_);
+        if (gk.device_location_.count(g)) { apply_galois(in, out, gk, g, o); return; }
+        std::vector<int> chain; // bfv/operator.cu:692-712
+        int rest = std::abs(shift);
+        const int sign = shift < 0 ? -1 : 1;
+        while (rest) {
+            const int p2 = 1 << (int) std::log2((double) rest);
+            rest -= p2;
+            auto it = gk.galois_elt.find(p2 * sign);
+            if (it == gk.galois_elt.end() || !gk.device_location_.count(it->second))
+                throw std::logic_error("Galois key not present!");
+            chain.push_back(it->second);
+        }
+        Ciphertext<S> cur = in;
+        for (int ge : chain) {
+            Ciphertext<S> nxt(cur);
+            apply_galois(cur, nxt, gk, ge, o);
+            cur = std::move(nxt);
+        }
+        out = std::move(cur);
+    }
+    void rotate_rows_inplace(Ciphertext<S>& a, Galoiskey<S>& gk, int shift, const ExecutionOptions& o = ExecutionOptions())
+    {
+        Ciphertext<S> tmp(a);
+        rotate_rows(tmp, a, gk, shift, o);
+    }
+    void apply_galois(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, int galois_elt,
+                      const ExecutionOptions& o = ExecutionOptions())
+    {
+        auto it = gk.device_location_.find(galois_elt);
+        if (it == gk.device_location_.end()) throw std::logic_error("Galois key not present!");
+        if (in.relinearization_required_) throw std::invalid_argument("Ciphertext should be relinearized first!");
+        const int l = limbs(in);
+        const size_t n = context_->n;
+        DeviceVector<Data64> m(2 * n * l, o.stream_);
+        const int op = (S == Scheme::CKKS) ? HEGPU_OP_CKKS_GALOIS : HEGPU_OP_BFV_GALOIS;
+        const size_t wsb = hegpu_workspace_bytes(context_->handle(), op, in.depth_, 1);
+        DeviceVector<Data64> ws(wsb / 8, o.stream_);
+        if (S == Scheme::CKKS)
+            detail::check(hegpu_ckks_apply_galois(context_->handle(), (const uint64_t*) in.data(), 0,
+                                                  (uint64_t*) m.data(), 0, (const uint64_t*) it->second.data(),
+                                                  galois_elt, in.depth_, 1, ws.data(), wsb, o.stream_));
+        else
+            detail::check(hegpu_bfv_apply_galois(context_->handle(), (const uint64_t*) in.data(), 0,
+                                                 (uint64_t*) m.data(), 0, (const uint64_t*) it->second.data(),
+                                                 galois_elt, 1, ws.data(), wsb, o.stream_));
+        if (&in != &out) copy_meta(in, out);
+        out.memory_set(std::move(m));
+    }
+
+  private:
+    int limbs(const Ciphertext<S>& a) const { return context_->Q_size - a.depth_; }
+    static void copy_meta(const Ciphertext<S>& a, Ciphertext<S>& out)
+    {
+        out.ring_size_ = a.ring_size_;
+        out.coeff_modulus_count_ = a.coeff_modulus_count_;
+        out.cipher_size_ = a.cipher_size_;
+        out.depth_ = a.depth_;
+        out.scale_ = a.scale_;
+        out.in_ntt_domain_ = a.in_ntt_domain_;
+        out.rescale_required_ = a.rescale_required_;
+        out.relinearization_required_ = a.relinearization_required_;
+        out.ciphertext_generated_ = true;
+    }
+    void binary(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, int op, const ExecutionOptions& o)
+    {
+        if (a.depth_ != b.depth_) throw std::logic_error("Ciphertexts leveled are not equal");
+        if (a.cipher_size_ != b.cipher_size_) throw std::invalid_argument("Ciphertexts sizes have to be equal");
+        const int l = limbs(a);
+        DeviceVector<Data64> m((size_t) a.cipher_size_ * l * context_->n, o.stream_);
+        detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), (const uint64_t*) b.data(),
+                                     (uint64_t*) m.data(), l, a.cipher_size_, 1, op, o.stream_));
+        copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+    HEContext<S> context_;
+};
+
+} // namespace heongpu

@@ -1,0 +1,177 @@
+// test_api.cpp -- the C++ class layer (include/heongpu/heongpu.hpp) used the way
+// the reference's tests use its API (test/test_ckks_relinearization.cpp:36-111,
+// test_bfv_rotation_method_1.cpp:30-86), checked bit-for-bit against the CPU
+// oracle (test infrastructure).  Runs on the GPU box (pytest -m gpu wrapper).
+#include <heongpu/heongpu.hpp>
+#include <cstdio>
+#include <cstring>
+extern "C" {
+#include "hegpu_oracle.h"
+}
+
+using namespace heongpu;
+typedef std::vector<Data64> Vec;
+
+static int failures = 0;
+#define EXPECT(c, what)                                   \
+    do {                                                  \
+        if (!(c)) { printf("FAIL: %s\n", what); failures++; } \
+        else printf("ok:   %s\n", what);                  \
+    } while (0)
+
+static Vec synth_ct(const Vec& primes, int limbs, int parts, size_t n, u64 seed)
+{
+    Vec out((size_t) parts * limbs * n);
+    for (int p = 0; p < parts; p++)
+        for (int j = 0; j < limbs; j++) o_fill_poly((u64*) &out[((size_t) p * limbs + j) * n], seed * 1000 + p, j, n, primes[j]);
+    return out;
+}
+static Vec synth_key(const Vec& primes, int digits, int Qp, size_t n, u64 seed)
+{
+    Vec out((size_t) digits * 2 * Qp * n);
+    for (int i = 0; i < digits; i++)
+        for (int c = 0; c < 2; c++)
+            for (int j = 0; j < Qp; j++)
+                o_fill_poly((u64*) &out[(((size_t) i * 2 + c) * Qp + j) * n], seed * 100000 + i * 2 + c, j, n, primes[j]);
+    return out;
+}
+static bool same(const Vec& a, const u64* b, size_t cnt) { return a.size() >= cnt && !memcmp(a.data(), b, cnt * 8); }
+
+template <typename F> static bool throws_invalid(F f)
+{
+    try { f(); } catch (const std::invalid_argument&) { return true; } catch (...) { return false; }
+    return false;
+}
+template <typename F> static bool throws_logic(F f)
+{
+    try { f(); } catch (const std::logic_error&) { return true; } catch (...) { return false; }
+    return false;
+}
+
+static void ckks()
+{
+    constexpr auto S = Scheme::CKKS;
+    const size_t n = 8192;
+    HEContext<S> ctx = GenHEContext<S>(sec_level_type::none);
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_bit_sizes({40, 35, 35, 35}, {40});
+    ctx->generate();
+    const int Q = ctx->get_ciphertext_modulus_count(), Qp = ctx->get_key_modulus_count();
+    Vec primes = ctx->get_key_modulus();
+    octx_t* o = o_ctx_create(O_CKKS, 13, (const u64*) primes.data(), Q, 1, 0);
+
+    Vec h1 = synth_ct(primes, Q, 2, n, 1), h2 = synth_ct(primes, Q, 2, n, 2), hk = synth_key(primes, Q, Qp, n, 3);
+    Ciphertext<S> c1(ctx), c2(ctx), c3(ctx);
+    c1.load(h1, 2, 0, std::pow(2.0, 35));
+    c2.load(h2, 2, 0, std::pow(2.0, 35));
+    Relinkey<S> rk(ctx);
+    rk.load(hk);
+    HEArithmeticOperator<S> op(ctx);
+
+    op.multiply(c1, c2, c3);
+    EXPECT(c3.size() == 3 && c3.relinearization_required() && c3.rescale_required(), "ckks multiply metadata");
+    EXPECT(throws_invalid([&] { op.multiply(c3, c1, c3); }), "multiply on a non-relinearized ciphertext throws");
+    op.relinearize_inplace(c3, rk);
+    op.rescale_inplace(c3);
+    EXPECT(c3.depth() == 1 && c3.size() == 2, "ckks depth after rescale");
+    Vec got;
+    c3.get_data(got);
+    Vec w(3 * Q * n);
+    o_ckks_multiply(o, (const u64*) h1.data(), (const u64*) h2.data(), (u64*) w.data(), 0);
+    o_ckks_relinearize(o, (u64*) w.data(), (const u64*) hk.data(), 0);
+    o_ckks_rescale(o, (u64*) w.data(), 0);
+    EXPECT(same(got, (const u64*) w.data(), 2 * (Q - 1) * n), "ckks multiply+relinearize+rescale == oracle");
+    EXPECT(std::fabs(c3.scale() - std::pow(2.0, 70) / (double) primes[Q - 1]) < 1.0, "ckks scale bookkeeping");
+
+    // rotations: direct key (shift 1) and power-of-two chain (shift 3 = 2 + 1)
+    Galoiskey<S> gk(ctx, std::vector<int>{1, 2});
+    Vec k1 = synth_key(primes, Q, Qp, n, 7), k2 = synth_key(primes, Q, Qp, n, 8);
+    gk.load(gk.galois_elt[1], k1);
+    gk.load(gk.galois_elt[2], k2);
+    Ciphertext<S> r1(ctx), r3(ctx);
+    op.rotate_rows(c1, r1, gk, 1);
+    r1.get_data(got);
+    Vec wr(2 * Q * n), wr2(2 * Q * n);
+    o_ckks_apply_galois(o, (const u64*) h1.data(), (u64*) wr.data(), (const u64*) k1.data(), gk.galois_elt[1], 0);
+    EXPECT(same(got, (const u64*) wr.data(), 2 * Q * n), "ckks rotate_rows(1) == oracle");
+    op.rotate_rows(c1, r3, gk, 3);
+    r3.get_data(got);
+    o_ckks_apply_galois(o, (const u64*) h1.data(), (u64*) wr.data(), (const u64*) k2.data(), gk.galois_elt[2], 0);
+    o_ckks_apply_galois(o, (const u64*) wr.data(), (u64*) wr2.data(), (const u64*) k1.data(), gk.galois_elt[1], 0);
+    EXPECT(same(got, (const u64*) wr2.data(), 2 * Q * n), "ckks rotate_rows(3) via 2+1 chain == oracle");
+    EXPECT(throws_logic([&] { op.rotate_rows(c1, r3, gk, 4); }), "missing Galois key throws logic_error");
+
+    // add / sub on a non-default stream
+    hipStream_t st;
+    detail::hip(hipStreamCreate(&st));
+    ExecutionOptions opt;
+    opt.set_stream(st);
+    {
+        Ciphertext<S> s(ctx, opt); // must not outlive its stream
+        op.add(c1, c2, s, opt);
+        s.get_data(got, st);
+        Vec wa(2 * Q * n);
+        o_addition((const u64*) h1.data(), (const u64*) h2.data(), (u64*) wa.data(), o->mod, 13, Q, 2);
+        EXPECT(same(got, (const u64*) wa.data(), 2 * Q * n), "ckks add on a user stream == oracle");
+    }
+    detail::hip(hipStreamSynchronize(st));
+    detail::hip(hipStreamDestroy(st));
+    o_ctx_free(o);
+}
+
+static void bfv()
+{
+    constexpr auto S = Scheme::BFV;
+    const size_t n = 4096;
+    HEContext<S> ctx = GenHEContext<S>();
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_default_values(1);
+    ctx->set_plain_modulus(1032193);
+    ctx->generate();
+    const int Q = ctx->Q_size, Qp = ctx->Q_prime_size;
+    Vec primes = ctx->get_key_modulus();
+    octx_t* o = o_ctx_create(O_BFV, 12, (const u64*) primes.data(), Q, 1, 1032193);
+    Vec h1 = synth_ct(primes, Q, 2, n, 1), h2 = synth_ct(primes, Q, 2, n, 2), hk = synth_key(primes, Q, Qp, n, 3);
+    Ciphertext<S> c1(ctx), c2(ctx);
+    c1.load(h1, 2, 0);
+    c2.load(h2, 2, 0);
+    Relinkey<S> rk(ctx);
+    rk.load(hk);
+    HEArithmeticOperator<S> op(ctx);
+    op.multiply_inplace(c1, c2);
+    op.relinearize_inplace(c1, rk);
+    Vec got;
+    c1.get_data(got);
+    Vec w(3 * Q * n);
+    o_bfv_multiply(o, (const u64*) h1.data(), (const u64*) h2.data(), (u64*) w.data());
+    o_bfv_relinearize(o, (u64*) w.data(), (const u64*) hk.data());
+    EXPECT(same(got, (const u64*) w.data(), 2 * Q * n), "bfv multiply_inplace+relinearize == oracle");
+    Galoiskey<S> gk(ctx, std::vector<int>{1});
+    gk.load(gk.galois_elt[1], hk);
+    Ciphertext<S> r(ctx);
+    op.rotate_rows(c2, r, gk, 1);
+    r.get_data(got);
+    Vec wr(2 * Q * n);
+    o_bfv_apply_galois(o, (const u64*) h2.data(), (u64*) wr.data(), (const u64*) hk.data(), gk.galois_elt[1]);
+    EXPECT(same(got, (const u64*) wr.data(), 2 * Q * n), "bfv rotate_rows(1) == oracle");
+    o_ctx_free(o);
+}
+
+int main()
+{
+    setvbuf(stdout, NULL, _IONBF, 0);
+    {
+        auto bad = GenHEContext<Scheme::CKKS>();
+        EXPECT(throws_logic([&] { bad->set_poly_modulus_degree(1000); }), "degree must be a power of two");
+        auto sec = GenHEContext<Scheme::CKKS>();
+        sec->set_poly_modulus_degree(4096);
+        sec->set_coeff_modulus_bit_sizes({40, 30, 30}, {40});
+        bool thrown = false;
+        try { sec->generate(); } catch (const std::runtime_error&) { thrown = true; }
+        EXPECT(thrown, "140-bit chain at N=4096 violates the 128-bit security table");
+    }
+    ckks();
+    bfv();
+    printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
+    return failures ? 1 : 0;
+}

@@ -337,3 +337,17 @@ def test_bfv_method_II(hg, oracle, torch):
     got = hg.to_host(rot).reshape(batch, -1)
     for b in range(batch):
         assert np.array_equal(got[b], o.bfv_apply_galois_II(ct1[b], key, g)), "bfv method II rotate"
+
+
+def test_cpp_class_layer(torch):
+    """include/heongpu/heongpu.hpp (HEContext / Ciphertext / Relinkey / Galoiskey /
+    HEArithmeticOperator over the C ABI): tests/cpp/test_api.cpp vs the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "heongpu_amd", "lib", "test_cpp_api")
+    assert os.path.exists(exe), "build it with __graft_entry__.build() (make -C heongpu_amd/csrc cpptest)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "PASSED" in r.stdout
