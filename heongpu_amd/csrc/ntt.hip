@@ -242,6 +242,7 @@ __device__ __forceinline__ void gs_radix_last(u64 (&x)[1 << LOGR], const ulonglo
 struct PolySel {
     u64 in_off, out_off; // element offsets of this polynomial
     int mod;             // modulus index into the plan
+    int digit;           // RNS digit of a decomposing launch (else -1)
 };
 
 __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
@@ -268,7 +269,8 @@ __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
     if (a.mod_order) k = a.mod_order[k];
     s.mod = a.mod_offset + k;
     u64 slot = a.poly_order ? (u64) a.poly_order[j] : (u64) j;
-    u64 in_slot = a.decomp_mods ? (u64) (j / a.decomp_mods) : slot;
+    s.digit = a.decomp_mods ? j / a.decomp_mods : -1;
+    u64 in_slot = a.decomp_mods ? (u64) s.digit : slot;
     s.in_off = (u64) item * a.in_item_stride + (in_slot << a.n_power);
     s.out_off = (u64) item * a.out_item_stride + (slot << a.n_power);
     return s;
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
 {
     __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
     const PolySel ps = select_poly(a, blockIdx.y);
+    if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const PolySel ps = select_poly(a, blockIdx.y);
+    if (a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.bit <= NTT_LAZY_BITS) fwd_row_body<true>(a, ps, md, lds);
     else fwd_row_body<false>(a, ps, md, lds);
@@ -519,7 +523,7 @@ static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
     NttArgs b = a;
     b.in = a.out;
     b.in_item_stride = a.out_item_stride;
-    b.decomp_mods = 0;
+    // the row pass is in place on `out`; it keeps decomp_mods only to know the digit
     hipLaunchKernelGGL(ntt_fwd_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, b);
 }
 

@@ -41,6 +41,10 @@ struct NttArgs {
     // through reduce64 first.  Replaces cipher_broadcast*_kernel + NTT
     // (reference switchkey.cu:11-59 followed by ckks/operator.cu:956).
     int decomp_mods;
+    // With decomp_mods: skip polynomial (digit d, modulus index d).  For that
+    // pair NTT_d(INTT_d(x) mod q_d) == x, so the caller copies the NTT-domain
+    // limb into the slot instead (rns_copy_diag) and both passes exit early.
+    int skip_identity;
     // Set by ntt_launch: when > 0 the grid walks polynomials modulus-major
     // (all polynomials of one modulus back to back) so that concurrently
     // running workgroups share one modulus' twiddle table in L2.

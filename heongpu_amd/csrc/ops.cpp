@@ -58,6 +58,9 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     u64* c2 = ct + ((u64) l << (np + 1));
     const Mod* mods = c.plan_qp.mods;
 
+    // digit d re-reduced into its own modulus d and transformed back is the
+    // NTT-domain limb itself: keep it before the INTT overwrites it
+    TRY(rns_copy_diag(c2, cs, temp1, per, np, l, rc, batch, st));
     NttArgs a = c.ntt_args(0);
     // INTT(c2), batch l per item                                     (:919)
     a.in = c2; a.out = c2; a.mod_count = l; a.polys_per_item = l;
@@ -67,6 +70,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     // first load; modulus order skips dropped primes                (:932-960)
     a = c.ntt_args(0);
     a.in = c2; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
+    a.skip_identity = 1;
     a.in_item_stride = cs; a.out_item_stride = per;
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     TRY(ntt_launch(a, l * rc * batch, false, st));
@@ -139,12 +143,15 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, 2 * l * batch, true, st));                                           // :1461
+    TRY(rns_copy_diag(ct + (u64) l * n, cs, temp2, per, np, l, rc, batch, st)); // NTT-domain c1 limbs
     a = c.ntt_args(0); // ckks_duplicate_kernel fused into the NTT load          :1467-1494
     a.in = temp0 + (u64) l * n; a.out = temp2; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
+    a.skip_identity = 1;
     a.in_item_stride = a.out_item_stride = per;
     a.mod_order = order;
     TRY(ntt_launch(a, l * rc * batch, false, st));
     a.decomp_mods = 0;
+    a.skip_identity = 0;
     TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, depth, batch, st)); // :1501
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1524

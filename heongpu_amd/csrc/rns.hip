@@ -512,6 +512,23 @@ hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64*
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(RNS_THREADS) void k_copy_diag(const u64* __restrict__ in, u64 in_stride,
+                                                           u64* __restrict__ out, u64 out_stride, int n_power, int rc)
+{
+    const u64 c = coeff0();
+    const u64 d = blockIdx.y;
+    st2(out + out_stride * blockIdx.z + ((d * (rc + 1)) << n_power) + c,
+        ld2(in + in_stride * blockIdx.z + (d << n_power) + c));
+}
+
+hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride, int n_power, int limbs, int rc,
+                         int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_diag, grid3(n_power, limbs, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
+                       out_stride, n_power, rc);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- BFV BEHZ kernels
 #define BEHZ_MAX 40
 

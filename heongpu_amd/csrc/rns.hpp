@@ -82,6 +82,11 @@ hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64*
                           u64 out_part_stride, u64 out_stride, int n_power, int limbs, int parts,
                           int batch, hipStream_t st);
 
+// out[b][d*(rc+1)][*] = in[b][d][*] for d < limbs: places NTT-domain limb d in
+// the (digit d, modulus d) slot of a [l][rc][N] key-switch buffer
+hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride, int n_power, int limbs, int rc,
+                         int batch, hipStream_t st);
+
 struct BehzDev {
     const Mod* ibase;       // q_0..q_{Q-1}
     const Mod* obase;       // Bsk
