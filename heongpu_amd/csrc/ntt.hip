@@ -400,6 +400,12 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
     }
+#if defined(NTT_ROW_DIRECT_STORE)
+    // 16 contiguous results per lane, written as eight 16-byte stores
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&p[row * 256 + 16 * i0 + 2 * k]) = make_ulonglong2(x[2 * k], x[2 * k + 1]);
+#else
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -408,6 +414,7 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) gst(&p[row * 256 + i0 + 16 * k], lds[row_phys(row * 256 + i0 + 16 * k)]);
+#endif
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)

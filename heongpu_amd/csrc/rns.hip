@@ -164,6 +164,7 @@ __device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
 // workgroups that read the same key tile (same limb, same 512 coefficients)
 // are dispatched back to back, so the evaluation key streams from HBM once
 // per tile instead of once per ciphertext (it is reused out of L2 / MALL).
+template <int ITEMS>
 __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __restrict__ in, u64 in_stride,
                                                                const u64* __restrict__ key,
                                                                u64* __restrict__ out, u64 out_stride,
@@ -171,35 +172,45 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __rest
                                                                int digits, int nmods, int key_limbs, int split,
                                                                int level)
 {
-    const int item = blockIdx.x;
+    const int item0 = blockIdx.x * ITEMS;
     const int y = blockIdx.z;
     const int kidx = (y < split) ? y : y + level;
     const Mod m = mods[kidx];
     const u64 c = ((u64) blockIdx.y * RNS_THREADS + threadIdx.x) * 2;
-    const u64* pin = in + in_stride * item + ((u64) y << n_power) + c;
+    const u64* pin = in + in_stride * item0 + ((u64) y << n_power) + c;
     const u64* pk = key + ((u64) kidx << n_power) + c;
     const u64 key_off1 = (u64) key_limbs << n_power;
     const u64 key_off2 = (u64) key_limbs << (n_power + 1);
     const u64 dig_off = (u64) nmods << n_power;
-    u64 h00 = 0, l00 = 0, h01 = 0, l01 = 0, h10 = 0, l10 = 0, h11 = 0, l11 = 0;
+    u64 h[ITEMS][4], l[ITEMS][4];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[t][e] = l[t][e] = 0;
 #pragma unroll 2
     for (int i = 0; i < digits; i++) {
-        ulonglong2 d = ld2(pin + dig_off * i);
-        ulonglong2 k0 = ld2(pk + key_off2 * i);
-        ulonglong2 k1 = ld2(pk + key_off2 * i + key_off1);
-        acc_mad(h00, l00, d.x, k0.x);
-        acc_mad(h01, l01, d.y, k0.y);
-        acc_mad(h10, l10, d.x, k1.x);
-        acc_mad(h11, l11, d.y, k1.y);
+        const ulonglong2 k0 = ld2(pk + key_off2 * i);
+        const ulonglong2 k1 = ld2(pk + key_off2 * i + key_off1);
+#pragma unroll
+        for (int t = 0; t < ITEMS; t++) {
+            const ulonglong2 d = ld2(pin + in_stride * t + dig_off * i);
+            acc_mad(h[t][0], l[t][0], d.x, k0.x);
+            acc_mad(h[t][1], l[t][1], d.y, k0.y);
+            acc_mad(h[t][2], l[t][2], d.x, k1.x);
+            acc_mad(h[t][3], l[t][3], d.y, k1.y);
+        }
     }
-    ulonglong2 r0, r1;
-    r0.x = reduce128(h00, l00, m);
-    r0.y = reduce128(h01, l01, m);
-    r1.x = reduce128(h10, l10, m);
-    r1.y = reduce128(h11, l11, m);
-    u64* po = out + out_stride * item + ((u64) y << n_power) + c;
-    st2(po, r0);
-    st2(po + dig_off, r1);
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        ulonglong2 r0, r1;
+        r0.x = reduce128(h[t][0], l[t][0], m);
+        r0.y = reduce128(h[t][1], l[t][1], m);
+        r1.x = reduce128(h[t][2], l[t][2], m);
+        r1.y = reduce128(h[t][3], l[t][3], m);
+        u64* po = out + out_stride * (item0 + t) + ((u64) y << n_power) + c;
+        st2(po, r0);
+        st2(po + dig_off, r1);
+    }
 }
 
 hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
@@ -207,9 +218,20 @@ hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* 
                              int level, int batch, hipStream_t st)
 {
     if (digits > 64) return hipErrorInvalidValue; // 128-bit accumulator bound
-    dim3 g(batch, (1u << n_power) / RNS_PER_BLOCK, nmods);
-    hipLaunchKernelGGL(k_keyswitch_mac, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride, mods,
-                       n_power, digits, nmods, key_limbs, split, level);
+    // up to four ciphertexts per workgroup share every key load when the batch allows it
+    if (batch % 4 == 0) {
+        dim3 g(batch / 4, (1u << n_power) / RNS_PER_BLOCK, nmods);
+        hipLaunchKernelGGL(k_keyswitch_mac<4>, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride,
+                           mods, n_power, digits, nmods, key_limbs, split, level);
+    } else if (batch % 2 == 0) {
+        dim3 g(batch / 2, (1u << n_power) / RNS_PER_BLOCK, nmods);
+        hipLaunchKernelGGL(k_keyswitch_mac<2>, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride,
+                           mods, n_power, digits, nmods, key_limbs, split, level);
+    } else {
+        dim3 g(batch, (1u << n_power) / RNS_PER_BLOCK, nmods);
+        hipLaunchKernelGGL(k_keyswitch_mac<1>, g, dim3(RNS_THREADS), 0, st, in, in_stride, key, out, out_stride,
+                           mods, n_power, digits, nmods, key_limbs, split, level);
+    }
     return hipGetLastError();
 }
 
