@@ -2,6 +2,7 @@
 #include "context.hpp"
 #include "host_params.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -300,6 +301,7 @@ static void free_plan(NttPlan& p)
 hipError_t Context::upload()
 {
     if (uploaded) return hipSuccess;
+    if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0');
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if ((e = build_plan(plan_qp, host["modulus"], host["ntt_table"], host["intt_table"], host["n_inverse"],

@@ -50,6 +50,8 @@ struct Context {
     };
     std::vector<M2Level> m2_levels;
     int m2_width = 0; // digit width m: 2 for BFV, P_size for CKKS
+    // use the fused "row pass + key-switch MAC" kernel (HEGPU_FUSED_ROW_MAC=0 disables)
+    bool fused_row_mac = true;
 
     // ---- device state (valid after upload())
     bool uploaded = false;

@@ -427,6 +427,111 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
     else fwd_row_body<false>(a, ps, md, lds);
 }
 
+// ------------------------------------------------------------------ fused row pass + key-switch MAC
+__device__ __forceinline__ void acc128(u64& hi, u64& lo, u64 a, u64 b)
+{
+    u64 h, l;
+    mul64wide(a, b, h, l);
+    lo += l;
+    hi += h + (lo < l);
+}
+
+template <bool LAZY>
+__device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict__ p, u64* lds,
+                                             const ulonglong2* __restrict__ tw, const ulonglong2* __restrict__ tb,
+                                             u32 root_a, const QC& qc, const Mod& md, int row, int i0)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = gld(&p[row * 256 + i0 + 16 * k]);
+    ct_radix<4, LAZY>(x, tw, root_a, qc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = x[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+        x[2 * k] = v.x;
+        x[2 * k + 1] = v.y;
+    }
+    ct_radix16_tb<LAZY>(x, tb, qc);
+    if (LAZY) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+            make_ulonglong2(x[2 * k], x[2 * k + 1]);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = lds[row_phys(row * 256 + i0 + 16 * k)];
+    wave_lds_fence();
+}
+
+// grid = (items, N/4096, rc): ciphertext fastest so the workgroups that share
+// a key tile run back to back
+__global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    const int t = threadIdx.x;
+    const int item = blockIdx.x, tile = blockIdx.y, slot = blockIdx.z;
+    const int midx = a.mod_order ? a.mod_order[slot] : slot;
+    const Mod md = a.mods[midx];
+    const QC qc = make_qc(md.q);
+    const int s1 = a.n_power - 8;
+    const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
+    const int row = t >> 4, i0 = t & 15;
+    const u32 crow = tile * 16 + row;
+    const ulonglong2* __restrict__ tb = a.twB + ((u64) midx * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0);
+    const u64 n = (u64) 1 << a.n_power;
+    const u64* __restrict__ pin = a.in + a.in_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096;
+    const u64* __restrict__ pk = a.key + ((u64) midx << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+    const u64 dig_off = (u64) a.rc << a.n_power;
+    const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
+    const bool lazy = md.bit <= NTT_LAZY_BITS;
+
+    u64 h0[16], l0[16], h1[16], l1[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) h0[k] = l0[k] = h1[k] = l1[k] = 0;
+    for (int i = 0; i < a.digits; i++) {
+        u64 x[16];
+        const u64* p = pin + dig_off * i;
+        if (a.skip_identity && i == midx) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = gld(&p[row * 256 + i0 + 16 * k]);
+        } else if (lazy) {
+            ks_row_digit<true>(x, p, lds, tw, tb, (1u << s1) + crow, qc, md, row, i0);
+        } else {
+            ks_row_digit<false>(x, p, lds, tw, tb, (1u << s1) + crow, qc, md, row, i0);
+        }
+        const u64* k0 = pk + key_off2 * i;
+        const u64* k1 = k0 + key_off1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            acc128(h0[k], l0[k], x[k], k0[16 * k]);
+            acc128(h1[k], l1[k], x[k], k1[16 * k]);
+        }
+    }
+    u64* po = a.out + a.out_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        po[16 * k] = reduce128(h0[k], l0[k], md);
+        po[dig_off + 16 * k] = reduce128(h1[k], l1[k], md);
+    }
+    (void) n;
+}
+
+hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
+{
+    if (a.digits > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ks_row_mac, dim3(items, (1u << a.n_power) / 4096, a.rc), dim3(NTT_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ inverse
 // Row pass first (GS stages with t = 1..128), reads a.in, writes a.out.
 __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
@@ -520,6 +625,16 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
 
 // ------------------------------------------------------------------ launch
 template <int S1>
+static void launch_fwd_col_only(const NttArgs& a, int batch, hipStream_t st)
+{
+    constexpr int CT = 4096 >> S1;
+    if (a.decomp_mods)
+        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((ntt_fwd_col<S1, false>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
+}
+
+template <int S1>
 static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
@@ -543,6 +658,24 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
     b.in = a.out;
     b.in_item_stride = a.out_item_stride;
     hipLaunchKernelGGL(ntt_inv_col<S1>, dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, b);
+}
+
+hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (a.n_power < 12 || a.n_power > 16 || batch > 65535 || a.poly_order) return hipErrorInvalidValue;
+    NttArgs g = a;
+    g.group_span = 0;
+    if (a.mod_count > 1 && batch % a.mod_count == 0 && (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
+        g.group_span = batch / a.mod_count;
+    switch (a.n_power - 8) {
+        case 4: launch_fwd_col_only<4>(g, batch, st); break;
+        case 5: launch_fwd_col_only<5>(g, batch, st); break;
+        case 6: launch_fwd_col_only<6>(g, batch, st); break;
+        case 7: launch_fwd_col_only<7>(g, batch, st); break;
+        case 8: launch_fwd_col_only<8>(g, batch, st); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)

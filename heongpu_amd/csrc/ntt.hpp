@@ -52,5 +52,30 @@ struct NttArgs {
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);
+// forward column pass only (the row pass is done by ks_row_mac_launch)
+hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st);
+
+// Fused "row pass + key-switch inner product" (method I/II): for every
+// (ciphertext, target limb k, 4096-coefficient tile) one workgroup walks the
+// digits, finishes each digit's forward NTT (the 8 contiguous stages) in
+// registers/LDS and accumulates digit * key[digit][c][limb] in 128-bit lazy
+// accumulators; only the two accumulated polynomials are written.  Replaces
+// the row pass of GPU_NTT_Modulus_Ordered_Inplace + keyswitch_multiply_accumulate*
+// (reference ckks/operator.cu:956-988): the [digits][rc][N] NTT output is
+// never stored or re-read.
+struct KsMacArgs {
+    const u64* in;          // column-pass output, [item][digit][rc][N]
+    u64 in_item_stride;
+    const u64* key;         // [digit][2][key_limbs][N]
+    u64* out;               // [item][2][rc][N]
+    u64 out_item_stride;
+    const Mod* mods;
+    const ulonglong2* tw;
+    const ulonglong2* twB;
+    const int* mod_order;   // modulus index of limb slot k (NULL: k)
+    int n_power, digits, rc, key_limbs;
+    int skip_identity;      // digit d at modulus d holds NTT-domain data already
+};
+hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 
 } // namespace hegpu

@@ -18,6 +18,39 @@ static int prime_loc_offset(const Context& c, int depth)
     return location;
 }
 
+// Forward NTT of the key-switch digits followed by the inner product with the
+// key.  `a` is the fully configured forward transform (plain or decomposing)
+// whose output is [digits][rc][N] per ciphertext at a.out; the result
+// [2][rc][N] goes to `acc`.  Fused path: column pass + ks_row_mac; otherwise
+// two-pass NTT + rns_keyswitch_mac.
+static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
+                                    int digits, int rc, int split, int level, int skip_identity, int batch,
+                                    hipStream_t st)
+{
+    const int ppi = digits * rc;
+    if (!c.fused_row_mac) {
+        TRY(ntt_launch(a, ppi * batch, false, st));
+        return rns_keyswitch_mac(a.out, a.out_item_stride, key, acc, acc_stride, c.plan_qp.mods, c.n_power, digits, rc,
+                                 c.Qp_size, split, level, batch, st);
+    }
+    const int chunk = 65535 / ppi; // gridDim.y limit of the column pass
+    if (chunk < 1) return hipErrorInvalidValue;
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        NttArgs ca = a;
+        ca.in = a.in + (u64) b0 * a.in_item_stride;
+        ca.out = a.out + (u64) b0 * a.out_item_stride;
+        TRY(ntt_launch_fwd_col(ca, ppi * nb, st));
+        KsMacArgs k{};
+        k.in = ca.out; k.in_item_stride = a.out_item_stride; k.key = key;
+        k.out = acc + (u64) b0 * acc_stride; k.out_item_stride = acc_stride;
+        k.mods = c.plan_qp.mods; k.tw = c.plan_qp.tw; k.twB = c.plan_qp.twB; k.mod_order = a.mod_order;
+        k.n_power = c.n_power; k.digits = digits; k.rc = rc; k.key_limbs = c.Qp_size; k.skip_identity = skip_identity;
+        TRY(ks_row_mac_launch(k, nb, st));
+    }
+    return hipSuccess;
+}
+
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
 {
     const u64 n = c.n;
@@ -73,9 +106,8 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.skip_identity = 1;
     a.in_item_stride = cs; a.out_item_stride = per;
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
-    TRY(ntt_launch(a, l * rc * batch, false, st));
-    // inner product with the key                                     (:967)
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, l, rc, Qp, l, depth, batch, st));
+    // forward NTT of the digits + inner product with the key      (:956-988)
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, 1, batch, st));
     // INTT of the two P-limb polynomials only                        (:996)
     a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
@@ -149,10 +181,9 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     a.skip_identity = 1;
     a.in_item_stride = a.out_item_stride = per;
     a.mod_order = order;
-    TRY(ntt_launch(a, l * rc * batch, false, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, l, rc, l, depth, 1, batch, st));          // :1490-1520
     a.decomp_mods = 0;
     a.skip_identity = 0;
-    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, l, rc, Qp, l, depth, batch, st)); // :1501
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1524
     TRY(rns_moddown_permute(temp3, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
@@ -200,9 +231,8 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
     a.in = ct + ((u64) Q << (np + 1)); a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(ntt_launch(a, Q * Qp * batch, false, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, 0, batch, st));             // :531-566
     a.decomp_mods = 0; a.in_item_stride = per;
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, Qp, 0, batch, st)); // :540
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
     return rns_divide_round_lastq(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
@@ -225,9 +255,8 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
     a.in = ct + (u64) Q * n; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(ntt_launch(a, Q * Qp * batch, false, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, 0, batch, st));             // :805-840
     a.decomp_mods = 0; a.in_item_stride = per;
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, Q, Qp, Qp, Qp, 0, batch, st)); // :814
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846
     return rns_moddown_permute(temp2, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
@@ -269,8 +298,7 @@ hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* 
     a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, d * rc * batch, false, st));                                         // :1095
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, d, rc, Qp, l, depth, batch, st)); // :1110
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, rc, l, depth, 0, batch, st));          // :1095-1125
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1131
     TRY(rns_moddown_extended(temp2, per, nullptr, 0, temp1, per, mods, c.d64("half"), c.d64("half_mod"),
@@ -306,8 +334,7 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
     a = c.ntt_args(0);
     a.in = temp3; a.out = temp3; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, d * rc * batch, false, st));
-    TRY(rns_keyswitch_mac(temp3, per, key, temp4, per, mods, np, d, rc, Qp, l, depth, batch, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp4, per, d, rc, l, depth, 0, batch, st));
     a.in = temp4; a.out = temp4; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));
     TRY(rns_moddown_permute(temp4, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
@@ -334,8 +361,7 @@ hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* k
     NttArgs a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, d * Qp * batch, false, st));                                         // :619
-    TRY(rns_keyswitch_mac(temp1, per, key, temp2, per, mods, np, d, Qp, Qp, Qp, 0, batch, st)); // :629
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, Qp, Qp, 0, 0, batch, st));             // :619-650
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :657
     return rns_moddown_extended(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
@@ -358,8 +384,7 @@ hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* 
     NttArgs a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(ntt_launch(a, d * Qp * batch, false, st));
-    TRY(rns_keyswitch_mac(temp2, per, key, temp3, per, mods, np, d, Qp, Qp, Qp, 0, batch, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, d, Qp, Qp, 0, 0, batch, st));
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));
     return rns_moddown_permute(temp3, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
