@@ -329,10 +329,10 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
             u64 y[RA];
 #pragma unroll
             for (int k = 0; k < RA; k++) y[k] = gld(&src[(u64) (rb + 16 * k) * 256 + c]);
-            if (DECOMP) {
-#pragma unroll
-                for (int k = 0; k < RA; k++) y[k] = reduce64(y[k], md);
-            }
+            // DECOMP: the digit (< 2^60, a residue of another prime) is NOT reduced
+            // first: the lazy butterflies only need x < 8q (q >= 2^57 here) or, on
+            // the correction-free path, x + 64q < 2^64; congruence mod q is kept
+            // and the row pass ends with an exact reduction.
             ct_radix<NSA, LAZY>(y, tw, 1u, qc);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = y[k];
@@ -343,10 +343,6 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = gld(&src[(u64) k * 256 + col]);
-        if (DECOMP) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
-        }
     }
     ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
@@ -454,13 +450,14 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
         x[2 * k + 1] = v.y;
     }
     ct_radix16_tb<LAZY>(x, tb, qc);
-    if (LAZY) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = reduce64(x[k], md);
-    } else {
+    if (!LAZY) {
+        // q >= 2^57: bring [0,8q) down to [0,q) so that 64 products stay below 2^128
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
     }
+    // LAZY (q < 2^57): the transform output stays un-reduced (< 65q < 2^64);
+    // x * key < 2^121, so even 64 digits fit the 128-bit accumulator and the one
+    // exact reduction happens on the accumulated sum.
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
