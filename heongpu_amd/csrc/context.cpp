@@ -254,12 +254,26 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     std::vector<ulonglong2> htw((size_t) cnt * n), hitw((size_t) cnt * n), hn(cnt), hw(cnt);
     const u64 rows = n / 256, perB = rows * 15 * 16; // re-laid entries per modulus
     std::vector<ulonglong2> htwB((size_t) cnt * perB), hitwB((size_t) cnt * perB);
+    // HEGPU_FP_NTT=0 keeps every modulus on the integer butterflies
+    const char* fp_env = getenv("HEGPU_FP_NTT");
+    const bool fp_on = !(fp_env && fp_env[0] == '0');
     for (int k = 0; k < cnt; k++) {
         const u64 q = mods[k];
         hm[k] = make_mod(q);
+        // moduli below 2^50: forward transform in FP64 (ntt.hip), the forward
+        // tables hold (double(w), RN(w/q)) instead of (w, Shoup companion)
+        hm[k].fp = (fp_on && hm[k].bit <= 50) ? 1 : 0;
         for (u64 j = 0; j < n; j++) {
             const u64 w = fwd[k * n + j], iw = inv[k * n + j];
-            htw[k * n + j] = make_ulonglong2(w, shoup_companion(w, q));
+            if (hm[k].fp) {
+                const double wd = (double) w, wi = wd / (double) q;
+                u64 a, b;
+                memcpy(&a, &wd, 8);
+                memcpy(&b, &wi, 8);
+                htw[k * n + j] = make_ulonglong2(a, b);
+            } else {
+                htw[k * n + j] = make_ulonglong2(w, shoup_companion(w, q));
+            }
             hitw[k * n + j] = make_ulonglong2(iw, shoup_companion(iw, q));
         }
         for (u64 c = 0; c < rows; c++)

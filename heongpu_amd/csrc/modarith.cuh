@@ -28,7 +28,7 @@ struct Mod {
     u64 r_lo;   // floor(2^128 / q) low word
     u64 r64;    // floor(2^64 / q)
     u32 bit;    // floor(log2 q) + 1
-    u32 pad;
+    u32 fp;     // 1: the plan's FORWARD twiddle tables of this modulus hold FP64 pairs (ntt.hip)
 };
 
 #if defined(__HIPCC__)
@@ -138,7 +138,7 @@ inline Mod make_mod(u64 q)
     m.r_hi = (u64) (r >> 64);
     m.r_lo = (u64) r;
     m.r64 = (q == 1) ? 0 : (u64) ((((unsigned __int128) 1) << 64) / q);
-    m.pad = 0;
+    m.fp = 0;
     return m;
 }
 inline u64 shoup_companion(u64 w, u64 q)

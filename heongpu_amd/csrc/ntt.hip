@@ -55,6 +55,103 @@ __device__ __forceinline__ void gst(u64* p, u64 v)
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
 
+// ------------------------------------------------------------------ FP64 path
+// Moduli below 2^50 (Mod::fp set by the plan builder) run the forward
+// transform in double precision: every value is an integer held exactly in a
+// double (|v| < 2^53), and a modular product costs 6 full-rate FP64
+// instructions instead of ~18 integer ones (9 of them 32-bit multiplies):
+//   h = RN(y*w), l = y*w - h (exact, FMA), k = rint(RN(y*w'))  with w' = RN(w/q),
+//   t = (h - k*q) + l.
+// |k - y*w/q| <= 1/2 + |y|*2^-52, so |h - k*q| < 2^52 is an integer and the FMA
+// that forms it is exact, as is the final sum: t == y*w - k*q EXACTLY,
+// |t| <= q*(1/2 + |y|*2^-52).  A butterfly then adds/subtracts t; magnitudes
+// grow from b*q to at most (1.25*b + 0.5)*q per stage (q < 2^50), i.e. from
+// b <= 1 to b <= 5.4 over the four stages of one register round, always
+// below 2^53; each round ends with a centred reduction x - q*rint(x/q)
+// (|x| <= q/2 afterwards).  Everything is exact integer arithmetic modulo q,
+// so the canonical result is bit-identical to the integer path's.
+struct FC {
+    double q;  // modulus
+    double qi; // RN(1/q)
+};
+__device__ __forceinline__ FC make_fc(u64 q)
+{
+    FC c;
+    c.q = (double) q;
+    c.qi = 1.0 / c.q;
+    return c;
+}
+__device__ __forceinline__ double as_f64(u64 v) { return __longlong_as_double((long long) v); }
+__device__ __forceinline__ u64 as_bits(double v) { return (u64) __double_as_longlong(v); }
+// v < 2^52: OR the integer into the mantissa of 2^52 and subtract 2^52 (one
+// integer and one FP64 instruction; v_cvt_f64_u32 is a slow-rate instruction)
+__device__ __forceinline__ double fp_from_u64(u64 v)
+{
+    return as_f64(v | 0x4330000000000000ull) - 4503599627370496.0;
+}
+__device__ __forceinline__ double fp_from_u32(u32 v) { return fp_from_u64((u64) v); }
+// r an integer in [0, 2^52)
+__device__ __forceinline__ u64 fp_to_u64(double r) { return as_bits(r + 4503599627370496.0) & 0xFFFFFFFFFFFFFull; }
+// centred residue, |result| <= q/2 (1 + 2^-40); exact for |x| < 2^53
+__device__ __forceinline__ double fp_reduce(double x, const FC& c)
+{
+    return __builtin_fma(-__builtin_rint(x * c.qi), c.q, x);
+}
+// canonical residue in [0, q)
+__device__ __forceinline__ double fp_canon(double x, const FC& c)
+{
+    const double r = fp_reduce(x, c);
+    return r < 0.0 ? r + c.q : r;
+}
+// y*w - k*q, see above; w = (w, RN(w/q)) as doubles
+__device__ __forceinline__ double fp_mul(double y, double wx, double wy, const FC& c)
+{
+    const double h = y * wx;
+    const double l = __builtin_fma(y, wx, -h);
+    const double k = __builtin_rint(y * wy);
+    return __builtin_fma(-k, c.q, h) + l;
+}
+__device__ __forceinline__ void fp_ct_bfly(double& x, double& y, ulonglong2 w, const FC& c)
+{
+    const double t = fp_mul(y, as_f64(w.x), as_f64(w.y), c);
+    y = x - t;
+    x = x + t;
+}
+// LOGR CT stages + the centred reduction that ends a register round
+template <int LOGR>
+__device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, u32 root0,
+                                            const FC& c)
+{
+#pragma unroll
+    for (int s = 0; s < LOGR; s++) {
+        const int half = (1 << LOGR) >> (s + 1);
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = tw[(root0 << s) + b];
+#pragma unroll
+            for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
+}
+// last four stages of the row pass (re-laid table), result canonical in [0,q)
+__device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglong2* __restrict__ tb, const FC& c)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+#pragma unroll
+            for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fp_canon(x[k], c);
+}
+
 // Per-modulus constants of the lazy butterflies.
 struct QC {
     u64 q;   // modulus
@@ -349,6 +446,64 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     for (int k = 0; k < 16; k++) gst(&dst[(u64) (16 * r1 + k) * 256 + col], x[k]);
 }
 
+// FP64 column pass (Mod::fp).  Output: centred residues as raw doubles -- the
+// row pass of the same modulus consumes them as such.
+template <int S1, bool DECOMP, bool WIDE>
+__device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
+{
+    constexpr int R = 1 << S1;
+    constexpr int CT = 4096 / R;
+    constexpr int NSA = S1 - 4;
+    constexpr int RA = 1 << NSA;
+    constexpr int G = 16 / RA;
+    const int t = threadIdx.x;
+    const FC fc = make_fc(md.q);
+    const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
+    const u64* __restrict__ src = a.in + ps.in_off + blockIdx.x * CT;
+    u64* __restrict__ dst = a.out + ps.out_off + blockIdx.x * CT;
+
+    // DECOMP: the input is a residue of the digit's own prime.  Up to 52 bits it
+    // converts exactly and is reduced in floating point; a wider digit goes
+    // through its halves: v = vh*2^32 + vl == vh*(2^32 mod q) + vl (mod q).
+    // (WIDE is uniform per workgroup; the caller branches once.)
+    double c32 = 0.0, c32i = 0.0;
+    if constexpr (DECOMP && WIDE) {
+        c32 = (double) reduce64(1ull << 32, md);
+        c32i = c32 * fc.qi;
+    }
+    auto load = [&](const u64* p) -> double {
+        const u64 v = *p;
+        if constexpr (DECOMP && WIDE) return fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
+        else if constexpr (DECOMP) return fp_reduce(fp_from_u64(v), fc);
+        else return fp_from_u64(v);
+    };
+
+    double x[16];
+    const int col = t % CT, r1 = t / CT;
+    if constexpr (NSA > 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int L = t + NTT_THREADS * g;
+            const int c = L % CT, rb = L / CT;
+            double y[RA];
+#pragma unroll
+            for (int k = 0; k < RA; k++) y[k] = load(&src[(u64) (rb + 16 * k) * 256 + c]);
+            fp_ct_radix<NSA>(y, tw, 1u, fc);
+#pragma unroll
+            for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = as_f64(lds[col_phys((16 * r1 + k) * CT + col)]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = load(&src[(u64) k * 256 + col]);
+    }
+    fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(u64) (16 * r1 + k) * 256 + col] = as_bits(x[k]);
+}
+
 template <int S1, bool DECOMP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
 {
@@ -356,7 +511,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     const PolySel ps = select_poly(a, blockIdx.y);
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
-    if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
+    if (md.fp) {
+        if (DECOMP && a.mods[ps.digit].bit > 52) fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds);
+        else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds);
+    } else if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
 
@@ -413,13 +571,49 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
 #endif
 }
 
+// FP64 row pass: raw doubles in (column pass output), canonical u64 out.
+__device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
+{
+    const int t = threadIdx.x;
+    const FC fc = make_fc(md.q);
+    const int s1 = a.n_power - 8;
+    const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
+    u64* __restrict__ p = a.out + ps.out_off + (u64) blockIdx.x * 4096;
+
+    const int row = t >> 4, i0 = t & 15;
+    const u32 crow = blockIdx.x * 16 + row;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);
+    fp_ct_radix<4>(x, tw, (1u << s1) + crow, fc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+        x[2 * k] = as_f64(v.x);
+        x[2 * k + 1] = as_f64(v.y);
+    }
+    fp_ct_radix16_tb(x, a.twB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), fc);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+            make_ulonglong2(fp_to_u64(x[2 * k]), fp_to_u64(x[2 * k + 1]));
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[row * 256 + i0 + 16 * k] = lds[row_phys(row * 256 + i0 + 16 * k)];
+}
+
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const PolySel ps = select_poly(a, blockIdx.y);
     if (a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
-    if (md.bit <= NTT_LAZY_BITS) fwd_row_body<true>(a, ps, md, lds);
+    if (md.fp) fwd_row_body_fp(a, ps, md, lds);
+    else if (md.bit <= NTT_LAZY_BITS) fwd_row_body<true>(a, ps, md, lds);
     else fwd_row_body<false>(a, ps, md, lds);
 }
 
@@ -478,6 +672,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
     const int item = blockIdx.x, tile = blockIdx.y, slot = blockIdx.z;
     const int midx = a.mod_order ? a.mod_order[slot] : slot;
     const Mod md = a.mods[midx];
+    if (md.fp) return; // FP64 moduli are handled by ks_row_mac_fp
     const QC qc = make_qc(md.q);
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
@@ -522,9 +717,116 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
     (void) n;
 }
 
+// FP64 moduli (Mod::fp): same fused row pass + inner product, but the inner
+// product is accumulated in FP64 as well: each digit*key product is reduced by
+// fp_mul (|t| <= 0.7 q for |digit| <= q/2), the running sums are re-centred
+// every fourth digit (|acc| < 3.5 q < 2^53) and made canonical once at the end.
+// Two double accumulators per coefficient instead of two 128-bit integers
+// halve the register footprint (3 waves per SIMD instead of 2).
+__global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    const int t = threadIdx.x;
+    const int item = blockIdx.x, tile = blockIdx.y, slot = blockIdx.z;
+    const int midx = a.mod_order ? a.mod_order[slot] : slot;
+    const Mod md = a.mods[midx];
+    if (!md.fp) return; // integer moduli are handled by ks_row_mac
+    const FC fc = make_fc(md.q);
+    const int s1 = a.n_power - 8;
+    const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
+    const int row = t >> 4, i0 = t & 15;
+    const u32 crow = tile * 16 + row;
+    const ulonglong2* __restrict__ tb = a.twB + ((u64) midx * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0);
+    const u64* __restrict__ pin = a.in + a.in_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096;
+    const u64* __restrict__ pk = a.key + ((u64) midx << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+    const u64 dig_off = (u64) a.rc << a.n_power;
+    const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
+
+    double a0[16], a1[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a0[k] = a1[k] = 0.0;
+    for (int i = 0; i < a.digits; i++) {
+        double x[16];
+        const u64* p = pin + dig_off * i;
+        // key tile of this digit: requested before the transform so that the
+        // loads are in flight while the butterflies run
+        const u64* k0 = pk + key_off2 * i;
+        const u64* k1 = k0 + key_off1;
+        u64 kv0[16], kv1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            kv0[k] = k0[16 * k];
+            kv1[k] = k1[16 * k];
+        }
+        if (a.skip_identity && i == midx) {
+            // NTT-domain limb (canonical u64) copied in by rns_copy_diag
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(p[row * 256 + i0 + 16 * k]), fc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);
+            fp_ct_radix<4>(x, tw, (1u << s1) + crow, fc);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+                x[2 * k] = as_f64(v.x);
+                x[2 * k + 1] = as_f64(v.y);
+            }
+            // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int half = 8 >> s;
+#pragma unroll
+                for (int b = 0; b < (1 << s); b++) {
+                    const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+#pragma unroll
+                    for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+                    make_ulonglong2(as_bits(x[2 * k]), as_bits(x[2 * k + 1]));
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = as_f64(lds[row_phys(row * 256 + i0 + 16 * k)]);
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            // x plays the role of the "twiddle": companion RN(x/q) ~ x*qi (|x| <= q/2 keeps
+            // the quotient error below 1), the key (canonical, < q < 2^50) is the operand
+            const double xi = x[k] * fc.qi;
+            a0[k] += fp_mul(fp_from_u64(kv0[k]), x[k], xi, fc);
+            a1[k] += fp_mul(fp_from_u64(kv1[k]), x[k], xi, fc);
+        }
+        if ((i & 3) == 3) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                a0[k] = fp_reduce(a0[k], fc);
+                a1[k] = fp_reduce(a1[k], fc);
+            }
+        }
+    }
+    u64* po = a.out + a.out_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        po[16 * k] = fp_to_u64(fp_canon(a0[k], fc));
+        po[dig_off + 16 * k] = fp_to_u64(fp_canon(a1[k], fc));
+    }
+}
+
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
 {
     if (a.digits > 64) return hipErrorInvalidValue;
+    // both kernels cover the whole grid; each exits at once on the other's moduli
+    hipLaunchKernelGGL(ks_row_mac_fp, dim3(items, (1u << a.n_power) / 4096, a.rc), dim3(NTT_THREADS), 0, st, a);
     hipLaunchKernelGGL(ks_row_mac, dim3(items, (1u << a.n_power) / 4096, a.rc), dim3(NTT_THREADS), 0, st, a);
     return hipGetLastError();
 }

@@ -11,7 +11,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
            "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o x -- $REPO/tools/exp/ntt_exp0 "$@" > $OUT/run$i.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o x -- ${BIN:-$REPO/tools/exp/ntt_exp0} "$@" > $OUT/run$i.txt 2>&1
   find $OUT/p$i -name '*counter_collection.csv' -exec cp {} $OUT/pmc$i.csv \;
   rm -rf $OUT/p$i
 done

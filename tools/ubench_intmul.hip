@@ -42,6 +42,23 @@ __global__ __launch_bounds__(256) void k(u64* out, u32 a0, u32 b0)
                 float f = __uint_as_float((u32) acc[c]);
                 f = fmaf(f, 1.0000001f, 0.5f);
                 acc[c] = __float_as_uint(f);
+            } else if (KIND == 10) { // v_add_f64
+                double d = __longlong_as_double(acc[c]);
+                d = d + __longlong_as_double(acc[(c + 1) % CH]);
+                acc[c] = __double_as_longlong(d);
+            } else if (KIND == 11) { // v_mul_f64
+                double d = __longlong_as_double(acc[c]);
+                d = d * 1.0000001;
+                acc[c] = __double_as_longlong(d);
+            } else if (KIND == 12) { // v_rndne_f64 (+ add so it is not idempotent-folded)
+                double d = __longlong_as_double(acc[c]);
+                d = __builtin_rint(d) + 0.5;
+                acc[c] = __double_as_longlong(d);
+            } else if (KIND == 13) { // v_cvt_f64_u32 + v_cvt_u32_f64
+                double d = (double) (u32) acc[c];
+                acc[c] = (u32) (d * 0.5);
+            } else if (KIND == 14) { // v_lshl_add_u64
+                acc[c] = (acc[c] << 1) + acc[(c + 1) % CH];
             } else if (KIND == 6) { // v_mul_u32_u24 (full-rate 24-bit)
                 acc[c] = __umul24((u32) acc[c], x) + 1;
             }
@@ -83,5 +100,10 @@ int main()
     run<7>("add_u32", d);
     run<8>("cmp64+sel+sub", d);
     run<9>("xor+shift32", d);
+    run<10>("v_add_f64", d);
+    run<11>("v_mul_f64", d);
+    run<12>("rndne_f64+add", d);
+    run<13>("cvt f64<->u32+mul", d);
+    run<14>("v_lshl_add_u64", d);
     return 0;
 }
