@@ -693,8 +693,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
         u64 x[16];
         const u64* p = pin + dig_off * i;
         if (a.skip_identity && i == midx) {
+            const u64* pi = a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = gld(&p[row * 256 + i0 + 16 * k]);
+            for (int k = 0; k < 16; k++) x[k] = gld(&pi[row * 256 + i0 + 16 * k]);
         } else if (lazy) {
             ks_row_digit<true>(x, p, lds, tw, tb, (1u << s1) + crow, qc, md, row, i0);
         } else {
@@ -759,9 +760,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
             kv1[k] = k1[16 * k];
         }
         if (a.skip_identity && i == midx) {
-            // NTT-domain limb (canonical u64) copied in by rns_copy_diag
+            // NTT-domain limb (canonical u64) of the decomposed polynomial itself
+            const u64* pi = a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(p[row * 256 + i0 + 16 * k]), fc);
+            for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(pi[row * 256 + i0 + 16 * k]), fc);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);

@@ -74,7 +74,9 @@ struct KsMacArgs {
     const ulonglong2* twB;
     const int* mod_order;   // modulus index of limb slot k (NULL: k)
     int n_power, digits, rc, key_limbs;
-    int skip_identity;      // digit d at modulus d holds NTT-domain data already
+    int skip_identity;      // digit d at modulus d is not transformed: its NTT-domain limb is read from `ident`
+    const u64* ident;       // [item][digit][N] NTT-domain limbs (the polynomial that was decomposed)
+    u64 ident_item_stride;
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 

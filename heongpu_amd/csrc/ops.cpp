@@ -23,12 +23,18 @@ static int prime_loc_offset(const Context& c, int depth)
 // whose output is [digits][rc][N] per ciphertext at a.out; the result
 // [2][rc][N] goes to `acc`.  Fused path: column pass + ks_row_mac; otherwise
 // two-pass NTT + rns_keyswitch_mac.
+// `ident` (with a.skip_identity): the NTT-domain limbs [digits][N] of the
+// polynomial being decomposed, `ident_stride` apart; digit d at modulus d is
+// taken from there instead of being transformed.
 static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
-                                    int digits, int rc, int split, int level, int skip_identity, int batch,
-                                    hipStream_t st)
+                                    int digits, int rc, int split, int level, const u64* ident, u64 ident_stride,
+                                    int batch, hipStream_t st)
 {
     const int ppi = digits * rc;
+    const int skip_identity = ident ? 1 : 0;
+    a.skip_identity = skip_identity;
     if (!c.fused_row_mac) {
+        if (ident) TRY(rns_copy_diag(ident, ident_stride, a.out, a.out_item_stride, c.n_power, digits, rc, batch, st));
         TRY(ntt_launch(a, ppi * batch, false, st));
         return rns_keyswitch_mac(a.out, a.out_item_stride, key, acc, acc_stride, c.plan_qp.mods, c.n_power, digits, rc,
                                  c.Qp_size, split, level, batch, st);
@@ -46,6 +52,7 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         k.out = acc + (u64) b0 * acc_stride; k.out_item_stride = acc_stride;
         k.mods = c.plan_qp.mods; k.tw = c.plan_qp.tw; k.twB = c.plan_qp.twB; k.mod_order = a.mod_order;
         k.n_power = c.n_power; k.digits = digits; k.rc = rc; k.key_limbs = c.Qp_size; k.skip_identity = skip_identity;
+        k.ident = ident ? ident + (u64) b0 * ident_stride : nullptr; k.ident_item_stride = ident_stride;
         TRY(ks_row_mac_launch(k, nb, st));
     }
     return hipSuccess;
@@ -91,23 +98,21 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     u64* c2 = ct + ((u64) l << (np + 1));
     const Mod* mods = c.plan_qp.mods;
 
-    // digit d re-reduced into its own modulus d and transformed back is the
-    // NTT-domain limb itself: keep it before the INTT overwrites it
-    TRY(rns_copy_diag(c2, cs, temp1, per, np, l, rc, batch, st));
     NttArgs a = c.ntt_args(0);
-    // INTT(c2), batch l per item                                     (:919)
-    a.in = c2; a.out = c2; a.mod_count = l; a.polys_per_item = l;
-    a.in_item_stride = a.out_item_stride = cs;
+    // INTT(c2), batch l per item (:919) -- out of place into the (not yet used)
+    // accumulator region: c2 itself stays in the NTT domain because digit d
+    // re-reduced into its own modulus d and transformed back is that limb
+    a.in = c2; a.out = temp2; a.mod_count = l; a.polys_per_item = l;
+    a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, l * batch, true, st));
     // digit decomposition c2 -> [l][rc][N] fused into the forward NTT's
     // first load; modulus order skips dropped primes                (:932-960)
     a = c.ntt_args(0);
-    a.in = c2; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
-    a.skip_identity = 1;
-    a.in_item_stride = cs; a.out_item_stride = per;
+    a.in = temp2; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
+    a.in_item_stride = per; a.out_item_stride = per;
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     // forward NTT of the digits + inner product with the key      (:956-988)
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, 1, batch, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, c2, cs, batch, st));
     // INTT of the two P-limb polynomials only                        (:996)
     a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
@@ -175,13 +180,11 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(ntt_launch(a, 2 * l * batch, true, st));                                           // :1461
-    TRY(rns_copy_diag(ct + (u64) l * n, cs, temp2, per, np, l, rc, batch, st)); // NTT-domain c1 limbs
     a = c.ntt_args(0); // ckks_duplicate_kernel fused into the NTT load          :1467-1494
     a.in = temp0 + (u64) l * n; a.out = temp2; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
-    a.skip_identity = 1;
     a.in_item_stride = a.out_item_stride = per;
     a.mod_order = order;
-    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, l, rc, l, depth, 1, batch, st));          // :1490-1520
+    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, l, rc, l, depth, ct + (u64) l * n, cs, batch, st)); // :1490-1520
     a.decomp_mods = 0;
     a.skip_identity = 0;
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * rc;
@@ -231,7 +234,7 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
     a.in = ct + ((u64) Q << (np + 1)); a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, 0, batch, st));             // :531-566
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, nullptr, 0, batch, st));             // :531-566
     a.decomp_mods = 0; a.in_item_stride = per;
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
@@ -255,7 +258,7 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
     a.in = ct + (u64) Q * n; a.out = temp1; a.mod_count = Qp; a.polys_per_item = Q * Qp;
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, 0, batch, st));             // :805-840
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, nullptr, 0, batch, st));             // :805-840
     a.decomp_mods = 0; a.in_item_stride = per;
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846
@@ -298,7 +301,7 @@ hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* 
     a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, rc, l, depth, 0, batch, st));          // :1095-1125
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, rc, l, depth, nullptr, 0, batch, st));          // :1095-1125
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1131
     TRY(rns_moddown_extended(temp2, per, nullptr, 0, temp1, per, mods, c.d64("half"), c.d64("half_mod"),
@@ -334,7 +337,7 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
     a = c.ntt_args(0);
     a.in = temp3; a.out = temp3; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp4, per, d, rc, l, depth, 0, batch, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp4, per, d, rc, l, depth, nullptr, 0, batch, st));
     a.in = temp4; a.out = temp4; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));
     TRY(rns_moddown_permute(temp4, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),
@@ -361,7 +364,7 @@ hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* k
     NttArgs a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, Qp, Qp, 0, 0, batch, st));             // :619-650
+    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, Qp, Qp, 0, nullptr, 0, batch, st));             // :619-650
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :657
     return rns_moddown_extended(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
@@ -384,7 +387,7 @@ hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* 
     NttArgs a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
-    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, d, Qp, Qp, 0, 0, batch, st));
+    TRY(keyswitch_ntt_mac(c, a, key, temp3, per, d, Qp, Qp, 0, nullptr, 0, batch, st));
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));
     return rns_moddown_permute(temp3, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
