@@ -552,8 +552,13 @@ hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride,
 }
 
 // ---------------------------------------------------------------- BFV BEHZ kernels
+// One thread per coefficient; the per-coefficient vectors (ibase / Bsk
+// residues) must stay in registers, so the kernels are instantiated for a
+// padded base size MAXB with every loop fully unrolled and guarded by the
+// (wave-uniform) real size.  Runtime-indexed arrays would live in scratch.
 #define BEHZ_MAX 40
 
+template <int MAXB>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __restrict__ in1, u64 s1,
                                                                  const u64* __restrict__ in2, u64 s2,
                                                                  u64* __restrict__ out1, u64 so, BehzDev b,
@@ -564,29 +569,39 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     const int ib = b.ibase_size, ob = b.obase_size;
     const u64* input = ((idy >> 1) == 0) ? (in1 + s1 * blockIdx.z) : (in2 + s2 * blockIdx.z);
     const u64 location = idx + ((u64) ((idy & 1) * ib) << n_power);
-    u64 temp[BEHZ_MAX];
+    u64 temp[MAXB];
     u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * (ob + ib)) << n_power);
-    for (int i = 0; i < ib; i++) {
-        const Mod mi = b.ibase[i];
-        u64 v = input[location + ((u64) i << n_power)];
-        po[(u64) i << n_power] = v;
-        v = mul_barrett(v, b.m_tilde.q, mi);
-        temp[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+#pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        temp[i] = 0;
+        if (i < ib) {
+            const Mod mi = b.ibase[i];
+            u64 v = input[location + ((u64) i << n_power)];
+            po[(u64) i << n_power] = v;
+            v = mul_barrett(v, b.m_tilde.q, mi);
+            temp[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+        }
     }
     // m_tilde channel
     u64 acc_mt = 0;
-    for (int j = 0; j < ib; j++) {
-        u64 ti = reduce64(temp[j], b.m_tilde);
-        u64 mu = mul_barrett(ti, b.base_change_matrix_m_tilde[j], b.m_tilde);
-        acc_mt = add_mod(acc_mt, mu, b.m_tilde.q);
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        if (j < ib) {
+            u64 ti = reduce64(temp[j], b.m_tilde);
+            u64 mu = mul_barrett(ti, b.base_change_matrix_m_tilde[j], b.m_tilde);
+            acc_mt = add_mod(acc_mt, mu, b.m_tilde.q);
+        }
     }
     const u64 mt = b.m_tilde.q;
     u64 r_mt = mul_barrett(acc_mt, b.inv_prod_q_mod_m_tilde, b.m_tilde);
     r_mt = mt - r_mt;
     for (int i = 0; i < ob; i++) {
         const Mod mo = b.obase[i];
+        const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
         u64 hi = 0, lo = 0;
-        for (int j = 0; j < ib; j++) acc_mad(hi, lo, temp[j], b.base_change_matrix_Bsk[j + i * ib]);
+#pragma unroll
+        for (int j = 0; j < MAXB; j++)
+            if (j < ib) acc_mad(hi, lo, temp[j], row[j]);
         u64 t2 = reduce128(hi, lo, mo);
         u64 t3 = r_mt;
         if (t3 >= (mt >> 1)) {
@@ -604,10 +619,18 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
 {
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 4, batch);
-    hipLaunchKernelGGL(k_fast_convertion, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power);
+    const int m = b.ibase_size;
+#define LAUNCH(M) hipLaunchKernelGGL(k_fast_convertion<M>, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
+    if (m <= 4) LAUNCH(4);
+    else if (m <= 8) LAUNCH(8);
+    else if (m <= 16) LAUNCH(16);
+    else if (m <= 24) LAUNCH(24);
+    else LAUNCH(BEHZ_MAX);
+#undef LAUNCH
     return hipGetLastError();
 }
 
+template <int MAXB>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restrict__ in, u64 si,
                                                             u64* __restrict__ out1, u64 so, BehzDev b, int n_power)
 {
@@ -617,28 +640,41 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     const u64 t = b.plain.q;
     const u64* pq = in + si * blockIdx.z + idx + ((u64) (idy * (ib + ob)) << n_power);
     const u64* pB = pq + ((u64) ib << n_power);
-    u64 reg_q[BEHZ_MAX], temp3[BEHZ_MAX];
-    for (int i = 0; i < ib; i++) {
-        const Mod mi = b.ibase[i];
-        u64 v = mul_barrett(pq[(u64) i << n_power], t, mi);
-        reg_q[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+    u64 reg_q[MAXB], temp3[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        reg_q[i] = 0;
+        if (i < ib) {
+            const Mod mi = b.ibase[i];
+            u64 v = mul_barrett(pq[(u64) i << n_power], t, mi);
+            reg_q[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+        }
     }
     u64 reg_Bsk_last = 0;
-    for (int i = 0; i < ob; i++) {
-        const Mod mo = b.obase[i];
-        u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
-        u64 hi = 0, lo = 0;
-        for (int j = 0; j < ib; j++) acc_mad(hi, lo, reg_q[j], b.base_change_matrix_Bsk[j + i * ib]);
-        u64 tmp = reduce128(hi, lo, mo);
-        u64 t2 = sub_mod(mo.q, tmp, mo.q);
-        t2 = add_mod(t2, rb, mo.q);
-        rb = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
-        if (i < ob - 1) temp3[i] = mul_barrett(rb, b.inv_punctured_prod_mod_B_array[i], mo);
-        else reg_Bsk_last = rb;
+#pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        temp3[i] = 0;
+        if (i < ob) {
+            const Mod mo = b.obase[i];
+            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
+            u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
+            u64 hi = 0, lo = 0;
+#pragma unroll
+            for (int j = 0; j < MAXB; j++)
+                if (j < ib) acc_mad(hi, lo, reg_q[j], row[j]);
+            u64 tmp = reduce128(hi, lo, mo);
+            u64 t2 = sub_mod(mo.q, tmp, mo.q);
+            t2 = add_mod(t2, rb, mo.q);
+            rb = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
+            if (i < ob - 1) temp3[i] = mul_barrett(rb, b.inv_punctured_prod_mod_B_array[i], mo);
+            else reg_Bsk_last = rb;
+        }
     }
     const Mod msk = b.obase[ob - 1];
     u64 hi = 0, lo = 0;
-    for (int j = 0; j < ob - 1; j++) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j]);
+#pragma unroll
+    for (int j = 0; j < MAXB; j++)
+        if (j < ob - 1) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j]);
     u64 t4sk = reduce128(hi, lo, msk);
     u64 alpha_sk = sub_mod(msk.q, reg_Bsk_last, msk.q);
     alpha_sk = add_mod(alpha_sk, t4sk, msk.q);
@@ -647,9 +683,11 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * ib) << n_power);
     for (int i = 0; i < ib; i++) {
         const Mod mi = b.ibase[i];
+        const u64* __restrict__ row = b.base_change_matrix_q + i * (ob - 1);
         u64 h2 = 0, l2 = 0;
-        for (int j = 0; j < ob - 1; j++)
-            acc_mad(h2, l2, reduce64(temp3[j], mi), b.base_change_matrix_q[j + i * (ob - 1)]);
+#pragma unroll
+        for (int j = 0; j < MAXB; j++)
+            if (j < ob - 1) acc_mad(h2, l2, temp3[j], row[j]); // un-reduced: < 2^61 * 2^61 * 40 terms fits 128 bits
         u64 t4 = reduce128(h2, l2, mi);
         u64 obase_ = reduce64(msk.q, mi);
         u64 alpha_ = reduce64(alpha_sk, mi);
@@ -670,7 +708,14 @@ hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev
 {
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
-    hipLaunchKernelGGL(k_fast_floor, g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power);
+    const int m = b.ibase_size > b.obase_size ? b.ibase_size : b.obase_size;
+#define LAUNCH(M) hipLaunchKernelGGL(k_fast_floor<M>, g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
+    if (m <= 4) LAUNCH(4);
+    else if (m <= 8) LAUNCH(8);
+    else if (m <= 16) LAUNCH(16);
+    else if (m <= 24) LAUNCH(24);
+    else LAUNCH(BEHZ_MAX);
+#undef LAUNCH
     return hipGetLastError();
 }
 
