@@ -269,10 +269,15 @@ class TfheContext:
 
     def prepare_bootkey(self, boot_key, stream=None):
         import torch
-        out = torch.empty_like(boot_key)
+        out = torch.empty(self.int("prepared_bootkey_elems"), dtype=torch.int64, device=boot_key.device)
         _check(self._lib.hegpu_tfhe_prepare_bootkey(self._h, _ptr(boot_key), _ptr(out),
                                                     stream if stream is not None else _stream()))
         return out
+
+    @staticmethod
+    def prepared_is_fp64(prepared):
+        """True when the prepared key uses the FP64 blind-rotate layout (real torus32 key)."""
+        return int(prepared[0].item()) == 1
 
     def gate_precompute(self, gate, out_a, out_b, a1, b1, a2, b2, shape, stream=None):
         _check(self._lib.hegpu_tfhe_gate_precompute(self._h, gate, _ptr(out_a), _ptr(out_b), _ptr(a1), _ptr(b1),

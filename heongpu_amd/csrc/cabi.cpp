@@ -476,11 +476,23 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, 
 // ------------------------------------------------------------------ TFHE
 struct hegpu_tfhe_context {
     TfheDev p{};
-    std::vector<ulonglong2> htw, hitw;
+    std::vector<ulonglong2> htw, hitw, hftw, hfitw;
     ulonglong2* dtw = nullptr;
     ulonglong2* ditw = nullptr;
+    ulonglong2* dftw = nullptr;
+    ulonglong2* dfitw = nullptr;
     bool uploaded = false;
+    bool allow_fp = true; // HEGPU_TFHE_FP=0 keeps the integer blind rotate
 };
+
+static ulonglong2 fp_pair(u64 w, u64 q)
+{
+    const double wd = (double) w, wi = wd / (double) q;
+    u64 a, b;
+    memcpy(&a, &wd, 8);
+    memcpy(&b, &wi, 8);
+    return make_ulonglong2(a, b);
+}
 
 int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
 {
@@ -509,6 +521,25 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
         for (int i = 1; i <= p.bk_l; i++) sum += 1LL << (32 - i * p.bk_bg_bit);
         p.offset = (int) (sum * p.half_bg);
         p.ks_base_bit = 2; p.ks_length = 8;
+        // FP64 blind rotate: our own 44-bit NTT prime (tfhe.hip)
+        {
+            const u64 fq = host::find_primes(1024, std::vector<int>{44})[0];
+            const u64 fpsi = host::minimal_primitive_root(2048, fq);
+            std::vector<u64> ff = host::power_table_bitrev(fpsi, fq, np);
+            std::vector<u64> fi = host::power_table_bitrev(host::inv_mod_prime(fpsi, fq), fq, np);
+            h->hftw.resize(1024);
+            h->hfitw.resize(1024);
+            for (int j = 0; j < 1024; j++) {
+                h->hftw[j] = fp_pair(ff[j], fq);
+                h->hfitw[j] = fp_pair(fi[j], fq);
+            }
+            const u64 fn = host::inv_mod_prime(1024, fq);
+            p.fprime = fq;
+            p.fninv = fp_pair(fn, fq);
+            p.fw1ninv = fp_pair(host::mul_mod(fi[1], fn, fq), fq);
+            const char* e = getenv("HEGPU_TFHE_FP");
+            h->allow_fp = !(e && e[0] == '0');
+        }
         *out = h;
         return 0;
     });
@@ -519,6 +550,8 @@ void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx)
     if (!ctx) return;
     if (ctx->dtw) (void) hipFree(ctx->dtw);
     if (ctx->ditw) (void) hipFree(ctx->ditw);
+    if (ctx->dftw) (void) hipFree(ctx->dftw);
+    if (ctx->dfitw) (void) hipFree(ctx->dfitw);
     delete ctx;
 }
 
@@ -535,6 +568,8 @@ long hegpu_tfhe_context_int(const hegpu_tfhe_context* ctx, const char* name)
     if (!strcmp(name, "ks_length")) return p.ks_length;
     if (!strcmp(name, "offset")) return p.offset;
     if (!strcmp(name, "bootkey_elems")) return (long) p.n * (p.k + 1) * p.bk_l * (p.k + 1) * p.N;
+    if (!strcmp(name, "prepared_bootkey_elems"))
+        return (long) TFHE_PREP_HEADER + 2L * p.n * (p.k + 1) * p.bk_l * (p.k + 1) * p.N;
     if (!strcmp(name, "kskey_b_elems")) return (long) p.N * p.k * p.ks_length * ((1 << p.ks_base_bit) - 1);
     if (!strcmp(name, "kskey_a_elems")) return (long) p.N * p.k * p.ks_length * ((1 << p.ks_base_bit) - 1) * p.n;
     return -1;
@@ -556,8 +591,14 @@ static int tfhe_need(hegpu_tfhe_context* ctx)
     if ((e = hipMalloc((void**) &ctx->ditw, 1024 * sizeof(ulonglong2))) != hipSuccess) return hip_ret(e, "tfhe upload");
     (void) hipMemcpy(ctx->dtw, ctx->htw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
     (void) hipMemcpy(ctx->ditw, ctx->hitw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    if ((e = hipMalloc((void**) &ctx->dftw, 1024 * sizeof(ulonglong2))) != hipSuccess) return hip_ret(e, "tfhe upload");
+    if ((e = hipMalloc((void**) &ctx->dfitw, 1024 * sizeof(ulonglong2))) != hipSuccess) return hip_ret(e, "tfhe upload");
+    (void) hipMemcpy(ctx->dftw, ctx->hftw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    (void) hipMemcpy(ctx->dfitw, ctx->hfitw.data(), 1024 * sizeof(ulonglong2), hipMemcpyHostToDevice);
     ctx->p.tw = ctx->dtw;
     ctx->p.itw = ctx->ditw;
+    ctx->p.ftw = ctx->dftw;
+    ctx->p.fitw = ctx->dfitw;
     ctx->uploaded = true;
     return 0;
 }
@@ -577,7 +618,8 @@ int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key
     if (r) return r;
     const TfheDev& p = ctx->p;
     const u64 polys = (u64) p.n * (p.k + 1) * p.bk_l * (p.k + 1);
-    return hip_ret(tfhe_prepare_bootkey((const u64*) boot_key, (u64*) prepared, polys, (hipStream_t) stream),
+    return hip_ret(tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp,
+                                        (hipStream_t) stream),
                    "hegpu_tfhe_prepare_bootkey");
 }
 

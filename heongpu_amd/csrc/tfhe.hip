@@ -18,6 +18,8 @@
 // accumulator.  All arithmetic is exact (60-bit NTT prime), so the int32 torus
 // results are identical to the reference's.
 #include "tfhe.hpp"
+#include <cstdlib>
+#include "fpmod.cuh"
 
 namespace hegpu {
 
@@ -211,11 +213,13 @@ __global__ __launch_bounds__(256) void k_tfhe_prepare_bootkey(const u64* __restr
 
 // Blind rotation + sample extraction for one gate per workgroup.
 // in_a [shape][n], in_b [shape]; bk = prepared boot key; out_a [shape][N], out_b [shape].
-__global__ __launch_bounds__(TF_THREADS) void k_tfhe_blind_rotate(const int* __restrict__ in_a,
+__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tfhe_blind_rotate(const int* __restrict__ in_a,
                                                                   const int* __restrict__ in_b,
                                                                   const u64* __restrict__ bk, int* __restrict__ out_a,
                                                                   int* __restrict__ out_b, TfheDev p, int encoded)
 {
+    if (bk[0] != 0) return; // FP64-layout key: k_tfhe_blind_rotate_fp runs instead
+    bk += TFHE_PREP_HEADER;
     __shared__ int acc[2][TF_N];
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -325,6 +329,289 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfhe_blind_rotate(const int* __r
     if (t == 0) out_b[g] = acc[1][0];
 }
 
+// ------------------------------------------------------------------ FP64 blind rotate
+// The external product is an exact integer negacyclic convolution whose result
+// is only needed modulo 2^32.  For a real boot key (torus32 coefficients v) it
+// is computed modulo a 44-bit prime p' in FP64 (fpmod.cuh; ~3x fewer
+// instructions per butterfly than with the reference's 60-bit prime) after
+// splitting v = hi*2^16 + lo, 0 <= lo < 2^16, |hi| <= 2^15:
+//   |conv(d, lo or hi)| <= (k+1)*l * N * Bg/2 * 2^16 = 4 * 1024 * 512 * 65536 = 2^37 < p'/2,
+// so both halves are recovered exactly and  lo-part + (hi-part << 16) mod 2^32
+// equals the reference's centred result mod 2^32.  Four output polynomials
+// (c = 0,1 x {lo,hi}) -> one inverse transform per wavefront: no idle waves.
+// The boot key is converted once (k_tfhe_prepare_bootkey_fp); a key whose
+// coefficients do not fit int32 keeps the integer path.
+__device__ __forceinline__ void f_ct(double& x, double& y, ulonglong2 w, const FC& c)
+{
+    const double t = fp_mul(y, as_f64(w.x), as_f64(w.y), c);
+    y = x - t;
+    x = x + t;
+}
+__device__ __forceinline__ void f_gs(double& x, double& y, ulonglong2 w, const FC& c)
+{
+    const double s = x + y, d = x - y;
+    x = s;
+    y = fp_mul(d, as_f64(w.x), as_f64(w.y), c);
+}
+
+// Forward 1024-point NTT mod p' by one wavefront.  In: x[k] = element lane + 64k,
+// |x| <= p'.  Out: x[k] = slot 16*lane + k, centred (|x| <= p'/2).  Magnitudes
+// grow by at most 0.51 p' per stage (10 stages: < 7 p' < 2^47): no reduction
+// before the end.
+__device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const ulonglong2* __restrict__ tw,
+                                              const FC& c, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = tw[(1 << s) + b];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_ct(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(lane + 64 * k)] = as_bits(x[k]);
+    wave_fence();
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = tw[((16 + b) << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_ct(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(16 * lane + k)]);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const ulonglong2 w8 = tw[256 + 4 * lane + g];
+        f_ct(x[4 * g + 0], x[4 * g + 2], w8, c);
+        f_ct(x[4 * g + 1], x[4 * g + 3], w8, c);
+        const ulonglong2 w9a = tw[512 + 8 * lane + 2 * g], w9b = tw[512 + 8 * lane + 2 * g + 1];
+        f_ct(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        f_ct(x[4 * g + 2], x[4 * g + 3], w9b, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], c);
+    wave_fence();
+}
+
+// Inverse 1024-point NTT mod p' by one wavefront.  In: x[k] = slot 16*lane + k,
+// |x| <= 2.2 p'.  Out: x[k] = coefficient lane + 64k as the centred residue
+// (exact integer when the true value is below p'/2 - 2^40 in magnitude), N^-1
+// applied.  The un-multiplied outputs double per stage: 2.2 p' -> 141 p' < 2^52
+// after six stages, one centred reduction, then 8 p' before the last stage.
+__device__ __forceinline__ void fwave_intt1024(double (&x)[16], u64* buf, const ulonglong2* __restrict__ itw,
+                                               ulonglong2 ninv, ulonglong2 w1ninv, const FC& c, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const ulonglong2 w9a = itw[512 + 8 * lane + 2 * g], w9b = itw[512 + 8 * lane + 2 * g + 1];
+        f_gs(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        f_gs(x[4 * g + 2], x[4 * g + 3], w9b, c);
+        const ulonglong2 w8 = itw[256 + 4 * lane + g];
+        f_gs(x[4 * g + 0], x[4 * g + 2], w8, c);
+        f_gs(x[4 * g + 1], x[4 * g + 3], w8, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(16 * lane + k)] = as_bits(x[k]);
+    wave_fence();
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = itw[((16 + b) << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = fp_reduce(x[m], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(lane + 64 * k)]);
+#pragma unroll
+    for (int s = 3; s >= 1; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = itw[(1 << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const double s = x[j] + x[j + 8], d = x[j] - x[j + 8];
+        x[j] = fp_mul(s, as_f64(ninv.x), as_f64(ninv.y), c);
+        x[j + 8] = fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), c);
+    }
+    wave_fence();
+}
+
+// low 32 bits (two's complement) of an integer-valued double, |v| < 2^51
+__device__ __forceinline__ u32 f_low32(double v) { return (u32) as_bits(v + 6755399441055744.0); }
+
+// Boot key conversion: one wavefront per polynomial.  src: reference layout,
+// NTT domain mod q (slot order); dst: [poly][half][k][lane] doubles = forward
+// NTT mod p' of the lo / hi halves of the int32 coefficients, centred.  Sets
+// *bad when a coefficient does not fit int32.
+__global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                                u64 polys, TfheDev p, int* bad)
+{
+    __shared__ __attribute__((aligned(16))) u64 buf[TF_BUF];
+    const u64 pi = blockIdx.x;
+    if (pi >= polys) return;
+    const int lane = threadIdx.x;
+    TQ c;
+    c.q = p.mod.q;
+    c.q4 = 4 * c.q;
+    {
+        u64 nq = 0 - c.q;
+        c.nq0 = (u32) nq;
+        c.nq1 = (u32) (nq >> 32);
+    }
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = src[pi * TF_N + 16 * lane + k];
+    wave_intt1024(x, buf, p.itw, p.ninv, p.w1ninv, c, lane);
+    const FC fc = make_fc(p.fprime);
+    double lo[16], hi[16];
+    bool oob = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const long long v = (x[k] > (c.q >> 1)) ? (long long) (x[k] - c.q) : (long long) x[k];
+        oob |= (v < -2147483648LL) || (v > 2147483647LL);
+        const int vi = (int) v;
+        lo[k] = (double) (vi & 0xffff);
+        hi[k] = (double) (vi >> 16);
+    }
+    if (oob) atomicOr(bad, 1);
+    fwave_ntt1024(lo, buf, p.ftw, fc, lane);
+    fwave_ntt1024(hi, buf, p.ftw, fc, lane);
+    u64* d = dst + pi * 2 * TF_N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        d[k * 64 + lane] = as_bits(lo[k]);
+        d[TF_N + k * 64 + lane] = as_bits(hi[k]);
+    }
+}
+
+__global__ void k_tfhe_set_header(u64* hdr, u64 fmt) { hdr[0] = fmt; }
+
+// TF_G gates per workgroup, wavefront w = (y,z): digit polynomial z of accumulator
+// y -> forward NTT -> products with the four key polynomials BK_i[y][z][c][half]
+// summed over the wavefronts in LDS -> wavefront w inverse-transforms output
+// o = w (c = w >> 1, half = w & 1) and adds it into the accumulator.  The 64
+// key values a lane needs in iteration i are loaded once and reused for the
+// TF_G gates (the 64 MiB key stream is the other resource next to the ALU).
+#define TF_G 4
+__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tfhe_blind_rotate_fp(const int* __restrict__ in_a,
+                                                                     const int* __restrict__ in_b,
+                                                                     const u64* __restrict__ prepared,
+                                                                     int* __restrict__ out_a, int* __restrict__ out_b,
+                                                                     TfheDev p, int encoded, int shape, int exp_mode)
+{
+    if (prepared[0] != 1) return; // integer-layout key: k_tfhe_blind_rotate runs instead
+    const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
+    __shared__ int acc[TF_G][2][TF_N];
+    __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int y = wv >> 1, z = wv & 1;
+    const int g0 = blockIdx.x * TF_G;
+    const int ng = (shape - g0 < TF_G) ? shape - g0 : TF_G;
+    const int n = p.n;
+    const FC fc = make_fc(p.fprime);
+    for (int gi = 0; gi < ng; gi++) {
+        const int bN = 2 * TF_N - modswitch(in_b[g0 + gi], 10);
+        for (int j = t; j < TF_N; j += TF_THREADS) {
+            acc[gi][0][j] = 0;
+            acc[gi][1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
+        }
+    }
+    __syncthreads();
+
+    const int shift = 32 - 10 * (z + 1);
+    const int cc = wv >> 1, sh = (wv & 1) ? 16 : 0;
+    for (int i = 0; i < n; i++) {
+        // key polynomials of this wavefront: [(i,y,z)][o = 2c+half][k][lane].  The per-CU load
+        // pipeline (~20 GB/s of L2 hits) cannot stream 128 KiB per gate and iteration, so the
+        // 64 values a lane needs stay in registers for the TF_G gates of the workgroup.
+        // kv[r] = key polynomial of output (wv + r) & 3: r = 0 is this wavefront's own output
+        const u64* bkp = bk + ((((u64) i * 2 + y) * 2 + z) * 4) * TF_N + lane;
+        double kv[4][16];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                kv[r][k] = (exp_mode & 1) ? 3.0 : as_f64(bkp[(u64) ((wv + r) & 3) * TF_N + k * 64]);
+        for (int gi = 0; gi < ng; gi++) {
+            const int aN = modswitch(in_a[(u64) (g0 + gi) * n + i], 10);
+            double x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int j = lane + 64 * k;
+                int r;
+                if (aN < TF_N) r = (j < aN) ? -acc[gi][y][TF_N - aN + j] : acc[gi][y][j - aN];
+                else {
+                    const int m = aN - TF_N;
+                    r = (j < m) ? acc[gi][y][TF_N - m + j] : -acc[gi][y][j - m];
+                }
+                const u32 diff = (u32) r - (u32) acc[gi][y][j];
+                const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
+                x[k] = (double) d;
+            }
+            fwave_ntt1024(x, buf[wv], p.ftw, fc, lane);
+            // x is the "twiddle" of the products: companion RN(x/p') ~ x * RN(1/p'), recomputed
+            // per product (one multiply) rather than held in 32 more registers
+            // own output first (plain store into the own staging area, free after the transform)
+#pragma unroll
+            for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc));
+            __syncthreads();
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                double* ob = reinterpret_cast<double*>(&buf[(wv + r) & 3][lane]);
+#pragma unroll
+                for (int k = 0; k < 16; k++) atomicAdd(&ob[k * 64], fp_mul(kv[r][k], x[k], x[k] * fc.qi, fc));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = as_f64(buf[wv][k * 64 + lane]);
+            wave_fence();
+            fwave_intt1024(x, buf[wv], p.fitw, p.fninv, p.fw1ninv, fc, lane);
+            // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                atomicAdd(reinterpret_cast<u32*>(&acc[gi][cc][lane + 64 * k]), f_low32(x[k]) << sh);
+            __syncthreads();
+        }
+    }
+    for (int gi = 0; gi < ng; gi++) {
+        const int g = g0 + gi;
+        for (int j = t; j < TF_N; j += TF_THREADS)
+            out_a[(u64) g * TF_N + j] = (j < 1) ? acc[gi][0][j] : (int) (0u - (u32) acc[gi][0][TF_N - j]);
+        if (t == 0) out_b[g] = acc[gi][1][0];
+    }
+}
+
 // out = enc + m*(s1*in1 + s2*in2) on the 32-bit torus (bootstrapping.cu:378-660)
 __global__ __launch_bounds__(256) void k_tfhe_gate_pre(int* __restrict__ out_a, int* __restrict__ out_b,
                                                        const int* __restrict__ a1, const int* __restrict__ b1,
@@ -384,15 +671,36 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
     if (t == 0) out_b[g] = (int) accb;
 }
 
-hipError_t tfhe_prepare_bootkey(const u64* src, u64* dst, u64 polys, hipStream_t st)
+// Synchronous (one-time): tries the FP64 layout, falls back to the integer
+// layout when a key coefficient does not fit int32.
+hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_tfhe_prepare_bootkey, dim3((unsigned) polys), dim3(256), 0, st, src, dst, polys);
+    hipError_t e;
+    if (allow_fp) {
+        if ((e = hipMemsetAsync(dst, 0, TFHE_PREP_HEADER * sizeof(u64), st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_tfhe_prepare_bootkey_fp, dim3((unsigned) polys), dim3(64), 0, st, src,
+                           dst + TFHE_PREP_HEADER, polys, p, reinterpret_cast<int*>(dst + 1));
+        int bad = 0;
+        if ((e = hipMemcpyAsync(&bad, dst + 1, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if (!bad) {
+            hipLaunchKernelGGL(k_tfhe_set_header, dim3(1), dim3(1), 0, st, dst, (u64) 1);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL(k_tfhe_prepare_bootkey, dim3((unsigned) polys), dim3(256), 0, st, src, dst + TFHE_PREP_HEADER,
+                       polys);
+    hipLaunchKernelGGL(k_tfhe_set_header, dim3(1), dim3(1), 0, st, dst, (u64) 0);
     return hipGetLastError();
 }
 
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
                              int* out_b, int encoded, int shape, hipStream_t st)
 {
+    // both kernels cover all gates; the one whose key layout is absent exits at once
+    static const int exp_mode = getenv("HEGPU_TFHE_EXP") ? atoi(getenv("HEGPU_TFHE_EXP")) : 0; // timing ablations only
+    hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3((shape + TF_G - 1) / TF_G), dim3(TF_THREADS), 0, st, in_a, in_b,
+                       bk_prepared, out_a, out_b, p, encoded, shape, exp_mode);
     hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
                        out_b, p, encoded);
     return hipGetLastError();

@@ -192,10 +192,14 @@ enum {
 /* HEContextImpl<TFHE>::HEContextImpl (tfhe/context.cu:15-57); host only */
 int hegpu_tfhe_context_create(hegpu_tfhe_context** out);
 void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
-/* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems","kskey_a_elems","kskey_b_elems" */
+/* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems",
+ * "prepared_bootkey_elems","kskey_a_elems","kskey_b_elems" */
 long hegpu_tfhe_context_int(const hegpu_tfhe_context* ctx, const char* name);
 uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx);
-/* one-time device re-layout of a boot key (reference layout -> wave-coalesced layout) */
+/* One-time conversion of a boot key (reference layout, NTT domain) into the layout the
+ * blind rotate reads; `prepared` holds "prepared_bootkey_elems" uint64.  Synchronises the
+ * stream once: a real key (torus32 coefficients) is re-encoded for the FP64 blind rotate,
+ * any other key keeps the reference's 60-bit prime (results are identical either way). */
 int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
                                hegpu_stream stream);
 /* tfhe_{nand,and,and_first_not,nor,or,xnor,xor}_pre_comp_kernel / tfhe_not_comp_kernel

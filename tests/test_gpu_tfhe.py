@@ -1,22 +1,34 @@
 """GPU parity, config C5 shapes: TFHE gate bootstrapping (pre-computation ->
 blind rotate + sample extraction -> key switching) through the C ABI vs the CPU
-oracle, bit-exact on the int32 torus.  Keys and inputs are seeded random data
-(the arithmetic is exact for any key material)."""
+oracle, bit-exact on the int32 torus.  Two kinds of seeded boot keys: a real
+one (torus32 coefficients, NTT'd by the oracle: takes the FP64 blind rotate) and
+arbitrary 60-bit residues (the arithmetic is exact for any key material: takes
+the integer blind rotate with the reference's prime)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup(hg, oracle):
+@pytest.fixture(scope="module", params=["torus32", "residues60"])
+def setup(hg, oracle, request):
     import torch
     assert torch.cuda.is_available()
     t = hg.TfheContext()
     o = oracle.OracleTfhe()
     assert t.prime == o.prime
     rng = np.random.default_rng(11)
-    bk = rng.integers(0, o.prime, t.int("bootkey_elems"), dtype=np.uint64)
+    if request.param == "torus32":
+        polys = t.int("bootkey_elems") // 1024
+        coeff = rng.integers(-2**31, 2**31, (polys, 1024), dtype=np.int64).astype(np.int32)
+        coeff[0, :4] = [-2**31, 2**31 - 1, 0, -1]  # range corners of the lo/hi split
+        coeff[1, :] = -2**31
+        coeff[2, :] = 2**31 - 1
+        bk = np.concatenate([o.to_ntt(coeff[i]) for i in range(polys)])
+    else:
+        bk = rng.integers(0, o.prime, t.int("bootkey_elems"), dtype=np.uint64)
+    prepared = t.prepare_bootkey(hg.to_device(bk))
+    assert t.prepared_is_fp64(prepared) == (request.param == "torus32")
     ks_a = rng.integers(-2**31, 2**31, t.int("kskey_a_elems"), dtype=np.int64).astype(np.int32)
     ks_b = rng.integers(-2**31, 2**31, t.int("kskey_b_elems"), dtype=np.int64).astype(np.int32)
     return t, o, rng, bk, ks_a, ks_b

@@ -20,7 +20,15 @@ args = ap.parse_args()
 t = hg.TfheContext()
 rng = np.random.default_rng(1)
 S = args.gates
-bk = torch.from_numpy(rng.integers(0, t.prime, t.int("bootkey_elems"), dtype=np.uint64).view(np.int64)).cuda()
+if os.environ.get("TFHE_BENCH_KEY", "torus32") == "torus32":
+    # a real key has torus32 coefficients.  The NTT image of a constant polynomial v is v in
+    # every slot, so per-polynomial constants give a valid key without needing a transform here.
+    polys = t.int("bootkey_elems") // 1024
+    v = rng.integers(-2**31, 2**31, polys, dtype=np.int64)
+    lifted = np.where(v < 0, v + t.prime, v).astype(np.uint64)
+    bk = torch.from_numpy(np.repeat(lifted, 1024).view(np.int64)).cuda()
+else:
+    bk = torch.from_numpy(rng.integers(0, t.prime, t.int("bootkey_elems"), dtype=np.uint64).view(np.int64)).cuda()
 ks_a = torch.randint(-2**31, 2**31, (t.int("kskey_a_elems"),), dtype=torch.int64, device="cuda").to(torch.int32)
 ks_b = torch.randint(-2**31, 2**31, (t.int("kskey_b_elems"),), dtype=torch.int64, device="cuda").to(torch.int32)
 a1 = torch.randint(-2**31, 2**31, (S * 512,), dtype=torch.int64, device="cuda").to(torch.int32)
@@ -28,6 +36,7 @@ a2 = torch.randint(-2**31, 2**31, (S * 512,), dtype=torch.int64, device="cuda").
 b1 = torch.randint(-2**31, 2**31, (S,), dtype=torch.int64, device="cuda").to(torch.int32)
 b2 = torch.randint(-2**31, 2**31, (S,), dtype=torch.int64, device="cuda").to(torch.int32)
 prepared = t.prepare_bootkey(bk)
+print('prepared key layout:', 'FP64' if t.prepared_is_fp64(prepared) else 'integer')
 out_a = torch.empty(S * 512, dtype=torch.int32, device="cuda")
 out_b = torch.empty(S, dtype=torch.int32, device="cuda")
 ws = torch.empty((512 + 1024 + 2) * S, dtype=torch.int32, device="cuda")
