@@ -59,6 +59,38 @@ def test_ntt_forward_inverse(hg, oracle, torch, n_power):
     assert np.array_equal(hg.to_host(d), want_i)
 
 
+@pytest.mark.parametrize("n_power", [12, 16])
+def test_ntt_fp64_path_extremes(hg, oracle, torch, n_power):
+    """Forward transform of the moduli that take the FP64 butterflies (< 2^50) next to the
+    integer ones (51 bits and up), on the inputs that maximise intermediate magnitudes:
+    all q-1, all zero, alternating 0 / q-1, a single q-1, random."""
+    n = 1 << n_power
+    bits = [50, 50, 49, 36, 51, 57]
+    c, o, primes = _ckks_pair(hg, oracle, n, bits, [58], sec=hg.SEC_NONE)
+    Qp = len(bits) + 1
+    rows = []
+    for m in range(Qp):
+        q = int(primes[m])
+        rows.append(np.full(n, q - 1, dtype=np.uint64))
+        rows.append(np.zeros(n, dtype=np.uint64))
+        alt = np.zeros(n, dtype=np.uint64); alt[::2] = q - 1
+        rows.append(alt)
+        one = np.zeros(n, dtype=np.uint64); one[n - 1] = q - 1
+        rows.append(one)
+        rows.append(oracle.fill_poly(1000 + m, m, n, q))
+    # layout for the batched call: polynomial i uses modulus i % Qp
+    per = len(rows) // Qp
+    x = np.concatenate([rows[(i % Qp) * per + i // Qp] for i in range(per * Qp)])
+    want = o.ntt(x.copy(), per * Qp, Qp)
+    d = hg.to_device(x)
+    c.ntt(d, d, False, per * Qp, Qp)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+    c.ntt(d, d, True, per * Qp, Qp)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), x)
+
+
 def test_ntt_bsk_61bit_and_offsets(hg, oracle, torch):
     """61-bit Bsk primes (merged q|Bsk tables) and caller-offset tables."""
     c, o, primes = _bfv_pair(hg, oracle, 4096, 1032193)
@@ -189,6 +221,35 @@ def test_ckks_mul_relin_rescale(hg, oracle, torch, depth):
         for b in range(batch):
             w = o.ckks_rescale(want_rel[b][:2 * l * n].copy(), depth)
             assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_ckks_keyswitch_mixed_widths_extreme_values(hg, oracle, torch, depth):
+    """Key switch over a chain that mixes FP64 moduli (50/36/45/49 bits) with integer ones
+    (60/55 bits): wide digits into narrow FP64 targets and vice versa, with the tensor input at
+    its extremes (every residue q-1, then 0/q-1 patterns) and a key of all q-1."""
+    n = 4096
+    bits = [60, 50, 36, 45, 55, 49]
+    c, o, primes = _ckks_pair(hg, oracle, n, bits, [60], sec=hg.SEC_NONE)
+    Q, Qp = len(bits), len(bits) + 1
+    l = Q - depth
+    key = np.concatenate([np.full(n, primes[j] - 1, dtype=np.uint64) for _ in range(Q) for _c in range(2)
+                          for j in range(Qp)])
+    cts = []
+    full = np.concatenate([np.full(n, primes[j] - 1, dtype=np.uint64) for _p in range(3) for j in range(l)])
+    cts.append(full)
+    pat = full.copy().reshape(3 * l, n); pat[:, ::3] = 0
+    cts.append(pat.reshape(-1))
+    cts.append(synth_ct(primes, range(l), 3, n, 77))
+    batch = len(cts)
+    d = hg.to_device(np.concatenate(cts))
+    ws = c.workspace(hg.OP_CKKS_RELIN, depth, batch)
+    c.ckks_relinearize_inplace(d, 3 * l * n, hg.to_device(key), depth, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(d).reshape(batch, -1)
+    for b in range(batch):
+        want = o.ckks_relinearize(cts[b].copy(), key, depth)
+        assert np.array_equal(got[b][:2 * l * n], want[:2 * l * n]), f"ciphertext {b}"
 
 
 @pytest.mark.parametrize("depth", [0, 2])
