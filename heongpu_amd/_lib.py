@@ -55,6 +55,14 @@ SIGNATURES = [
     ("hegpu_bfv_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, voidp, c_size_t, voidp]),
     ("hegpu_bfv_apply_galois", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_rng_create", c_int, [u64, ctypes.POINTER(voidp)]),
+    ("hegpu_rng_destroy", None, [voidp]),
+    ("hegpu_generate_secret_key", c_int, [voidp, voidp, c_int, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_generate_public_key", c_int, [voidp, voidp, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_generate_relin_key", c_int, [voidp, voidp, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_generate_galois_key", c_int, [voidp, voidp, u64p, c_int, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_decrypt", c_int, [voidp, u64p, u64p, c_int, u64p, voidp]),
     ("hegpu_tfhe_context_create", c_int, [ctypes.POINTER(voidp)]),
     ("hegpu_tfhe_context_destroy", None, [voidp]),
     ("hegpu_tfhe_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),

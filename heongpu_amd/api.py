@@ -15,6 +15,7 @@ BFV, CKKS = 1, 2
 SEC_NONE, SEC_128 = 0, 128
 TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
+OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT = 7, 8, 9, 10
 
 E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
 
@@ -237,7 +238,85 @@ class Context:
                                                 stream if stream is not None else _stream()))
 
 
+    # ---- key generation / encryption / decryption (method I keys)
+    def _kg_ws(self, op):
+        return self.workspace(op, 0, 1)
+
+    def generate_secret_key(self, rng, hamming_weight=None, stream=None):
+        import torch
+        n, Qp = self.n, self.Q_prime_size
+        sk = torch.empty(Qp * n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_KEYGEN_SECRET)
+        hw = n // 2 if hamming_weight is None else hamming_weight  # secretkey.cu:23
+        _check(self._lib.hegpu_generate_secret_key(self._h, rng._h, hw, _ptr(sk), _ptr(ws),
+                                                   ws.numel() * ws.element_size(),
+                                                   stream if stream is not None else _stream()))
+        return sk
+
+    def generate_public_key(self, rng, sk, stream=None):
+        import torch
+        pk = torch.empty(2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_KEYGEN_PUBLIC)
+        _check(self._lib.hegpu_generate_public_key(self._h, rng._h, _ptr(sk), _ptr(pk), _ptr(ws),
+                                                   ws.numel() * ws.element_size(),
+                                                   stream if stream is not None else _stream()))
+        return pk
+
+    def generate_relin_key(self, rng, sk, stream=None):
+        import torch
+        rk = torch.empty(self.Q_size * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_KEYGEN_SWITCH)
+        _check(self._lib.hegpu_generate_relin_key(self._h, rng._h, _ptr(sk), _ptr(rk), _ptr(ws),
+                                                  ws.numel() * ws.element_size(),
+                                                  stream if stream is not None else _stream()))
+        return rk
+
+    def generate_galois_key(self, rng, sk, galois_elt, stream=None):
+        import torch
+        gk = torch.empty(self.Q_size * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_KEYGEN_SWITCH)
+        _check(self._lib.hegpu_generate_galois_key(self._h, rng._h, _ptr(sk), galois_elt, _ptr(gk), _ptr(ws),
+                                                   ws.numel() * ws.element_size(),
+                                                   stream if stream is not None else _stream()))
+        return gk
+
+    def ckks_encrypt(self, rng, pk, plain, stream=None):
+        import torch
+        ct = torch.empty(2 * self.Q_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_CKKS_ENCRYPT)
+        _check(self._lib.hegpu_ckks_encrypt(self._h, rng._h, _ptr(pk), _ptr(plain), _ptr(ct), _ptr(ws),
+                                            ws.numel() * ws.element_size(),
+                                            stream if stream is not None else _stream()))
+        return ct
+
+    def ckks_decrypt(self, ct, sk, depth=0, stream=None):
+        import torch
+        plain = torch.empty((self.Q_size - depth) * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_ckks_decrypt(self._h, _ptr(ct), _ptr(sk), depth, _ptr(plain),
+                                            stream if stream is not None else _stream()))
+        return plain
+
+
+
 GATE_NAND, GATE_AND, GATE_AND_FIRST_NOT, GATE_NOR, GATE_OR, GATE_XNOR, GATE_XOR, GATE_NOT = range(8)
+
+
+class Rng:
+    """The backend's DRBG handle (Philox4x32-10 streams, csrc/drbg.hpp)."""
+
+    def __init__(self, seed):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _check(self._lib.hegpu_rng_create(int(seed) & (2**64 - 1), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.hegpu_rng_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class TfheContext:

@@ -473,6 +473,96 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, 
                    "hegpu_bfv_apply_galois");
 }
 
+// ------------------------------------------------------------------ key generation / encryption / decryption
+struct hegpu_rng {
+    Rng r;
+};
+
+int hegpu_rng_create(uint64_t seed, hegpu_rng** out)
+{
+    return guarded([&]() -> int {
+        if (!out) throw std::invalid_argument("null output");
+        hegpu_rng* h = new hegpu_rng();
+        h->r.seed = seed;
+        *out = h;
+        return 0;
+    });
+}
+
+void hegpu_rng_destroy(hegpu_rng* rng) { delete rng; }
+
+#define CHECK_KG(ctx, rng, op, ws, ws_bytes)                                                          \
+    do {                                                                                              \
+        if (!(rng)) return fail(HEGPU_E_INVALID, "null random generator");                            \
+        if (!(ws) || (ws_bytes) < hegpu_workspace_bytes(ctx, op, 0, 1))                               \
+            return fail(HEGPU_E_INVALID, "workspace too small");                                      \
+    } while (0)
+
+int hegpu_generate_secret_key(hegpu_context* ctx, hegpu_rng* rng, int hamming_weight, uint64_t* sk, void* ws,
+                              size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_KG(ctx, rng, OP_KEYGEN_SECRET, ws, ws_bytes);
+    if (hamming_weight <= 0 || hamming_weight > (int) ctx->c.n)
+        return fail(HEGPU_E_INVALID, "hamming weight has to be in range 0 to ring size"); // secretkey.cu:43
+    return hip_ret(op_gen_secret_key(ctx->c, rng->r, hamming_weight, (u64*) sk, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_generate_secret_key");
+}
+
+int hegpu_generate_public_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* pk, void* ws,
+                              size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_KG(ctx, rng, OP_KEYGEN_PUBLIC, ws, ws_bytes);
+    return hip_ret(op_gen_public_key(ctx->c, rng->r, (const u64*) sk, (u64*) pk, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_generate_public_key");
+}
+
+int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* rk, void* ws,
+                             size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_KG(ctx, rng, OP_KEYGEN_SWITCH, ws, ws_bytes);
+    if (ctx->c.P_size != 1) return fail(HEGPU_E_LOGIC, "key generation implements key-switching method I (P_size == 1)");
+    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, 0, (u64*) rk, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_generate_relin_key");
+}
+
+int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, int galois_elt, uint64_t* gk,
+                              void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_KG(ctx, rng, OP_KEYGEN_SWITCH, ws, ws_bytes);
+    if (ctx->c.P_size != 1) return fail(HEGPU_E_LOGIC, "key generation implements key-switching method I (P_size == 1)");
+    if (!(galois_elt & 1) || galois_elt <= 0 || galois_elt >= (int) (2 * ctx->c.n))
+        return fail(HEGPU_E_INVALID, "galois element must be odd and below 2N");
+    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, galois_elt, (u64*) gk, (u64*) ws,
+                                     (hipStream_t) stream),
+                   "hegpu_generate_galois_key");
+}
+
+int hegpu_ckks_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, const uint64_t* plain, uint64_t* ct,
+                       void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    CHECK_KG(ctx, rng, OP_CKKS_ENCRYPT, ws, ws_bytes);
+    return hip_ret(op_ckks_encrypt(ctx->c, rng->r, (const u64*) pk, (const u64*) plain, (u64*) ct, (u64*) ws,
+                                   (hipStream_t) stream),
+                   "hegpu_ckks_encrypt");
+}
+
+int hegpu_ckks_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, int depth, uint64_t* plain,
+                       hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (depth < 0 || depth >= ctx->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");
+    return hip_ret(op_ckks_decrypt(ctx->c, (const u64*) ct, (const u64*) sk, depth, (u64*) plain,
+                                   (hipStream_t) stream),
+                   "hegpu_ckks_decrypt");
+}
+
 // ------------------------------------------------------------------ TFHE
 struct hegpu_tfhe_context {
     TfheDev p{};

@@ -12,6 +12,7 @@
 #include "rns.hpp"
 #include <map>
 #include <string>
+#include "drbg.hpp"
 #include <vector>
 
 namespace hegpu {
@@ -52,6 +53,7 @@ struct Context {
     int m2_width = 0; // digit width m: 2 for BFV, P_size for CKKS
     // use the fused "row pass + key-switch MAC" kernel (HEGPU_FUSED_ROW_MAC=0 disables)
     bool fused_row_mac = true;
+    GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 
     // ---- device state (valid after upload())
     bool uploaded = false;

@@ -1,0 +1,196 @@
+// keygen.hip -- key generation / encryption / decryption kernels for gfx950
+// (SURVEY.md 8f next-1).  All of them are element-wise streams over
+// [poly][limb][N] arrays (HBM-bound); the transforms between them are the NTT
+// kernels of the hot path.
+#include "keygen.hpp"
+
+namespace hegpu {
+
+#define KG_THREADS 256
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_uniform(u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                           int n_power, int limbs, u64 seed, u64 stream)
+{
+    const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
+    const int limb = blockIdx.y, poly = blockIdx.z;
+    const u64 e = (((u64) poly * limbs + limb) << n_power) + n;
+    out[e] = drbg_uniform(seed, stream, e, mods[limb]);
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_gaussian(u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                            int n_power, int limbs, u64 seed, u64 stream,
+                                                            GaussCdt cdt)
+{
+    const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
+    const int poly = blockIdx.y;
+    const int v = drbg_gaussian(seed, stream, ((u64) poly << n_power) + n, cdt);
+    for (int j = 0; j < limbs; j++) out[(((u64) poly * limbs + j) << n_power) + n] = lift_small(v, mods[j].q);
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_ternary(u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                           int n_power, int limbs, u64 seed, u64 stream)
+{
+    const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
+    const int poly = blockIdx.y;
+    const int v = drbg_ternary(seed, stream, ((u64) poly << n_power) + n);
+    for (int j = 0; j < limbs; j++) out[(((u64) poly * limbs + j) << n_power) + n] = lift_small(v, mods[j].q);
+}
+
+hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_uniform, dim3((1u << n_power) / KG_THREADS, limbs, polys), dim3(KG_THREADS), 0, st, out,
+                       mods, n_power, limbs, seed, stream);
+    return hipGetLastError();
+}
+hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                       const GaussCdt& cdt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_gaussian, dim3((1u << n_power) / KG_THREADS, polys), dim3(KG_THREADS), 0, st, out, mods,
+                       n_power, limbs, seed, stream, cdt);
+    return hipGetLastError();
+}
+hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_ternary, dim3((1u << n_power) / KG_THREADS, polys), dim3(KG_THREADS), 0, st, out, mods,
+                       n_power, limbs, seed, stream);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_secret_rns(const int* __restrict__ positions,
+                                                              const int* __restrict__ values, int count,
+                                                              u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                              int n_power, int limbs)
+{
+    const int i = blockIdx.x * KG_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const int pos = positions[i], v = values[i];
+    for (int j = 0; j < limbs; j++) out[((u64) j << n_power) + pos] = lift_small(v, mods[j].q);
+}
+
+hipError_t kg_secret_rns(const int* positions, const int* values, int count, u64* out, const Mod* mods, int n_power,
+                         int limbs, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out, 0, ((size_t) limbs << n_power) * sizeof(u64), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_kg_secret_rns, dim3((count + KG_THREADS - 1) / KG_THREADS), dim3(KG_THREADS), 0, st,
+                       positions, values, count, out, mods, n_power, limbs);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_publickey(u64* __restrict__ pk, const u64* __restrict__ sk,
+                                                             const u64* __restrict__ e, const u64* __restrict__ a,
+                                                             const Mod* __restrict__ mods, int n_power, int limbs)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    const Mod m = mods[blockIdx.y];
+    const u64 av = a[loc];
+    u64 t = mul_barrett(sk[loc], av, m);
+    t = add_mod(t, e[loc], m.q);
+    pk[loc] = sub_mod(0, t, m.q);
+    pk[loc + ((u64) limbs << n_power)] = av;
+}
+
+hipError_t kg_publickey(u64* pk, const u64* sk, const u64* e, const u64* a, const Mod* mods, int n_power, int limbs,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_publickey, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, pk, sk, e,
+                       a, mods, n_power, limbs);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ u32 bitrev(u32 v, int bits) { return __brev(v) >> (32 - bits); }
+
+// slot permutation of an NTT-domain polynomial under X -> X^g (keygeneration.cu:742-755)
+__device__ __forceinline__ u32 ntt_permutation(u32 index, u32 galois_elt, int n_power)
+{
+    const u32 n = 1u << n_power;
+    const u32 reversed = bitrev(index + n, n_power + 1);
+    const u32 raw = ((galois_elt * reversed) >> 1) & (n - 1);
+    return bitrev(raw, n_power);
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_switchkey(u64* __restrict__ key, const u64* __restrict__ sk,
+                                                             const u64* __restrict__ e, const u64* __restrict__ a,
+                                                             const Mod* __restrict__ mods,
+                                                             const u64* __restrict__ factor, int galois_elt,
+                                                             int n_power, int limbs)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const int y = blockIdx.y;
+    const Mod m = mods[y];
+    const u64 s = sk[idx + ((u64) y << n_power)];
+    // secret the key is encrypted under / polynomial it carries
+    const u64 sp = galois_elt ? sk[((u64) y << n_power) + ntt_permutation(idx, (u32) galois_elt, n_power)] : s;
+    const u64 carried = galois_elt ? s : mul_barrett(s, s, m);
+    for (int i = 0; i < limbs - 1; i++) {
+        const u64 src = idx + ((u64) y << n_power) + ((u64) (limbs * i) << n_power);
+        const u64 av = a[src];
+        u64 k0 = mul_barrett(sp, av, m);
+        k0 = add_mod(k0, e[src], m.q);
+        k0 = sub_mod(0, k0, m.q);
+        if (i == y) k0 = add_mod(k0, mul_barrett(carried, factor[y], m), m.q);
+        const u64 dst = idx + ((u64) y << n_power) + ((u64) (limbs * i) << (n_power + 1));
+        key[dst] = k0;
+        key[dst + ((u64) limbs << n_power)] = av;
+    }
+}
+
+hipError_t kg_switchkey(u64* key, const u64* sk, const u64* e, const u64* a, const Mod* mods, const u64* factor,
+                        int galois_elt, int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_switchkey, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, key, sk, e,
+                       a, mods, factor, galois_elt, n_power, limbs);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_pk_u(const u64* __restrict__ pk, const u64* __restrict__ u,
+                                                        u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                        int n_power, int limbs)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    const u64 z = ((u64) limbs << n_power) * blockIdx.z;
+    out[loc + z] = mul_barrett(pk[loc + z], u[loc], mods[blockIdx.y]);
+}
+
+hipError_t kg_pk_u(const u64* pk, const u64* u, u64* out, const Mod* mods, int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_pk_u, dim3((1u << n_power) / KG_THREADS, limbs, 2), dim3(KG_THREADS), 0, st, pk, u, out,
+                       mods, n_power, limbs);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_message_add(u64* __restrict__ ct, const u64* __restrict__ plain,
+                                                               const Mod* __restrict__ mods, int n_power)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    ct[loc] = add_mod(ct[loc], plain[loc], mods[blockIdx.y].q);
+}
+
+hipError_t kg_message_add(u64* ct, const u64* plain, const Mod* mods, int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_message_add, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, ct, plain,
+                       mods, n_power);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_sk_mul_ckks(const u64* __restrict__ ct, u64* __restrict__ plain,
+                                                               const u64* __restrict__ sk,
+                                                               const Mod* __restrict__ mods, int n_power, int limbs)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    const Mod m = mods[blockIdx.y];
+    const u64 c1 = mul_barrett(ct[loc + ((u64) limbs << n_power)], sk[loc], m);
+    plain[loc] = add_mod(c1, ct[loc], m.q);
+}
+
+hipError_t kg_sk_multiplication_ckks(const u64* ct, u64* plain, const u64* sk, const Mod* mods, int n_power,
+                                     int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_sk_mul_ckks, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, ct, plain,
+                       sk, mods, n_power, limbs);
+    return hipGetLastError();
+}
+
+} // namespace hegpu

@@ -1,0 +1,37 @@
+// keygen.hpp -- samplers and element-wise kernels of key generation,
+// encryption and decryption; internal C++.
+#pragma once
+#include "drbg.hpp"
+
+namespace hegpu {
+
+// out[poly][limb][N] uniform mod q_limb                    (random.cuh: modular_uniform_*)
+hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                      hipStream_t st);
+// out[poly][limb][N]: one rounded Gaussian per (poly, coefficient), lifted into every limb
+hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                       const GaussCdt& cdt, hipStream_t st);
+// same with a uniform ternary value
+hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+                      hipStream_t st);
+// secretkey_gen_kernel_v2 + secretkey_rns_kernel (keygeneration.cu:39-88): scatter `count`
+// (position, +-1) pairs into an all-zero polynomial and lift it into `limbs` limbs
+hipError_t kg_secret_rns(const int* positions, const int* values, int count, u64* out, const Mod* mods, int n_power,
+                         int limbs, hipStream_t st);
+// publickey_gen_kernel (keygeneration.cu:93-116): pk = [-(s*a + e), a], all NTT domain
+hipError_t kg_publickey(u64* pk, const u64* sk, const u64* e, const u64* a, const Mod* mods, int n_power, int limbs,
+                        hipStream_t st);
+// relinkey_gen_kernel / galoiskey_gen_kernel (keygeneration.cu:145-185, 757-805), method I:
+// key[d][0][j] = -(s'_j * a_dj + e_dj) + (d == j) * factor_j * t_j,  key[d][1][j] = a_dj with
+// (s', t) = (s, s*s) for relinearisation, (sigma_g(s), s) for a Galois key (galois_elt != 0)
+hipError_t kg_switchkey(u64* key, const u64* sk, const u64* e, const u64* a, const Mod* mods, const u64* factor,
+                        int galois_elt, int n_power, int limbs, hipStream_t st);
+// pk_u_kernel (encryption.cu:10-26): out[z][j] = pk[z][j] * u[j]
+hipError_t kg_pk_u(const u64* pk, const u64* u, u64* out, const Mod* mods, int n_power, int limbs, hipStream_t st);
+// cipher_message_add_kernel (encryption.cu:254-267): ct[0][j] += plain[j]
+hipError_t kg_message_add(u64* ct, const u64* plain, const Mod* mods, int n_power, int limbs, hipStream_t st);
+// sk_multiplication_ckks (decryption.cu:349-367): plain[j] = ct[0][j] + ct[1][j] * sk[j]
+hipError_t kg_sk_multiplication_ckks(const u64* ct, u64* plain, const u64* sk, const Mod* mods, int n_power,
+                                     int limbs, hipStream_t st);
+
+} // namespace hegpu

@@ -2,6 +2,8 @@
 // over independent ciphertexts and free of allocation: all temporaries live in
 // a caller-provided workspace so the sequences can be captured in a hipGraph.
 #include "ops.hpp"
+#include <vector>
+#include <utility>
 
 namespace hegpu {
 
@@ -72,6 +74,10 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_BFV_MULTIPLY: per = (u64) 7 * L * n; break;
         case OP_BFV_RELIN: per = ((u64) Q * Qp + 2 * Qp) * n; break;
         case OP_BFV_GALOIS: per = ((u64) Q * Qp + 2 * Qp) * n; break;
+        case OP_KEYGEN_SECRET: per = n; break;                      // 2 x hamming weight ints
+        case OP_KEYGEN_PUBLIC: per = (u64) 2 * Qp * n; break;        // e, a
+        case OP_KEYGEN_SWITCH: per = (u64) 2 * Q * Qp * n; break;    // e, a per digit
+        case OP_CKKS_ENCRYPT: per = (u64) 5 * Qp * n; break;         // u, e[2], pk*u[2]
         default: return 0;
     }
     return per * (u64) batch;
@@ -392,6 +398,102 @@ hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* 
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));
     return rns_moddown_permute(temp3, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),
                                c.d64("last_q_modinv"), galois_elt, np, Qp, Q, Qp, Q, c.P_size, batch, st);
+}
+
+// ------------------------------------------------------------------ keygen / encrypt / decrypt
+static u64 inv_mod_2n(u64 g, u64 two_n)
+{
+    // g odd, two_n a power of two: Newton iteration
+    u64 x = g;
+    for (int i = 0; i < 6; i++) x *= 2 - g * x;
+    return x & (two_n - 1);
+}
+
+hipError_t op_gen_secret_key(const Context& c, Rng& r, int hamming_weight, u64* sk, u64* ws, hipStream_t st)
+{
+    const int n = (int) c.n;
+    if (hamming_weight <= 0 || hamming_weight > n) return hipErrorInvalidValue;
+    // partial Fisher-Yates over the coefficient indices (the reference's v2 generator
+    // does the same on the host with mt19937, ckks/keygenerator.cu:100-118)
+    std::vector<int> index(n), host(2 * (size_t) hamming_weight);
+    for (int i = 0; i < n; i++) index[i] = i;
+    const u64 stream = r.stream++;
+    for (int i = 0; i < hamming_weight; i++) {
+        const PhiloxOut o = drbg_block(r.seed, stream, (u64) i);
+        const int j = i + (int) (((u64) o.w[0] * (u64) (n - i)) >> 32);
+        std::swap(index[i], index[j]);
+        host[i] = index[i];
+        host[hamming_weight + i] = (o.w[1] & 1) ? 1 : -1;
+    }
+    int* dpos = reinterpret_cast<int*>(ws);
+    TRY(hipMemcpyAsync(dpos, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    TRY(hipStreamSynchronize(st)); // the staging vector dies with this call
+    TRY(kg_secret_rns(dpos, dpos + hamming_weight, hamming_weight, sk, c.plan_qp.mods, c.n_power, c.Qp_size, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = sk; a.out = sk; a.mod_count = c.Qp_size;
+    return ntt_launch(a, c.Qp_size, false, st);
+}
+
+hipError_t op_gen_public_key(const Context& c, Rng& r, const u64* sk, u64* pk, u64* ws, hipStream_t st)
+{
+    const int Qp = c.Qp_size;
+    u64* e = ws;
+    u64* av = ws + (u64) Qp * c.n;
+    TRY(kg_uniform(av, c.plan_qp.mods, c.n_power, Qp, 1, r.seed, r.stream++, st));
+    TRY(kg_gaussian(e, c.plan_qp.mods, c.n_power, Qp, 1, r.seed, r.stream++, c.gauss_cdt, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = e; a.out = e; a.mod_count = Qp;
+    TRY(ntt_launch(a, Qp, false, st));
+    return kg_publickey(pk, sk, e, av, c.plan_qp.mods, c.n_power, Qp, st);
+}
+
+hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, u64* key, u64* ws,
+                             hipStream_t st)
+{
+    if (c.P_size != 1) return hipErrorNotSupported; // method I keys only
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    u64* e = ws;
+    u64* av = ws + (u64) Q * Qp * c.n;
+    TRY(kg_uniform(av, c.plan_qp.mods, c.n_power, Qp, Q, r.seed, r.stream++, st));
+    TRY(kg_gaussian(e, c.plan_qp.mods, c.n_power, Qp, Q, r.seed, r.stream++, c.gauss_cdt, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = e; a.out = e; a.mod_count = Qp;
+    TRY(ntt_launch(a, Q * Qp, false, st));
+    const int inv = galois_elt ? (int) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0; // keygenerator.cu:474
+    return kg_switchkey(key, sk, e, av, c.plan_qp.mods, c.d64("factor"), inv, c.n_power, Qp, st);
+}
+
+hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
+                           hipStream_t st)
+{
+    const int np = c.n_power, Q = c.Q_size, Qp = c.Qp_size;
+    const u64 n = c.n;
+    u64* u = ws;                       // [Q'][N]
+    u64* e = u + (u64) Qp * n;         // [2][Q'][N]
+    u64* pku = e + (u64) 2 * Qp * n;   // [2][Q'][N]
+    const Mod* mods = c.plan_qp.mods;
+    TRY(kg_ternary(u, mods, np, Qp, 1, r.seed, r.stream++, st));
+    TRY(kg_gaussian(e, mods, np, Qp, 2, r.seed, r.stream++, c.gauss_cdt, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = u; a.out = u; a.mod_count = Qp;
+    TRY(ntt_launch(a, Qp, false, st));                                                     // :73
+    TRY(kg_pk_u(pk, u, pku, mods, np, Qp, st));                                            // :77
+    a.in = pku; a.out = pku;
+    TRY(ntt_launch(a, 2 * Qp, true, st));                                                  // :91
+    // enc_div_lastq_ckks_kernel (:95): (pk*u + e) divided-and-rounded by the P primes
+    TRY(rns_addition(pku, e, pku, mods, np, Qp, 2, 1, 0, st));
+    TRY(rns_moddown_extended(pku, 0, nullptr, 0, ct, 0, mods, c.d64("half"), c.d64("half_mod"),
+                             c.d64("last_q_modinv"), np, Qp, Q, Qp, Q, c.P_size, 0, 1, st));
+    a.in = ct; a.out = ct; a.mod_count = Q;
+    TRY(ntt_launch(a, 2 * Q, false, st));                                                  // :103
+    return kg_message_add(ct, plain, mods, np, Q, st);                                     // :107
+}
+
+hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)
+{
+    const int l = c.Q_size - depth;
+    if (l < 1) return hipErrorInvalidValue;
+    return kg_sk_multiplication_ckks(ct, plain, sk, c.plan_qp.mods, c.n_power, l, st);
 }
 
 } // namespace hegpu

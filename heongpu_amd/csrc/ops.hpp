@@ -1,11 +1,12 @@
 // ops.hpp -- batched operator sequences on a Context (internal C++).
 #pragma once
 #include "context.hpp"
+#include "keygen.hpp"
 
 namespace hegpu {
 
 enum { OP_CKKS_RELIN = 1, OP_CKKS_RESCALE = 2, OP_CKKS_GALOIS = 3, OP_BFV_MULTIPLY = 4, OP_BFV_RELIN = 5,
-       OP_BFV_GALOIS = 6 };
+       OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10 };
 
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
@@ -32,5 +33,25 @@ hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* k
                                  hipStream_t st);
 hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                   int galois_elt, int batch, u64* ws, hipStream_t st);
+
+// ---- key generation / encryption / decryption, key-switch method I
+// The generator state: every sampling call consumes one stream id of the DRBG (drbg.hpp).
+struct Rng {
+    u64 seed = 0;
+    u64 stream = 0;
+};
+// HEKeyGenerator::generate_secret_key_v2 (ckks/keygenerator.cu:85-160); sk [Q'][N], NTT domain
+hipError_t op_gen_secret_key(const Context& c, Rng& r, int hamming_weight, u64* sk, u64* ws, hipStream_t st);
+// generate_public_key (ckks/keygenerator.cu:167-240); pk [2][Q'][N]
+hipError_t op_gen_public_key(const Context& c, Rng& r, const u64* sk, u64* pk, u64* ws, hipStream_t st);
+// generate_relin_key_method_I (:242-324) / generate_galois_key_method_I (:415-560); key [Q][2][Q'][N];
+// galois_elt == 0: relinearisation key
+hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, u64* key, u64* ws,
+                             hipStream_t st);
+// HEEncryptor<CKKS>::encrypt_ckks (ckks/encryptor.cu:36-110); plain [Q][N] NTT domain, ct [2][Q][N]
+hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
+                           hipStream_t st);
+// HEDecryptor<CKKS>::decrypt_ckks (ckks/decryptor.cu:38-58); plain [l][N], l = Q - depth
+hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st);
 
 } // namespace hegpu

@@ -136,7 +136,11 @@ enum {
     HEGPU_OP_CKKS_GALOIS = 3,
     HEGPU_OP_BFV_MULTIPLY = 4,
     HEGPU_OP_BFV_RELIN = 5,
-    HEGPU_OP_BFV_GALOIS = 6
+    HEGPU_OP_BFV_GALOIS = 6,
+    HEGPU_OP_KEYGEN_SECRET = 7,
+    HEGPU_OP_KEYGEN_PUBLIC = 8,
+    HEGPU_OP_KEYGEN_SWITCH = 9, /* relinearisation and Galois keys */
+    HEGPU_OP_CKKS_ENCRYPT = 10
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -174,6 +178,35 @@ int hegpu_bfv_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_
 int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
                            uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int batch, void* ws,
                            size_t ws_bytes, hegpu_stream stream);
+
+/* ---- key generation, encryption, decryption (key-switching method I) ----
+ * The random values are the backend's own (Philox4x32-10 counter DRBG seeded by the caller,
+ * csrc/drbg.hpp): the reference's AES generator is seeded from RAND_bytes and cannot be
+ * reproduced, only its distributions (uniform mod q_i, rounded Gaussian sigma = 3.2 clipped at
+ * 6 sigma, uniform ternary; src/include/heongpu/util/random.cuh:52-708).  Workspaces:
+ * hegpu_workspace_bytes(ctx, HEGPU_OP_KEYGEN_* / HEGPU_OP_CKKS_ENCRYPT, 0, 1).  All keys NTT domain. */
+typedef struct hegpu_rng hegpu_rng;
+int hegpu_rng_create(uint64_t seed, hegpu_rng** out);
+void hegpu_rng_destroy(hegpu_rng* rng);
+/* HEKeyGenerator::generate_secret_key_v2 (src/lib/host/ckks/keygenerator.cu:85-160):
+ * ternary with exactly hamming_weight non-zeros; sk [Q'][N].  Synchronises the stream once. */
+int hegpu_generate_secret_key(hegpu_context* ctx, hegpu_rng* rng, int hamming_weight, uint64_t* sk, void* ws,
+                              size_t ws_bytes, hegpu_stream stream);
+/* generate_public_key (keygenerator.cu:167-240, kernel/keygeneration.cu:93-116); pk [2][Q'][N] */
+int hegpu_generate_public_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* pk, void* ws,
+                              size_t ws_bytes, hegpu_stream stream);
+/* generate_relin_key_method_I (keygenerator.cu:242-324, keygeneration.cu:145-185); rk [Q][2][Q'][N] */
+int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* rk, void* ws,
+                             size_t ws_bytes, hegpu_stream stream);
+/* generate_galois_key_method_I, one element (keygenerator.cu:415-560, keygeneration.cu:742-805) */
+int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, int galois_elt, uint64_t* gk,
+                              void* ws, size_t ws_bytes, hegpu_stream stream);
+/* HEEncryptor<CKKS>::encrypt_ckks (src/lib/host/ckks/encryptor.cu:36-110); plain [Q][N], ct [2][Q][N] */
+int hegpu_ckks_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, const uint64_t* plain, uint64_t* ct,
+                       void* ws, size_t ws_bytes, hegpu_stream stream);
+/* HEDecryptor<CKKS>::decrypt_ckks (src/lib/host/ckks/decryptor.cu:38-58); plain [Q-depth][N] */
+int hegpu_ckks_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, int depth, uint64_t* plain,
+                       hegpu_stream stream);
 
 /* ------------------------------------------------------------------ TFHE
  * Gate bootstrapping on the reference's fixed STD128 set

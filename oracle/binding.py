@@ -79,6 +79,11 @@ def lib():
     L.o_bfv_apply_galois_II.argtypes = [vp, vp, vp, vp, ci]
     L.o_ckks_relinearize_II.argtypes = [vp, vp, vp, ci]
     L.o_ckks_apply_galois_II.argtypes = [vp, vp, vp, vp, ci, ci]
+    L.o_gen_secret_key.argtypes = [vp, vp, ci, vp]
+    L.o_gen_public_key.argtypes = [vp, vp, vp, vp]
+    L.o_gen_switch_key.argtypes = [vp, vp, vp, ci, vp]
+    L.o_ckks_encrypt.argtypes = [vp, vp, vp, vp, vp]
+    L.o_ckks_decrypt.argtypes = [vp, vp, vp, ci, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
@@ -118,6 +123,14 @@ def fill_poly(seed, limb, n, q):
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64) + np.uint64(seed) + (np.uint64(limb) << np.uint64(32))
         return splitmix64(idx) % np.uint64(q)
+
+
+class ORng(ctypes.Structure):
+    """orng_t of o_keygen.c: (seed, next stream id)."""
+    _fields_ = [("seed", ctypes.c_uint64), ("stream", ctypes.c_uint64)]
+
+    def __init__(self, seed):
+        super().__init__(int(seed) & (2**64 - 1), 0)
 
 
 class OracleContext:
@@ -199,6 +212,34 @@ class OracleContext:
         out = np.zeros(2 * l * self.n, dtype=np.uint64)
         self.L.o_ckks_apply_galois(self.h, _p(ct), _p(out), _p(key), galois_elt, depth)
         return out
+
+    # key generation / encryption / decryption (o_keygen.c); rng = ORng(seed)
+    def gen_secret_key(self, rng, hamming_weight=None):
+        sk = np.zeros(self.Qp * self.n, dtype=np.uint64)
+        self.L.o_gen_secret_key(self.h, ctypes.byref(rng), self.n // 2 if hamming_weight is None else hamming_weight,
+                                _p(sk))
+        return sk
+
+    def gen_public_key(self, rng, sk):
+        pk = np.zeros(2 * self.Qp * self.n, dtype=np.uint64)
+        self.L.o_gen_public_key(self.h, ctypes.byref(rng), _p(sk), _p(pk))
+        return pk
+
+    def gen_switch_key(self, rng, sk, galois_elt=0):
+        key = np.zeros(self.Q * 2 * self.Qp * self.n, dtype=np.uint64)
+        self.L.o_gen_switch_key(self.h, ctypes.byref(rng), _p(sk), galois_elt, _p(key))
+        return key
+
+    def ckks_encrypt(self, rng, pk, plain):
+        ct = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_ckks_encrypt(self.h, ctypes.byref(rng), _p(pk), _p(np.ascontiguousarray(plain, dtype=np.uint64)),
+                              _p(ct))
+        return ct
+
+    def ckks_decrypt(self, ct, sk, depth=0):
+        plain = np.zeros((self.Q - depth) * self.n, dtype=np.uint64)
+        self.L.o_ckks_decrypt(self.h, _p(ct), _p(sk), depth, _p(plain))
+        return plain
 
     # key-switching method II (P_size > 1)
     def ckks_relinearize_II(self, ct3, key, depth=0):

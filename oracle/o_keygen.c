@@ -1,0 +1,292 @@
+/*
+ * o_keygen.c -- CPU restatement of key generation, CKKS encryption and
+ * decryption.  TEST INFRASTRUCTURE ONLY (see
+ * hegpu_oracle.h).
+ *
+ * The reference's random values cannot be reproduced (AES generator seeded
+ * from RAND_bytes, src/lib/util/random.cu:20-60); what is restated here is
+ * (a) the backend's published sampling rule -- Philox4x32-10 (Salmon et al.,
+ * SC'11) keyed by the caller's seed, counter = (index, stream), the three
+ * samplers of random.cuh:52-708 (uniform mod q_i from 128 bits, rounded
+ * Gaussian sigma = 3.2 by CDT inversion clipped at 6 sigma, uniform ternary)
+ * -- written independently of the product's csrc/drbg.hpp, and (b) the
+ * reference's kernels and host sequences that consume those values, index for
+ * index.  PARITY UNPINNED by the reference (no vectors exist); pinned by the
+ * semantic round trips in tests/test_oracle_keygen.py.
+ */
+#include "hegpu_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+static void philox(uint32_t key0, uint32_t key1, const uint32_t ctr_in[4], uint32_t out[4])
+{
+    uint32_t c[4] = { ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3] };
+    uint32_t k0 = key0, k1 = key1;
+    for (int round = 0; round < 10; round++) {
+        u64 prod0 = (u64) 0xD2511F53u * c[0];
+        u64 prod1 = (u64) 0xCD9E8D57u * c[2];
+        uint32_t n[4];
+        n[0] = (uint32_t) (prod1 >> 32) ^ c[1] ^ k0;
+        n[1] = (uint32_t) prod1;
+        n[2] = (uint32_t) (prod0 >> 32) ^ c[3] ^ k1;
+        n[3] = (uint32_t) prod0;
+        memcpy(c, n, sizeof(c));
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    memcpy(out, c, 4 * sizeof(uint32_t));
+}
+
+static void block(u64 seed, u64 stream, u64 index, uint32_t out[4])
+{
+    uint32_t ctr[4] = { (uint32_t) index, (uint32_t) (index >> 32), (uint32_t) stream, (uint32_t) (stream >> 32) };
+    philox((uint32_t) seed, (uint32_t) (seed >> 32), ctr, out);
+}
+
+#define GAUSS_MAX 19
+static void gauss_cdt(u64 t[GAUSS_MAX])
+{
+    /* P(|round(N(0, sigma^2))| <= k) = erf((k + 1/2) / (sigma sqrt 2)), scaled to 63 bits */
+    for (int k = 0; k < GAUSS_MAX; k++) t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);
+}
+
+static int sample_gaussian(u64 seed, u64 stream, u64 index, const u64* t)
+{
+    uint32_t w[4];
+    block(seed, stream, index, w);
+    u64 r = (u64) w[0] | ((u64) w[1] << 32);
+    u64 u = r >> 1;
+    int k = 0;
+    while (k < GAUSS_MAX && u >= t[k]) k++;
+    return (r & 1) ? -k : k;
+}
+
+static int sample_ternary(u64 seed, u64 stream, u64 index)
+{
+    uint32_t w[4];
+    block(seed, stream, index, w);
+    return (int) (((u64) w[0] * 3) >> 32) - 1;
+}
+
+static u64 sample_uniform(u64 seed, u64 stream, u64 index, u64 q)
+{
+    uint32_t w[4];
+    block(seed, stream, index, w);
+    u128 v = ((u128) ((u64) w[2] | ((u64) w[3] << 32)) << 64) | ((u64) w[0] | ((u64) w[1] << 32));
+    return (u64) (v % q);
+}
+
+static u64 lift(int v, u64 q) { return v < 0 ? q - (u64) (-v) : (u64) v; }
+
+typedef struct { u64 seed, stream; } orng_t;
+
+/* out[poly][limb][N] */
+static void fill_uniform(const octx_t* c, orng_t* r, u64* out, int limbs, int polys)
+{
+    u64 stream = r->stream++;
+    for (int p = 0; p < polys; p++)
+        for (int j = 0; j < limbs; j++)
+            for (u64 n = 0; n < c->n; n++) {
+                u64 e = (((u64) p * limbs + j) << c->n_power) + n;
+                out[e] = sample_uniform(r->seed, stream, e, c->mod[j].value);
+            }
+}
+static void fill_gaussian(const octx_t* c, orng_t* r, u64* out, int limbs, int polys)
+{
+    u64 t[GAUSS_MAX];
+    gauss_cdt(t);
+    u64 stream = r->stream++;
+    for (int p = 0; p < polys; p++)
+        for (u64 n = 0; n < c->n; n++) {
+            int v = sample_gaussian(r->seed, stream, ((u64) p << c->n_power) + n, t);
+            for (int j = 0; j < limbs; j++) out[(((u64) p * limbs + j) << c->n_power) + n] = lift(v, c->mod[j].value);
+        }
+}
+static void fill_ternary(const octx_t* c, orng_t* r, u64* out, int limbs, int polys)
+{
+    u64 stream = r->stream++;
+    for (int p = 0; p < polys; p++)
+        for (u64 n = 0; n < c->n; n++) {
+            int v = sample_ternary(r->seed, stream, ((u64) p << c->n_power) + n);
+            for (int j = 0; j < limbs; j++) out[(((u64) p * limbs + j) << c->n_power) + n] = lift(v, c->mod[j].value);
+        }
+}
+
+/* HEKeyGenerator::generate_secret_key_v2 (ckks/keygenerator.cu:85-160) with the
+ * backend's generator in place of mt19937; secretkey_rns_kernel
+ * (keygeneration.cu:62-88); forward NTT over the Q' limbs. */
+void o_gen_secret_key(const octx_t* c, orng_t* r, int hamming_weight, u64* sk)
+{
+    const int n = (int) c->n, Qp = c->Qp_size;
+    int* index = (int*) malloc(sizeof(int) * n);
+    int* coeff = (int*) calloc(n, sizeof(int));
+    for (int i = 0; i < n; i++) index[i] = i;
+    u64 stream = r->stream++;
+    for (int i = 0; i < hamming_weight; i++) {
+        uint32_t w[4];
+        block(r->seed, stream, (u64) i, w);
+        int j = i + (int) (((u64) w[0] * (u64) (n - i)) >> 32);
+        int tmp = index[i]; index[i] = index[j]; index[j] = tmp;
+        coeff[index[i]] = (w[1] & 1) ? 1 : -1;
+    }
+    for (int j = 0; j < Qp; j++)
+        for (int i = 0; i < n; i++) sk[((u64) j << c->n_power) + i] = coeff[i] < 0 ? c->mod[j].value - 1 : (u64) coeff[i];
+    o_gpu_ntt(sk, sk, c->ntt_table, c->mod, c->n_power, Qp, Qp);
+    free(index);
+    free(coeff);
+}
+
+/* generate_public_key (ckks/keygenerator.cu:167-240) + publickey_gen_kernel (keygeneration.cu:93-116) */
+void o_gen_public_key(const octx_t* c, orng_t* r, const u64* sk, u64* pk)
+{
+    const int Qp = c->Qp_size;
+    const u64 sz = (u64) Qp << c->n_power;
+    u64* e = (u64*) malloc(2 * sz * sizeof(u64));
+    u64* a = e + sz;
+    fill_uniform(c, r, a, Qp, 1);
+    fill_gaussian(c, r, e, Qp, 1);
+    o_gpu_ntt(e, e, c->ntt_table, c->mod, c->n_power, Qp, Qp);
+    for (int y = 0; y < Qp; y++)
+        for (u64 i = 0; i < c->n; i++) {
+            u64 loc = i + ((u64) y << c->n_power);
+            u64 t = o_mult(sk[loc], a[loc], &c->mod[y]);
+            t = o_add(t, e[loc], &c->mod[y]);
+            pk[loc] = o_sub(0, t, &c->mod[y]);
+            pk[loc + sz] = a[loc];
+        }
+    free(e);
+}
+
+static uint32_t bitrev(uint32_t v, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+/* keygeneration.cu:742-755 */
+static int permutation(int index, int galois_elt, int coeff_count, int n_power)
+{
+    int i = index + coeff_count;
+    int reversed = (int) bitrev((uint32_t) i, n_power + 1);
+    int index_raw = (int) (((uint32_t) galois_elt * (uint32_t) reversed) >> 1);
+    index_raw &= coeff_count - 1;
+    return (int) bitrev((uint32_t) index_raw, n_power);
+}
+static u64 modinv_2n(u64 g, u64 two_n)
+{
+    for (u64 x = 1; x < two_n; x += 2)
+        if (((g * x) & (two_n - 1)) == 1) return x;
+    return 0;
+}
+
+/* generate_relin_key_method_I (ckks/keygenerator.cu:242-324, relinkey_gen_kernel
+ * keygeneration.cu:145-185) when galois_elt == 0, else generate_galois_key_method_I for
+ * one element (keygenerator.cu:415-500, galoiskey_gen_kernel keygeneration.cu:757-805). */
+void o_gen_switch_key(const octx_t* c, orng_t* r, const u64* sk, int galois_elt, u64* key)
+{
+    const int Q = c->Q_size, Qp = c->Qp_size, np = c->n_power;
+    const u64 sz = ((u64) Q * Qp) << np;
+    u64* e = (u64*) malloc(2 * sz * sizeof(u64));
+    u64* a = e + sz;
+    fill_uniform(c, r, a, Qp, Q);
+    fill_gaussian(c, r, e, Qp, Q);
+    o_gpu_ntt(e, e, c->ntt_table, c->mod, np, Q * Qp, Qp);
+    const int inv = galois_elt ? (int) modinv_2n((u64) galois_elt, 2 * c->n) : 0;
+    for (int y = 0; y < Qp; y++)
+        for (int idx = 0; idx < (int) c->n; idx++) {
+            u64 s = sk[idx + ((u64) y << np)];
+            u64 sp = galois_elt ? sk[((u64) y << np) + permutation(idx, inv, (int) c->n, np)] : s;
+            for (int i = 0; i < Qp - 1; i++) {
+                u64 src = idx + ((u64) y << np) + ((u64) (Qp * i) << np);
+                u64 k0 = o_mult(sp, a[src], &c->mod[y]);
+                k0 = o_add(k0, e[src], &c->mod[y]);
+                k0 = o_sub(0, k0, &c->mod[y]);
+                if (i == y) {
+                    u64 t = galois_elt ? s : o_mult(s, s, &c->mod[y]);
+                    t = o_mult(t, c->factor[y], &c->mod[y]);
+                    k0 = o_add(k0, t, &c->mod[y]);
+                }
+                u64 dst = idx + ((u64) y << np) + ((u64) (Qp * i) << (np + 1));
+                key[dst] = k0;
+                key[dst + ((u64) Qp << np)] = a[src];
+            }
+        }
+    free(e);
+}
+
+/* enc_div_lastq_ckks_kernel (encryption.cu:181-252) */
+static void enc_div_lastq_ckks(const octx_t* c, const u64* pk, const u64* e, u64* ct)
+{
+    const int np = c->n_power, Qp = c->Qp_size, Q = c->Q_size, P = c->P_size;
+    for (int z = 0; z < 2; z++)
+        for (int y = 0; y < Q; y++)
+            for (u64 idx = 0; idx < c->n; idx++) {
+                u64 last_pk[15];
+                for (int i = 0; i < P; i++) {
+                    u64 loc = idx + ((u64) (Q + i) << np) + (((u64) Qp << np) * z);
+                    last_pk[i] = o_add(pk[loc], e[loc], &c->mod[Q + i]);
+                }
+                u64 loc = idx + ((u64) y << np) + (((u64) Qp << np) * z);
+                u64 input = o_add(pk[loc], e[loc], &c->mod[y]);
+                int location = 0;
+                for (int i = 0; i < P; i++) {
+                    u64 lh = o_add(last_pk[P - 1 - i], c->half[i], &c->mod[Qp - 1 - i]);
+                    for (int j = 0; j < P - 1 - i; j++) {
+                        u64 t1 = o_reduce_forced(lh, &c->mod[Q + j]);
+                        t1 = o_sub(t1, c->half_mod[location + Q + j], &c->mod[Q + j]);
+                        t1 = o_sub(last_pk[j], t1, &c->mod[Q + j]);
+                        last_pk[j] = o_mult(t1, c->last_q_modinv[location + Q + j], &c->mod[Q + j]);
+                    }
+                    u64 t1 = o_reduce_forced(lh, &c->mod[y]);
+                    t1 = o_sub(t1, c->half_mod[location + y], &c->mod[y]);
+                    t1 = o_sub(input, t1, &c->mod[y]);
+                    input = o_mult(t1, c->last_q_modinv[location + y], &c->mod[y]);
+                    location += Qp - 1 - i;
+                }
+                ct[idx + ((u64) y << np) + (((u64) Q << np) * z)] = input;
+            }
+}
+
+/* HEEncryptor<CKKS>::encrypt_ckks (ckks/encryptor.cu:36-110) */
+void o_ckks_encrypt(const octx_t* c, orng_t* r, const u64* pk, const u64* plain, u64* ct)
+{
+    const int np = c->n_power, Qp = c->Qp_size, Q = c->Q_size;
+    const u64 sz = (u64) Qp << np;
+    u64* u = (u64*) malloc(5 * sz * sizeof(u64));
+    u64* e = u + sz;
+    u64* pku = e + 2 * sz;
+    fill_ternary(c, r, u, Qp, 1);
+    fill_gaussian(c, r, e, Qp, 2);
+    o_gpu_ntt(u, u, c->ntt_table, c->mod, np, Qp, Qp);
+    for (int z = 0; z < 2; z++) /* pk_u_kernel, encryption.cu:10-26 */
+        for (int y = 0; y < Qp; y++)
+            for (u64 i = 0; i < c->n; i++) {
+                u64 loc = i + ((u64) y << np);
+                pku[loc + sz * z] = o_mult(pk[loc + sz * z], u[loc], &c->mod[y]);
+            }
+    o_gpu_intt(pku, pku, c->intt_table, c->mod, c->n_inv, np, 2 * Qp, Qp);
+    enc_div_lastq_ckks(c, pku, e, ct);
+    o_gpu_ntt(ct, ct, c->ntt_table, c->mod, np, 2 * Q, Q);
+    for (int y = 0; y < Q; y++) /* cipher_message_add_kernel, encryption.cu:254-267 */
+        for (u64 i = 0; i < c->n; i++) {
+            u64 loc = i + ((u64) y << np);
+            ct[loc] = o_add(ct[loc], plain[loc], &c->mod[y]);
+        }
+    free(u);
+}
+
+/* HEDecryptor<CKKS>::decrypt_ckks + sk_multiplication_ckks (ckks/decryptor.cu:38-58,
+ * decryption.cu:349-367) */
+void o_ckks_decrypt(const octx_t* c, const u64* ct, const u64* sk, int depth, u64* plain)
+{
+    const int np = c->n_power, l = c->Q_size - depth;
+    for (int y = 0; y < l; y++)
+        for (u64 i = 0; i < c->n; i++) {
+            u64 loc = i + ((u64) y << np);
+            u64 c1 = o_mult(ct[loc + ((u64) l << np)], sk[loc], &c->mod[y]);
+            plain[loc] = o_add(c1, ct[loc], &c->mod[y]);
+        }
+}

@@ -1,0 +1,110 @@
+"""GPU parity of key generation, CKKS encryption and decryption through
+the C ABI: every output is bit-identical to the CPU oracle's for the same DRBG seed and call
+sequence, and the whole pipeline -- keygen -> encrypt -> multiply -> relinearize -> rescale ->
+rotate -> decrypt -- run on the GPU alone returns the message."""
+import numpy as np
+import pytest
+
+from he_math import RLWE, negacyclic_mul
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _pair(hg, oracle, n, log_q, log_p):
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, log_p, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, c.n_power, primes, len(log_q), len(log_p))
+    c.upload()
+    return c, o, primes
+
+
+@pytest.mark.parametrize("n,log_q,log_p", [(4096, [50, 40, 40], [55]), (8192, [60, 45, 36, 50], [60])])
+def test_keygen_encrypt_decrypt_bit_exact(hg, oracle, torch, n, log_q, log_p):
+    c, o, primes = _pair(hg, oracle, n, log_q, log_p)
+    Q = len(log_q)
+    seed = 424242 + n
+    rg, ro = hg.Rng(seed), oracle.ORng(seed)
+    sk = c.generate_secret_key(rg)
+    sk_o = o.gen_secret_key(ro)
+    assert np.array_equal(hg.to_host(sk), sk_o), "secret key"
+    pk = c.generate_public_key(rg, sk)
+    pk_o = o.gen_public_key(ro, sk_o)
+    assert np.array_equal(hg.to_host(pk), pk_o), "public key"
+    rk = c.generate_relin_key(rg, sk)
+    rk_o = o.gen_switch_key(ro, sk_o, 0)
+    assert np.array_equal(hg.to_host(rk), rk_o), "relinearisation key"
+    gal = hg.steps_to_galois_elt(3, n, 5)
+    gk = c.generate_galois_key(rg, sk, gal)
+    gk_o = o.gen_switch_key(ro, sk_o, gal)
+    assert np.array_equal(hg.to_host(gk), gk_o), "galois key"
+    plain = np.concatenate([oracle.fill_poly(9, j, n, primes[j]) for j in range(Q)])
+    ct = c.ckks_encrypt(rg, pk, hg.to_device(plain))
+    ct_o = o.ckks_encrypt(ro, pk_o, plain)
+    assert np.array_equal(hg.to_host(ct), ct_o), "ciphertext"
+    for depth in range(min(2, Q - 1) + 1):
+        l = Q - depth
+        ctl = np.concatenate([ct_o.reshape(2, Q, n)[p, :l].reshape(-1) for p in range(2)])
+        dec = c.ckks_decrypt(hg.to_device(ctl), sk, depth)
+        assert np.array_equal(hg.to_host(dec), o.ckks_decrypt(ctl, sk_o, depth)), f"decrypt depth {depth}"
+    # a second generator with another seed gives other keys
+    sk2 = c.generate_secret_key(hg.Rng(seed + 1))
+    assert not np.array_equal(hg.to_host(sk2), sk_o)
+
+
+def test_gpu_only_pipeline_returns_message(hg, oracle, torch):
+    """keygen, encryption, multiply, relinearize, rescale, rotate, decrypt on the GPU; only the
+    encoding of the test message (big-integer NTT) and the final CRT use the host helpers."""
+    n = 4096
+    c, o, primes = _pair(hg, oracle, n, [50, 30, 30, 30], [50])
+    Q = 4
+    rg = hg.Rng(7)
+    sk = c.generate_secret_key(rg)
+    pk = c.generate_public_key(rg, sk)
+    rk = c.generate_relin_key(rg, sk)
+    gal = hg.steps_to_galois_elt(1, n, 5)
+    gk = c.generate_galois_key(rg, sk, gal)
+    he = RLWE(o, seed=1)
+    scale = 1 << 30
+    g = np.random.default_rng(12)
+    m1, m2 = g.integers(-8, 9, n), g.integers(-8, 9, n)
+    p1 = he.to_ntt([int(v) * scale for v in m1], range(Q)).reshape(-1)
+    p2 = he.to_ntt([int(v) * scale for v in m2], range(Q)).reshape(-1)
+    ct1 = c.ckks_encrypt(rg, pk, hg.to_device(p1))
+    ct2 = c.ckks_encrypt(rg, pk, hg.to_device(p2))
+
+    def decode(dec, l):
+        coeff = he.ntt_limbs(hg.to_host(dec).reshape(l, n), list(range(l)), inverse=True)
+        return he.crt_centered(coeff, list(range(l)))[0]
+
+    # fresh ciphertext
+    x = decode(c.ckks_decrypt(ct1, sk, 0), Q)
+    assert max(abs(int(a) - int(b) * scale) for a, b in zip(x, m1)) < 1 << 16
+    # multiply + relinearize
+    out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(ct1, 2 * Q * n, ct2, 2 * Q * n, out, 3 * Q * n, 0, 1)
+    ws = c.workspace(hg.OP_CKKS_RELIN, 0, 1)
+    c.ckks_relinearize_inplace(out, 3 * Q * n, rk, 0, 1, ws)
+    prod = negacyclic_mul(m1, m2)
+    x = decode(c.ckks_decrypt(out[:2 * Q * n].contiguous(), sk, 0), Q)
+    assert max(abs(int(a) - int(b) * scale * scale) for a, b in zip(x, prod)) < scale * scale // 2 ** 8
+    # rescale
+    ws2 = c.workspace(hg.OP_CKKS_RESCALE, 0, 1)
+    c.ckks_rescale_inplace(out, 3 * Q * n, 0, 1, ws2)
+    l = Q - 1
+    x = decode(c.ckks_decrypt(out[:2 * l * n].contiguous(), sk, 1), l)
+    q_last = primes[Q - 1]
+    assert max(abs(int(a) * q_last - int(b) * scale * scale) for a, b in zip(x, prod)) < scale * scale // 2 ** 8
+    # rotate the fresh ciphertext
+    rot = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    ws3 = c.workspace(hg.OP_CKKS_GALOIS, 0, 1)
+    c.ckks_apply_galois(ct1, 2 * Q * n, rot, 2 * Q * n, gk, gal, 0, 1, ws3)
+    x = decode(c.ckks_decrypt(rot, sk, 0), Q)
+    want = he.apply_galois_poly(np.array([int(v) * scale for v in m1], dtype=object), gal)
+    assert max(abs(int(a) - int(b)) for a, b in zip(x, want)) < scale // 2 ** 8

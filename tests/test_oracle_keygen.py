@@ -1,0 +1,113 @@
+"""Semantic checks of the oracle's key generation / CKKS encryption / decryption
+restatement (oracle/o_keygen.c) in the shape of the reference's own tests
+(encrypt -> operate -> decrypt): the generated keys must be valid RLWE samples under the
+generated secret, the public-key encryption must decrypt to the message, and the generated
+relinearisation / Galois keys must work with the operator restatement."""
+import numpy as np
+import pytest
+
+from he_math import RLWE, negacyclic_mul
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    import ctypes
+    n_power = 10
+    n = 1 << n_power
+    bits = [40, 30, 30]
+    arr = (ctypes.c_int * 4)(*(bits + [40]))
+    out = (ctypes.c_uint64 * 4)()
+    assert oracle.lib().o_generate_primes(n, arr, 4, out) == 0
+    primes = [int(v) for v in out]
+    o = oracle.OracleContext(oracle.CKKS, n_power, primes, len(bits), 1)
+    rng = oracle.ORng(20260928)
+    sk = o.gen_secret_key(rng)
+    he = RLWE(o, seed=1)
+    # adopt the generated secret: coefficients from the inverse NTT of limb 0
+    s0 = np.ascontiguousarray(sk.reshape(o.Qp, n)[0].copy())
+    o.ntt(s0, 1, 1, mod_offset=0, inverse=True)
+    q0 = primes[0]
+    he.s = np.array([int(v) - q0 if int(v) > q0 // 2 else int(v) for v in s0])
+    he.s_ntt = sk.reshape(o.Qp, n).copy()
+    return o, he, rng, sk, primes
+
+
+def test_secret_key_shape(setup):
+    o, he, rng, sk, primes = setup
+    assert set(np.unique(he.s)) <= {-1, 0, 1}
+    assert int(np.count_nonzero(he.s)) == o.n // 2          # secretkey.cu:23 default hamming weight
+    # every limb is the NTT of the same ternary polynomial
+    assert np.array_equal(he.to_ntt(he.s, range(o.Qp)), sk.reshape(o.Qp, o.n))
+
+
+def test_public_key_is_rlwe_sample(setup):
+    o, he, rng, sk, primes = setup
+    pk = o.gen_public_key(rng, sk)
+    # pk0 + pk1*s = -e: a "ciphertext" of zero whose decryption is the negated error
+    x, M = he.decrypt(pk, o.Qp, 2, ntt_domain=True)
+    e = np.array([int(v) for v in x])
+    assert np.max(np.abs(e)) <= 19, "clipped at 6 sigma"
+    assert 2.6 < np.std(e) < 3.8 and abs(np.mean(e)) < 0.5
+    a = pk.reshape(2, o.Qp, o.n)[1]
+    for j in range(o.Qp):
+        assert int(a[j].max()) < primes[j]
+        assert abs(float(np.mean(a[j].astype(np.float64))) / primes[j] - 0.5) < 0.05
+
+
+def test_encrypt_decrypt_round_trip(setup):
+    o, he, rng, sk, primes = setup
+    n, Q = o.n, o.Q
+    pk = o.gen_public_key(rng, sk)
+    scale = 1 << 30
+    m = np.random.default_rng(3).integers(-100, 101, n)
+    plain = he.to_ntt([int(v) * scale for v in m], range(Q)).reshape(-1)
+    ct = o.ckks_encrypt(rng, pk, plain)
+    dec = o.ckks_decrypt(ct, sk)
+    coeff = he.ntt_limbs(dec.reshape(Q, n), list(range(Q)), inverse=True)
+    x, M = he.crt_centered(coeff, list(range(Q)))
+    err = max(abs(int(a) - int(b) * scale) for a, b in zip(x, m))
+    # u*e_pk + e0 + e1*s after the division by P: a few hundred at most for n = 1024
+    assert err < 1 << 14
+    # two encryptions of the same plaintext differ (fresh streams)
+    ct2 = o.ckks_encrypt(rng, pk, plain)
+    assert not np.array_equal(ct, ct2)
+
+
+def test_generated_relin_key_works(setup):
+    o, he, rng, sk, primes = setup
+    n, Q = o.n, o.Q
+    rk = o.gen_switch_key(rng, sk, 0)
+    scale = 1 << 25
+    g = np.random.default_rng(5)
+    m1, m2 = g.integers(-8, 9, n), g.integers(-8, 9, n)
+    ct1 = he.encrypt([int(v) * scale for v in m1], Q, ntt_domain=True)
+    ct2 = he.encrypt([int(v) * scale for v in m2], Q, ntt_domain=True)
+    ct3 = o.ckks_multiply(ct1, ct2, 0)
+    o.ckks_relinearize(ct3, rk, 0)
+    x, M = he.decrypt(ct3[:2 * Q * n], Q, 2, ntt_domain=True)
+    prod = negacyclic_mul(m1, m2)
+    err = max(abs(int(a) - int(b) * scale * scale) for a, b in zip(x, prod))
+    assert err < scale * scale // 2 ** 10
+
+
+def test_generated_galois_key_works(setup, oracle):
+    o, he, rng, sk, primes = setup
+    n, Q = o.n, o.Q
+    gal = oracle.lib().o_steps_to_galois_elt(1, n, 5)
+    gk = o.gen_switch_key(rng, sk, gal)
+    scale = 1 << 30
+    m = np.random.default_rng(6).integers(-50, 51, n)
+    ct = he.encrypt([int(v) * scale for v in m], Q, ntt_domain=True)
+    rot = o.ckks_apply_galois(ct, gk, gal, 0)
+    x, M = he.decrypt(rot, Q, 2, ntt_domain=True)
+    want = he.apply_galois_poly(np.array([int(v) * scale for v in m], dtype=object), gal)
+    err = max(abs(int(a) - int(b)) for a, b in zip(x, want))
+    assert err < scale // 2 ** 8
+
+
+def test_streams_are_reproducible(setup, oracle):
+    o, he, rng, sk, primes = setup
+    a = o.gen_secret_key(oracle.ORng(77))
+    b = o.gen_secret_key(oracle.ORng(77))
+    c = o.gen_secret_key(oracle.ORng(78))
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
