@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <random>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -270,7 +271,18 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
                                    hipMemcpyDeviceToHost, s));
         detail::hip(hipStreamSynchronize(s));
     }
-    // Until the encryptor exists: fill with residues laid out [size][Q - depth][N].
+    // used by the encryptor: take ownership of freshly produced residues
+    void adopt(DeviceVector<Data64>&& m, int cipher_size, int depth, double scale)
+    {
+        device_locations_ = std::move(m);
+        cipher_size_ = cipher_size;
+        depth_ = depth;
+        scale_ = scale;
+        ciphertext_generated_ = true;
+        relinearization_required_ = false;
+        rescale_required_ = false;
+    }
+    // Without the encryptor: fill with residues laid out [size][Q - depth][N].
     void load(const std::vector<Data64>& host, int cipher_size, int depth, double scale = 1.0, hipStream_t s = nullptr)
     {
         const size_t want = (size_t) cipher_size * (coeff_modulus_count_ - depth) * ring_size_;
@@ -305,12 +317,15 @@ template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N 
     }
     Data64* data() { return device_location_.data(); }
     size_t size() const { return relinkey_size_; }
-    void load(const std::vector<Data64>& host, hipStream_t s = nullptr) // until the key generator exists
+    void load(const std::vector<Data64>& host, hipStream_t s = nullptr) // a key produced elsewhere
     {
         if (host.size() != relinkey_size_) throw std::invalid_argument("Invalid relinkey size!");
         device_location_ = DeviceVector<Data64>(host, s);
+        relin_key_generated_ = true;
     }
+    void memory_set(DeviceVector<Data64>&& m) { device_location_ = std::move(m); }
     int key_type = 1;
+    bool relin_key_generated_ = false;
 
   private:
     HEContext<S> context_;
@@ -336,6 +351,7 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
         if (host.size() != galoiskey_size_) throw std::invalid_argument("Invalid galoiskey size!");
         device_location_[galois_element] = DeviceVector<Data64>(host, s);
     }
+    bool galois_key_generated_ = false;
     std::map<int, int> galois_elt;                           // shift -> Galois element
     std::map<int, DeviceVector<Data64>> device_location_;    // Galois element -> key
     int group_order_ = 5;
@@ -343,6 +359,223 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
   private:
     HEContext<S> context_;
     size_t galoiskey_size_ = 0;
+};
+
+// ------------------------------------------------------------------ secret / public key, plaintext
+template <Scheme S> class Secretkey { // host/*/secretkey.cuh; [Q'][N], NTT domain
+  public:
+    explicit Secretkey(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        hamming_weight_ = context_->n >> 1; // secretkey.cu:23
+    }
+    Secretkey(HEContext<S> context, int hamming_weight) : Secretkey(std::move(context))
+    {
+        if (hamming_weight <= 0 || hamming_weight > context_->n)
+            throw std::invalid_argument("hamming weight has to be in range 0 to ring size."); // secretkey.cu:43
+        hamming_weight_ = hamming_weight;
+    }
+    Data64* data() { return device_locations_.data(); }
+    const Data64* data() const { return device_locations_.data(); }
+    void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    int hamming_weight_ = 0;
+    bool secret_key_generated_ = false;
+
+  private:
+    HEContext<S> context_;
+    DeviceVector<Data64> device_locations_;
+};
+
+template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT domain
+  public:
+    explicit Publickey(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+    }
+    Data64* data() { return device_locations_.data(); }
+    const Data64* data() const { return device_locations_.data(); }
+    void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    bool public_key_generated_ = false;
+
+  private:
+    HEContext<S> context_;
+    DeviceVector<Data64> device_locations_;
+};
+
+template <Scheme S> class Plaintext { // host/ckks/plaintext.cuh: [Q - depth][N], NTT domain, with depth and scale
+  public:
+    explicit Plaintext(HEContext<S> context, const ExecutionOptions& options = ExecutionOptions())
+        : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        device_locations_.set_stream(options.stream_);
+    }
+    Data64* data() { return device_locations_.data(); }
+    const Data64* data() const { return device_locations_.data(); }
+    size_t size() const { return device_locations_.size(); }
+    void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    // until the encoders exist: residues [Q - depth][N] of the scaled message, NTT domain
+    void load(const std::vector<Data64>& host, int depth, double scale, hipStream_t s = nullptr)
+    {
+        if (host.size() != (size_t) (context_->Q_size - depth) * context_->n)
+            throw std::invalid_argument("Invalid plaintext size!");
+        device_locations_ = DeviceVector<Data64>(host, s);
+        depth_ = depth;
+        scale_ = scale;
+        plaintext_generated_ = true;
+    }
+    void get_data(std::vector<Data64>& out, hipStream_t s = nullptr) const
+    {
+        out.resize(device_locations_.size());
+        detail::hip(hipMemcpyAsync(out.data(), device_locations_.data(), out.size() * sizeof(Data64),
+                                   hipMemcpyDeviceToHost, s));
+        detail::hip(hipStreamSynchronize(s));
+    }
+    int depth_ = 0;
+    double scale_ = 0;
+    bool plaintext_generated_ = false;
+
+  private:
+    HEContext<S> context_;
+    DeviceVector<Data64> device_locations_;
+};
+
+// ------------------------------------------------------------------ key generator / encryptor / decryptor
+// Key-switching method I (P_size == 1).  Random values come from the backend's DRBG
+// (csrc/drbg.hpp); like the reference's generator it is seeded from std::random_device unless
+// a seed is given.
+template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
+  public:
+    explicit HEKeyGenerator(HEContext<S> context) : HEKeyGenerator(std::move(context), std::random_device{}()) {}
+    HEKeyGenerator(HEContext<S> context, std::uint64_t seed) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        detail::check(hegpu_rng_create(seed, &rng_));
+    }
+    ~HEKeyGenerator() { hegpu_rng_destroy(rng_); }
+    HEKeyGenerator(const HEKeyGenerator&) = delete;
+    HEKeyGenerator& operator=(const HEKeyGenerator&) = delete;
+
+    void generate_secret_key(Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (sk.secret_key_generated_) throw std::logic_error("Secretkey is already generated!");
+        DeviceVector<Data64> out((size_t) context_->Q_prime_size * context_->n, o.stream_);
+        Workspace ws(context_, HEGPU_OP_KEYGEN_SECRET, o.stream_);
+        detail::check(hegpu_generate_secret_key(context_->handle(), rng_, sk.hamming_weight_, (uint64_t*) out.data(),
+                                                ws.p(), ws.bytes(), o.stream_));
+        sk.memory_set(std::move(out));
+        sk.secret_key_generated_ = true;
+    }
+    void generate_public_key(Publickey<S>& pk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        if (pk.public_key_generated_) throw std::logic_error("Publickey is already generated!");
+        DeviceVector<Data64> out((size_t) 2 * context_->Q_prime_size * context_->n, o.stream_);
+        Workspace ws(context_, HEGPU_OP_KEYGEN_PUBLIC, o.stream_);
+        detail::check(hegpu_generate_public_key(context_->handle(), rng_, (const uint64_t*) sk.data(),
+                                                (uint64_t*) out.data(), ws.p(), ws.bytes(), o.stream_));
+        pk.memory_set(std::move(out));
+        pk.public_key_generated_ = true;
+    }
+    void generate_relin_key(Relinkey<S>& rk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        if (rk.relin_key_generated_) throw std::logic_error("Relinkey is already generated!");
+        DeviceVector<Data64> out(rk.size(), o.stream_);
+        Workspace ws(context_, HEGPU_OP_KEYGEN_SWITCH, o.stream_);
+        detail::check(hegpu_generate_relin_key(context_->handle(), rng_, (const uint64_t*) sk.data(),
+                                               (uint64_t*) out.data(), ws.p(), ws.bytes(), o.stream_));
+        rk.memory_set(std::move(out));
+        rk.relin_key_generated_ = true;
+    }
+    void generate_galois_key(Galoiskey<S>& gk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        if (gk.galois_key_generated_) throw std::logic_error("Galoiskey is already generated!");
+        Workspace ws(context_, HEGPU_OP_KEYGEN_SWITCH, o.stream_);
+        for (auto& g : gk.galois_elt) {
+            if (gk.device_location_.count(g.second)) continue;
+            DeviceVector<Data64> out(gk.size(), o.stream_);
+            detail::check(hegpu_generate_galois_key(context_->handle(), rng_, (const uint64_t*) sk.data(), g.second,
+                                                    (uint64_t*) out.data(), ws.p(), ws.bytes(), o.stream_));
+            gk.device_location_[g.second] = std::move(out);
+        }
+        gk.galois_key_generated_ = true;
+    }
+
+  private:
+    struct Workspace {
+        Workspace(const HEContext<S>& c, int op, hipStream_t s)
+            : v((hegpu_workspace_bytes(c->handle(), op, 0, 1) + 7) / 8, s)
+        {
+        }
+        void* p() { return v.data(); }
+        size_t bytes() const { return v.size() * sizeof(Data64); }
+        DeviceVector<Data64> v;
+    };
+    HEContext<S> context_;
+    hegpu_rng* rng_ = nullptr;
+};
+
+template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key encryption)
+    static_assert(S == Scheme::CKKS, "encryption is built for CKKS (BFV: SURVEY.md 8f, still open)");
+
+  public:
+    HEEncryptor(HEContext<S> context, Publickey<S>& pk) : HEEncryptor(std::move(context), pk, std::random_device{}()) {}
+    HEEncryptor(HEContext<S> context, Publickey<S>& pk, std::uint64_t seed) : context_(std::move(context)), pk_(&pk)
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        if (!pk.public_key_generated_) throw std::logic_error("Publickey is not generated!");
+        detail::check(hegpu_rng_create(seed, &rng_));
+    }
+    ~HEEncryptor() { hegpu_rng_destroy(rng_); }
+    HEEncryptor(const HEEncryptor&) = delete;
+    HEEncryptor& operator=(const HEEncryptor&) = delete;
+
+    void encrypt(Ciphertext<S>& ct, Plaintext<S>& pt, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!pt.plaintext_generated_ || pt.depth_ != 0) throw std::invalid_argument("Invalid plaintext size."); // encryptor.cuh:56
+        std::vector<Data64> none;
+        DeviceVector<Data64> out((size_t) 2 * context_->Q_size * context_->n, o.stream_);
+        DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_ENCRYPT, 0, 1) + 7) / 8,
+                                o.stream_);
+        detail::check(hegpu_ckks_encrypt(context_->handle(), rng_, (const uint64_t*) pk_->data(),
+                                         (const uint64_t*) pt.data(), (uint64_t*) out.data(), ws.data(),
+                                         ws.size() * sizeof(Data64), o.stream_));
+        ct.adopt(std::move(out), 2, 0, pt.scale_);
+    }
+
+  private:
+    HEContext<S> context_;
+    Publickey<S>* pk_;
+    hegpu_rng* rng_ = nullptr;
+};
+
+template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
+    static_assert(S == Scheme::CKKS, "decryption is built for CKKS (BFV: SURVEY.md 8f, still open)");
+
+  public:
+    HEDecryptor(HEContext<S> context, Secretkey<S>& sk) : context_(std::move(context)), sk_(&sk)
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+    }
+    void decrypt(Plaintext<S>& pt, Ciphertext<S>& ct, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (ct.size() != 2) throw std::invalid_argument("Ciphertext should be relinearized first!");
+        const int l = context_->Q_size - ct.depth();
+        DeviceVector<Data64> out((size_t) l * context_->n, o.stream_);
+        detail::check(hegpu_ckks_decrypt(context_->handle(), (const uint64_t*) ct.data(), (const uint64_t*) sk_->data(),
+                                         ct.depth(), (uint64_t*) out.data(), o.stream_));
+        pt.memory_set(std::move(out));
+        pt.depth_ = ct.depth();
+        pt.scale_ = ct.scale();
+        pt.plaintext_generated_ = true;
+    }
+
+  private:
+    HEContext<S> context_;
+    Secretkey<S>* sk_;
 };
 
 // ------------------------------------------------------------------ operator

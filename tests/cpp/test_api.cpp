@@ -3,7 +3,9 @@
 // test_bfv_rotation_method_1.cpp:30-86), checked bit-for-bit against the CPU
 // oracle (test infrastructure).  Runs on the GPU box (pytest -m gpu wrapper).
 #include <heongpu/heongpu.hpp>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 extern "C" {
 #include "hegpu_oracle.h"
@@ -157,6 +159,102 @@ static void bfv()
     o_ctx_free(o);
 }
 
+
+// keygen -> encrypt -> multiply -> relinearize -> rotate -> decrypt through the class layer, the
+// way the reference's tests do it (test/test_ckks_relinearization.cpp:36-111); messages are encoded
+// here as scaled integer polynomials (the encoders are SURVEY.md 8f next-2).
+static void ckks_pipeline()
+{
+    constexpr auto S = Scheme::CKKS;
+    const size_t n = 4096;
+    const int n_power = 12;
+    HEContext<S> ctx = GenHEContext<S>(sec_level_type::none);
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_bit_sizes({40, 35, 35}, {40});
+    ctx->generate();
+    const int Q = ctx->get_ciphertext_modulus_count();
+    Vec primes = ctx->get_key_modulus();
+    octx_t* oc = o_ctx_create(O_CKKS, n_power, (const u64*) primes.data(), Q, 1, 0);
+
+    HEKeyGenerator<S> keygen(ctx, 2026);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk(ctx);
+    keygen.generate_relin_key(rk, sk);
+    Galoiskey<S> gk(ctx, std::vector<int>{1});
+    keygen.generate_galois_key(gk, sk);
+    EXPECT(throws_logic([&] { keygen.generate_secret_key(sk); }), "Secretkey is already generated");
+
+    const long long scale = 1LL << 16;
+    std::vector<long long> m1(n, 0), m2(n, 0);
+    m1[0] = 3; m1[1] = 2; m1[100] = -4;
+    m2[0] = 5; m2[2] = -1;
+    auto encode = [&](const std::vector<long long>& m) {
+        Vec r((size_t) Q * n);
+        for (int j = 0; j < Q; j++) {
+            for (size_t i = 0; i < n; i++) {
+                long long v = m[i] * scale;
+                r[(size_t) j * n + i] = v < 0 ? primes[j] - (Data64) (-v) : (Data64) v;
+            }
+            o_ntt_limb((u64*) &r[(size_t) j * n], oc->ntt_table + (size_t) j * n, &oc->mod[j], n_power);
+        }
+        return r;
+    };
+    auto decode0 = [&](Plaintext<S>& pt) { // centred coefficients of limb 0
+        Vec h;
+        pt.get_data(h);
+        o_intt_limb((u64*) h.data(), oc->intt_table, &oc->mod[0], oc->n_inv[0], n_power);
+        std::vector<long long> out(n);
+        for (size_t i = 0; i < n; i++)
+            out[i] = h[i] > primes[0] / 2 ? -(long long) (primes[0] - h[i]) : (long long) h[i];
+        return out;
+    };
+    auto maxerr = [&](const std::vector<long long>& got, const std::vector<long long>& want, long long f) {
+        long long e = 0;
+        for (size_t i = 0; i < n; i++) e = std::max(e, std::llabs(got[i] - want[i] * f));
+        return e;
+    };
+
+    HEEncryptor<S> enc(ctx, pk, 7);
+    HEDecryptor<S> dec(ctx, sk);
+    HEArithmeticOperator<S> op(ctx);
+    Plaintext<S> p1(ctx), p2(ctx), out(ctx);
+    p1.load(encode(m1), 0, (double) scale);
+    p2.load(encode(m2), 0, (double) scale);
+    Ciphertext<S> c1(ctx), c2(ctx), c3(ctx), rot(ctx);
+    enc.encrypt(c1, p1);
+    enc.encrypt(c2, p2);
+    dec.decrypt(out, c1);
+    EXPECT(maxerr(decode0(out), m1, scale) < (1 << 12), "decrypt(encrypt(m)) = m (+ fresh noise)");
+
+    op.multiply(c1, c2, c3);
+    EXPECT(throws_invalid([&] { dec.decrypt(out, c3); }), "3-part ciphertext must be relinearized before decryption");
+    op.relinearize_inplace(c3, rk);
+    dec.decrypt(out, c3);
+    std::vector<long long> prod(n, 0);
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) {
+            if (!m1[i] || !m2[j]) continue;
+            size_t k = i + j;
+            if (k >= n) prod[k - n] -= m1[i] * m2[j]; else prod[k] += m1[i] * m2[j];
+        }
+    EXPECT(maxerr(decode0(out), prod, scale * scale) < scale * scale / 8, "decrypt(relinearize(c1 * c2)) = m1 * m2");
+
+    op.rotate_rows(c1, rot, gk, 1);
+    dec.decrypt(out, rot);
+    const int g = gk.galois_elt[1];
+    std::vector<long long> want(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (!m1[i]) continue;
+        const size_t r = (i * (size_t) g) % (2 * n);
+        if (r >= n) want[r - n] = -m1[i]; else want[r] = m1[i];
+    }
+    EXPECT(maxerr(decode0(out), want, scale) < (1 << 14), "decrypt(rotate(c1)) = sigma_g(m1)");
+    o_ctx_free(oc);
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -172,6 +270,7 @@ int main()
     }
     ckks();
     bfv();
+    ckks_pipeline();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }
