@@ -15,7 +15,7 @@ BFV, CKKS = 1, 2
 SEC_NONE, SEC_128 = 0, 128
 TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
-OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT = 7, 8, 9, 10
+OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT = 7, 8, 9, 10, 11, 12
 
 E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
 
@@ -288,6 +288,24 @@ class Context:
                                             ws.numel() * ws.element_size(),
                                             stream if stream is not None else _stream()))
         return ct
+
+    def bfv_encrypt(self, rng, pk, plain, stream=None):
+        import torch
+        ct = torch.empty(2 * self.Q_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_BFV_ENCRYPT)
+        _check(self._lib.hegpu_bfv_encrypt(self._h, rng._h, _ptr(pk), _ptr(plain), _ptr(ct), _ptr(ws),
+                                           ws.numel() * ws.element_size(),
+                                           stream if stream is not None else _stream()))
+        return ct
+
+    def bfv_decrypt(self, ct, sk, stream=None):
+        import torch
+        plain = torch.empty(self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_BFV_DECRYPT)
+        _check(self._lib.hegpu_bfv_decrypt(self._h, _ptr(ct), _ptr(sk), _ptr(plain), _ptr(ws),
+                                           ws.numel() * ws.element_size(),
+                                           stream if stream is not None else _stream()))
+        return plain
 
     def ckks_decrypt(self, ct, sk, depth=0, stream=None):
         import torch

@@ -563,6 +563,31 @@ int hegpu_ckks_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* s
                    "hegpu_ckks_decrypt");
 }
 
+int hegpu_bfv_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, const uint64_t* plain, uint64_t* ct,
+                      void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    CHECK_KG(ctx, rng, OP_BFV_ENCRYPT, ws, ws_bytes);
+    return hip_ret(op_bfv_encrypt(ctx->c, rng->r, (const u64*) pk, (const u64*) plain, (u64*) ct, (u64*) ws,
+                                  (hipStream_t) stream),
+                   "hegpu_bfv_encrypt");
+}
+
+int hegpu_bfv_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* plain, void* ws,
+                      size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_BFV_DECRYPT, 0, 1))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return guarded([&]() -> int {
+        return hip_ret(op_bfv_decrypt(ctx->c, (const u64*) ct, (const u64*) sk, (u64*) plain, (u64*) ws,
+                                      (hipStream_t) stream),
+                       "hegpu_bfv_decrypt");
+    });
+}
+
 // ------------------------------------------------------------------ TFHE
 struct hegpu_tfhe_context {
     TfheDev p{};

@@ -232,6 +232,64 @@ void Context::build_host()
         host["q_Bsk_merge_ntt_tables"] = mfwd;
         host["q_Bsk_merge_intt_tables"] = minv;
         host["q_Bsk_n_inverse"] = mninv;
+
+        // ---- encryption / decryption constants (bfv/context.cu:501-516, 605-620, 939-983, 1239-1343)
+        {
+            u64 Q_mod_t = 1;
+            for (int i = 0; i < Q; i++) Q_mod_t = mul_mod(Q_mod_t, primes[i] % t, t);
+            host["Q_mod_t"] = vec{Q_mod_t};
+            host["upper_threshold"] = vec{(t + 1) >> 1};
+            // floor(prod(q) / t) mod q_i with a little-endian multi-word integer
+            std::vector<u64> big{1};
+            for (int i = 0; i < Q; i++) {
+                unsigned __int128 carry = 0;
+                for (u64& w : big) {
+                    unsigned __int128 v = (unsigned __int128) w * primes[i] + carry;
+                    w = (u64) v;
+                    carry = v >> 64;
+                }
+                if (carry) big.push_back((u64) carry);
+            }
+            {
+                unsigned __int128 rem = 0; // divide by t, most significant word first
+                for (size_t k = big.size(); k-- > 0;) {
+                    unsigned __int128 cur = (rem << 64) | big[k];
+                    big[k] = (u64) (cur / t);
+                    rem = cur % t;
+                }
+            }
+            vec cdiv;
+            for (int i = 0; i < Q; i++) {
+                unsigned __int128 rem = 0;
+                for (size_t k = big.size(); k-- > 0;) rem = ((rem << 64) | big[k]) % primes[i];
+                cdiv.push_back((u64) rem);
+            }
+            host["coeff_div_plain_modulus"] = cdiv;
+            vec Qi_t, Qi_gamma, Qi_inverse;
+            for (int i = 0; i < Q; i++) {
+                u64 a = 1, b = 1, c = 1;
+                for (int j = 0; j < Q; j++)
+                    if (j != i) {
+                        a = mul_mod(a, primes[j] % t, t);
+                        b = mul_mod(b, primes[j] % gamma, gamma);
+                        c = mul_mod(c, inv_mod_prime(primes[j] % primes[i], primes[i]), primes[i]);
+                    }
+                Qi_t.push_back(a);
+                Qi_gamma.push_back(b);
+                Qi_inverse.push_back(c);
+            }
+            host["Qi_t"] = Qi_t;
+            host["Qi_gamma"] = Qi_gamma;
+            host["Qi_inverse"] = Qi_inverse;
+            u64 mt_ = 1, mg_ = 1;
+            for (int i = 0; i < Q; i++) {
+                mt_ = mul_mod(mt_, inv_mod_prime(primes[i] % t, t), t);
+                mg_ = mul_mod(mg_, inv_mod_prime(primes[i] % gamma, gamma), gamma);
+            }
+            host["mulq_inv_t"] = vec{t - mt_};
+            host["mulq_inv_gamma"] = vec{gamma - mg_};
+            host["inv_gamma"] = vec{inv_mod_prime(gamma % t, t)};
+        }
     }
 }
 
@@ -342,6 +400,10 @@ hipError_t Context::upload()
                                        "base_change_matrix_msk",
                                        "inv_punctured_prod_mod_B_array",
                                        "prod_B_mod_q",
+                                       "coeff_div_plain_modulus",
+                                       "Qi_t",
+                                       "Qi_gamma",
+                                       "Qi_inverse",
                                        "m2_Mi_inv",
                                        "m2_matrix",
                                        "m2_prod"};

@@ -70,6 +70,8 @@ struct Context {
     void release_device();
 
     const u64* d64(const char* name) const;
+    // host copy of a named table (throws if absent)
+    const std::vector<u64>& h64(const char* name) const { return host.at(name); }
     const int* d32(const char* name) const;
     NttArgs ntt_args(int table_set) const; // 0 = Q' chain, 1 = merged q|Bsk
 };

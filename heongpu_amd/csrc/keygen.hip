@@ -193,4 +193,94 @@ hipError_t kg_sk_multiplication_ckks(const u64* ct, u64* plain, const u64* sk, c
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_message_add(u64* __restrict__ ct, const u64* __restrict__ plain,
+                                                                   const Mod* __restrict__ mods,
+                                                                   const u64* __restrict__ coeff_div, u64 Q_mod_t,
+                                                                   u64 upper_threshold, u64 t, int n_power)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const int y = blockIdx.y;
+    const Mod m = mods[y];
+    const u64 message = plain[idx];
+    // 64-bit wrap-around and the detour through `int` are the reference's (encryption.cu:160-163)
+    u64 fix = message * Q_mod_t;
+    fix = fix + upper_threshold;
+    fix = (u64) (long long) (int) (fix / t);
+    u64 c0 = mul_barrett(message, coeff_div[y], m);
+    c0 = add_mod(c0, fix, m.q);
+    const u64 loc = idx + ((u64) y << n_power);
+    ct[loc] = add_mod(ct[loc], c0, m.q);
+}
+
+hipError_t kg_bfv_message_add(u64* ct, const u64* plain, const Mod* mods, const u64* coeff_div, u64 Q_mod_t,
+                              u64 upper_threshold, u64 t, int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_message_add, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, ct,
+                       plain, mods, coeff_div, Q_mod_t, upper_threshold, t, n_power);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_sk_mul(const u64* __restrict__ in, const u64* __restrict__ sk,
+                                                          u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                          int n_power)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    out[loc] = mul_barrett(in[loc], sk[loc], mods[blockIdx.y]);
+}
+
+hipError_t kg_sk_multiplication(const u64* in, const u64* sk, u64* out, const Mod* mods, int n_power, int limbs,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_sk_mul, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, in, sk, out,
+                       mods, n_power);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_decryption(const u64* __restrict__ ct0,
+                                                                  const u64* __restrict__ ct1,
+                                                                  u64* __restrict__ plain,
+                                                                  const Mod* __restrict__ mods, BfvDecryptDev d,
+                                                                  int n_power, int limbs)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const u64 t = d.plain.q, g = d.gamma.q;
+    u64 sum_t = 0, sum_g = 0;
+    for (int i = 0; i < limbs; i++) {
+        const Mod m = mods[i];
+        const u64 loc = idx + ((u64) i << n_power);
+        u64 mt = add_mod(ct0[loc], ct1[loc], m.q);
+        const u64 g_i = reduce64(g, m);
+        mt = mul_barrett(mt, t, m);
+        mt = mul_barrett(mt, g_i, m);
+        mt = mul_barrett(mt, d.Qi_inverse[i], m);
+        u64 in_t = reduce64(mt, d.plain), in_g = reduce64(mt, d.gamma);
+        in_t = mul_barrett(in_t, d.Qi_t[i], d.plain);
+        in_g = mul_barrett(in_g, d.Qi_gamma[i], d.gamma);
+        sum_t = add_mod(sum_t, in_t, t);
+        sum_g = add_mod(sum_g, in_g, g);
+    }
+    sum_t = mul_barrett(sum_t, d.mulq_inv_t, d.plain);
+    sum_g = mul_barrett(sum_g, d.mulq_inv_gamma, d.gamma);
+    u64 result;
+    if (sum_g > (g >> 1)) {
+        const u64 g_t = reduce64(g, d.plain), sg_t = reduce64(sum_g, d.plain);
+        result = sub_mod(g_t, sg_t, t);
+        result = add_mod(sum_t, result, t);
+        result = mul_barrett(result, d.inv_gamma, d.plain);
+    } else {
+        const u64 st = reduce64(sum_t, d.plain), sg_t = reduce64(sum_g, d.plain);
+        result = sub_mod(st, sg_t, t);
+        result = mul_barrett(result, d.inv_gamma, d.plain);
+    }
+    plain[idx] = result;
+}
+
+hipError_t kg_bfv_decryption(const u64* ct0, const u64* ct1s, u64* plain, const Mod* mods, const BfvDecryptDev& d,
+                             int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_decryption, dim3((1u << n_power) / KG_THREADS), dim3(KG_THREADS), 0, st, ct0, ct1s,
+                       plain, mods, d, n_power, limbs);
+    return hipGetLastError();
+}
+
 } // namespace hegpu

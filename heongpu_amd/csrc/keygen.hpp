@@ -34,4 +34,20 @@ hipError_t kg_message_add(u64* ct, const u64* plain, const Mod* mods, int n_powe
 hipError_t kg_sk_multiplication_ckks(const u64* ct, u64* plain, const u64* sk, const Mod* mods, int n_power,
                                      int limbs, hipStream_t st);
 
+// BFV: part 0 of a fresh encryption gets Delta*m + the rounding fix (tail of
+// enc_div_lastq_bfv_kernel, encryption.cu:158-172); plain [N] mod t, ct [2][Q][N] coefficient domain
+hipError_t kg_bfv_message_add(u64* ct, const u64* plain, const Mod* mods, const u64* coeff_div, u64 Q_mod_t,
+                              u64 upper_threshold, u64 t, int n_power, int limbs, hipStream_t st);
+// sk_multiplication (decryption.cu:10-23): out[j] = in[j] * sk[j]
+hipError_t kg_sk_multiplication(const u64* in, const u64* sk, u64* out, const Mod* mods, int n_power, int limbs,
+                                hipStream_t st);
+struct BfvDecryptDev {
+    Mod plain, gamma;
+    const u64 *Qi_t, *Qi_gamma, *Qi_inverse;
+    u64 mulq_inv_t, mulq_inv_gamma, inv_gamma;
+};
+// decryption_kernel (decryption.cu:44-120): plain [N] from c0 and c1*s, both [Q][N] coefficient domain
+hipError_t kg_bfv_decryption(const u64* ct0, const u64* ct1s, u64* plain, const Mod* mods, const BfvDecryptDev& d,
+                             int n_power, int limbs, hipStream_t st);
+
 } // namespace hegpu

@@ -77,7 +77,9 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_KEYGEN_SECRET: per = n; break;                      // 2 x hamming weight ints
         case OP_KEYGEN_PUBLIC: per = (u64) 2 * Qp * n; break;        // e, a
         case OP_KEYGEN_SWITCH: per = (u64) 2 * Q * Qp * n; break;    // e, a per digit
-        case OP_CKKS_ENCRYPT: per = (u64) 5 * Qp * n; break;         // u, e[2], pk*u[2]
+        case OP_CKKS_ENCRYPT:
+        case OP_BFV_ENCRYPT: per = (u64) 5 * Qp * n; break;          // u, e[2], pk*u[2]
+        case OP_BFV_DECRYPT: per = (u64) Q * n; break;               // c1*s
         default: return 0;
     }
     return per * (u64) batch;
@@ -463,8 +465,8 @@ hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois
     return kg_switchkey(key, sk, e, av, c.plan_qp.mods, c.d64("factor"), inv, c.n_power, Qp, st);
 }
 
-hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
-                           hipStream_t st)
+// (pk*u + e) / P with rounding: the common front of both encryptions (encryptor.cu:52-100)
+static hipError_t encrypt_zero(const Context& c, Rng& r, const u64* pk, u64* ct, u64* ws, hipStream_t st)
 {
     const int np = c.n_power, Q = c.Q_size, Qp = c.Qp_size;
     const u64 n = c.n;
@@ -476,17 +478,52 @@ hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* p
     TRY(kg_gaussian(e, mods, np, Qp, 2, r.seed, r.stream++, c.gauss_cdt, st));
     NttArgs a = c.ntt_args(0);
     a.in = u; a.out = u; a.mod_count = Qp;
-    TRY(ntt_launch(a, Qp, false, st));                                                     // :73
-    TRY(kg_pk_u(pk, u, pku, mods, np, Qp, st));                                            // :77
+    TRY(ntt_launch(a, Qp, false, st));
+    TRY(kg_pk_u(pk, u, pku, mods, np, Qp, st));
     a.in = pku; a.out = pku;
-    TRY(ntt_launch(a, 2 * Qp, true, st));                                                  // :91
-    // enc_div_lastq_ckks_kernel (:95): (pk*u + e) divided-and-rounded by the P primes
+    TRY(ntt_launch(a, 2 * Qp, true, st));
     TRY(rns_addition(pku, e, pku, mods, np, Qp, 2, 1, 0, st));
-    TRY(rns_moddown_extended(pku, 0, nullptr, 0, ct, 0, mods, c.d64("half"), c.d64("half_mod"),
-                             c.d64("last_q_modinv"), np, Qp, Q, Qp, Q, c.P_size, 0, 1, st));
-    a.in = ct; a.out = ct; a.mod_count = Q;
-    TRY(ntt_launch(a, 2 * Q, false, st));                                                  // :103
-    return kg_message_add(ct, plain, mods, np, Q, st);                                     // :107
+    return rns_moddown_extended(pku, 0, nullptr, 0, ct, 0, mods, c.d64("half"), c.d64("half_mod"),
+                                c.d64("last_q_modinv"), np, Qp, Q, Qp, Q, c.P_size, 0, 1, st);
+}
+
+hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
+                           hipStream_t st)
+{
+    TRY(encrypt_zero(c, r, pk, ct, ws, st));                                               // :52-100
+    NttArgs a = c.ntt_args(0);
+    a.in = ct; a.out = ct; a.mod_count = c.Q_size;
+    TRY(ntt_launch(a, 2 * c.Q_size, false, st));                                           // :103
+    return kg_message_add(ct, plain, c.plan_qp.mods, c.n_power, c.Q_size, st);             // :107
+}
+
+hipError_t op_bfv_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
+                          hipStream_t st)
+{
+    TRY(encrypt_zero(c, r, pk, ct, ws, st));
+    return kg_bfv_message_add(ct, plain, c.plan_qp.mods, c.d64("coeff_div_plain_modulus"), c.h64("Q_mod_t")[0],
+                              c.h64("upper_threshold")[0], c.plain_modulus, c.n_power, c.Q_size, st);
+}
+
+hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* plain, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power, Q = c.Q_size;
+    const u64* ct1 = ct + ((u64) Q << np);
+    u64* t1 = ws; // [Q][N]
+    NttArgs a = c.ntt_args(0);
+    a.in = ct1; a.out = t1; a.mod_count = Q;
+    TRY(ntt_launch(a, Q, false, st));                                                      // :62
+    TRY(kg_sk_multiplication(t1, sk, t1, c.plan_qp.mods, np, Q, st));                      // :65
+    a.in = t1; a.out = t1;
+    TRY(ntt_launch(a, Q, true, st));                                                       // :101
+    BfvDecryptDev d{};
+    d.plain = make_mod(c.plain_modulus);
+    d.gamma = make_mod(c.h64("gamma")[0]);
+    d.Qi_t = c.d64("Qi_t"); d.Qi_gamma = c.d64("Qi_gamma"); d.Qi_inverse = c.d64("Qi_inverse");
+    d.mulq_inv_t = c.h64("mulq_inv_t")[0];
+    d.mulq_inv_gamma = c.h64("mulq_inv_gamma")[0];
+    d.inv_gamma = c.h64("inv_gamma")[0];
+    return kg_bfv_decryption(ct, t1, plain, c.plan_qp.mods, d, np, Q, st);                 // :107
 }
 
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)

@@ -6,7 +6,8 @@
 namespace hegpu {
 
 enum { OP_CKKS_RELIN = 1, OP_CKKS_RESCALE = 2, OP_CKKS_GALOIS = 3, OP_BFV_MULTIPLY = 4, OP_BFV_RELIN = 5,
-       OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10 };
+       OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10, OP_BFV_ENCRYPT = 11,
+       OP_BFV_DECRYPT = 12 };
 
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
@@ -53,5 +54,10 @@ hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* p
                            hipStream_t st);
 // HEDecryptor<CKKS>::decrypt_ckks (ckks/decryptor.cu:38-58); plain [l][N], l = Q - depth
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st);
+// HEEncryptor<BFV>::encrypt_bfv (bfv/encryptor.cu:39-108); plain [N] mod t, ct [2][Q][N] coefficient domain
+hipError_t op_bfv_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
+                          hipStream_t st);
+// HEDecryptor<BFV>::decrypt_bfv (bfv/decryptor.cu:36-120), coefficient-domain ciphertext; plain [N]
+hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* plain, u64* ws, hipStream_t st);
 
 } // namespace hegpu

@@ -140,7 +140,9 @@ enum {
     HEGPU_OP_KEYGEN_SECRET = 7,
     HEGPU_OP_KEYGEN_PUBLIC = 8,
     HEGPU_OP_KEYGEN_SWITCH = 9, /* relinearisation and Galois keys */
-    HEGPU_OP_CKKS_ENCRYPT = 10
+    HEGPU_OP_CKKS_ENCRYPT = 10,
+    HEGPU_OP_BFV_ENCRYPT = 11,
+    HEGPU_OP_BFV_DECRYPT = 12
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -207,6 +209,14 @@ int hegpu_ckks_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, c
 /* HEDecryptor<CKKS>::decrypt_ckks (src/lib/host/ckks/decryptor.cu:38-58); plain [Q-depth][N] */
 int hegpu_ckks_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, int depth, uint64_t* plain,
                        hegpu_stream stream);
+/* HEEncryptor<BFV>::encrypt_bfv (src/lib/host/bfv/encryptor.cu:39-108, kernel/encryption.cu:91-179):
+ * plain [N] residues mod t (what the batch encoder produces), ct [2][Q][N] coefficient domain */
+int hegpu_bfv_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, const uint64_t* plain, uint64_t* ct,
+                      void* ws, size_t ws_bytes, hegpu_stream stream);
+/* HEDecryptor<BFV>::decrypt_bfv (src/lib/host/bfv/decryptor.cu:36-120, kernel/decryption.cu:10-120);
+ * coefficient-domain 2-part ciphertext, plain [N] mod t.  Workspace HEGPU_OP_BFV_DECRYPT. */
+int hegpu_bfv_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* plain, void* ws,
+                      size_t ws_bytes, hegpu_stream stream);
 
 /* ------------------------------------------------------------------ TFHE
  * Gate bootstrapping on the reference's fixed STD128 set

@@ -402,7 +402,7 @@ template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT d
     DeviceVector<Data64> device_locations_;
 };
 
-template <Scheme S> class Plaintext { // host/ckks/plaintext.cuh: [Q - depth][N], NTT domain, with depth and scale
+template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - depth][N] NTT domain (+ depth, scale); BFV: [N] mod t
   public:
     explicit Plaintext(HEContext<S> context, const ExecutionOptions& options = ExecutionOptions())
         : context_(std::move(context))
@@ -417,8 +417,8 @@ template <Scheme S> class Plaintext { // host/ckks/plaintext.cuh: [Q - depth][N]
     // until the encoders exist: residues [Q - depth][N] of the scaled message, NTT domain
     void load(const std::vector<Data64>& host, int depth, double scale, hipStream_t s = nullptr)
     {
-        if (host.size() != (size_t) (context_->Q_size - depth) * context_->n)
-            throw std::invalid_argument("Invalid plaintext size!");
+        const size_t want = (S == Scheme::CKKS) ? (size_t) (context_->Q_size - depth) * context_->n : (size_t) context_->n;
+        if (host.size() != want) throw std::invalid_argument("Invalid plaintext size!");
         device_locations_ = DeviceVector<Data64>(host, s);
         depth_ = depth;
         scale_ = scale;
@@ -518,8 +518,6 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
 };
 
 template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key encryption)
-    static_assert(S == Scheme::CKKS, "encryption is built for CKKS (BFV: SURVEY.md 8f, still open)");
-
   public:
     HEEncryptor(HEContext<S> context, Publickey<S>& pk) : HEEncryptor(std::move(context), pk, std::random_device{}()) {}
     HEEncryptor(HEContext<S> context, Publickey<S>& pk, std::uint64_t seed) : context_(std::move(context)), pk_(&pk)
@@ -535,13 +533,17 @@ template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key e
     void encrypt(Ciphertext<S>& ct, Plaintext<S>& pt, const ExecutionOptions& o = ExecutionOptions())
     {
         if (!pt.plaintext_generated_ || pt.depth_ != 0) throw std::invalid_argument("Invalid plaintext size."); // encryptor.cuh:56
-        std::vector<Data64> none;
         DeviceVector<Data64> out((size_t) 2 * context_->Q_size * context_->n, o.stream_);
-        DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_ENCRYPT, 0, 1) + 7) / 8,
-                                o.stream_);
-        detail::check(hegpu_ckks_encrypt(context_->handle(), rng_, (const uint64_t*) pk_->data(),
-                                         (const uint64_t*) pt.data(), (uint64_t*) out.data(), ws.data(),
-                                         ws.size() * sizeof(Data64), o.stream_));
+        const int opid = (S == Scheme::CKKS) ? HEGPU_OP_CKKS_ENCRYPT : HEGPU_OP_BFV_ENCRYPT;
+        DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), opid, 0, 1) + 7) / 8, o.stream_);
+        if (S == Scheme::CKKS)
+            detail::check(hegpu_ckks_encrypt(context_->handle(), rng_, (const uint64_t*) pk_->data(),
+                                             (const uint64_t*) pt.data(), (uint64_t*) out.data(), ws.data(),
+                                             ws.size() * sizeof(Data64), o.stream_));
+        else
+            detail::check(hegpu_bfv_encrypt(context_->handle(), rng_, (const uint64_t*) pk_->data(),
+                                            (const uint64_t*) pt.data(), (uint64_t*) out.data(), ws.data(),
+                                            ws.size() * sizeof(Data64), o.stream_));
         ct.adopt(std::move(out), 2, 0, pt.scale_);
     }
 
@@ -552,8 +554,6 @@ template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key e
 };
 
 template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
-    static_assert(S == Scheme::CKKS, "decryption is built for CKKS (BFV: SURVEY.md 8f, still open)");
-
   public:
     HEDecryptor(HEContext<S> context, Secretkey<S>& sk) : context_(std::move(context)), sk_(&sk)
     {
@@ -564,9 +564,18 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
     {
         if (ct.size() != 2) throw std::invalid_argument("Ciphertext should be relinearized first!");
         const int l = context_->Q_size - ct.depth();
-        DeviceVector<Data64> out((size_t) l * context_->n, o.stream_);
-        detail::check(hegpu_ckks_decrypt(context_->handle(), (const uint64_t*) ct.data(), (const uint64_t*) sk_->data(),
-                                         ct.depth(), (uint64_t*) out.data(), o.stream_));
+        DeviceVector<Data64> out((S == Scheme::CKKS) ? (size_t) l * context_->n : (size_t) context_->n, o.stream_);
+        if (S == Scheme::CKKS) {
+            detail::check(hegpu_ckks_decrypt(context_->handle(), (const uint64_t*) ct.data(),
+                                             (const uint64_t*) sk_->data(), ct.depth(), (uint64_t*) out.data(),
+                                             o.stream_));
+        } else {
+            DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), HEGPU_OP_BFV_DECRYPT, 0, 1) + 7) / 8,
+                                    o.stream_);
+            detail::check(hegpu_bfv_decrypt(context_->handle(), (const uint64_t*) ct.data(),
+                                            (const uint64_t*) sk_->data(), (uint64_t*) out.data(), ws.data(),
+                                            ws.size() * sizeof(Data64), o.stream_));
+        }
         pt.memory_set(std::move(out));
         pt.depth_ = ct.depth();
         pt.scale_ = ct.scale();

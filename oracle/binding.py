@@ -84,6 +84,8 @@ def lib():
     L.o_gen_switch_key.argtypes = [vp, vp, vp, ci, vp]
     L.o_ckks_encrypt.argtypes = [vp, vp, vp, vp, vp]
     L.o_ckks_decrypt.argtypes = [vp, vp, vp, ci, vp]
+    L.o_bfv_encrypt.argtypes = [vp, vp, vp, vp, vp]
+    L.o_bfv_decrypt.argtypes = [vp, vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
@@ -239,6 +241,17 @@ class OracleContext:
     def ckks_decrypt(self, ct, sk, depth=0):
         plain = np.zeros((self.Q - depth) * self.n, dtype=np.uint64)
         self.L.o_ckks_decrypt(self.h, _p(ct), _p(sk), depth, _p(plain))
+        return plain
+
+    def bfv_encrypt(self, rng, pk, plain):
+        ct = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_encrypt(self.h, ctypes.byref(rng), _p(pk), _p(np.ascontiguousarray(plain, dtype=np.uint64)),
+                             _p(ct))
+        return ct
+
+    def bfv_decrypt(self, ct, sk):
+        plain = np.zeros(self.n, dtype=np.uint64)
+        self.L.o_bfv_decrypt(self.h, _p(ct), _p(sk), _p(plain))
         return plain
 
     # key-switching method II (P_size > 1)

@@ -290,3 +290,162 @@ void o_ckks_decrypt(const octx_t* c, const u64* ct, const u64* sk, int depth, u6
             plain[loc] = o_add(c1, ct[loc], &c->mod[y]);
         }
 }
+
+/* ------------------------------------------------------------------ BFV encryption / decryption
+ * Constants of bfv/context.cu:501-516, 605-620 (generate_Q_mod_t :939-950,
+ * generate_coeff_div_plain_modulus :952-983 -- GMP there, 32-bit limbs here --,
+ * generate_Qi_t / Qi_gamma / Qi_inverse / mulq_inv_t / mulq_inv_gamma / inv_gamma :1239-1343). */
+typedef struct {
+    u64 Q_mod_t, upper_threshold, mulq_inv_t, mulq_inv_gamma, inv_gamma;
+    u64 coeff_div[O_MAX_MOD], Qi_t[O_MAX_MOD], Qi_gamma[O_MAX_MOD], Qi_inverse[O_MAX_MOD];
+} bfv_consts_t;
+
+static void bfv_consts(const octx_t* c, bfv_consts_t* k)
+{
+    const int Q = c->Q_size;
+    const omod_t* t = &c->plain_mod;
+    const omod_t* g = &c->gamma;
+    k->Q_mod_t = 1;
+    for (int i = 0; i < Q; i++) k->Q_mod_t = o_mult(k->Q_mod_t, c->mod[i].value % t->value, t);
+    k->upper_threshold = (t->value + 1) >> 1;
+    /* floor(prod q / t): little-endian 32-bit limbs */
+    uint32_t big[2 * O_MAX_MOD + 2];
+    int len = 1;
+    big[0] = 1;
+    for (int i = 0; i < Q; i++) {
+        /* multiply by the 64-bit prime as two 32-bit halves */
+        uint32_t lo = (uint32_t) c->mod[i].value, hi = (uint32_t) (c->mod[i].value >> 32);
+        uint32_t tmp[2 * O_MAX_MOD + 4];
+        memset(tmp, 0, sizeof(tmp));
+        for (int a = 0; a < len; a++) {
+            u64 carry = 0;
+            u64 v = (u64) big[a] * lo + tmp[a];
+            tmp[a] = (uint32_t) v; carry = v >> 32;
+            v = (u64) big[a] * hi + tmp[a + 1] + carry;
+            tmp[a + 1] = (uint32_t) v; carry = v >> 32;
+            for (int b = a + 2; carry; b++) { v = (u64) tmp[b] + carry; tmp[b] = (uint32_t) v; carry = v >> 32; }
+        }
+        len += 2;
+        while (len > 1 && tmp[len - 1] == 0) len--;
+        memcpy(big, tmp, sizeof(uint32_t) * len);
+    }
+    { /* divide by t (t < 2^62): schoolbook, most significant limb first */
+        u128 rem = 0;
+        for (int a = len - 1; a >= 0; a--) {
+            u128 cur = (rem << 32) | big[a];
+            big[a] = (uint32_t) (cur / t->value);
+            rem = cur % t->value;
+        }
+    }
+    for (int i = 0; i < Q; i++) {
+        u128 rem = 0;
+        for (int a = len - 1; a >= 0; a--) rem = ((rem << 32) | big[a]) % c->mod[i].value;
+        k->coeff_div[i] = (u64) rem;
+    }
+    for (int i = 0; i < Q; i++) {
+        u64 a = 1, b = 1, d = 1;
+        for (int j = 0; j < Q; j++) {
+            if (i == j) continue;
+            a = o_mult(a, c->mod[j].value % t->value, t);
+            b = o_mult(b, c->mod[j].value % g->value, g);
+            d = o_mult(d, o_modinv(c->mod[j].value % c->mod[i].value, &c->mod[i]), &c->mod[i]);
+        }
+        k->Qi_t[i] = a; k->Qi_gamma[i] = b; k->Qi_inverse[i] = d;
+    }
+    u64 mt = 1, mg = 1;
+    for (int i = 0; i < Q; i++) {
+        mt = o_mult(mt, o_modinv(c->mod[i].value % t->value, t), t);
+        mg = o_mult(mg, o_modinv(c->mod[i].value % g->value, g), g);
+    }
+    k->mulq_inv_t = t->value - mt;
+    k->mulq_inv_gamma = g->value - mg;
+    k->inv_gamma = o_modinv(g->value % t->value, t);
+}
+
+/* HEEncryptor<BFV>::encrypt_bfv (bfv/encryptor.cu:39-108) with enc_div_lastq_bfv_kernel
+ * (encryption.cu:91-179): the mod-down part equals the CKKS kernel's, part 0 then gets
+ * Delta*m + fix.  plain [N] mod t; ct [2][Q][N] coefficient domain. */
+void o_bfv_encrypt(const octx_t* c, orng_t* r, const u64* pk, const u64* plain, u64* ct)
+{
+    const int np = c->n_power, Qp = c->Qp_size, Q = c->Q_size;
+    const u64 sz = (u64) Qp << np;
+    bfv_consts_t k;
+    bfv_consts(c, &k);
+    u64* u = (u64*) malloc(5 * sz * sizeof(u64));
+    u64* e = u + sz;
+    u64* pku = e + 2 * sz;
+    fill_ternary(c, r, u, Qp, 1);
+    fill_gaussian(c, r, e, Qp, 2);
+    o_gpu_ntt(u, u, c->ntt_table, c->mod, np, Qp, Qp);
+    for (int z = 0; z < 2; z++)
+        for (int y = 0; y < Qp; y++)
+            for (u64 i = 0; i < c->n; i++) {
+                u64 loc = i + ((u64) y << np);
+                pku[loc + sz * z] = o_mult(pk[loc + sz * z], u[loc], &c->mod[y]);
+            }
+    o_gpu_intt(pku, pku, c->intt_table, c->mod, c->n_inv, np, 2 * Qp, Qp);
+    enc_div_lastq_ckks(c, pku, e, ct); /* identical arithmetic up to the message (encryption.cu:103-157) */
+    for (int y = 0; y < Q; y++)
+        for (u64 i = 0; i < c->n; i++) {
+            u64 message = plain[i];
+            u64 fix = message * k.Q_mod_t;
+            fix = fix + k.upper_threshold;
+            fix = (u64) (long long) (int) (fix / c->plain_mod.value); /* encryption.cu:163 `int(...)` */
+            u64 c0 = o_mult(message, k.coeff_div[y], &c->mod[y]);
+            c0 = o_add(c0, fix, &c->mod[y]);
+            u64 loc = i + ((u64) y << np);
+            ct[loc] = o_add(ct[loc], c0, &c->mod[y]);
+        }
+    free(u);
+}
+
+/* HEDecryptor<BFV>::decrypt_bfv (bfv/decryptor.cu:36-120), coefficient-domain input:
+ * NTT(c1) * s -> INTT -> decryption_kernel (decryption.cu:44-120) */
+void o_bfv_decrypt(const octx_t* c, const u64* ct, const u64* sk, u64* plain)
+{
+    const int np = c->n_power, Q = c->Q_size;
+    const u64 sz = (u64) Q << np;
+    bfv_consts_t k;
+    bfv_consts(c, &k);
+    u64* t1 = (u64*) malloc(sz * sizeof(u64));
+    o_gpu_ntt(ct + sz, t1, c->ntt_table, c->mod, np, Q, Q);
+    for (int y = 0; y < Q; y++)
+        for (u64 i = 0; i < c->n; i++) {
+            u64 loc = i + ((u64) y << np);
+            t1[loc] = o_mult(t1[loc], sk[loc], &c->mod[y]);
+        }
+    o_gpu_intt(t1, t1, c->intt_table, c->mod, c->n_inv, np, Q, Q);
+    const omod_t* t = &c->plain_mod;
+    const omod_t* g = &c->gamma;
+    for (u64 idx = 0; idx < c->n; idx++) {
+        u64 sum_t = 0, sum_g = 0;
+        for (int i = 0; i < Q; i++) {
+            u64 loc = idx + ((u64) i << np);
+            u64 mt = o_add(ct[loc], t1[loc], &c->mod[i]);
+            u64 g_i = o_reduce_forced(g->value, &c->mod[i]);
+            mt = o_mult(mt, t->value, &c->mod[i]);
+            mt = o_mult(mt, g_i, &c->mod[i]);
+            mt = o_mult(mt, k.Qi_inverse[i], &c->mod[i]);
+            u64 in_t = o_reduce_forced(mt, t), in_g = o_reduce_forced(mt, g);
+            in_t = o_mult(in_t, k.Qi_t[i], t);
+            in_g = o_mult(in_g, k.Qi_gamma[i], g);
+            sum_t = o_add(sum_t, in_t, t);
+            sum_g = o_add(sum_g, in_g, g);
+        }
+        sum_t = o_mult(sum_t, k.mulq_inv_t, t);
+        sum_g = o_mult(sum_g, k.mulq_inv_gamma, g);
+        u64 result;
+        if (sum_g > (g->value >> 1)) {
+            u64 g_t = o_reduce_forced(g->value, t), sg = o_reduce_forced(sum_g, t);
+            result = o_sub(g_t, sg, t);
+            result = o_add(sum_t, result, t);
+            result = o_mult(result, k.inv_gamma, t);
+        } else {
+            u64 st = o_reduce_forced(sum_t, t), sg = o_reduce_forced(sum_g, t);
+            result = o_sub(st, sg, t);
+            result = o_mult(result, k.inv_gamma, t);
+        }
+        plain[idx] = result;
+    }
+    free(t1);
+}

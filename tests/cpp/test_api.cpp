@@ -255,6 +255,52 @@ static void ckks_pipeline()
     o_ctx_free(oc);
 }
 
+// BFV through the class layer: keygen -> encrypt -> multiply -> relinearize -> decrypt, exact
+static void bfv_pipeline()
+{
+    constexpr auto S = Scheme::BFV;
+    const size_t n = 4096;
+    const Data64 t = 1032193;
+    HEContext<S> ctx = GenHEContext<S>();
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_default_values(1);
+    ctx->set_plain_modulus(t);
+    ctx->generate();
+    HEKeyGenerator<S> keygen(ctx, 11);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk(ctx);
+    keygen.generate_relin_key(rk, sk);
+    HEEncryptor<S> enc(ctx, pk, 12);
+    HEDecryptor<S> dec(ctx, sk);
+    HEArithmeticOperator<S> op(ctx);
+    Vec m1(n), m2(n, 0);
+    for (size_t i = 0; i < n; i++) m1[i] = (i * 2654435761ull) % t;
+    m2[0] = 7; m2[1] = t - 2; // 7 - 2X
+    Plaintext<S> p1(ctx), p2(ctx), out(ctx);
+    p1.load(m1, 0, 0.0);
+    p2.load(m2, 0, 0.0);
+    Ciphertext<S> c1(ctx), c2(ctx);
+    enc.encrypt(c1, p1);
+    enc.encrypt(c2, p2);
+    dec.decrypt(out, c1);
+    Vec got;
+    out.get_data(got);
+    EXPECT(got == m1, "bfv decrypt(encrypt(m)) == m");
+    op.multiply_inplace(c1, c2);
+    op.relinearize_inplace(c1, rk);
+    dec.decrypt(out, c1);
+    out.get_data(got);
+    Vec want(n);
+    for (size_t i = 0; i < n; i++) { // (7 - 2X) * m1 mod (X^N + 1, t)
+        const Data64 prev = i ? m1[i - 1] : (t - m1[n - 1]) % t;
+        want[i] = (7 * m1[i] + (t - 2) * prev) % t;
+    }
+    EXPECT(got == want, "bfv decrypt(relinearize(c1 * c2)) == m1 * m2 mod (X^N+1, t)");
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -271,6 +317,7 @@ int main()
     ckks();
     bfv();
     ckks_pipeline();
+    bfv_pipeline();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }

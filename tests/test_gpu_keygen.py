@@ -108,3 +108,44 @@ def test_gpu_only_pipeline_returns_message(hg, oracle, torch):
     x = decode(c.ckks_decrypt(rot, sk, 0), Q)
     want = he.apply_galois_poly(np.array([int(v) * scale for v in m1], dtype=object), gal)
     assert max(abs(int(a) - int(b)) for a, b in zip(x, want)) < scale // 2 ** 8
+
+
+def test_bfv_encrypt_decrypt_bit_exact_and_pipeline(hg, oracle, torch):
+    """BFV (config C1 parameters): encryption/decryption bit-identical to the oracle for the same
+    seed, then keygen -> encrypt -> multiply -> relinearize -> rotate -> decrypt on the GPU alone."""
+    n, t = 4096, 1032193
+    c = hg.Context.from_default(hg.BFV, n, 1, t)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, c.Q_size, c.P_size, t)
+    c.upload()
+    Q = c.Q_size
+    rg, ro = hg.Rng(31337), oracle.ORng(31337)
+    sk, sk_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    pk, pk_o = c.generate_public_key(rg, sk), o.gen_public_key(ro, sk_o)
+    assert np.array_equal(hg.to_host(pk), pk_o)
+    g = np.random.default_rng(8)
+    msgs = [g.integers(0, t, n).astype(np.uint64), np.full(n, t - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64)]
+    for m in msgs:
+        ct = c.bfv_encrypt(rg, pk, hg.to_device(m))
+        ct_o = o.bfv_encrypt(ro, pk_o, m)
+        assert np.array_equal(hg.to_host(ct), ct_o), "ciphertext"
+        dec = c.bfv_decrypt(ct, sk)
+        assert np.array_equal(hg.to_host(dec), o.bfv_decrypt(ct_o, sk_o)), "decryption == oracle"
+        assert np.array_equal(hg.to_host(dec), m), "decryption == message"
+    # GPU-only pipeline
+    rk = c.generate_relin_key(rg, sk)
+    gal = hg.steps_to_galois_elt(1, n, 3)
+    gk = c.generate_galois_key(rg, sk, gal)
+    m1, m2 = msgs[0], g.integers(0, t, n).astype(np.uint64)
+    c1, c2 = c.bfv_encrypt(rg, pk, hg.to_device(m1)), c.bfv_encrypt(rg, pk, hg.to_device(m2))
+    out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(c1, 2 * Q * n, c2, 2 * Q * n, out, 3 * Q * n, 1, c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+    c.bfv_relinearize_inplace(out, 3 * Q * n, rk, 1, c.workspace(hg.OP_BFV_RELIN, 0, 1))
+    got = hg.to_host(c.bfv_decrypt(out[:2 * Q * n].contiguous(), sk))
+    want = np.array([int(v) % t for v in negacyclic_mul(m1, m2)], dtype=np.uint64)
+    assert np.array_equal(got, want), "decrypt(relinearize(c1*c2)) = m1*m2 mod (X^N+1, t)"
+    rot = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_apply_galois(c1, 2 * Q * n, rot, 2 * Q * n, gk, gal, 1, c.workspace(hg.OP_BFV_GALOIS, 0, 1))
+    he = RLWE(o, seed=0)
+    want = np.array([int(v) % t for v in he.apply_galois_poly(m1.astype(object), gal)], dtype=np.uint64)
+    assert np.array_equal(hg.to_host(c.bfv_decrypt(rot, sk)), want), "decrypt(rotate(c1)) = sigma_g(m1)"

@@ -111,3 +111,52 @@ def test_streams_are_reproducible(setup, oracle):
     b = o.gen_secret_key(oracle.ORng(77))
     c = o.gen_secret_key(oracle.ORng(78))
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+# ---------------------------------------------------------------- BFV
+@pytest.fixture(scope="module")
+def bfv(oracle):
+    import ctypes
+    n_power, t = 10, 65537
+    n = 1 << n_power
+    arr = (ctypes.c_int * 3)(36, 36, 37)
+    out = (ctypes.c_uint64 * 3)()
+    assert oracle.lib().o_generate_primes(n, arr, 3, out) == 0
+    primes = [int(v) for v in out]
+    o = oracle.OracleContext(oracle.BFV, n_power, primes, 2, 1, t)
+    rng = oracle.ORng(99)
+    sk = o.gen_secret_key(rng)
+    pk = o.gen_public_key(rng, sk)
+    return o, rng, sk, pk, t
+
+
+def test_bfv_encrypt_decrypt_exact(bfv):
+    o, rng, sk, pk, t = bfv
+    g = np.random.default_rng(2)
+    for m in (g.integers(0, t, o.n).astype(np.uint64), np.zeros(o.n, dtype=np.uint64),
+              np.full(o.n, t - 1, dtype=np.uint64)):
+        ct = o.bfv_encrypt(rng, pk, m)
+        assert np.array_equal(o.bfv_decrypt(ct, sk), m)
+
+
+def test_bfv_homomorphic_multiply_with_generated_keys(bfv):
+    """encrypt -> multiply -> relinearize (generated key) -> decrypt = m1*m2 mod (X^N+1, t)"""
+    o, rng, sk, pk, t = bfv
+    n = o.n
+    rk = o.gen_switch_key(rng, sk, 0)
+    g = np.random.default_rng(4)
+    m1 = g.integers(0, t, n).astype(np.uint64)
+    m2 = g.integers(0, t, n).astype(np.uint64)
+    ct3 = o.bfv_multiply(o.bfv_encrypt(rng, pk, m1), o.bfv_encrypt(rng, pk, m2))
+    o.bfv_relinearize(ct3, rk)
+    got = o.bfv_decrypt(ct3[:2 * o.Q * n].copy(), sk)
+    want = np.array([int(v) % t for v in negacyclic_mul(m1, m2)], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    # rotation with a generated Galois key
+    from he_math import RLWE
+    gal = 3
+    gk = o.gen_switch_key(rng, sk, gal)
+    rot = o.bfv_apply_galois(o.bfv_encrypt(rng, pk, m1), gk, gal)
+    he = RLWE(o, seed=0)
+    want = np.array([int(v) % t for v in he.apply_galois_poly(m1.astype(object), gal)], dtype=np.uint64)
+    assert np.array_equal(o.bfv_decrypt(rot, sk), want)
