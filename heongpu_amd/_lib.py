@@ -65,6 +65,8 @@ SIGNATURES = [
     ("hegpu_ckks_decrypt", c_int, [voidp, u64p, u64p, c_int, u64p, voidp]),
     ("hegpu_bfv_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_decrypt", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_bfv_encode", c_int, [voidp, voidp, c_int, u64p, voidp]),
+    ("hegpu_bfv_decode", c_int, [voidp, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_tfhe_context_create", c_int, [ctypes.POINTER(voidp)]),
     ("hegpu_tfhe_context_destroy", None, [voidp]),
     ("hegpu_tfhe_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),

@@ -15,7 +15,8 @@ BFV, CKKS = 1, 2
 SEC_NONE, SEC_128 = 0, 128
 TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
-OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT = 7, 8, 9, 10, 11, 12
+OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE = 7, 8, 9, 10, 11, 12, 13
+TABLES_PLAIN = 2
 
 E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
 
@@ -306,6 +307,22 @@ class Context:
                                            ws.numel() * ws.element_size(),
                                            stream if stream is not None else _stream()))
         return plain
+
+    def bfv_encode(self, message, stream=None):
+        """message: device int64 tensor with at most N entries"""
+        import torch
+        plain = torch.empty(self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_bfv_encode(self._h, _ptr(message), message.numel(), _ptr(plain),
+                                          stream if stream is not None else _stream()))
+        return plain
+
+    def bfv_decode(self, plain, stream=None):
+        import torch
+        out = torch.empty(self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_BFV_DECODE)
+        _check(self._lib.hegpu_bfv_decode(self._h, _ptr(plain), _ptr(out), _ptr(ws), ws.numel() * ws.element_size(),
+                                          stream if stream is not None else _stream()))
+        return out
 
     def ckks_decrypt(self, ct, sk, depth=0, stream=None):
         import torch

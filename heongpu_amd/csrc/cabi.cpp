@@ -241,6 +241,8 @@ int hegpu_ntt(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* o
     const Context& c = ctx->c;
     if (table_set == HEGPU_TABLES_Q_BSK && c.scheme != SCHEME_BFV)
         return fail(HEGPU_E_INVALID, "q|Bsk tables exist only in a BFV context");
+    if (table_set < 0 || table_set > HEGPU_TABLES_PLAIN || (table_set == HEGPU_TABLES_PLAIN && !c.plan_plain.count))
+        return fail(HEGPU_E_INVALID, "no such table set in this context");
     NttArgs a = c.ntt_args(table_set);
     const int avail = a.mod_count;
     if (mod_count <= 0 || mod_offset < 0 || (!mod_order && mod_offset + mod_count > avail))
@@ -586,6 +588,33 @@ int hegpu_bfv_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk
                                       (hipStream_t) stream),
                        "hegpu_bfv_decrypt");
     });
+}
+
+int hegpu_bfv_encode(hegpu_context* ctx, const int64_t* message, int message_size, uint64_t* plain,
+                     hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (!ctx->c.plan_plain.count)
+        return fail(HEGPU_E_LOGIC, "batching needs a prime plain modulus with 2N | t - 1");
+    if (message_size < 0 || message_size > (int) ctx->c.n)
+        return fail(HEGPU_E_INVALID, "Message size can not be higher than the slot count."); // bfv/encoder.cuh:60
+    return hip_ret(op_bfv_encode(ctx->c, (const long long*) message, message_size, (u64*) plain,
+                                 (hipStream_t) stream),
+                   "hegpu_bfv_encode");
+}
+
+int hegpu_bfv_decode(hegpu_context* ctx, const uint64_t* plain, uint64_t* message, void* ws, size_t ws_bytes,
+                     hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (!ctx->c.plan_plain.count)
+        return fail(HEGPU_E_LOGIC, "batching needs a prime plain modulus with 2N | t - 1");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_BFV_DECODE, 0, 1))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return hip_ret(op_bfv_decode(ctx->c, (const u64*) plain, (u64*) message, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_bfv_decode");
 }
 
 // ------------------------------------------------------------------ TFHE

@@ -233,6 +233,34 @@ void Context::build_host()
         host["q_Bsk_merge_intt_tables"] = minv;
         host["q_Bsk_n_inverse"] = mninv;
 
+        // ---- batching (bfv/context.cu:489-499, bfv/encoder.cu:21-46): NTT tables of the plain
+        // modulus and the slot -> coefficient-position map; only when t is a prime with 2N | t-1
+        if (host::is_prime(t) && (t - 1) % (2 * n) == 0) {
+            const u64 ppsi = host::minimal_primitive_root(2 * n, t);
+            host["plain_modulus2"] = vec{t};
+            host["plain_psi"] = vec{ppsi};
+            host["plain_ntt_tables"] = host::power_table_bitrev(ppsi, t, n_power);
+            host["plain_intt_tables"] = host::power_table_bitrev(inv_mod_prime(ppsi, t), t, n_power);
+            host["n_plain_inverse"] = vec{inv_mod_prime(n % t, t)};
+            vec loc;
+            const u64 m = 2 * n;
+            u64 pos = 1;
+            auto brev = [&](u64 v) {
+                u64 r = 0;
+                for (int b = 0; b < n_power; b++) r |= ((v >> b) & 1) << (n_power - 1 - b);
+                return r;
+            };
+            for (u64 i = 0; i < n / 2; i++) {
+                loc.push_back(brev((pos - 1) >> 1));
+                pos = (pos * 3) & (m - 1);
+            }
+            for (u64 i = n / 2; i < n; i++) {
+                loc.push_back(brev((m - pos - 1) >> 1));
+                pos = (pos * 3) & (m - 1);
+            }
+            host["encoding_location"] = loc;
+        }
+
         // ---- encryption / decryption constants (bfv/context.cu:501-516, 605-620, 939-983, 1239-1343)
         {
             u64 Q_mod_t = 1;
@@ -414,7 +442,7 @@ hipError_t Context::upload()
         if ((e = to_device(it->second, &d)) != hipSuccess) return e;
         dev[nm] = d;
     }
-    for (const char* nm : {"new_prime_locations", "new_input_locations", "m2_I_j", "m2_I_location"}) {
+    for (const char* nm : {"new_prime_locations", "new_input_locations", "m2_I_j", "m2_I_location", "encoding_location"}) {
         auto it = host.find(nm);
         if (it == host.end()) continue;
         std::vector<int> v(it->second.begin(), it->second.end());
@@ -425,6 +453,10 @@ hipError_t Context::upload()
     if (scheme == SCHEME_BFV) {
         if ((e = build_plan(plan_merge, host["q_Bsk_merge_modulus"], host["q_Bsk_merge_ntt_tables"],
                             host["q_Bsk_merge_intt_tables"], host["q_Bsk_n_inverse"], n_power)) != hipSuccess)
+            return e;
+        if (host.count("plain_modulus2") &&
+            (e = build_plan(plan_plain, host["plain_modulus2"], host["plain_ntt_tables"], host["plain_intt_tables"],
+                            host["n_plain_inverse"], n_power)) != hipSuccess)
             return e;
         behz.ibase = plan_merge.mods;
         behz.obase = plan_merge.mods + Q_size;
@@ -453,6 +485,7 @@ void Context::release_device()
 {
     free_plan(plan_qp);
     free_plan(plan_merge);
+    free_plan(plan_plain);
     for (auto& kv : dev)
         if (kv.second) (void) hipFree(kv.second);
     dev.clear();
@@ -477,7 +510,7 @@ const int* Context::d32(const char* name) const
 
 NttArgs Context::ntt_args(int table_set) const
 {
-    const NttPlan& p = table_set ? plan_merge : plan_qp;
+    const NttPlan& p = table_set == 2 ? plan_plain : (table_set ? plan_merge : plan_qp);
     NttArgs a{};
     a.mods = p.mods;
     a.tw = p.tw;

@@ -60,6 +60,7 @@ struct Context {
     int device = -1;
     NttPlan plan_qp;    // tables for the Q' chain
     NttPlan plan_merge; // BFV: [q_0..q_{Q-1}, Bsk...]
+    NttPlan plan_plain; // BFV batching: the plain modulus t alone (bfv/context.cu:489-499), when 2N | t-1
     std::map<std::string, void*> dev; // named device arrays (u64 / int)
     Mod* bsk_mods = nullptr;
     BehzDev behz{};

@@ -283,4 +283,40 @@ hipError_t kg_bfv_decryption(const u64* ct0, const u64* ct1s, u64* plain, const 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_encode(u64* __restrict__ out,
+                                                              const long long* __restrict__ message,
+                                                              const int* __restrict__ location, u64 t,
+                                                              int message_size)
+{
+    const int idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const int loc = location[idx];
+    u64 v = 0;
+    if (idx < message_size) {
+        long long m = message[idx];
+        if (m < 0) m += (long long) t;
+        v = (u64) m;
+    }
+    out[loc] = v;
+}
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_decode(u64* __restrict__ message, const u64* __restrict__ in,
+                                                              const int* __restrict__ location)
+{
+    const int idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    message[idx] = in[location[idx]];
+}
+
+hipError_t kg_bfv_encode_scatter(u64* out, const long long* message, const int* location, u64 t, int message_size,
+                                 int n_power, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_encode, dim3((1u << n_power) / KG_THREADS), dim3(KG_THREADS), 0, st, out, message,
+                       location, t, message_size);
+    return hipGetLastError();
+}
+hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location, int n_power, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_decode, dim3((1u << n_power) / KG_THREADS), dim3(KG_THREADS), 0, st, message, in,
+                       location);
+    return hipGetLastError();
+}
+
 } // namespace hegpu

@@ -50,4 +50,9 @@ struct BfvDecryptDev {
 hipError_t kg_bfv_decryption(const u64* ct0, const u64* ct1s, u64* plain, const Mod* mods, const BfvDecryptDev& d,
                              int n_power, int limbs, hipStream_t st);
 
+// encode_kernel_bfv / decode_kernel_bfv (encoding.cu:11-41): slot idx <-> position location[idx]
+hipError_t kg_bfv_encode_scatter(u64* out, const long long* message, const int* location, u64 t, int message_size,
+                                 int n_power, hipStream_t st);
+hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location, int n_power, hipStream_t st);
+
 } // namespace hegpu

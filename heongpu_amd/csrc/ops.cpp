@@ -80,6 +80,7 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_CKKS_ENCRYPT:
         case OP_BFV_ENCRYPT: per = (u64) 5 * Qp * n; break;          // u, e[2], pk*u[2]
         case OP_BFV_DECRYPT: per = (u64) Q * n; break;               // c1*s
+        case OP_BFV_DECODE: per = n; break;
         default: return 0;
     }
     return per * (u64) batch;
@@ -524,6 +525,26 @@ hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* p
     d.mulq_inv_gamma = c.h64("mulq_inv_gamma")[0];
     d.inv_gamma = c.h64("inv_gamma")[0];
     return kg_bfv_decryption(ct, t1, plain, c.plan_qp.mods, d, np, Q, st);                 // :107
+}
+
+hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st)
+{
+    if (!c.plan_plain.count) return hipErrorNotSupported;
+    if (message_size < 0 || message_size > (int) c.n) return hipErrorInvalidValue;
+    TRY(kg_bfv_encode_scatter(plain, message, c.d32("encoding_location"), c.plain_modulus, message_size, c.n_power,
+                              st));                                                        // :66
+    NttArgs a = c.ntt_args(2);
+    a.in = plain; a.out = plain; a.mod_count = 1;
+    return ntt_launch(a, 1, true, st);                                                     // :81
+}
+
+hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* ws, hipStream_t st)
+{
+    if (!c.plan_plain.count) return hipErrorNotSupported;
+    NttArgs a = c.ntt_args(2);
+    a.in = plain; a.out = ws; a.mod_count = 1;
+    TRY(ntt_launch(a, 1, false, st));                                                      // :234
+    return kg_bfv_decode_gather(message, ws, c.d32("encoding_location"), c.n_power, st);   // :239
 }
 
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)

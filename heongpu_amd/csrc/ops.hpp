@@ -7,7 +7,7 @@ namespace hegpu {
 
 enum { OP_CKKS_RELIN = 1, OP_CKKS_RESCALE = 2, OP_CKKS_GALOIS = 3, OP_BFV_MULTIPLY = 4, OP_BFV_RELIN = 5,
        OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10, OP_BFV_ENCRYPT = 11,
-       OP_BFV_DECRYPT = 12 };
+       OP_BFV_DECRYPT = 12, OP_BFV_DECODE = 13 };
 
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
@@ -59,5 +59,9 @@ hipError_t op_bfv_encrypt(const Context& c, Rng& r, const u64* pk, const u64* pl
                           hipStream_t st);
 // HEDecryptor<BFV>::decrypt_bfv (bfv/decryptor.cu:36-120), coefficient-domain ciphertext; plain [N]
 hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* plain, u64* ws, hipStream_t st);
+// HEEncoder<BFV>::encode_bfv / decode_bfv (bfv/encoder.cu:48-95, 213-249): message [size <= N]
+// int64 (negative values wrap mod t) -> plain [N]; plain [N] -> message [N].  ws: N words (decode).
+hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st);
+hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* ws, hipStream_t st);
 
 } // namespace hegpu

@@ -33,7 +33,7 @@ typedef void* hegpu_stream;                 /* hipStream_t */
 
 enum { HEGPU_BFV = 1, HEGPU_CKKS = 2 };
 enum { HEGPU_SEC_NONE = 0, HEGPU_SEC_128 = 128 };
-enum { HEGPU_TABLES_QP = 0, HEGPU_TABLES_Q_BSK = 1 };
+enum { HEGPU_TABLES_QP = 0, HEGPU_TABLES_Q_BSK = 1, HEGPU_TABLES_PLAIN = 2 /* BFV plain modulus t, batching */ };
 enum {
     HEGPU_E_INVALID = 10001, /* std::invalid_argument in the reference */
     HEGPU_E_LOGIC = 10002,   /* std::logic_error */
@@ -142,7 +142,8 @@ enum {
     HEGPU_OP_KEYGEN_SWITCH = 9, /* relinearisation and Galois keys */
     HEGPU_OP_CKKS_ENCRYPT = 10,
     HEGPU_OP_BFV_ENCRYPT = 11,
-    HEGPU_OP_BFV_DECRYPT = 12
+    HEGPU_OP_BFV_DECRYPT = 12,
+    HEGPU_OP_BFV_DECODE = 13
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -217,6 +218,14 @@ int hegpu_bfv_encrypt(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* pk, co
  * coefficient-domain 2-part ciphertext, plain [N] mod t.  Workspace HEGPU_OP_BFV_DECRYPT. */
 int hegpu_bfv_decrypt(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* plain, void* ws,
                       size_t ws_bytes, hegpu_stream stream);
+
+/* HEEncoder<BFV>::encode_bfv / decode_bfv (src/lib/host/bfv/encoder.cu:21-95, 213-249,
+ * kernel/encoding.cu:11-41): batching over the slots of Z_t[X]/(X^N+1).  message: device int64
+ * [message_size <= N] (negative values wrap mod t, missing slots are zero); plain [N] mod t. */
+int hegpu_bfv_encode(hegpu_context* ctx, const int64_t* message, int message_size, uint64_t* plain,
+                     hegpu_stream stream);
+int hegpu_bfv_decode(hegpu_context* ctx, const uint64_t* plain, uint64_t* message, void* ws, size_t ws_bytes,
+                     hegpu_stream stream);
 
 /* ------------------------------------------------------------------ TFHE
  * Gate bootstrapping on the reference's fixed STD128 set

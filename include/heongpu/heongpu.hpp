@@ -587,6 +587,62 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
     Secretkey<S>* sk_;
 };
 
+// ------------------------------------------------------------------ encoder (BFV batching)
+template <Scheme S> class HEEncoder { // host/bfv/encoder.cuh
+    static_assert(S == Scheme::BFV, "the CKKS encoder (special FFT + CRT compose) is not built yet (SURVEY.md 8f next-2)");
+
+  public:
+    explicit HEEncoder(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+    }
+    inline int slot_count() const noexcept { return context_->n; }
+
+    void encode(Plaintext<S>& plain, const std::vector<int64_t>& message, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if ((int) message.size() > context_->n)
+            throw std::invalid_argument("Message size can not be higher than the slot count."); // bfv/encoder.cuh:60
+        DeviceVector<Data64> msg(message.size() ? message.size() : 1, o.stream_);
+        if (!message.empty())
+            detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(int64_t),
+                                       hipMemcpyHostToDevice, o.stream_));
+        DeviceVector<Data64> out((size_t) context_->n, o.stream_);
+        detail::check(hegpu_bfv_encode(context_->handle(), (const int64_t*) msg.data(), (int) message.size(),
+                                       (uint64_t*) out.data(), o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_)); // `message` may be a temporary
+        plain.memory_set(std::move(out));
+        plain.depth_ = 0;
+        plain.plaintext_generated_ = true;
+    }
+    void encode(Plaintext<S>& plain, const std::vector<uint64_t>& message, const ExecutionOptions& o = ExecutionOptions())
+    {
+        std::vector<int64_t> m(message.begin(), message.end());
+        encode(plain, m, o);
+    }
+    void decode(std::vector<uint64_t>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        DeviceVector<Data64> out((size_t) context_->n, o.stream_), ws((size_t) context_->n, o.stream_);
+        detail::check(hegpu_bfv_decode(context_->handle(), (const uint64_t*) plain.data(), (uint64_t*) out.data(),
+                                       ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        message.resize(context_->n);
+        detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+    }
+    void decode(std::vector<int64_t>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        std::vector<uint64_t> u;
+        decode(u, plain, o);
+        const uint64_t t = context_->plain_modulus_;
+        message.resize(u.size());
+        for (size_t i = 0; i < u.size(); i++) // centred representative, bfv/encoder.cu decode to int64
+            message[i] = u[i] > (t >> 1) ? (int64_t) u[i] - (int64_t) t : (int64_t) u[i];
+    }
+
+  private:
+    HEContext<S> context_;
+};
+
 // ------------------------------------------------------------------ operator
 template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
   public:

@@ -86,6 +86,8 @@ def lib():
     L.o_ckks_decrypt.argtypes = [vp, vp, vp, ci, vp]
     L.o_bfv_encrypt.argtypes = [vp, vp, vp, vp, vp]
     L.o_bfv_decrypt.argtypes = [vp, vp, vp, vp]
+    L.o_bfv_encode.argtypes = [vp, vp, ci, vp]
+    L.o_bfv_decode.argtypes = [vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
@@ -253,6 +255,17 @@ class OracleContext:
         plain = np.zeros(self.n, dtype=np.uint64)
         self.L.o_bfv_decrypt(self.h, _p(ct), _p(sk), _p(plain))
         return plain
+
+    def bfv_encode(self, message):
+        m = np.ascontiguousarray(message, dtype=np.int64)
+        plain = np.zeros(self.n, dtype=np.uint64)
+        self.L.o_bfv_encode(self.h, _p(m), len(m), _p(plain))
+        return plain
+
+    def bfv_decode(self, plain):
+        out = np.zeros(self.n, dtype=np.uint64)
+        self.L.o_bfv_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), _p(out))
+        return out
 
     # key-switching method II (P_size > 1)
     def ckks_relinearize_II(self, ct3, key, depth=0):

@@ -449,3 +449,58 @@ void o_bfv_decrypt(const octx_t* c, const u64* ct, const u64* sk, u64* plain)
     }
     free(t1);
 }
+
+/* ------------------------------------------------------------------ BFV batch encoder
+ * HEEncoder<BFV> ctor (bfv/encoder.cu:21-46: slot i sits at bit-reversed index of
+ * (3^i - 1)/2 resp. (2N - 3^i - 1)/2), encode_kernel_bfv / decode_kernel_bfv
+ * (encoding.cu:11-41), NTT mod t with the minimal 2N-th root (bfv/context.cu:489-499). */
+static void encoding_location(const octx_t* c, int* loc)
+{
+    const int n = (int) c->n, m = n << 1;
+    int pos = 1;
+    for (int i = 0; i < n / 2; i++) {
+        loc[i] = (int) bitrev((uint32_t) ((pos - 1) >> 1), c->n_power);
+        pos = (pos * 3) & (m - 1);
+    }
+    for (int i = n / 2; i < n; i++) {
+        loc[i] = (int) bitrev((uint32_t) ((m - pos - 1) >> 1), c->n_power);
+        pos = (pos * 3) & (m - 1);
+    }
+}
+
+void o_bfv_encode(const octx_t* c, const int64_t* message, int message_size, u64* plain)
+{
+    const int n = (int) c->n;
+    const u64 t = c->plain_mod.value;
+    int* loc = (int*) malloc(sizeof(int) * n);
+    u64* itab = (u64*) malloc(sizeof(u64) * n);
+    encoding_location(c, loc);
+    for (int i = 0; i < n; i++) {
+        int64_t v = i < message_size ? message[i] : 0;
+        if (v < 0) v += (int64_t) t;
+        plain[loc[i]] = (u64) v;
+    }
+    u64 psi = o_min_primitive_root(2 * c->n, t);
+    o_intt_table(psi, t, c->n_power, itab);
+    o_intt_limb(plain, itab, &c->plain_mod, o_n_inverse(c->n, t), c->n_power);
+    free(loc);
+    free(itab);
+}
+
+void o_bfv_decode(const octx_t* c, const u64* plain, u64* message)
+{
+    const int n = (int) c->n;
+    const u64 t = c->plain_mod.value;
+    int* loc = (int*) malloc(sizeof(int) * n);
+    u64* tab = (u64*) malloc(sizeof(u64) * n);
+    u64* tmp = (u64*) malloc(sizeof(u64) * n);
+    encoding_location(c, loc);
+    memcpy(tmp, plain, sizeof(u64) * n);
+    u64 psi = o_min_primitive_root(2 * c->n, t);
+    o_ntt_table(psi, t, c->n_power, tab);
+    o_ntt_limb(tmp, tab, &c->plain_mod, c->n_power);
+    for (int i = 0; i < n; i++) message[i] = tmp[loc[i]];
+    free(loc);
+    free(tab);
+    free(tmp);
+}

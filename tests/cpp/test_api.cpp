@@ -299,6 +299,35 @@ static void bfv_pipeline()
         want[i] = (7 * m1[i] + (t - 2) * prev) % t;
     }
     EXPECT(got == want, "bfv decrypt(relinearize(c1 * c2)) == m1 * m2 mod (X^N+1, t)");
+
+    // batching: slot-wise product and row rotation (reference example 1_basic_bfv.cpp)
+    HEEncoder<S> encoder(ctx);
+    Galoiskey<S> gk(ctx, std::vector<int>{1});
+    keygen.generate_galois_key(gk, sk);
+    std::vector<uint64_t> a(n), b(n);
+    for (size_t i = 0; i < n; i++) { a[i] = (i * 7 + 1) % t; b[i] = (i * i + 3) % t; }
+    Plaintext<S> pa(ctx), pb(ctx), pr(ctx);
+    encoder.encode(pa, a);
+    encoder.encode(pb, b);
+    Ciphertext<S> ca(ctx), cb(ctx), cr(ctx);
+    enc.encrypt(ca, pa);
+    enc.encrypt(cb, pb);
+    op.multiply_inplace(ca, cb);
+    op.relinearize_inplace(ca, rk);
+    std::vector<uint64_t> slots;
+    dec.decrypt(pr, ca);
+    encoder.decode(slots, pr);
+    bool ok = slots.size() == n;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == (a[i] * b[i]) % t;
+    EXPECT(ok, "bfv slots: decode(decrypt(enc(a) * enc(b))) == a .* b");
+    enc.encrypt(cb, pb);
+    op.rotate_rows(cb, cr, gk, 1);
+    dec.decrypt(pr, cr);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n / 2; i++)
+        ok = slots[i] == b[(i + 1) % (n / 2)] && slots[n / 2 + i] == b[n / 2 + (i + 1) % (n / 2)];
+    EXPECT(ok, "bfv slots: rotate_rows(1) shifts both rows left by one");
 }
 
 int main()

@@ -149,3 +149,24 @@ def test_bfv_encrypt_decrypt_bit_exact_and_pipeline(hg, oracle, torch):
     he = RLWE(o, seed=0)
     want = np.array([int(v) % t for v in he.apply_galois_poly(m1.astype(object), gal)], dtype=np.uint64)
     assert np.array_equal(hg.to_host(c.bfv_decrypt(rot, sk)), want), "decrypt(rotate(c1)) = sigma_g(m1)"
+
+
+@pytest.mark.parametrize("n,t", [(4096, 1032193), (8192, 65537)])
+def test_bfv_batch_encoder_bit_exact(hg, oracle, torch, n, t):
+    """encode / decode vs the oracle, decode(encode) = identity, short and negative messages,
+    and the plain-modulus table set through hegpu_ntt."""
+    c = hg.Context.from_default(hg.BFV, n, 1, t)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, c.Q_size, c.P_size, t)
+    c.upload()
+    g = np.random.default_rng(3)
+    for msg in (g.integers(0, t, n), g.integers(-t // 2, t // 2, n), np.array([-1, 5, -7, 3]), np.zeros(1)):
+        msg = msg.astype(np.int64)
+        plain = c.bfv_encode(torch.from_numpy(msg).cuda())
+        want = o.bfv_encode(msg)
+        assert np.array_equal(hg.to_host(plain), want), "encode"
+        dec = c.bfv_decode(plain)
+        assert np.array_equal(hg.to_host(dec), o.bfv_decode(want)), "decode"
+        full = np.zeros(n, dtype=np.int64)
+        full[:len(msg)] = msg
+        assert np.array_equal(hg.to_host(dec), (full % t).astype(np.uint64)), "decode(encode(m)) = m mod t"

@@ -160,3 +160,30 @@ def test_bfv_homomorphic_multiply_with_generated_keys(bfv):
     he = RLWE(o, seed=0)
     want = np.array([int(v) % t for v in he.apply_galois_poly(m1.astype(object), gal)], dtype=np.uint64)
     assert np.array_equal(o.bfv_decrypt(rot, sk), want)
+
+
+def test_bfv_batch_encoder_semantics(bfv):
+    """The encoder is pinned by what batching means: decode inverts encode, polynomial
+    multiplication mod (X^N+1, t) is slot-wise multiplication, and X -> X^3 rotates both rows
+    one slot to the left (the reference's rotate_rows semantics, bfv/evaluationkey.cu:308)."""
+    from he_math import RLWE
+    o, rng, sk, pk, t = bfv
+    n = o.n
+    g = np.random.default_rng(10)
+    a = g.integers(0, t, n)
+    b = g.integers(0, t, n)
+    pa, pb = o.bfv_encode(a), o.bfv_encode(b)
+    assert np.array_equal(o.bfv_decode(pa), a.astype(np.uint64))
+    prod = np.array([int(v) % t for v in negacyclic_mul(pa, pb)], dtype=np.uint64)
+    assert np.array_equal(o.bfv_decode(prod), (a * b % t).astype(np.uint64))
+    he = RLWE(o, seed=0)
+    rot = np.array([int(v) % t for v in he.apply_galois_poly(pa.astype(object), 3)], dtype=np.uint64)
+    want = np.concatenate([np.roll(a[:n // 2], -1), np.roll(a[n // 2:], -1)]).astype(np.uint64)
+    assert np.array_equal(o.bfv_decode(rot), want)
+    # short and negative messages
+    short = np.array([-1, 5, -7], dtype=np.int64)
+    dec = o.bfv_decode(o.bfv_encode(short))
+    assert list(dec[:3]) == [t - 1, 5, t - 7] and not dec[3:].any()
+    # end to end with encryption: encode -> encrypt -> decrypt -> decode
+    ct = o.bfv_encrypt(rng, pk, pa)
+    assert np.array_equal(o.bfv_decode(o.bfv_decrypt(ct, sk)), a.astype(np.uint64))
