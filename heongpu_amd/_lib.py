@@ -66,6 +66,8 @@ SIGNATURES = [
     ("hegpu_bfv_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_decrypt", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_encode", c_int, [voidp, voidp, c_int, u64p, voidp]),
+    ("hegpu_ckks_encode", c_int, [voidp, voidp, c_int, ctypes.c_double, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_decode", c_int, [voidp, u64p, c_int, ctypes.c_double, voidp, voidp, c_size_t, voidp]),
     ("hegpu_bfv_decode", c_int, [voidp, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_tfhe_context_create", c_int, [ctypes.POINTER(voidp)]),
     ("hegpu_tfhe_context_destroy", None, [voidp]),

@@ -16,6 +16,7 @@ SEC_NONE, SEC_128 = 0, 128
 TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
 OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE = 7, 8, 9, 10, 11, 12, 13
+OP_CKKS_ENCODE, OP_CKKS_DECODE = 14, 15
 TABLES_PLAIN = 2
 
 E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
@@ -322,6 +323,25 @@ class Context:
         ws = self._kg_ws(OP_BFV_DECODE)
         _check(self._lib.hegpu_bfv_decode(self._h, _ptr(plain), _ptr(out), _ptr(ws), ws.numel() * ws.element_size(),
                                           stream if stream is not None else _stream()))
+        return out
+
+    def ckks_encode(self, message, scale, stream=None):
+        """message: device float64 tensor with at most N/2 entries"""
+        import torch
+        plain = torch.empty(self.Q_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_CKKS_ENCODE)
+        _check(self._lib.hegpu_ckks_encode(self._h, _ptr(message), message.numel(), float(scale), _ptr(plain),
+                                           _ptr(ws), ws.numel() * ws.element_size(),
+                                           stream if stream is not None else _stream()))
+        return plain
+
+    def ckks_decode(self, plain, scale, depth=0, stream=None):
+        import torch
+        out = torch.empty(self.n // 2, dtype=torch.float64, device="cuda")
+        ws = self.workspace(OP_CKKS_DECODE, depth, 1)
+        _check(self._lib.hegpu_ckks_decode(self._h, _ptr(plain), depth, float(scale), _ptr(out), _ptr(ws),
+                                           ws.numel() * ws.element_size(),
+                                           stream if stream is not None else _stream()))
         return out
 
     def ckks_decrypt(self, ct, sk, depth=0, stream=None):

@@ -617,6 +617,33 @@ int hegpu_bfv_decode(hegpu_context* ctx, const uint64_t* plain, uint64_t* messag
                    "hegpu_bfv_decode");
 }
 
+int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
+                      void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (message_size < 0 || message_size > (int) (ctx->c.n >> 1))
+        return fail(HEGPU_E_INVALID, "Vector size can not be higher than slot count!"); // ckks/encoder.cuh:74
+    if (!(scale > 0.0)) return fail(HEGPU_E_INVALID, "scale must be positive");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_CKKS_ENCODE, 0, 1))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return hip_ret(op_ckks_encode(ctx->c, message, message_size, scale, (u64*) plain, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_ckks_encode");
+}
+
+int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
+                      size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (depth < 0 || depth >= ctx->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");
+    if (!(scale > 0.0)) return fail(HEGPU_E_INVALID, "scale must be positive");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_CKKS_DECODE, depth, 1))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return hip_ret(op_ckks_decode(ctx->c, (const u64*) plain, depth, scale, message, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_ckks_decode");
+}
+
 // ------------------------------------------------------------------ TFHE
 struct hegpu_tfhe_context {
     TfheDev p{};

@@ -70,6 +70,88 @@ void Context::build_host()
         host["rescaled_last_q_modinv"] = r_inv;
         host["rescaled_half_mod"] = r_half_mod;
         host["rescaled_half"] = r_half;
+        // ---- decoding: CRT composition tables per level (ckks/context.cu:370-421, util.cu:772-888):
+        // for l = Q - depth limbs, Mi[i] = prod_{j != i} q_j and M = prod q_j as l little-endian
+        // 64-bit words, Mi_inv[i] = (Mi[i] mod q_i)^-1, upper_half_threshold = (M + 1) >> 1
+        {
+            auto mul_word = [](std::vector<u64>& big, u64 f) {
+                unsigned __int128 carry = 0;
+                for (u64& w : big) {
+                    unsigned __int128 v = (unsigned __int128) w * f + carry;
+                    w = (u64) v;
+                    carry = v >> 64;
+                }
+                if (carry) big.push_back((u64) carry);
+            };
+            vec Mi, Mi_inv, uht, dmod;
+            for (int d = 0; d < Q; d++) {
+                const int l = Q - d;
+                for (int i = 0; i < l; i++) {
+                    std::vector<u64> big{1};
+                    u64 m = 1;
+                    for (int j = 0; j < l; j++)
+                        if (j != i) {
+                            mul_word(big, primes[j]);
+                            m = mul_mod(m, primes[j] % primes[i], primes[i]);
+                        }
+                    big.resize(l, 0);
+                    Mi.insert(Mi.end(), big.begin(), big.end());
+                    Mi_inv.push_back(inv_mod_prime(m, primes[i]));
+                }
+                std::vector<u64> M{1};
+                for (int j = 0; j < l; j++) mul_word(M, primes[j]);
+                M.resize(l, 0);
+                dmod.insert(dmod.end(), M.begin(), M.end());
+                std::vector<u64> h = M; // (M + 1) >> 1
+                h.push_back(0);
+                for (size_t k = 0; k < h.size(); k++)
+                    if (++h[k]) break;
+                for (size_t k = 0; k + 1 < h.size(); k++) h[k] = (h[k] >> 1) | (h[k + 1] << 63);
+                h.resize(l);
+                uht.insert(uht.end(), h.begin(), h.end());
+            }
+            host["Mi"] = Mi;
+            host["Mi_inv"] = Mi_inv;
+            host["upper_half_threshold"] = uht;
+            host["decryption_modulus"] = dmod;
+        }
+        // ---- encoding: special-FFT roots in the rotation-group order and the slot bit reversal
+        // (ckks/encoder.cu:21-98); doubles stored as bit patterns, (re, im) interleaved
+        {
+            const u64 slots = n >> 1, M = 2 * n;
+            int log_slots = 0;
+            while ((1ull << log_slots) < slots) log_slots++;
+            const double special_root = 2.0 * M_PI / (double) M;
+            std::vector<u64> rot(slots);
+            rot[0] = 1;
+            for (u64 i = 1; i < slots; i++) rot[i] = (5 * rot[i - 1]) % M;
+            vec fr(2 * slots, 0), ir(2 * slots, 0), rev(slots);
+            auto put = [](vec& v, u64 at, double re, double im) {
+                memcpy(&v[2 * at], &re, 8);
+                memcpy(&v[2 * at + 1], &im, 8);
+            };
+            for (int logm = 1; logm <= log_slots; logm++) {
+                const u64 idx_mod = 1ull << (logm + 2), gap = M / idx_mod, offset = 1ull << (logm - 1);
+                for (u64 i = 0; i < offset; i++) {
+                    // two separate libm calls on purpose (volatile keeps the compiler from merging
+                    // them into one sincos, whose last bit may differ): the table must be
+                    // reproducible by any other program calling cos() and sin()
+                    volatile double ang_c = (double) ((rot[i] % idx_mod) * gap) * special_root;
+                    volatile double ang_s = ang_c;
+                    const double cr = cos(ang_c), sr = sin(ang_s);
+                    put(fr, offset + i, cr, sr);
+                    put(ir, offset + i, cr, -sr);
+                }
+            }
+            for (u64 i = 0; i < slots; i++) {
+                u64 r = 0;
+                for (int b = 0; b < log_slots; b++) r |= ((i >> b) & 1) << (log_slots - 1 - b);
+                rev[i] = r;
+            }
+            host["special_fft_roots_table"] = fr;
+            host["special_ifft_roots_table"] = ir;
+            host["reverse_order"] = rev;
+        }
         // modulus-order / polynomial-order tables (ckks/operator.cu:24-56)
         vec ploc, iloc;
         for (int d = 0; d < Q; d++) {
@@ -428,6 +510,12 @@ hipError_t Context::upload()
                                        "base_change_matrix_msk",
                                        "inv_punctured_prod_mod_B_array",
                                        "prod_B_mod_q",
+                                       "Mi",
+                                       "Mi_inv",
+                                       "upper_half_threshold",
+                                       "decryption_modulus",
+                                       "special_fft_roots_table",
+                                       "special_ifft_roots_table",
                                        "coeff_div_plain_modulus",
                                        "Qi_t",
                                        "Qi_gamma",
@@ -442,7 +530,8 @@ hipError_t Context::upload()
         if ((e = to_device(it->second, &d)) != hipSuccess) return e;
         dev[nm] = d;
     }
-    for (const char* nm : {"new_prime_locations", "new_input_locations", "m2_I_j", "m2_I_location", "encoding_location"}) {
+    for (const char* nm : {"new_prime_locations", "new_input_locations", "m2_I_j", "m2_I_location", "encoding_location",
+                           "reverse_order"}) {
         auto it = host.find(nm);
         if (it == host.end()) continue;
         std::vector<int> v(it->second.begin(), it->second.end());

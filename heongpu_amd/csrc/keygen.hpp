@@ -55,4 +55,16 @@ hipError_t kg_bfv_encode_scatter(u64* out, const long long* message, const int* 
                                  int n_power, hipStream_t st);
 hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location, int n_power, hipStream_t st);
 
+// ---- CKKS encoder (encode.hip)
+// special FFT over `1 << log_slots` complex doubles in place; roots: the rotation-group-ordered
+// table; inverse: scaled by `fix`
+hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st);
+hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, hipStream_t st);
+hipError_t en_complex_to_double(const void* in, double* out, int slots, hipStream_t st);
+hipError_t en_conversion(u64* plain, const void* msg, const Mod* mods, int limbs, const int* reverse_order, int n_power,
+                         hipStream_t st);
+hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
+                      const u64* upper_half, const u64* M, int l, double scale, const int* reverse_order, int n_power,
+                      hipStream_t st);
+
 } // namespace hegpu

@@ -81,6 +81,8 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_BFV_ENCRYPT: per = (u64) 5 * Qp * n; break;          // u, e[2], pk*u[2]
         case OP_BFV_DECRYPT: per = (u64) Q * n; break;               // c1*s
         case OP_BFV_DECODE: per = n; break;
+        case OP_CKKS_ENCODE: per = n; break;                         // N/2 complex doubles
+        case OP_CKKS_DECODE: per = (u64) (l + 1) * n; break;         // coefficient-domain copy + complex
         default: return 0;
     }
     return per * (u64) batch;
@@ -545,6 +547,47 @@ hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* 
     a.in = plain; a.out = ws; a.mod_count = 1;
     TRY(ntt_launch(a, 1, false, st));                                                      // :234
     return kg_bfv_decode_gather(message, ws, c.d32("encoding_location"), c.n_power, st);   // :239
+}
+
+static int log2i(u64 v)
+{
+    int r = 0;
+    while ((1ull << r) < v) r++;
+    return r;
+}
+
+hipError_t op_ckks_encode(const Context& c, const double* message, int message_size, double scale, u64* plain,
+                          u64* ws, hipStream_t st)
+{
+    const int slots = (int) (c.n >> 1), Q = c.Q_size;
+    if (message_size < 0 || message_size > slots) return hipErrorInvalidValue;
+    void* cbuf = ws; // slots complex doubles = N words
+    TRY(en_double_to_complex(message, message_size, cbuf, slots, st));                     // :120
+    const double fix = scale / (double) slots;                                             // :127
+    TRY(en_special_fft(cbuf, c.d64("special_ifft_roots_table"), log2i(slots), true, fix, st));
+    TRY(en_conversion(plain, cbuf, c.plan_qp.mods, Q, c.d32("reverse_order"), c.n_power, st)); // :138
+    NttArgs a = c.ntt_args(0);
+    a.in = plain; a.out = plain; a.mod_count = Q;
+    return ntt_launch(a, Q, false, st);                                                    // :153
+}
+
+hipError_t op_ckks_decode(const Context& c, const u64* plain, int depth, double scale, double* message, u64* ws,
+                          hipStream_t st)
+{
+    const int slots = (int) (c.n >> 1), l = c.Q_size - depth;
+    if (l < 1) return hipErrorInvalidValue;
+    u64* coeff = ws;                      // [l][N]
+    void* cbuf = ws + (u64) l * c.n;      // slots complex doubles
+    NttArgs a = c.ntt_args(0);
+    a.in = plain; a.out = coeff; a.mod_count = l;
+    TRY(ntt_launch(a, l, true, st));                                                       // :469
+    int counter = c.Q_size, loc1 = 0, loc2 = 0;                                            // :474-482
+    for (int i = 0; i < depth; i++) { loc1 += counter; loc2 += counter * counter; counter--; }
+    TRY(en_compose(cbuf, coeff, c.plan_qp.mods, c.d64("Mi_inv") + loc1, c.d64("Mi") + loc2,
+                   c.d64("upper_half_threshold") + loc1, c.d64("decryption_modulus") + loc1, l, scale,
+                   c.d32("reverse_order"), c.n_power, st));                                // :485
+    TRY(en_special_fft(cbuf, c.d64("special_fft_roots_table"), log2i(slots), false, 1.0, st)); // :502
+    return en_complex_to_double(cbuf, message, slots, st);                                 // :505
 }
 
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)

@@ -143,7 +143,9 @@ enum {
     HEGPU_OP_CKKS_ENCRYPT = 10,
     HEGPU_OP_BFV_ENCRYPT = 11,
     HEGPU_OP_BFV_DECRYPT = 12,
-    HEGPU_OP_BFV_DECODE = 13
+    HEGPU_OP_BFV_DECODE = 13,
+    HEGPU_OP_CKKS_ENCODE = 14,
+    HEGPU_OP_CKKS_DECODE = 15 /* depth-dependent */
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -226,6 +228,18 @@ int hegpu_bfv_encode(hegpu_context* ctx, const int64_t* message, int message_siz
                      hegpu_stream stream);
 int hegpu_bfv_decode(hegpu_context* ctx, const uint64_t* plain, uint64_t* message, void* ws, size_t ws_bytes,
                      hegpu_stream stream);
+
+/* HEEncoder<CKKS>::encode_ckks / decode_ckks for real vectors (src/lib/host/ckks/encoder.cu:21-160,
+ * 449-513; kernel/encoding.cu:143-392).  The special FFT over the rotation group replaces
+ * gpufft::GPU_Special_FFT (thirdparty/GPU-FFT, unvendored; HEAAN's fftSpecial/fftSpecialInv as the
+ * root tables of encoder.cu:40-90 imply).  message: device doubles, at most N/2 slots (missing
+ * slots are zero); plain [Q - depth][N], NTT domain.  FP64: results agree with the CPU oracle
+ * bit for bit (same operation order, no FMA contraction); the reference's own rounding order
+ * inside GPU-FFT is not known. */
+int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
+                      void* ws, size_t ws_bytes, hegpu_stream stream);
+int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
+                      size_t ws_bytes, hegpu_stream stream);
 
 /* ------------------------------------------------------------------ TFHE
  * Gate bootstrapping on the reference's fixed STD128 set

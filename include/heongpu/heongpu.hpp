@@ -209,6 +209,7 @@ template <Scheme S> class HEContextImpl {
     inline int get_key_modulus_count() const noexcept { return Q_prime_size; }
     inline std::vector<Data64> get_key_modulus() const noexcept { return prime_vector_; }
     inline int get_log_poly_modulus_degree() const noexcept { return n_power; }
+    inline uint64_t get_plain_modulus() const noexcept { return plain_modulus_; }
     hegpu_context* handle() const { return h_; }
 
     int n = 0, n_power = 0, Q_size = 0, P_size = 0, Q_prime_size = 0;
@@ -587,9 +588,11 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
     Secretkey<S>* sk_;
 };
 
-// ------------------------------------------------------------------ encoder (BFV batching)
-template <Scheme S> class HEEncoder { // host/bfv/encoder.cuh
-    static_assert(S == Scheme::BFV, "the CKKS encoder (special FFT + CRT compose) is not built yet (SURVEY.md 8f next-2)");
+// ------------------------------------------------------------------ encoders
+template <Scheme S> class HEEncoder;
+
+template <> class HEEncoder<Scheme::BFV> { // host/bfv/encoder.cuh: batching over the slots of Z_t[X]/(X^N+1)
+    static constexpr Scheme S = Scheme::BFV;
 
   public:
     explicit HEEncoder(HEContext<S> context) : context_(std::move(context))
@@ -633,10 +636,57 @@ template <Scheme S> class HEEncoder { // host/bfv/encoder.cuh
     {
         std::vector<uint64_t> u;
         decode(u, plain, o);
-        const uint64_t t = context_->plain_modulus_;
+        const uint64_t t = context_->get_plain_modulus();
         message.resize(u.size());
-        for (size_t i = 0; i < u.size(); i++) // centred representative, bfv/encoder.cu decode to int64
+        for (size_t i = 0; i < u.size(); i++) // centred representative
             message[i] = u[i] > (t >> 1) ? (int64_t) u[i] - (int64_t) t : (int64_t) u[i];
+    }
+
+  private:
+    HEContext<S> context_;
+};
+
+template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 complex slots, real vectors here
+    static constexpr Scheme S = Scheme::CKKS;
+
+  public:
+    explicit HEEncoder(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+    }
+    inline int slot_count() const noexcept { return context_->n >> 1; }
+
+    void encode(Plaintext<S>& plain, const std::vector<double>& message, double scale,
+                const ExecutionOptions& o = ExecutionOptions())
+    {
+        if ((int) message.size() > slot_count())
+            throw std::invalid_argument("Vector size can not be higher than slot count!"); // ckks/encoder.cuh:74
+        DeviceVector<Data64> msg(message.size() ? message.size() : 1, o.stream_);
+        if (!message.empty())
+            detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(double),
+                                       hipMemcpyHostToDevice, o.stream_));
+        DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
+        DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_ENCODE, 0, 1) + 7) / 8,
+                                o.stream_);
+        detail::check(hegpu_ckks_encode(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
+                                        (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+        plain.memory_set(std::move(out));
+        plain.depth_ = 0;
+        plain.scale_ = scale;
+        plain.plaintext_generated_ = true;
+    }
+    void decode(std::vector<double>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        DeviceVector<Data64> out((size_t) slot_count(), o.stream_);
+        DeviceVector<Data64> ws(
+            (hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_DECODE, plain.depth_, 1) + 7) / 8, o.stream_);
+        detail::check(hegpu_ckks_decode(context_->handle(), (const uint64_t*) plain.data(), plain.depth_, plain.scale_,
+                                        (double*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        message.resize(slot_count());
+        detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                   o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
     }
 
   private:

@@ -87,6 +87,8 @@ def lib():
     L.o_bfv_encrypt.argtypes = [vp, vp, vp, vp, vp]
     L.o_bfv_decrypt.argtypes = [vp, vp, vp, vp]
     L.o_bfv_encode.argtypes = [vp, vp, ci, vp]
+    L.o_ckks_encode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
+    L.o_ckks_decode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_bfv_decode.argtypes = [vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
@@ -265,6 +267,17 @@ class OracleContext:
     def bfv_decode(self, plain):
         out = np.zeros(self.n, dtype=np.uint64)
         self.L.o_bfv_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), _p(out))
+        return out
+
+    def ckks_encode(self, message, scale):
+        m = np.ascontiguousarray(message, dtype=np.float64)
+        plain = np.zeros(self.Q * self.n, dtype=np.uint64)
+        self.L.o_ckks_encode(self.h, _p(m), len(m), float(scale), _p(plain))
+        return plain
+
+    def ckks_decode(self, plain, scale, depth=0):
+        out = np.zeros(self.n // 2, dtype=np.float64)
+        self.L.o_ckks_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), depth, float(scale), _p(out))
         return out
 
     # key-switching method II (P_size > 1)

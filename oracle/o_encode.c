@@ -1,0 +1,216 @@
+/*
+ * o_encode.c -- CPU restatement of the CKKS encoder / decoder for real vectors
+ * (SURVEY.md 8f next-2).  TEST INFRASTRUCTURE ONLY (see hegpu_oracle.h).
+ *
+ * Follows src/lib/host/ckks/encoder.cu:21-160, 449-513 and src/lib/kernel/encoding.cu:143-392.
+ * The special FFT itself lives in the unvendored thirdparty/GPU-FFT (.gitmodules); its
+ * algorithm is the one the root tables of encoder.cu:40-90 are built for -- HEAAN's
+ * fftSpecial / fftSpecialInv over the rotation group 5^j -- restated here from that
+ * definition.  PARITY UNPINNED against the reference (floating-point operation order inside
+ * GPU-FFT is unknown); pinned by what encoding means (tests/test_oracle_encode.py: decode
+ * inverts encode, polynomial product = slot-wise product, X -> X^5 rotates the slots).
+ */
+#include "hegpu_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { double re, im; } cx;
+
+static void tables(const octx_t* c, cx* fwd, cx* inv, int* rev, int* log_slots_out)
+{
+    const u64 slots = c->n >> 1, M = 2 * c->n;
+    int log_slots = 0;
+    while ((1ull << log_slots) < slots) log_slots++;
+    const double special_root = 2.0 * M_PI / (double) M;
+    u64* rot = (u64*) malloc(sizeof(u64) * slots);
+    rot[0] = 1;
+    for (u64 i = 1; i < slots; i++) rot[i] = (5 * rot[i - 1]) % M;
+    memset(fwd, 0, sizeof(cx) * slots);
+    memset(inv, 0, sizeof(cx) * slots);
+    for (int logm = 1; logm <= log_slots; logm++) {
+        const u64 idx_mod = 1ull << (logm + 2), gap = M / idx_mod, offset = 1ull << (logm - 1);
+        for (u64 i = 0; i < offset; i++) {
+            /* separate cos() and sin() calls (volatile: no merging into sincos) */
+            volatile double ang_c = (double) ((rot[i] % idx_mod) * gap) * special_root;
+            volatile double ang_s = ang_c;
+            const double cr = cos(ang_c), sr = sin(ang_s);
+            fwd[offset + i].re = cr; fwd[offset + i].im = sr;
+            inv[offset + i].re = cr; inv[offset + i].im = -sr;
+        }
+    }
+    for (u64 i = 0; i < slots; i++) {
+        u64 r = 0;
+        for (int b = 0; b < log_slots; b++) r |= ((i >> b) & 1) << (log_slots - 1 - b);
+        rev[i] = (int) r;
+    }
+    free(rot);
+    *log_slots_out = log_slots;
+}
+
+/* fftSpecialInv without its bit reversal (the conversion kernel reads through reverse_order) */
+static void special_ifft(cx* v, const cx* roots, u64 slots, double fix)
+{
+    for (u64 lenh = slots >> 1; lenh >= 1; lenh >>= 1) {
+        for (u64 i = 0; i < slots; i += 2 * lenh)
+            for (u64 j = 0; j < lenh; j++) {
+                cx a = v[i + j], b = v[i + j + lenh], w = roots[lenh + j];
+                cx d = { a.re - b.re, a.im - b.im };
+                v[i + j].re = a.re + b.re; v[i + j].im = a.im + b.im;
+                v[i + j + lenh].re = d.re * w.re - d.im * w.im;
+                v[i + j + lenh].im = d.re * w.im + d.im * w.re;
+            }
+        if (lenh == 1) break;
+    }
+    for (u64 i = 0; i < slots; i++) { v[i].re = v[i].re * fix; v[i].im = v[i].im * fix; }
+}
+
+/* fftSpecial on bit-reversed input */
+static void special_fft(cx* v, const cx* roots, u64 slots)
+{
+    for (u64 lenh = 1; lenh < slots; lenh <<= 1)
+        for (u64 i = 0; i < slots; i += 2 * lenh)
+            for (u64 j = 0; j < lenh; j++) {
+                cx a = v[i + j], b = v[i + j + lenh], w = roots[lenh + j];
+                cx bw = { b.re * w.re - b.im * w.im, b.re * w.im + b.im * w.re };
+                v[i + j].re = a.re + bw.re; v[i + j].im = a.im + bw.im;
+                v[i + j + lenh].re = a.re - bw.re; v[i + j + lenh].im = a.im - bw.im;
+            }
+}
+
+/* encode_kernel_ckks_conversion, one component (encoding.cu:176-201) */
+static void store_rns(const octx_t* c, u64* plain, u64 at, double value, int limbs)
+{
+    double v = round(value);
+    int neg = signbit(v) != 0;
+    v = fabs(v);
+    const double two64 = 18446744073709551616.0;
+    u64 lo = (u64) fmod(v, two64), hi = (u64) (v / two64);
+    u128 wide = ((u128) hi << 64) | lo;
+    for (int i = 0; i < limbs; i++) {
+        u64 r = (u64) (wide % c->mod[i].value);
+        plain[at + ((u64) i << c->n_power)] = neg ? o_sub(c->mod[i].value, r, &c->mod[i]) : r;
+    }
+}
+
+/* HEEncoder<CKKS>::encode_ckks(vector<double>) (ckks/encoder.cu:100-160); plain [Q][N] NTT domain */
+void o_ckks_encode(const octx_t* c, const double* message, int message_size, double scale, u64* plain)
+{
+    const u64 slots = c->n >> 1;
+    cx* fwd = (cx*) malloc(sizeof(cx) * slots);
+    cx* inv = (cx*) malloc(sizeof(cx) * slots);
+    int* rev = (int*) malloc(sizeof(int) * slots);
+    cx* v = (cx*) malloc(sizeof(cx) * slots);
+    int log_slots;
+    tables(c, fwd, inv, rev, &log_slots);
+    for (u64 i = 0; i < slots; i++) { v[i].re = (int) i < message_size ? message[i] : 0.0; v[i].im = 0.0; }
+    special_ifft(v, inv, slots, scale / (double) slots);
+    for (u64 idx = 0; idx < slots; idx++) {
+        cx z = v[rev[idx]];
+        store_rns(c, plain, idx, z.re, c->Q_size);
+        store_rns(c, plain, idx + slots, z.im, c->Q_size);
+    }
+    o_gpu_ntt(plain, plain, c->ntt_table, c->mod, c->n_power, c->Q_size, c->Q_size);
+    free(fwd); free(inv); free(rev); free(v);
+}
+
+/* one coefficient of encode_kernel_compose (encoding.cu:246-312): CRT composition with
+ * little-endian 64-bit words, then the word-wise conversion to double */
+static double compose_one(const octx_t* c, const u64* coeff, u64 at, int l, const u64* Mi, const u64* Mi_inv,
+                          const u64* M, const u64* half, double inv_scale)
+{
+    u64 acc[O_MAX_MOD];
+    memset(acc, 0, sizeof(u64) * l);
+    for (int i = 0; i < l; i++) {
+        u64 t = o_mult(coeff[at + ((u64) i << c->n_power)], Mi_inv[i], &c->mod[i]);
+        u128 carry = 0;
+        for (int k = 0; k < l; k++) {
+            u128 v = (u128) Mi[(u64) i * l + k] * t + acc[k] + carry;
+            acc[k] = (u64) v;
+            carry = v >> 64;
+        }
+        int geq = 1;
+        for (int k = l - 1; k >= 0; k--)
+            if (acc[k] != M[k]) { geq = acc[k] > M[k]; break; }
+        if (geq) {
+            u64 borrow = 0;
+            for (int k = 0; k < l; k++) {
+                u128 d = (u128) acc[k] - M[k] - borrow;
+                acc[k] = (u64) d;
+                borrow = (u64) (d >> 64) & 1;
+            }
+        }
+    }
+    int neg = 1;
+    for (int k = l - 1; k >= 0; k--)
+        if (acc[k] != half[k]) { neg = acc[k] > half[k]; break; }
+    const double two64 = 18446744073709551616.0;
+    double result = 0.0, w = inv_scale;
+    for (int j = 0; j < l; j++, w *= two64) {
+        if (neg) {
+            if (acc[j] > M[j]) { u64 d = acc[j] - M[j]; result += d ? (double) d * w : 0.0; }
+            else { u64 d = M[j] - acc[j]; result -= d ? (double) d * w : 0.0; }
+        } else {
+            result += acc[j] ? (double) acc[j] * w : 0.0;
+        }
+    }
+    return result;
+}
+
+/* HEEncoder<CKKS>::decode_ckks(vector<double>) (ckks/encoder.cu:449-513); plain [Q - depth][N] */
+void o_ckks_decode(const octx_t* c, const u64* plain, int depth, double scale, double* message)
+{
+    const int l = c->Q_size - depth, np = c->n_power;
+    const u64 slots = c->n >> 1;
+    u64* coeff = (u64*) malloc(sizeof(u64) * ((u64) l << np));
+    o_gpu_intt(plain, coeff, c->intt_table, c->mod, c->n_inv, np, l, l);
+    /* level tables (ckks/context.cu:370-421 via util.cu:772-888) */
+    u64* Mi = (u64*) calloc((size_t) l * l, sizeof(u64));
+    u64 Mi_inv[O_MAX_MOD], M[O_MAX_MOD + 1], half[O_MAX_MOD + 1];
+    for (int i = 0; i <= l; i++) {   /* i == l: the full product */
+        u64 big[O_MAX_MOD + 1];
+        memset(big, 0, sizeof(big));
+        big[0] = 1;
+        u64 m = 1;
+        for (int j = 0; j < l; j++) {
+            if (j == i) continue;
+            u128 carry = 0;
+            for (int k = 0; k <= l; k++) {
+                u128 v = (u128) big[k] * c->mod[j].value + carry;
+                big[k] = (u64) v;
+                carry = v >> 64;
+            }
+            if (i < l) m = o_mult(m, c->mod[j].value % c->mod[i].value, &c->mod[i]);
+        }
+        if (i < l) {
+            memcpy(Mi + (size_t) i * l, big, sizeof(u64) * l);
+            Mi_inv[i] = o_modinv(m, &c->mod[i]);
+        } else {
+            memcpy(M, big, sizeof(u64) * (l + 1));
+        }
+    }
+    { /* (M + 1) >> 1 */
+        u64 t[O_MAX_MOD + 2];
+        memcpy(t, M, sizeof(u64) * (l + 1));
+        t[l + 1] = 0;
+        for (int k = 0; k <= l; k++) if (++t[k]) break;
+        for (int k = 0; k <= l; k++) half[k] = (t[k] >> 1) | (t[k + 1] << 63);
+    }
+    cx* fwd = (cx*) malloc(sizeof(cx) * slots);
+    cx* inv = (cx*) malloc(sizeof(cx) * slots);
+    int* rev = (int*) malloc(sizeof(int) * slots);
+    cx* v = (cx*) malloc(sizeof(cx) * slots);
+    int log_slots;
+    tables(c, fwd, inv, rev, &log_slots);
+    const double inv_scale = 1.0 / scale;
+    for (u64 idx = 0; idx < slots; idx++) {
+        cx z;
+        z.re = compose_one(c, coeff, idx, l, Mi, Mi_inv, M, half, inv_scale);
+        z.im = compose_one(c, coeff, idx + slots, l, Mi, Mi_inv, M, half, inv_scale);
+        v[rev[idx]] = z;
+    }
+    special_fft(v, fwd, slots);
+    for (u64 i = 0; i < slots; i++) message[i] = v[i].re;
+    free(coeff); free(Mi); free(fwd); free(inv); free(rev); free(v);
+}

@@ -4,6 +4,7 @@
 // oracle (test infrastructure).  Runs on the GPU box (pytest -m gpu wrapper).
 #include <heongpu/heongpu.hpp>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -330,6 +331,54 @@ static void bfv_pipeline()
     EXPECT(ok, "bfv slots: rotate_rows(1) shifts both rows left by one");
 }
 
+// the reference's basic CKKS example flow (example/basic/4_basic_ckks.cpp) through the class layer
+static void ckks_encoder_flow()
+{
+    constexpr auto S = Scheme::CKKS;
+    const size_t n = 8192;
+    HEContext<S> ctx = GenHEContext<S>(sec_level_type::none);
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_bit_sizes({60, 40, 40, 40}, {60});
+    ctx->generate();
+    HEKeyGenerator<S> keygen(ctx, 3);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk(ctx);
+    keygen.generate_relin_key(rk, sk);
+    Galoiskey<S> gk(ctx, std::vector<int>{1});
+    keygen.generate_galois_key(gk, sk);
+    HEEncoder<S> encoder(ctx);
+    HEEncryptor<S> enc(ctx, pk, 4);
+    HEDecryptor<S> dec(ctx, sk);
+    HEArithmeticOperator<S> op(ctx);
+    const int slots = encoder.slot_count();
+    const double scale = std::pow(2.0, 40);
+    std::vector<double> x(slots), y(slots), got;
+    for (int i = 0; i < slots; i++) { x[i] = 0.001 * i - 2.0; y[i] = 3.0 - 0.0005 * i; }
+    Plaintext<S> px(ctx), py(ctx), pr(ctx);
+    encoder.encode(px, x, scale);
+    encoder.encode(py, y, scale);
+    Ciphertext<S> cx(ctx), cy(ctx), cr(ctx);
+    enc.encrypt(cx, px);
+    enc.encrypt(cy, py);
+    op.multiply_inplace(cx, cy);
+    op.relinearize_inplace(cx, rk);
+    op.rescale_inplace(cx);
+    dec.decrypt(pr, cx);
+    encoder.decode(got, pr);
+    double e = 0;
+    for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - x[i] * y[i]));
+    EXPECT(e < 1e-5, "ckks: decode(decrypt(rescale(relin(enc(x) * enc(y))))) = x .* y");
+    op.rotate_rows(cy, cr, gk, 1);
+    dec.decrypt(pr, cr);
+    encoder.decode(got, pr);
+    e = 0;
+    for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - y[(i + 1) % slots]));
+    EXPECT(e < 1e-6, "ckks: rotate_rows(1) shifts the slots left by one");
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -347,6 +396,7 @@ int main()
     bfv();
     ckks_pipeline();
     bfv_pipeline();
+    ckks_encoder_flow();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }

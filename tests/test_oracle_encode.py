@@ -1,0 +1,75 @@
+"""The oracle's CKKS encoder restatement (oracle/o_encode.c) pinned by what encoding means:
+decode inverts encode, the product of two encoded polynomials decodes to the slot-wise
+product, and the automorphism X -> X^5 rotates the slots by one (the reference's
+rotate_rows semantics, ckks/evaluationkey.cu:408)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from he_math import RLWE
+
+
+@pytest.fixture(scope="module")
+def ctx(oracle):
+    n_power = 11
+    arr = (ctypes.c_int * 4)(50, 40, 40, 50)
+    out = (ctypes.c_uint64 * 4)()
+    assert oracle.lib().o_generate_primes(1 << n_power, arr, 4, out) == 0
+    primes = [int(v) for v in out]
+    return oracle.OracleContext(oracle.CKKS, n_power, primes, 3, 1), primes
+
+
+def test_decode_inverts_encode(ctx):
+    o, primes = ctx
+    slots = o.n // 2
+    g = np.random.default_rng(1)
+    x = g.uniform(-10, 10, slots)
+    scale = 2.0 ** 40
+    plain = o.ckks_encode(x, scale)
+    assert np.max(np.abs(o.ckks_decode(plain, scale) - x)) < 1e-7
+    # short message: the missing slots are zero
+    y = o.ckks_decode(o.ckks_encode(x[:5], scale), scale)
+    assert np.max(np.abs(y[:5] - x[:5])) < 1e-7 and np.max(np.abs(y[5:])) < 1e-7
+    # lower level: the first l limbs of the same plaintext
+    l = o.Q - 1
+    sub = plain.reshape(o.Q, o.n)[:l].reshape(-1)
+    assert np.max(np.abs(o.ckks_decode(sub, scale, depth=1) - x)) < 1e-7
+
+
+def test_polynomial_product_is_slotwise_product(ctx):
+    o, primes = ctx
+    slots = o.n // 2
+    g = np.random.default_rng(2)
+    x, y = g.uniform(-4, 4, slots), g.uniform(-4, 4, slots)
+    scale = 2.0 ** 30
+    px = o.ckks_encode(x, scale).reshape(o.Q, o.n)
+    py = o.ckks_encode(y, scale).reshape(o.Q, o.n)
+    prod = np.stack([np.array([(int(a) * int(b)) % primes[j] for a, b in zip(px[j], py[j])], dtype=np.uint64)
+                     for j in range(o.Q)]).reshape(-1)
+    got = o.ckks_decode(prod, scale * scale)
+    assert np.max(np.abs(got - x * y)) < 1e-5
+
+
+def test_galois_5_rotates_slots(ctx):
+    o, primes = ctx
+    n, slots = o.n, o.n // 2
+    he = RLWE(o, seed=0)
+    g = np.random.default_rng(3)
+    x = g.uniform(-4, 4, slots)
+    scale = 2.0 ** 40
+    plain = o.ckks_encode(x, scale).reshape(o.Q, n)
+    ids = list(range(o.Q))
+    coeff = he.ntt_limbs(plain, ids, inverse=True)
+    rot = np.zeros_like(coeff)
+    for j in ids:
+        q = primes[j]
+        for i in range(n):
+            r = (i * 5) % (2 * n)
+            if r >= n:
+                rot[j][r - n] = (q - int(coeff[j][i])) % q
+            else:
+                rot[j][r] = coeff[j][i]
+    back = he.ntt_limbs(rot, ids).reshape(-1)
+    got = o.ckks_decode(back, scale)
+    assert np.max(np.abs(got - np.roll(x, -1))) < 1e-7
