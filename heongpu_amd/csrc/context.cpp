@@ -485,6 +485,7 @@ hipError_t Context::upload()
 {
     if (uploaded) return hipSuccess;
     if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0');
+    if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)
         gauss_cdt.t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);

@@ -53,6 +53,7 @@ struct Context {
     int m2_width = 0; // digit width m: 2 for BFV, P_size for CKKS
     // use the fused "row pass + key-switch MAC" kernel (HEGPU_FUSED_ROW_MAC=0 disables)
     bool fused_row_mac = true;
+    bool fused_moddown = true; // HEGPU_FUSED_MODDOWN=0: separate stage-two kernel
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 
     // ---- device state (valid after upload())

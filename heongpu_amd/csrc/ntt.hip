@@ -286,6 +286,7 @@ struct PolySel {
     u64 in_off, out_off; // element offsets of this polynomial
     int mod;             // modulus index into the plan
     int digit;           // RNS digit of a decomposing launch (else -1)
+    int item, j;         // ciphertext of the batch, polynomial index inside it
 };
 
 __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
@@ -313,9 +314,11 @@ __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
     s.mod = a.mod_offset + k;
     u64 slot = a.poly_order ? (u64) a.poly_order[j] : (u64) j;
     s.digit = a.decomp_mods ? j / a.decomp_mods : -1;
-    u64 in_slot = a.decomp_mods ? (u64) s.digit : slot;
+    u64 in_slot = a.decomp_mods ? (u64) s.digit * (a.decomp_in_mul ? a.decomp_in_mul : 1) + a.decomp_in_add : slot;
     s.in_off = (u64) item * a.in_item_stride + (in_slot << a.n_power);
     s.out_off = (u64) item * a.out_item_stride + (slot << a.n_power);
+    s.item = item;
+    s.j = j;
     return s;
 }
 
@@ -361,6 +364,15 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     const u64* __restrict__ src = a.in + ps.in_off + blockIdx.x * CT;
     u64* __restrict__ dst = a.out + ps.out_off + blockIdx.x * CT;
 
+    // half_on (mod-down stage one as a load transform): exact residue, the butterflies' input
+    // range does not cover v + q - half_mod for a 60-bit source modulus
+    const u64 half_qP = a.half_on ? a.mods[a.half_src_mod].q : 0;
+    const u64 half_hm = a.half_on ? a.half_mod[ps.mod] : 0;
+    auto ld = [&](const u64* p) -> u64 {
+        u64 v = gld(p);
+        if (DECOMP && a.half_on) v = sub_mod(reduce64(add_mod(v, a.half, half_qP), md), half_hm, md.q);
+        return v;
+    };
     u64 x[16];
     const int col = t % CT, r1 = t / CT;
     if constexpr (NSA > 0) {
@@ -371,7 +383,7 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
             const int c = L % CT, rb = L / CT;
             u64 y[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = gld(&src[(u64) (rb + 16 * k) * 256 + c]);
+            for (int k = 0; k < RA; k++) y[k] = ld(&src[(u64) (rb + 16 * k) * 256 + c]);
             // DECOMP: the digit (< 2^60, a residue of another prime) is NOT reduced
             // first: the lazy butterflies only need x < 8q (q >= 2^57 here) or, on
             // the correction-free path, x + 64q < 2^64; congruence mod q is kept
@@ -385,7 +397,7 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
         for (int k = 0; k < 16; k++) x[k] = lds[col_phys((16 * r1 + k) * CT + col)];
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = gld(&src[(u64) k * 256 + col]);
+        for (int k = 0; k < 16; k++) x[k] = ld(&src[(u64) k * 256 + col]);
     }
     ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
@@ -417,11 +429,17 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
         c32 = (double) reduce64(1ull << 32, md);
         c32i = c32 * fc.qi;
     }
+    const u64 half_qP = (DECOMP && a.half_on) ? a.mods[a.half_src_mod].q : 0;
+    const double half_hm = (DECOMP && a.half_on) ? fp_from_u64(a.half_mod[ps.mod]) : 0.0;
     auto load = [&](const u64* p) -> double {
-        const u64 v = *p;
-        if constexpr (DECOMP && WIDE) return fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
-        else if constexpr (DECOMP) return fp_reduce(fp_from_u64(v), fc);
-        else return fp_from_u64(v);
+        u64 v = *p;
+        if (DECOMP && a.half_on) v = add_mod(v, a.half, half_qP);
+        double r;
+        if constexpr (DECOMP && WIDE) r = fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
+        else if constexpr (DECOMP) r = fp_reduce(fp_from_u64(v), fc);
+        else r = fp_from_u64(v);
+        if (DECOMP && a.half_on) r = fp_reduce(r - half_hm, fc);
+        return r;
     };
 
     double x[16];
@@ -458,10 +476,29 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.fp) {
-        if (DECOMP && a.mods[ps.digit].bit > 52) fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds);
+        if (DECOMP && a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52)
+            fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds);
         else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds);
     } else if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
+}
+
+// Store of the forward row pass: plain, or through the mod-down epilogue (NttEpilogue).
+// `e` = element offset inside the limb; x canonical.
+__device__ __forceinline__ void row_store(const NttArgs& a, const PolySel& ps, const Mod& md, u64* __restrict__ p, u64 e,
+                                          u64 x)
+{
+    if (!a.epi.on) {
+        gst(&p[e], x);
+        return;
+    }
+    const NttEpilogue& ep = a.epi;
+    const int part = ps.j / ep.limbs, limb = ps.j - part * ep.limbs;
+    const u64 ks = ep.ks[ep.ks_item_stride * ps.item + ((u64) (part * ep.ks_part_limbs + limb) << a.n_power) + e];
+    const u64 off = ((u64) (part * ep.limbs + limb) << a.n_power) + e;
+    u64 r = mul_barrett(sub_mod(ks, x, md.q), ep.inv[ps.mod], md);
+    if (ep.ct) r = add_mod(ep.ct[ep.ct_item_stride * ps.item + off], r, md.q);
+    ep.out[ep.out_item_stride * ps.item + off] = r;
 }
 
 // Row pass: stages S1..S1+7 on contiguous rows of 256, 16 rows per block.
@@ -513,7 +550,9 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
             make_ulonglong2(x[2 * k], x[2 * k + 1]);
     wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 16; k++) gst(&p[row * 256 + i0 + 16 * k], lds[row_phys(row * 256 + i0 + 16 * k)]);
+    for (int k = 0; k < 16; k++)
+        row_store(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0 + 16 * k,
+                  lds[row_phys(row * 256 + i0 + 16 * k)]);
 #endif
 }
 
@@ -549,7 +588,9 @@ __device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel&
             make_ulonglong2(fp_to_u64(x[2 * k]), fp_to_u64(x[2 * k + 1]));
     wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 16; k++) p[row * 256 + i0 + 16 * k] = lds[row_phys(row * 256 + i0 + 16 * k)];
+    for (int k = 0; k < 16; k++)
+        row_store(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0 + 16 * k,
+                  lds[row_phys(row * 256 + i0 + 16 * k)]);
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)

@@ -8,6 +8,24 @@ namespace hegpu {
 // Arguments of one batched transform.  Mirrors what the reference hands to
 // gpuntt:: (table/modulus pointers + ntt_rns_configuration + batch,mod_count
 // [+ order]); see include/hegpu.h for the file:line citations.
+// Optional epilogue of the forward row pass: instead of storing the transformed limb x the
+// kernel writes (ks - x) * inv[modulus] + ct -- the second stage of the leveled mod-down
+// (divide_round_lastq_leveled_stage_two_kernel, reference switchkey.cu:707-771) fused into the
+// transform that produces its operand.  Polynomial j of an item is (part = j / limbs,
+// limb = j % limbs); ks/ct/out are [part][*][N] per item.
+struct NttEpilogue {
+    const u64* ks;      // accumulated key-switch result, limb at ((part * ks_part_limbs + limb) << n_power)
+    u64 ks_item_stride;
+    int ks_part_limbs;
+    const u64* ct;      // added term (NULL: none), limb at ((part * limbs + limb) << n_power); may alias out
+    u64 ct_item_stride;
+    u64* out;           // same layout as ct
+    u64 out_item_stride;
+    const u64* inv;     // per-modulus P^-1
+    int limbs;
+    int on;
+};
+
 struct NttArgs {
     const u64* in;            // batch polynomials (or base for poly_order)
     u64* out;                 // may equal in
@@ -49,6 +67,16 @@ struct NttArgs {
     // (all polynomials of one modulus back to back) so that concurrently
     // running workgroups share one modulus' twiddle table in L2.
     int group_span; // polynomials per modulus class = batch / mod_count
+    NttEpilogue epi; // forward only, needs polys_per_item
+    // Decomposing launches read digit d from input slot d * decomp_in_mul + decomp_in_add
+    // (0 means 1 / 0).  half_on: the loaded residue v of modulus `half_src_mod` becomes
+    // ((v + half) mod that modulus) mod q_j - half_mod[j] -- the first stage of the leveled
+    // mod-down (divide_round_lastq_leveled_stage_one_kernel, switchkey.cu:678-705) as the load
+    // transform of the NTT that follows it.
+    int decomp_in_mul, decomp_in_add;
+    int half_on, half_src_mod;
+    u64 half;
+    const u64* half_mod;
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

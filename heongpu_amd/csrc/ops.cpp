@@ -131,13 +131,27 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.poly_order = c.d32("new_input_locations") + 2 * depth;
     TRY(ntt_launch(a, 2 * batch, true, st));
     // stage one: P limb (+half) reduced into every q_j               (:1003)
-    TRY(rns_moddown_stage_one(temp2, per, temp1, per, mods, c.d64("half"), c.d64("half_mod"), np, Q, l, batch, st));
-    // forward NTT of that                                            (:1011)
+    if (!c.fused_moddown)
+        TRY(rns_moddown_stage_one(temp2, per, temp1, per, mods, c.d64("half"), c.d64("half_mod"), np, Q, l, batch,
+                                  st));
+    // forward NTT of that (:1011) with stage one as its load transform and stage two -- (x - last) * P^-1 + ct, written over ct
+    // parts 0,1 (:1015) -- as the epilogue of its row pass
     a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = a.out_item_stride = per;
+    if (c.fused_moddown) {
+        // input: the P limb (slot l) of each of the two parts of temp2 [2][l+1][N]
+        a.in = temp2; a.decomp_mods = l; a.decomp_in_mul = l + 1; a.decomp_in_add = l;
+        a.half_on = 1; a.half_src_mod = Q; a.half = c.h64("half")[0]; a.half_mod = c.d64("half_mod");
+        a.epi.on = 1;
+        a.epi.ks = temp2; a.epi.ks_item_stride = per; a.epi.ks_part_limbs = l + 1;
+        a.epi.ct = ct; a.epi.ct_item_stride = cs;
+        a.epi.out = ct; a.epi.out_item_stride = cs;
+        a.epi.inv = c.d64("last_q_modinv");
+        a.epi.limbs = l;
+        return ntt_launch(a, 2 * l * batch, false, st);
+    }
     TRY(ntt_launch(a, 2 * l * batch, false, st));
-    // stage two: (x - last) * P^-1 + ct, written over ct parts 0,1   (:1015)
     return rns_moddown_stage_two(temp1, per, temp2, per, l + 1, ct, cs, ct, cs, mods, c.d64("last_q_modinv"), np, l,
                                  1, batch, st);
 }
@@ -161,6 +175,25 @@ hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int bat
     a.in_item_stride = a.out_item_stride = cs;
     a.poly_order = c.d32("new_input_locations") + (depth + P) * 2;
     TRY(ntt_launch(a, 2 * batch, true, st));                                               // :1197
+    if (c.fused_moddown) {
+        // stage one (:1205) as the load transform and stage two (:1225) as the row-pass epilogue
+        // of the forward NTT (:1214); the copy of the kept limbs (:1219) comes first because the
+        // epilogue writes the compacted ciphertext over them
+        TRY(rns_copy_limbs(ct, (u64) l * n, cs, temp2, (u64) l * n, per, np, l - 1, 2, batch, st));
+        a = c.ntt_args(0);
+        a.in = ct; a.out = temp1; a.mod_count = l - 1; a.polys_per_item = 2 * (l - 1);
+        a.in_item_stride = cs; a.out_item_stride = per;
+        a.decomp_mods = l - 1; a.decomp_in_mul = l; a.decomp_in_add = l - 1;
+        a.half_on = 1; a.half_src_mod = l - 1; a.half = c.h64("rescaled_half")[depth];
+        a.half_mod = c.d64("rescaled_half_mod") + location;
+        a.epi.on = 1;
+        a.epi.ks = temp2; a.epi.ks_item_stride = per; a.epi.ks_part_limbs = l;
+        a.epi.ct = nullptr; a.epi.ct_item_stride = 0;
+        a.epi.out = ct; a.epi.out_item_stride = cs;
+        a.epi.inv = c.d64("rescaled_last_q_modinv") + location;
+        a.epi.limbs = l - 1;
+        return ntt_launch(a, 2 * (l - 1) * batch, false, st);
+    }
     TRY(rns_moddown_stage_one(ct, cs, temp1, per, mods, c.d64("rescaled_half") + depth,
                               c.d64("rescaled_half_mod") + location, np, l - 1, l - 1, batch, st)); // :1205
     a = c.ntt_args(0);
