@@ -18,10 +18,17 @@
 // Header-only; link against heongpu_amd/lib/libhegpu.so and the HIP runtime.
 #pragma once
 #include "../hegpu.h"
+#if defined(HEONGPU_WITH_ZLIB)
+#include <zlib.h> // serializer::compress / decompress (reference util/serializer.cpp)
+#endif
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <fstream>
+#include <istream>
 #include <map>
+#include <ostream>
+#include <sstream>
 #include <random>
 #include <memory>
 #include <stdexcept>
@@ -294,6 +301,73 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         scale_ = scale;
         ciphertext_generated_ = true;
         relinearization_required_ = cipher_size == 3;
+    }
+
+    // Wire format of the reference, field for field (ckks/ciphertext.cu:171-300,
+    // bfv/ciphertext.cu:165-290): scheme (u8), ring size, modulus count, size [, depth] (int),
+    // ntt flag (bool), storage (u8) [, scale (double), encoding (u8), rescale flag (bool)],
+    // relinearization flag, generated flag (bool), element count (u32), residues (u64).
+    void save(std::ostream& os) const
+    {
+        if (!ciphertext_generated_) throw std::runtime_error("Ciphertext is not generated so can not be serialized!");
+        const std::uint8_t scheme = (std::uint8_t) S, storage = (std::uint8_t) storage_type::DEVICE, enc = 0;
+        os.write((const char*) &scheme, 1);
+        os.write((const char*) &ring_size_, sizeof(int));
+        os.write((const char*) &coeff_modulus_count_, sizeof(int));
+        os.write((const char*) &cipher_size_, sizeof(int));
+        if (S == Scheme::CKKS) os.write((const char*) &depth_, sizeof(int));
+        os.write((const char*) &in_ntt_domain_, sizeof(bool));
+        os.write((const char*) &storage, 1);
+        if (S == Scheme::CKKS) {
+            os.write((const char*) &scale_, sizeof(double));
+            os.write((const char*) &enc, 1);
+            os.write((const char*) &rescale_required_, sizeof(bool));
+        }
+        os.write((const char*) &relinearization_required_, sizeof(bool));
+        os.write((const char*) &ciphertext_generated_, sizeof(bool));
+        const std::uint32_t count = (std::uint32_t) ((size_t) cipher_size_ * (coeff_modulus_count_ - depth_) * ring_size_);
+        std::vector<Data64> host;
+        get_data(host, device_locations_.stream());
+        if (host.size() < count) throw std::runtime_error("Ciphertext memory is smaller than its description!");
+        os.write((const char*) &count, sizeof(count));
+        os.write((const char*) host.data(), sizeof(Data64) * count);
+    }
+    void load(std::istream& is)
+    {
+        if (ciphertext_generated_) throw std::runtime_error("Ciphertext has been already exist!");
+        std::uint8_t scheme = 0, storage = 0, enc = 0;
+        is.read((char*) &scheme, 1);
+        if (scheme != (std::uint8_t) S) throw std::runtime_error("Invalid scheme binary!");
+        int ring = 0, count_mod = 0;
+        is.read((char*) &ring, sizeof(int));
+        is.read((char*) &count_mod, sizeof(int));
+        if (ring != ring_size_ || count_mod != coeff_modulus_count_)
+            throw std::runtime_error("Ciphertext binary does not match the context!");
+        is.read((char*) &cipher_size_, sizeof(int));
+        depth_ = 0;
+        if (S == Scheme::CKKS) is.read((char*) &depth_, sizeof(int));
+        is.read((char*) &in_ntt_domain_, sizeof(bool));
+        is.read((char*) &storage, 1);
+        if (S == Scheme::CKKS) {
+            is.read((char*) &scale_, sizeof(double));
+            is.read((char*) &enc, 1);
+            is.read((char*) &rescale_required_, sizeof(bool));
+        }
+        is.read((char*) &relinearization_required_, sizeof(bool));
+        bool generated = false;
+        is.read((char*) &generated, sizeof(bool));
+        std::uint32_t count = 0;
+        is.read((char*) &count, sizeof(count));
+        if (!is || depth_ < 0 || depth_ >= coeff_modulus_count_ ||
+            count != (std::uint32_t) ((size_t) cipher_size_ * ring_size_ * (coeff_modulus_count_ - depth_)))
+            throw std::runtime_error("Ciphertext size is not correct!");
+        std::vector<Data64> host(count);
+        is.read((char*) host.data(), sizeof(Data64) * count);
+        if (!is) throw std::runtime_error("Ciphertext binary is truncated!");
+        device_locations_ = DeviceVector<Data64>(host, device_locations_.stream());
+        detail::hip(hipStreamSynchronize(device_locations_.stream()));
+        storage_type_ = storage_type::DEVICE;
+        ciphertext_generated_ = true;
     }
 
   private:
@@ -880,5 +954,78 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     }
     HEContext<S> context_;
 };
+
+// ------------------------------------------------------------------ serializer (util/serializer.h:20-131)
+// file = u64 size + zlib stream of the object's save() bytes
+namespace serializer {
+inline std::vector<std::uint8_t> to_buffer(const std::stringstream& ss)
+{
+    const std::string str = ss.str();
+    return {str.begin(), str.end()};
+}
+inline void from_buffer(std::stringstream& ss, const std::vector<std::uint8_t>& buffer)
+{
+    ss.str(std::string(buffer.begin(), buffer.end()));
+}
+#if defined(HEONGPU_WITH_ZLIB)
+inline std::vector<std::uint8_t> compress(const std::vector<std::uint8_t>& data)
+{
+    uLongf bound = compressBound(data.size());
+    std::vector<std::uint8_t> out(bound);
+    if (::compress(out.data(), &bound, data.data(), data.size()) != Z_OK)
+        throw std::runtime_error("Zlib compression failed");
+    out.resize(bound);
+    return out;
+}
+inline std::vector<std::uint8_t> decompress(const std::vector<std::uint8_t>& data)
+{
+    // the reference sizes the output at 4x the input and fails beyond; grow instead
+    for (size_t factor = 4; factor <= 4096; factor *= 4) {
+        std::vector<std::uint8_t> out(data.size() * factor + 64);
+        uLongf out_size = out.size();
+        const int rc = ::uncompress(out.data(), &out_size, data.data(), data.size());
+        if (rc == Z_OK) {
+            out.resize(out_size);
+            return out;
+        }
+        if (rc != Z_BUF_ERROR) break;
+    }
+    throw std::runtime_error("Zlib decompression failed");
+}
+template <typename T> std::vector<std::uint8_t> serialize(const T& obj)
+{
+    std::stringstream ss;
+    obj.save(ss);
+    return compress(to_buffer(ss));
+}
+// the object is constructed by the caller (it needs its context)
+template <typename T> void deserialize(T& obj, const std::vector<std::uint8_t>& buffer)
+{
+    std::stringstream ss;
+    from_buffer(ss, decompress(buffer));
+    obj.load(ss);
+}
+template <typename T> void save_to_file(const T& obj, const std::string& filename)
+{
+    const std::vector<std::uint8_t> data = serialize(obj);
+    const std::uint64_t size = data.size();
+    std::ofstream ofs(filename, std::ios::binary);
+    if (!ofs) throw std::runtime_error("Cannot open file for writing: " + filename);
+    ofs.write((const char*) &size, sizeof(size));
+    ofs.write((const char*) data.data(), (std::streamsize) size);
+}
+template <typename T> void load_from_file(T& obj, const std::string& filename)
+{
+    std::ifstream ifs(filename, std::ios::binary);
+    if (!ifs) throw std::runtime_error("Cannot open file for reading: " + filename);
+    std::uint64_t size = 0;
+    ifs.read((char*) &size, sizeof(size));
+    std::vector<std::uint8_t> buffer(size);
+    ifs.read((char*) buffer.data(), (std::streamsize) size);
+    if (!ifs) throw std::runtime_error("File is truncated: " + filename);
+    deserialize(obj, buffer);
+}
+#endif // HEONGPU_WITH_ZLIB
+} // namespace serializer
 
 } // namespace heongpu

@@ -2,10 +2,13 @@
 // the reference's tests use its API (test/test_ckks_relinearization.cpp:36-111,
 // test_bfv_rotation_method_1.cpp:30-86), checked bit-for-bit against the CPU
 // oracle (test infrastructure).  Runs on the GPU box (pytest -m gpu wrapper).
+#define HEONGPU_WITH_ZLIB 1
 #include <heongpu/heongpu.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <fstream>
+#include <sstream>
 #include <cstdlib>
 #include <cstring>
 extern "C" {
@@ -379,6 +382,48 @@ static void ckks_encoder_flow()
     EXPECT(e < 1e-6, "ckks: rotate_rows(1) shifts the slots left by one");
 }
 
+// save / load in the reference's wire format + zlib file framing (util/serializer.h)
+static void serializer_round_trip()
+{
+    constexpr auto S = Scheme::CKKS;
+    const size_t n = 4096;
+    HEContext<S> ctx = GenHEContext<S>(sec_level_type::none);
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_bit_sizes({40, 35, 35}, {40});
+    ctx->generate();
+    Vec primes = ctx->get_key_modulus();
+    const int Q = 3;
+    Ciphertext<S> a(ctx), b(ctx);
+    Vec data = synth_ct(primes, Q - 1, 2, n, 5);
+    a.load(data, 2, 1, 1099511627776.0);
+    std::stringstream ss;
+    a.save(ss);
+    const std::string bytes = ss.str();
+    // header: u8 scheme(2) | int 4096 | int 3 | int 2 | int depth 1 | bool ntt | u8 storage(2) | double | u8 | bool x3 | u32
+    const size_t header = 1 + 4 * 4 + 1 + 1 + 8 + 1 + 1 + 1 + 1 + 4;
+    EXPECT(bytes.size() == header + data.size() * 8 && (unsigned char) bytes[0] == 2, "ciphertext wire size and scheme tag");
+    b.load(ss);
+    Vec back;
+    b.get_data(back);
+    EXPECT(back == data && b.depth() == 1 && b.scale() == 1099511627776.0 && b.size() == 2, "ciphertext save -> load");
+    const char* path = "/tmp/hegpu_ct.bin";
+    serializer::save_to_file(a, path);
+    Ciphertext<S> c(ctx);
+    serializer::load_from_file(c, path);
+    c.get_data(back);
+    EXPECT(back == data, "ciphertext file round trip (u64 size + zlib stream)");
+    std::ifstream f(path, std::ios::binary);
+    uint64_t sz = 0;
+    f.read((char*) &sz, 8);
+    f.seekg(0, std::ios::end);
+    EXPECT((uint64_t) f.tellg() == 8 + sz, "file = u64 size + payload");
+    Ciphertext<Scheme::BFV>* none = nullptr;
+    (void) none;
+    bool thrown = false;
+    try { Ciphertext<S> d(ctx); std::stringstream bad("\x01garbage"); d.load(bad); } catch (const std::runtime_error&) { thrown = true; }
+    EXPECT(thrown, "a BFV-tagged binary is rejected by a CKKS ciphertext");
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -397,6 +442,7 @@ int main()
     ckks_pipeline();
     bfv_pipeline();
     ckks_encoder_flow();
+    serializer_round_trip();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }
