@@ -65,6 +65,9 @@ SIGNATURES = [
     ("hegpu_ckks_decrypt", c_int, [voidp, u64p, u64p, c_int, u64p, voidp]),
     ("hegpu_bfv_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_decrypt", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_cipherplain_multiplication", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),
+    ("hegpu_bfv_plain_addsub", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),
+    ("hegpu_bfv_multiply_plain", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_encode", c_int, [voidp, voidp, c_int, u64p, voidp]),
     ("hegpu_ckks_encode", c_int, [voidp, voidp, c_int, ctypes.c_double, u64p, voidp, c_size_t, voidp]),
     ("hegpu_ckks_decode", c_int, [voidp, u64p, c_int, ctypes.c_double, voidp, voidp, c_size_t, voidp]),

@@ -644,6 +644,46 @@ int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, doub
                    "hegpu_ckks_decode");
 }
 
+// ---- ciphertext (x) plaintext operations
+int hegpu_cipherplain_multiplication(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out,
+                                     int limbs, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (limbs <= 0 || limbs > ctx->c.Qp_size) return fail(HEGPU_E_INVALID, "bad limb count");
+    return hip_ret(kg_pk_u((const u64*) ct, (const u64*) plain, (u64*) out, ctx->c.plan_qp.mods, ctx->c.n_power, limbs,
+                           (hipStream_t) stream),
+                   "hegpu_cipherplain_multiplication");
+}
+
+int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, int sub,
+                           hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    const Context& c = ctx->c;
+    return guarded([&]() -> int {
+        return hip_ret(kg_bfv_plain_addsub((const u64*) ct, (const u64*) plain, (u64*) out, c.plan_qp.mods,
+                                           c.d64("coeff_div_plain_modulus"), c.h64("Q_mod_t")[0],
+                                           c.h64("upper_threshold")[0], c.plain_modulus, c.n_power, c.Q_size, sub,
+                                           (hipStream_t) stream),
+                       "hegpu_bfv_plain_addsub");
+    });
+}
+
+int hegpu_bfv_multiply_plain(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, void* ws,
+                             size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_BFV_MULTIPLY_PLAIN, 0, 1))
+        return fail(HEGPU_E_INVALID, "workspace too small");
+    return guarded([&]() -> int {
+        return hip_ret(op_bfv_multiply_plain(ctx->c, (const u64*) ct, (const u64*) plain, (u64*) out, (u64*) ws,
+                                             (hipStream_t) stream),
+                       "hegpu_bfv_multiply_plain");
+    });
+}
+
 // ------------------------------------------------------------------ TFHE
 struct hegpu_tfhe_context {
     TfheDev p{};

@@ -349,6 +349,9 @@ void Context::build_host()
             for (int i = 0; i < Q; i++) Q_mod_t = mul_mod(Q_mod_t, primes[i] % t, t);
             host["Q_mod_t"] = vec{Q_mod_t};
             host["upper_threshold"] = vec{(t + 1) >> 1};
+            vec inc; // plain_upper_half_increment (bfv/context.cu:503-508)
+            for (int i = 0; i < Q; i++) inc.push_back(primes[i] - t);
+            host["upper_halfincrement"] = inc;
             // floor(prod(q) / t) mod q_i with a little-endian multi-word integer
             std::vector<u64> big{1};
             for (int i = 0; i < Q; i++) {
@@ -518,6 +521,7 @@ hipError_t Context::upload()
                                        "special_fft_roots_table",
                                        "special_ifft_roots_table",
                                        "coeff_div_plain_modulus",
+                                       "upper_halfincrement",
                                        "Qi_t",
                                        "Qi_gamma",
                                        "Qi_inverse",

@@ -220,6 +220,58 @@ hipError_t kg_bfv_message_add(u64* ct, const u64* plain, const Mod* mods, const 
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_plain_addsub(const u64* __restrict__ ct,
+                                                                    const u64* __restrict__ plain, u64* __restrict__ out,
+                                                                    const Mod* __restrict__ mods,
+                                                                    const u64* __restrict__ coeff_div, u64 Q_mod_t,
+                                                                    u64 upper_threshold, u64 t, int n_power, int limbs,
+                                                                    int sub)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const int y = blockIdx.y, z = blockIdx.z;
+    const Mod m = mods[y];
+    const u64 loc = idx + ((u64) y << n_power) + (((u64) limbs * z) << n_power);
+    u64 c = ct[loc];
+    if (z == 0) {
+        const u64 message = plain[idx];
+        u64 fix = message * Q_mod_t;
+        fix = fix + upper_threshold;
+        fix = (u64) (long long) (int) (fix / t);
+        u64 r = mul_barrett(message, coeff_div[y], m);
+        r = add_mod(r, fix, m.q);
+        c = sub ? sub_mod(c, r, m.q) : add_mod(r, c, m.q);
+    }
+    out[loc] = c;
+}
+
+hipError_t kg_bfv_plain_addsub(const u64* ct, const u64* plain, u64* out, const Mod* mods, const u64* coeff_div,
+                               u64 Q_mod_t, u64 upper_threshold, u64 t, int n_power, int limbs, int sub,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_plain_addsub, dim3((1u << n_power) / KG_THREADS, limbs, 2), dim3(KG_THREADS), 0, st,
+                       ct, plain, out, mods, coeff_div, Q_mod_t, upper_threshold, t, n_power, limbs, sub);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_bfv_threshold(const u64* __restrict__ plain, u64* __restrict__ out,
+                                                                 const Mod* __restrict__ mods,
+                                                                 const u64* __restrict__ inc, u64 upper_threshold,
+                                                                 int n_power)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const int y = blockIdx.y;
+    const u64 v = plain[idx];
+    out[idx + ((u64) y << n_power)] = (v >= upper_threshold) ? add_mod(v, inc[y], mods[y].q) : v;
+}
+
+hipError_t kg_bfv_threshold(const u64* plain, u64* out, const Mod* mods, const u64* upper_half_increment,
+                            u64 upper_threshold, int n_power, int limbs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_bfv_threshold, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, plain,
+                       out, mods, upper_half_increment, upper_threshold, n_power);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(KG_THREADS) void k_kg_sk_mul(const u64* __restrict__ in, const u64* __restrict__ sk,
                                                           u64* __restrict__ out, const Mod* __restrict__ mods,
                                                           int n_power)

@@ -38,6 +38,14 @@ hipError_t kg_sk_multiplication_ckks(const u64* ct, u64* plain, const u64* sk, c
 // enc_div_lastq_bfv_kernel, encryption.cu:158-172); plain [N] mod t, ct [2][Q][N] coefficient domain
 hipError_t kg_bfv_message_add(u64* ct, const u64* plain, const Mod* mods, const u64* coeff_div, u64 Q_mod_t,
                               u64 upper_threshold, u64 t, int n_power, int limbs, hipStream_t st);
+// addition_plain_bfv_poly / substraction_plain_bfv_poly (addition.cu:50-176): out = ct +- (Delta*m + fix)
+// on part 0, part 1 copied; sub != 0 subtracts
+hipError_t kg_bfv_plain_addsub(const u64* ct, const u64* plain, u64* out, const Mod* mods, const u64* coeff_div,
+                               u64 Q_mod_t, u64 upper_threshold, u64 t, int n_power, int limbs, int sub,
+                               hipStream_t st);
+// threshold_kernel (multiplication.cu:274-296): plain [N] mod t -> [limbs][N] centred lift into each q_i
+hipError_t kg_bfv_threshold(const u64* plain, u64* out, const Mod* mods, const u64* upper_half_increment,
+                            u64 upper_threshold, int n_power, int limbs, hipStream_t st);
 // sk_multiplication (decryption.cu:10-23): out[j] = in[j] * sk[j]
 hipError_t kg_sk_multiplication(const u64* in, const u64* sk, u64* out, const Mod* mods, int n_power, int limbs,
                                 hipStream_t st);

@@ -81,6 +81,7 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_BFV_ENCRYPT: per = (u64) 5 * Qp * n; break;          // u, e[2], pk*u[2]
         case OP_BFV_DECRYPT: per = (u64) Q * n; break;               // c1*s
         case OP_BFV_DECODE: per = n; break;
+        case OP_BFV_MULTIPLY_PLAIN: per = (u64) Q * n; break;        // lifted + transformed plaintext
         case OP_CKKS_ENCODE: per = n; break;                         // N/2 complex doubles
         case OP_CKKS_DECODE: per = (u64) (l + 1) * n; break;         // coefficient-domain copy + complex
         default: return 0;
@@ -580,6 +581,22 @@ hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* 
     a.in = plain; a.out = ws; a.mod_count = 1;
     TRY(ntt_launch(a, 1, false, st));                                                      // :234
     return kg_bfv_decode_gather(message, ws, c.d32("encoding_location"), c.n_power, st);   // :239
+}
+
+hipError_t op_bfv_multiply_plain(const Context& c, const u64* ct, const u64* plain, u64* out, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power, Q = c.Q_size;
+    u64* pl = ws; // [Q][N]
+    TRY(kg_bfv_threshold(plain, pl, c.plan_qp.mods, c.d64("upper_halfincrement"), c.h64("upper_threshold")[0], np, Q,
+                         st));                                                             // :454
+    NttArgs a = c.ntt_args(0);
+    a.in = pl; a.out = pl; a.mod_count = Q;
+    TRY(ntt_launch(a, Q, false, st));                                                      // :479
+    a.in = ct; a.out = out;
+    TRY(ntt_launch(a, 2 * Q, false, st));                                                  // :484
+    TRY(kg_pk_u(out, pl, out, c.plan_qp.mods, np, Q, st));                                 // :489 cipherplain_kernel
+    a.in = out; a.out = out;
+    return ntt_launch(a, 2 * Q, true, st);                                                 // :496
 }
 
 static int log2i(u64 v)

@@ -8,7 +8,7 @@ namespace hegpu {
 enum { OP_CKKS_RELIN = 1, OP_CKKS_RESCALE = 2, OP_CKKS_GALOIS = 3, OP_BFV_MULTIPLY = 4, OP_BFV_RELIN = 5,
        OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10, OP_BFV_ENCRYPT = 11,
        OP_BFV_DECRYPT = 12, OP_BFV_DECODE = 13, OP_CKKS_ENCODE = 14,
-       OP_CKKS_DECODE = 15 };
+       OP_CKKS_DECODE = 15, OP_BFV_MULTIPLY_PLAIN = 16 };
 
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
@@ -64,6 +64,8 @@ hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* p
 // int64 (negative values wrap mod t) -> plain [N]; plain [N] -> message [N].  ws: N words (decode).
 hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st);
 hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* ws, hipStream_t st);
+// HEOperator<BFV>::multiply_plain_bfv, coefficient-domain ciphertext (bfv/operator.cu:432-503)
+hipError_t op_bfv_multiply_plain(const Context& c, const u64* ct, const u64* plain, u64* out, u64* ws, hipStream_t st);
 // HEEncoder<CKKS>::encode_ckks / decode_ckks, real vectors (ckks/encoder.cu:100-160, 449-513):
 // message: device doubles (size <= N/2 slots); plain [Q - depth][N] NTT domain
 hipError_t op_ckks_encode(const Context& c, const double* message, int message_size, double scale, u64* plain,

@@ -145,7 +145,8 @@ enum {
     HEGPU_OP_BFV_DECRYPT = 12,
     HEGPU_OP_BFV_DECODE = 13,
     HEGPU_OP_CKKS_ENCODE = 14,
-    HEGPU_OP_CKKS_DECODE = 15 /* depth-dependent */
+    HEGPU_OP_CKKS_DECODE = 15, /* depth-dependent */
+    HEGPU_OP_BFV_MULTIPLY_PLAIN = 16
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -240,6 +241,21 @@ int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_siz
                       void* ws, size_t ws_bytes, hegpu_stream stream);
 int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
                       size_t ws_bytes, hegpu_stream stream);
+
+/* ---- ciphertext (x) plaintext
+ * cipherplain_kernel (src/lib/kernel/multiplication.cu:298-311): out[z][j] = ct[z][j] * plain[j] for the
+ * two parts, `limbs` limbs each, everything in the NTT domain (CKKS multiply_plain,
+ * ckks/operator.cu multiply_plain_ckks).  CKKS add/sub of a plaintext is hegpu_addition on part 0. */
+int hegpu_cipherplain_multiplication(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out,
+                                     int limbs, hegpu_stream stream);
+/* addition_plain_bfv_poly / substraction_plain_bfv_poly (src/lib/kernel/addition.cu:50-176): part 0 gets
+ * +-(floor(Q/t)*m + fix), part 1 is copied; plain [N] mod t, coefficient-domain ciphertext */
+int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, int sub,
+                           hegpu_stream stream);
+/* HEOperator<BFV>::multiply_plain_bfv (src/lib/host/bfv/operator.cu:432-503): threshold lift, NTT,
+ * cipherplain product, INTT.  Workspace HEGPU_OP_BFV_MULTIPLY_PLAIN. */
+int hegpu_bfv_multiply_plain(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, void* ws,
+                             size_t ws_bytes, hegpu_stream stream);
 
 /* ------------------------------------------------------------------ TFHE
  * Gate bootstrapping on the reference's fixed STD128 set

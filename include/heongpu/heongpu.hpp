@@ -22,9 +22,16 @@
 #include <zlib.h> // serializer::compress / decompress (reference util/serializer.cpp)
 #endif
 #include <hip/hip_runtime.h>
+#if defined(HEONGPU_CUDA_NAMES)
+#include "cuda_names.hpp" // lets unmodified consumers of the reference (benchmark/*.cpp) use their cuda* calls
+#endif
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
+#include <complex>
 #include <fstream>
+#include <iomanip>
+#include <iostream>
 #include <istream>
 #include <map>
 #include <ostream>
@@ -416,6 +423,7 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
         group_order_ = (S == Scheme::BFV) ? 3 : 5; // bfv/evaluationkey.cu:308, ckks/evaluationkey.cu:408
         for (int sh : shifts) galois_elt[sh] = hegpu_steps_to_galois_elt(sh, context_->n, group_order_);
+        galois_elt_zero = hegpu_steps_to_galois_elt(0, context_->n, group_order_); // column rotation / conjugation
         const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
         const int d = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
         galoiskey_size_ = (size_t) 2 * d * context_->Q_prime_size * context_->n;
@@ -427,6 +435,7 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
         device_location_[galois_element] = DeviceVector<Data64>(host, s);
     }
     bool galois_key_generated_ = false;
+    int galois_elt_zero = 0;
     std::map<int, int> galois_elt;                           // shift -> Galois element
     std::map<int, DeviceVector<Data64>> device_location_;    // Galois element -> key
     int group_order_ = 5;
@@ -574,6 +583,13 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
             detail::check(hegpu_generate_galois_key(context_->handle(), rng_, (const uint64_t*) sk.data(), g.second,
                                                     (uint64_t*) out.data(), ws.p(), ws.bytes(), o.stream_));
             gk.device_location_[g.second] = std::move(out);
+        }
+        if (!gk.device_location_.count(gk.galois_elt_zero)) { // "Columns Rotate" key (keygenerator.cu:508-560)
+            DeviceVector<Data64> out(gk.size(), o.stream_);
+            detail::check(hegpu_generate_galois_key(context_->handle(), rng_, (const uint64_t*) sk.data(),
+                                                    gk.galois_elt_zero, (uint64_t*) out.data(), ws.p(), ws.bytes(),
+                                                    o.stream_));
+            gk.device_location_[gk.galois_elt_zero] = std::move(out);
         }
         gk.galois_key_generated_ = true;
     }
@@ -774,6 +790,8 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
     }
+    // the reference's constructor takes the encoder (operator.cuh: used by its bootstrapping code only)
+    HEArithmeticOperator(HEContext<S> context, HEEncoder<S>&) : HEArithmeticOperator(std::move(context)) {}
 
     void add(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
@@ -927,6 +945,62 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         out.memory_set(std::move(m));
     }
 
+    // ---- ciphertext (+,-,*) plaintext (host/*/operator.cuh add_plain / sub_plain / multiply_plain)
+    void add_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        plain_addsub(a, p, out, 0, o);
+    }
+    void sub_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        plain_addsub(a, p, out, 1, o);
+    }
+    void add_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
+    {
+        plain_addsub(a, p, a, 0, o);
+    }
+    void sub_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
+    {
+        plain_addsub(a, p, a, 1, o);
+    }
+    void multiply_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out,
+                        const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (a.relinearization_required_) throw std::invalid_argument("Ciphertext should be relinearized first!");
+        const int l = limbs(a);
+        const size_t n = context_->n;
+        DeviceVector<Data64> m(2 * n * l, o.stream_);
+        if (S == Scheme::CKKS) {
+            if (a.rescale_required_) throw std::invalid_argument("Ciphertext should be rescaled first!");
+            if (p.depth_ != a.depth_) throw std::logic_error("Ciphertext and Plaintext levels are not equal");
+            detail::check(hegpu_cipherplain_multiplication(context_->handle(), (const uint64_t*) a.data(),
+                                                           (const uint64_t*) p.data(), (uint64_t*) m.data(), l,
+                                                           o.stream_));
+        } else {
+            const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_BFV_MULTIPLY_PLAIN, 0, 1);
+            DeviceVector<Data64> ws(wsb / 8, o.stream_);
+            detail::check(hegpu_bfv_multiply_plain(context_->handle(), (const uint64_t*) a.data(),
+                                                   (const uint64_t*) p.data(), (uint64_t*) m.data(), ws.data(), wsb,
+                                                   o.stream_));
+        }
+        const double ps = p.scale_;
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
+        if (S == Scheme::CKKS) {
+            out.scale_ = a.scale_ * ps; // ckks/operator.cuh multiply_plain
+            out.rescale_required_ = true;
+        }
+    }
+    void multiply_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
+    {
+        multiply_plain(a, p, a, o);
+    }
+    // BFV: swap the two rows of the slot matrix (Galois element 2N - 1, bfv/operator.cu:975-1068)
+    void rotate_columns(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk,
+                        const ExecutionOptions& o = ExecutionOptions())
+    {
+        apply_galois(in, out, gk, gk.galois_elt_zero, o);
+    }
+
   private:
     int limbs(const Ciphertext<S>& a) const { return context_->Q_size - a.depth_; }
     static void copy_meta(const Ciphertext<S>& a, Ciphertext<S>& out)
@@ -950,6 +1024,26 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), (const uint64_t*) b.data(),
                                      (uint64_t*) m.data(), l, a.cipher_size_, 1, op, o.stream_));
         copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+    void plain_addsub(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, int sub, const ExecutionOptions& o)
+    {
+        if (a.relinearization_required_) throw std::invalid_argument("Ciphertext should be relinearized first!");
+        const int l = limbs(a);
+        const size_t n = context_->n;
+        DeviceVector<Data64> m(2 * n * l, o.stream_);
+        if (S == Scheme::CKKS) {
+            if (p.depth_ != a.depth_) throw std::logic_error("Ciphertext and Plaintext levels are not equal");
+            // part 0 +- plaintext, part 1 unchanged (addition.cu: addition_plain_ckks_poly)
+            detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), (const uint64_t*) p.data(),
+                                         (uint64_t*) m.data(), l, 1, 1, sub, o.stream_));
+            detail::hip(hipMemcpyAsync(m.data() + n * l, a.data() + n * l, n * l * sizeof(Data64),
+                                       hipMemcpyDeviceToDevice, o.stream_));
+        } else {
+            detail::check(hegpu_bfv_plain_addsub(context_->handle(), (const uint64_t*) a.data(),
+                                                 (const uint64_t*) p.data(), (uint64_t*) m.data(), sub, o.stream_));
+        }
+        if (&a != &out) copy_meta(a, out);
         out.memory_set(std::move(m));
     }
     HEContext<S> context_;

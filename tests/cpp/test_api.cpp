@@ -332,6 +332,21 @@ static void bfv_pipeline()
     for (size_t i = 0; ok && i < n / 2; i++)
         ok = slots[i] == b[(i + 1) % (n / 2)] && slots[n / 2 + i] == b[n / 2 + (i + 1) % (n / 2)];
     EXPECT(ok, "bfv slots: rotate_rows(1) shifts both rows left by one");
+    op.rotate_columns(cb, cr, gk);
+    dec.decrypt(pr, cr);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n / 2; i++) ok = slots[i] == b[n / 2 + i] && slots[n / 2 + i] == b[i];
+    EXPECT(ok, "bfv slots: rotate_columns swaps the two rows");
+    enc.encrypt(cb, pb);
+    op.add_plain_inplace(cb, pa);
+    op.multiply_plain(cb, pa, cb);
+    op.sub_plain_inplace(cb, pb);
+    dec.decrypt(pr, cb);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == (((a[i] + b[i]) % t) * a[i] % t + t - b[i]) % t;
+    EXPECT(ok, "bfv slots: ((b + a) .* a) - b with plaintext operands");
 }
 
 // the reference's basic CKKS example flow (example/basic/4_basic_ckks.cpp) through the class layer
@@ -380,6 +395,23 @@ static void ckks_encoder_flow()
     e = 0;
     for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - y[(i + 1) % slots]));
     EXPECT(e < 1e-6, "ckks: rotate_rows(1) shifts the slots left by one");
+    // ciphertext (+,-,*) plaintext
+    Ciphertext<S> cz(ctx);
+    enc.encrypt(cz, px);
+    op.add_plain_inplace(cz, py);
+    dec.decrypt(pr, cz);
+    encoder.decode(got, pr);
+    e = 0;
+    for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - (x[i] + y[i])));
+    EXPECT(e < 1e-6, "ckks: add_plain_inplace");
+    op.sub_plain_inplace(cz, py);
+    op.multiply_plain(cz, py, cz);
+    op.rescale_inplace(cz);
+    dec.decrypt(pr, cz);
+    encoder.decode(got, pr);
+    e = 0;
+    for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - x[i] * y[i]));
+    EXPECT(e < 1e-5, "ckks: sub_plain_inplace, multiply_plain (aliased output), rescale");
 }
 
 // save / load in the reference's wire format + zlib file framing (util/serializer.h)

@@ -412,3 +412,19 @@ def test_cpp_class_layer(torch):
     print(r.stdout[-3000:], r.stderr[-1000:])
     assert r.returncode == 0, r.stdout[-2000:]
     assert "PASSED" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["ckks", "bfv"])
+def test_reference_benchmark_runs_unchanged(torch, name):
+    """benchmark/benchmark_{ckks,bfv}.cpp of the reference, compiled unchanged against the class
+    layer by __graft_entry__.build() (where the reference tree is available), run to completion."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "heongpu_amd", "lib", "ref_benchmark_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("reference benchmark binary not built (no /root/reference at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2500:], r.stderr[-500:])
+    assert r.returncode == 0
+    assert r.stdout.count("Average multiplication timing") >= 4
