@@ -80,6 +80,14 @@ SIGNATURES = [
     ("hegpu_tfhe_gate_precompute", c_int, [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_bootstrapping", c_int, [voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_key_switching", c_int, [voidp, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
+    ("hegpu_tfhe_generate_secret_key", c_int, [voidp, voidp, voidp, voidp, voidp]),
+    ("hegpu_tfhe_generate_bootstrapping_key", c_int,
+     [voidp, voidp, voidp, voidp, u64p, voidp, voidp, voidp, c_size_t, voidp]),
+    ("hegpu_tfhe_encrypt", c_int, [voidp, voidp, voidp, voidp, c_int, voidp, voidp, voidp]),
+    ("hegpu_tfhe_decrypt_phase", c_int, [voidp, voidp, voidp, voidp, c_int, voidp, voidp]),
+    ("hegpu_tfhe_mux", c_int,
+     [voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp, c_size_t,
+      voidp]),
     ("hegpu_tfhe_gate", c_int,
      [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp, c_size_t, voidp]),
 ]

@@ -427,6 +427,49 @@ class TfheContext:
                                                   _ptr(ks_a), _ptr(ks_b), shape,
                                                   stream if stream is not None else _stream()))
 
+    # ---- front end: keys, bit encryption, decryption, MUX
+    def generate_secret_key(self, rng, stream=None):
+        import torch
+        lwe = torch.empty(self.int("n"), dtype=torch.int32, device="cuda")
+        tlwe = torch.empty(self.int("N") * self.int("k"), dtype=torch.int32, device="cuda")
+        _check(self._lib.hegpu_tfhe_generate_secret_key(self._h, rng._h, _ptr(lwe), _ptr(tlwe),
+                                                        stream if stream is not None else _stream()))
+        return lwe, tlwe
+
+    def generate_bootstrapping_key(self, rng, lwe, tlwe, stream=None):
+        """returns (boot key in the reference layout, ks_a, ks_b)"""
+        import torch
+        bk = torch.empty(self.int("bootkey_elems"), dtype=torch.int64, device="cuda")
+        ks_a = torch.empty(self.int("kskey_a_elems"), dtype=torch.int32, device="cuda")
+        ks_b = torch.empty(self.int("kskey_b_elems"), dtype=torch.int32, device="cuda")
+        ws = torch.empty(self.int("N"), dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_tfhe_generate_bootstrapping_key(self._h, rng._h, _ptr(lwe), _ptr(tlwe), _ptr(bk),
+                                                               _ptr(ks_a), _ptr(ks_b), _ptr(ws), ws.numel() * 8,
+                                                               stream if stream is not None else _stream()))
+        return bk, ks_a, ks_b
+
+    def encrypt(self, rng, lwe, messages, stream=None):
+        import torch
+        shape = messages.numel()
+        a = torch.empty(shape * self.int("n"), dtype=torch.int32, device="cuda")
+        b = torch.empty(shape, dtype=torch.int32, device="cuda")
+        _check(self._lib.hegpu_tfhe_encrypt(self._h, rng._h, _ptr(lwe), _ptr(messages), shape, _ptr(a), _ptr(b),
+                                            stream if stream is not None else _stream()))
+        return a, b
+
+    def decrypt_phase(self, lwe, a, b, stream=None):
+        import torch
+        out = torch.empty(b.numel(), dtype=torch.int32, device="cuda")
+        _check(self._lib.hegpu_tfhe_decrypt_phase(self._h, _ptr(lwe), _ptr(a), _ptr(b), b.numel(), _ptr(out),
+                                                  stream if stream is not None else _stream()))
+        return out
+
+    def mux(self, a1, b1, a2, b2, ca, cb, out_a, out_b, prepared_bk, ks_a, ks_b, shape, ws, stream=None):
+        _check(self._lib.hegpu_tfhe_mux(self._h, _ptr(a1), _ptr(b1), _ptr(a2), _ptr(b2), _ptr(ca), _ptr(cb),
+                                        _ptr(out_a), _ptr(out_b), _ptr(prepared_bk), _ptr(ks_a), _ptr(ks_b), shape,
+                                        _ptr(ws), ws.numel() * ws.element_size(),
+                                        stream if stream is not None else _stream()))
+
     def gate(self, gate, a1, b1, a2, b2, out_a, out_b, prepared_bk, ks_a, ks_b, shape, ws, stream=None):
         _check(self._lib.hegpu_tfhe_gate(self._h, gate, _ptr(a1), _ptr(b1), _ptr(a2), _ptr(b2), _ptr(out_a),
                                          _ptr(out_b), _ptr(prepared_bk), _ptr(ks_a), _ptr(ks_b), shape, _ptr(ws),

@@ -694,6 +694,8 @@ struct hegpu_tfhe_context {
     ulonglong2* dfitw = nullptr;
     bool uploaded = false;
     bool allow_fp = true; // HEGPU_TFHE_FP=0 keeps the integer blind rotate
+    // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
+    double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
 };
 
 static ulonglong2 fp_pair(u64 w, u64 q)
@@ -897,6 +899,95 @@ int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, con
     if ((r = hegpu_tfhe_gate_precompute(ctx, gate, t_a, t_b, in1_a, in1_b, in2_a, in2_b, shape, stream))) return r;
     if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e_a, e_b, shape, stream))) return r;
     return hegpu_tfhe_key_switching(ctx, e_a, e_b, out_a, out_b, ks_a, ks_b, shape, stream);
+}
+
+// ---- TFHE front end (reference tfhe/keygenerator.cu, encryptor.cu, decryptor.cu, operator.cuh:676-800)
+static const double TFHE_IH = 1.1547005383792517; // sqrt(16/12), see drbg_torus_gaussian
+
+int hegpu_tfhe_generate_secret_key(hegpu_tfhe_context* ctx, hegpu_rng* rng, int32_t* lwe_key, int32_t* tlwe_key,
+                                   hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
+    const u64 s0 = rng->r.stream;
+    rng->r.stream += 2;
+    return hip_ret(tfhe_gen_secret(lwe_key, tlwe_key, ctx->p.n, ctx->p.k * ctx->p.N, rng->r.seed, s0,
+                                   (hipStream_t) stream),
+                   "hegpu_tfhe_generate_secret_key");
+}
+
+int hegpu_tfhe_generate_bootstrapping_key(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* lwe_key,
+                                          const int32_t* tlwe_key, uint64_t* boot_key, int32_t* ks_a, int32_t* ks_b,
+                                          void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
+    const TfheDev& p = ctx->p;
+    if (!ws || ws_bytes < (size_t) p.N * sizeof(u64)) return fail(HEGPU_E_INVALID, "workspace too small");
+    const u64 s0 = rng->r.stream;
+    rng->r.stream += 4;
+    hipError_t e = tfhe_gen_bootkey(p, (u64*) boot_key, lwe_key, tlwe_key, (u64*) ws, ctx->bk_stdev / TFHE_IH,
+                                    rng->r.seed, s0, s0 + 1, (hipStream_t) stream);
+    if (e != hipSuccess) return hip_ret(e, "hegpu_tfhe_generate_bootstrapping_key");
+    const u64 rows = (u64) p.N * p.k * p.ks_length * ((1 << p.ks_base_bit) - 1);
+    return hip_ret(tfhe_lwe_encrypt(ks_a, ks_b, lwe_key, nullptr, 1, tlwe_key, p.ks_base_bit, p.ks_length, p.n, rows,
+                                    ctx->ks_stdev / TFHE_IH, rng->r.seed, s0 + 2, s0 + 3, (hipStream_t) stream),
+                   "hegpu_tfhe_generate_bootstrapping_key");
+}
+
+int hegpu_tfhe_encrypt(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* lwe_key, const int32_t* messages,
+                       int shape, int32_t* out_a, int32_t* out_b, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
+    if (shape <= 0) return fail(HEGPU_E_INVALID, "shape must be positive");
+    const u64 s0 = rng->r.stream;
+    rng->r.stream += 2;
+    return hip_ret(tfhe_lwe_encrypt(out_a, out_b, lwe_key, messages, 0, nullptr, 0, 1, ctx->p.n, (u64) shape,
+                                    ctx->ks_stdev / TFHE_IH, rng->r.seed, s0, s0 + 1, (hipStream_t) stream),
+                   "hegpu_tfhe_encrypt");
+}
+
+int hegpu_tfhe_decrypt_phase(hegpu_tfhe_context* ctx, const int32_t* lwe_key, const int32_t* a, const int32_t* b,
+                             int shape, int32_t* phase, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    return hip_ret(tfhe_lwe_phase(a, b, lwe_key, phase, ctx->p.n, shape, (hipStream_t) stream),
+                   "hegpu_tfhe_decrypt_phase");
+}
+
+int hegpu_tfhe_mux(hegpu_tfhe_context* ctx, const int32_t* in1_a, const int32_t* in1_b, const int32_t* in2_a,
+                   const int32_t* in2_b, const int32_t* c_a, const int32_t* c_b, int32_t* out_a, int32_t* out_b,
+                   const uint64_t* prepared_boot_key, const int32_t* ks_a, const int32_t* ks_b, int shape, void* ws,
+                   size_t ws_bytes, hegpu_stream stream)
+{
+    int r = tfhe_need(ctx);
+    if (r) return r;
+    const TfheDev& p = ctx->p;
+    const size_t kN = (size_t) p.k * p.N;
+    const size_t need = ((size_t) p.n + 1 + 2 * (kN + 1)) * shape * sizeof(int32_t);
+    if (!ws || ws_bytes < need) return fail(HEGPU_E_INVALID, "workspace too small");
+    int32_t* t_a = (int32_t*) ws;
+    int32_t* t_b = t_a + (size_t) p.n * shape;
+    int32_t* e1_a = t_b + shape;
+    int32_t* e1_b = e1_a + kN * shape;
+    int32_t* e2_a = e1_b + shape;
+    int32_t* e2_b = e2_a + kN * shape;
+    // AND(c, in1) and AND(NOT c, in2), bootstrapped; OR of the two extracted samples; key switch
+    if ((r = hegpu_tfhe_gate_precompute(ctx, HEGPU_GATE_AND, t_a, t_b, c_a, c_b, in1_a, in1_b, shape, stream))) return r;
+    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e1_a, e1_b, shape, stream))) return r;
+    if ((r = hegpu_tfhe_gate_precompute(ctx, HEGPU_GATE_AND_FIRST_NOT, t_a, t_b, c_a, c_b, in2_a, in2_b, shape,
+                                        stream)))
+        return r;
+    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e2_a, e2_b, shape, stream))) return r;
+    hipError_t e = tfhe_gate_pre(e1_a, e1_b, e1_a, e1_b, e2_a, e2_b, encode_to_torus32(1, 8), 1, 1, 1, (int) kN, shape,
+                                 (hipStream_t) stream); // OR_pre_computation on the N-dimensional samples
+    if (e != hipSuccess) return hip_ret(e, "hegpu_tfhe_mux");
+    return hegpu_tfhe_key_switching(ctx, e1_a, e1_b, out_a, out_b, ks_a, ks_b, shape, stream);
 }
 
 } // extern "C"

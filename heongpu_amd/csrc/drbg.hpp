@@ -76,6 +76,31 @@ HG_HD u64 drbg_uniform(u64 seed, u64 stream, u64 index, const Mod& m)
     return reduce128(hi, lo, m);
 }
 
+// Torus32 Gaussian noise for the TFHE front end (stddev alpha as a fraction of the torus; the
+// reference draws curand / std::normal_distribution values, tfhe/encryptor.cu:55,
+// keygenerator.cu).  A sum of 16 uniform 32-bit words (Irwin-Hall: mean 8*2^32, stddev
+// 2^32*sqrt(16/12), support +-6.9 sigma) scaled by one FP64 multiply and rounded: integer
+// arithmetic plus a single IEEE operation, hence identical on the device, the host and in the
+// CPU oracle.  c = alpha * 2^32 / (2^32 * sqrt(4/3)) = alpha / 1.1547005383792517.
+HG_HD int drbg_torus_gaussian(u64 seed, u64 stream, u64 index, double c)
+{
+    u64 sum = 0;
+    for (int j = 0; j < 4; j++) {
+        const PhiloxOut o = drbg_block(seed, stream, 4 * index + j);
+        sum += (u64) o.w[0] + (u64) o.w[1] + (u64) o.w[2] + (u64) o.w[3];
+    }
+    const double g = (double) ((long long) sum - (8ll << 32));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = rint(g * c);
+#else
+    const double r = __builtin_rint(g * c);
+#endif
+    return (int) (u32) (long long) r; // wraps on the 32-bit torus
+}
+// uniform torus32 value / uniform bit
+HG_HD int drbg_torus_uniform(u64 seed, u64 stream, u64 index) { return (int) drbg_block(seed, stream, index).w[0]; }
+HG_HD int drbg_bit(u64 seed, u64 stream, u64 index) { return (int) (drbg_block(seed, stream, index).w[0] & 1u); }
+
 // signed small integer -> residue
 HG_HD u64 lift_small(int v, u64 q) { return v < 0 ? q - (u64) (-v) : (u64) v; }
 

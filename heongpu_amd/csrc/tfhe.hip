@@ -20,6 +20,7 @@
 #include "tfhe.hpp"
 #include <cstdlib>
 #include "fpmod.cuh"
+#include "drbg.hpp"
 
 namespace hegpu {
 
@@ -669,6 +670,172 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
     out_a[(u64) g * n + t] = (int) acc0;
     if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1;
     if (t == 0) out_b[g] = (int) accb;
+}
+
+// ------------------------------------------------------------------ front end: keys, encryption, decryption
+__global__ __launch_bounds__(256) void k_tfhe_gen_bits(int* __restrict__ out, int count, u64 seed, u64 stream)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = drbg_bit(seed, stream, (u64) i);
+}
+
+hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, u64 seed, u64 stream0, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tfhe_gen_bits, dim3((n + 255) / 256), dim3(256), 0, st, lwe_key, n, seed, stream0);
+    hipLaunchKernelGGL(k_tfhe_gen_bits, dim3((kN + 255) / 256), dim3(256), 0, st, tlwe_key, kN, seed, stream0 + 1);
+    return hipGetLastError();
+}
+
+// one workgroup per LWE sample
+__global__ __launch_bounds__(256) void k_tfhe_lwe_encrypt(int* __restrict__ out_a, int* __restrict__ out_b,
+                                                          const int* __restrict__ key, const int* __restrict__ msg,
+                                                          int ks_mode, const int* __restrict__ tlwe_key, int base_bit,
+                                                          int len, int n, double noise_c, u64 seed, u64 stream_a,
+                                                          u64 stream_e)
+{
+    __shared__ u32 red[256];
+    const u64 s = blockIdx.x;
+    const int t = threadIdx.x;
+    u32 acc = 0;
+    for (int j = t; j < n; j += 256) {
+        const int a = drbg_torus_uniform(seed, stream_a, s * n + j);
+        out_a[s * n + j] = a;
+        acc += (u32) a * (u32) key[j];
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        u32 m;
+        if (ks_mode) {
+            const int mask = (1 << base_bit) - 1;
+            const u64 v = s % mask + 1, j = (s / mask) % len, i = s / ((u64) mask * len);
+            m = (u32) tlwe_key[i] * (u32) v * (1u << (32 - (j + 1) * base_bit));
+        } else {
+            m = (u32) msg[s];
+        }
+        out_b[s] = (int) (red[0] + m + (u32) drbg_torus_gaussian(seed, stream_e, s, noise_c));
+    }
+}
+
+hipError_t tfhe_lwe_encrypt(int* out_a, int* out_b, const int* key, const int* msg, int ks_mode, const int* tlwe_key,
+                            int base_bit, int len, int n, u64 shape, double noise_c, u64 seed, u64 stream_a,
+                            u64 stream_e, hipStream_t st)
+{
+    if (shape == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tfhe_lwe_encrypt, dim3((unsigned) shape), dim3(256), 0, st, out_a, out_b, key, msg, ks_mode,
+                       tlwe_key, base_bit, len, n, noise_c, seed, stream_a, stream_e);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ TQ make_tq(u64 q)
+{
+    TQ c;
+    c.q = q;
+    c.q4 = 4 * q;
+    const u64 nq = 0 - q;
+    c.nq0 = (u32) nq;
+    c.nq1 = (u32) (nq >> 32);
+    return c;
+}
+__device__ __forceinline__ u64 lift32(int v, u64 q) { return v < 0 ? q - (u64) (-(long long) v) : (u64) v; }
+
+// NTT of the lifted TLWE key, one wavefront; out in slot order
+__global__ __launch_bounds__(64) void k_tfhe_key_ntt(const int* __restrict__ tlwe_key, u64* __restrict__ out, TfheDev p)
+{
+    __shared__ __attribute__((aligned(16))) u64 buf[TF_BUF];
+    const int lane = threadIdx.x;
+    const TQ c = make_tq(p.mod.q);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = lift32(tlwe_key[lane + 64 * k], c.q);
+    wave_ntt1024(x, buf, p.tw, c, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[16 * lane + k] = x[k];
+}
+
+// one wavefront per boot-key row (i, y, z), k = 1
+__global__ __launch_bounds__(64) void k_tfhe_gen_bootkey(u64* __restrict__ boot_key, const int* __restrict__ lwe_key,
+                                                         const u64* __restrict__ tlwe_ntt, TfheDev p, double noise_c,
+                                                         u64 seed, u64 stream_a, u64 stream_e)
+{
+    __shared__ __attribute__((aligned(16))) u64 buf[TF_BUF];
+    const int lane = threadIdx.x;
+    const u64 row = blockIdx.x; // (i*2 + y)*l + z
+    const int z = (int) (row % p.bk_l), y = (int) ((row / p.bk_l) % 2);
+    const u64 i = row / (2 * (u64) p.bk_l);
+    const TQ c = make_tq(p.mod.q);
+    const u32 mu = (u32) lwe_key[i] << (32 - (z + 1) * p.bk_bg_bit);
+    int a[16], b[16];
+    u64 x[16];
+    // a uniform; a*S through the transform
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        a[k] = drbg_torus_uniform(seed, stream_a, row * TF_N + lane + 64 * k);
+        x[k] = lift32(a[k], c.q);
+    }
+    wave_ntt1024(x, buf, p.tw, c, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = mul_barrett(x[k], tlwe_ntt[16 * lane + k], p.mod);
+    wave_intt1024(x, buf, p.itw, p.ninv, p.w1ninv, c, lane);
+    const u64 half = c.q >> 1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const long long prod = x[k] > half ? -(long long) (c.q - x[k]) : (long long) x[k];
+        b[k] = (int) ((u32) prod + (u32) drbg_torus_gaussian(seed, stream_e, row * TF_N + lane + 64 * k, noise_c));
+    }
+    if (lane == 0) { // coefficient 0 lives in x[0] of lane 0
+        if (y == 0) a[0] = (int) ((u32) a[0] + mu);
+        else b[0] = (int) ((u32) b[0] + mu);
+    }
+    u64* out = boot_key + row * 2 * TF_N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = lift32(a[k], c.q);
+    wave_ntt1024(x, buf, p.tw, c, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[16 * lane + k] = x[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = lift32(b[k], c.q);
+    wave_ntt1024(x, buf, p.tw, c, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[TF_N + 16 * lane + k] = x[k];
+}
+
+hipError_t tfhe_gen_bootkey(const TfheDev& p, u64* boot_key, const int* lwe_key, const int* tlwe_key, u64* tlwe_ntt,
+                            double noise_c, u64 seed, u64 stream_a, u64 stream_e, hipStream_t st)
+{
+    if (p.k != 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tfhe_key_ntt, dim3(1), dim3(64), 0, st, tlwe_key, tlwe_ntt, p);
+    hipLaunchKernelGGL(k_tfhe_gen_bootkey, dim3((unsigned) (p.n * 2 * p.bk_l)), dim3(64), 0, st, boot_key, lwe_key,
+                       tlwe_ntt, p, noise_c, seed, stream_a, stream_e);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_tfhe_lwe_phase(const int* __restrict__ a, const int* __restrict__ b,
+                                                        const int* __restrict__ key, int* __restrict__ phase, int n)
+{
+    __shared__ u32 red[256];
+    const u64 s = blockIdx.x;
+    const int t = threadIdx.x;
+    u32 acc = 0;
+    for (int j = t; j < n; j += 256) acc += (u32) a[s * n + j] * (u32) key[j];
+    red[t] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) phase[s] = (int) ((u32) b[s] - red[0]);
+}
+
+hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase, int n, int shape, hipStream_t st)
+{
+    if (shape <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tfhe_lwe_phase, dim3(shape), dim3(256), 0, st, a, b, key, phase, n);
+    return hipGetLastError();
 }
 
 // Synchronous (one-time): tries the FP64 layout, falls back to the integer

@@ -305,6 +305,30 @@ int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, con
                     const uint64_t* prepared_boot_key, const int32_t* ks_key_a, const int32_t* ks_key_b, int shape,
                     void* ws, size_t ws_bytes, hegpu_stream stream);
 
+/* ---- TFHE front end: keys, bit encryption, decryption, MUX
+ * (src/lib/host/tfhe/keygenerator.cu, encryptor.cu, decryptor.cu, include/.../tfhe/operator.cuh:676-800).
+ * Own DRBG as for the RLWE schemes; torus noise = scaled Irwin-Hall(16) (csrc/drbg.hpp) with the
+ * reference's standard deviations (tfhe/context.cu:39-42).  Keys are binary. */
+int hegpu_tfhe_generate_secret_key(hegpu_tfhe_context* ctx, hegpu_rng* rng, int32_t* lwe_key /* [n] */,
+                                   int32_t* tlwe_key /* [k*N] */, hegpu_stream stream);
+/* boot_key: reference layout [n][k+1][l][k+1][N] (NTT domain), then hegpu_tfhe_prepare_bootkey;
+ * ks_a [N*k][ks_length][base-1][n], ks_b [N*k][ks_length][base-1]; ws: N uint64 */
+int hegpu_tfhe_generate_bootstrapping_key(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* lwe_key,
+                                          const int32_t* tlwe_key, uint64_t* boot_key, int32_t* ks_a, int32_t* ks_b,
+                                          void* ws, size_t ws_bytes, hegpu_stream stream);
+/* LWE encryption of torus32 messages (a bit is +-1/8 = +-2^29): a [shape][n], b [shape] */
+int hegpu_tfhe_encrypt(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* lwe_key, const int32_t* messages,
+                       int shape, int32_t* out_a, int32_t* out_b, hegpu_stream stream);
+/* phase = b - <a, key>; the bit is phase > 0 */
+int hegpu_tfhe_decrypt_phase(hegpu_tfhe_context* ctx, const int32_t* lwe_key, const int32_t* a, const int32_t* b,
+                             int shape, int32_t* phase, hegpu_stream stream);
+/* MUX(in1, in2, control) = OR(AND(control, in1), AND(NOT control, in2)) with two bootstraps and one
+ * key switch (operator.cuh:688-800).  ws: (n + 1 + 2*(k*N + 1)) * shape int32. */
+int hegpu_tfhe_mux(hegpu_tfhe_context* ctx, const int32_t* in1_a, const int32_t* in1_b, const int32_t* in2_a,
+                   const int32_t* in2_b, const int32_t* c_a, const int32_t* c_b, int32_t* out_a, int32_t* out_b,
+                   const uint64_t* prepared_boot_key, const int32_t* ks_a, const int32_t* ks_b, int shape, void* ws,
+                   size_t ws_bytes, hegpu_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,10 @@ def lib():
     L.o_bfv_encrypt.argtypes = [vp, vp, vp, vp, vp]
     L.o_bfv_decrypt.argtypes = [vp, vp, vp, vp]
     L.o_bfv_encode.argtypes = [vp, vp, ci, vp]
+    L.o_tfhe_gen_secret.argtypes = [vp, vp, vp]
+    L.o_tfhe_gen_bootkey.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.o_tfhe_encrypt.argtypes = [vp, vp, vp, ci, vp, vp]
+    L.o_tfhe_phase.argtypes = [vp, vp, vp, ci, vp]
     L.o_ckks_encode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_decode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_bfv_decode.argtypes = [vp, vp, vp]
@@ -346,6 +350,33 @@ class OracleTfhe:
         out = np.zeros(self.N, dtype=np.int32)
         self.L.o_tfhe_polymul(self.h, _p(np.ascontiguousarray(a, dtype=np.int32)),
                               _p(np.ascontiguousarray(s, dtype=np.int32)), _p(out))
+        return out
+
+    # front end (o_keygen.c); rng = ORng(seed)
+    def gen_secret(self, rng):
+        lwe = np.zeros(self.n, dtype=np.int32)
+        tlwe = np.zeros(self.N * self.k, dtype=np.int32)
+        self.L.o_tfhe_gen_secret(ctypes.byref(rng), _p(lwe), _p(tlwe))
+        return lwe, tlwe
+
+    def gen_bootkey(self, rng, lwe, tlwe):
+        bk = np.zeros(self.n * 2 * self.l * 2 * self.N, dtype=np.uint64)
+        rows = self.N * self.ks_length * (self.ks_base - 1)
+        ks_a = np.zeros(rows * self.n, dtype=np.int32)
+        ks_b = np.zeros(rows, dtype=np.int32)
+        self.L.o_tfhe_gen_bootkey(self.h, ctypes.byref(rng), _p(lwe), _p(tlwe), _p(bk), _p(ks_a), _p(ks_b))
+        return bk, ks_a, ks_b
+
+    def encrypt(self, rng, lwe, messages):
+        m = np.ascontiguousarray(messages, dtype=np.int32)
+        a = np.zeros(len(m) * self.n, dtype=np.int32)
+        b = np.zeros(len(m), dtype=np.int32)
+        self.L.o_tfhe_encrypt(ctypes.byref(rng), _p(lwe), _p(m), len(m), _p(a), _p(b))
+        return a, b
+
+    def phase(self, lwe, a, b):
+        out = np.zeros(len(b), dtype=np.int32)
+        self.L.o_tfhe_phase(_p(lwe), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), len(b), _p(out))
         return out
 
     def gate_pre(self, gate, a1, b1, a2, b2):

@@ -504,3 +504,101 @@ void o_bfv_decode(const octx_t* c, const u64* plain, u64* message)
     free(tab);
     free(tmp);
 }
+
+/* ------------------------------------------------------------------ TFHE front end
+ * Binary keys, the boot key TGSW rows in the reference layout [n][k+1][l][k+1][N] (NTT domain;
+ * bootstrapping.cu:1037-1041), the key-switch key [N][ks_length][base-1][n]
+ * (bootstrapping.cu:1385-1412), LWE bit encryption and the decryption phase
+ * (tfhe/keygenerator.cu, encryptor.cu, decryptor.cu).  Noise: the backend's published rule, a
+ * scaled Irwin-Hall(16) sum (one FP64 multiply + rint). */
+static int32_t torus_gaussian(u64 seed, u64 stream, u64 index, double c)
+{
+    u64 sum = 0;
+    for (int j = 0; j < 4; j++) {
+        uint32_t w[4];
+        block(seed, stream, 4 * index + j, w);
+        sum += (u64) w[0] + w[1] + w[2] + w[3];
+    }
+    double g = (double) ((int64_t) sum - ((int64_t) 8 << 32));
+    return (int32_t) (uint32_t) (int64_t) rint(g * c);
+}
+static int32_t torus_uniform(u64 seed, u64 stream, u64 index)
+{
+    uint32_t w[4];
+    block(seed, stream, index, w);
+    return (int32_t) w[0];
+}
+
+#define TF_n 512
+#define TF_N 1024
+#define TF_l 2
+#define TF_bg 10
+#define TF_ksl 8
+#define TF_ksb 2
+static const double IH = 1.1547005383792517;
+static const double KS_STDEV = (1.0 / 32768.0) * 0.7978845608028654, BK_STDEV = 9e-9 * 0.7978845608028654;
+
+void o_tfhe_gen_secret(orng_t* r, int32_t* lwe_key, int32_t* tlwe_key)
+{
+    u64 s0 = r->stream;
+    r->stream += 2;
+    for (int i = 0; i < TF_n; i++) { uint32_t w[4]; block(r->seed, s0, (u64) i, w); lwe_key[i] = (int32_t) (w[0] & 1u); }
+    for (int i = 0; i < TF_N; i++) { uint32_t w[4]; block(r->seed, s0 + 1, (u64) i, w); tlwe_key[i] = (int32_t) (w[0] & 1u); }
+}
+
+static void lwe_encrypt(const int32_t* key, u64 s, uint32_t msg, int32_t* a, int32_t* b, double c, u64 seed,
+                        u64 stream_a, u64 stream_e)
+{
+    uint32_t acc = 0;
+    for (int j = 0; j < TF_n; j++) {
+        a[j] = torus_uniform(seed, stream_a, s * TF_n + j);
+        acc += (uint32_t) a[j] * (uint32_t) key[j];
+    }
+    *b = (int32_t) (acc + msg + (uint32_t) torus_gaussian(seed, stream_e, s, c));
+}
+
+void o_tfhe_gen_bootkey(const otfhe_t* c, orng_t* r, const int32_t* lwe_key, const int32_t* tlwe_key, u64* boot_key,
+                        int32_t* ks_a, int32_t* ks_b)
+{
+    u64 s0 = r->stream;
+    r->stream += 4;
+    const double cb = BK_STDEV / IH, ck = KS_STDEV / IH;
+    int32_t a[TF_N], b[TF_N], prod[TF_N];
+    for (u64 row = 0; row < (u64) TF_n * 2 * TF_l; row++) {
+        const int z = (int) (row % TF_l), y = (int) ((row / TF_l) % 2);
+        const u64 i = row / (2 * TF_l);
+        for (int t = 0; t < TF_N; t++) a[t] = torus_uniform(r->seed, s0, row * TF_N + t);
+        o_tfhe_polymul(c, a, tlwe_key, prod);
+        for (int t = 0; t < TF_N; t++)
+            b[t] = (int32_t) ((uint32_t) prod[t] + (uint32_t) torus_gaussian(r->seed, s0 + 1, row * TF_N + t, cb));
+        const uint32_t mu = (uint32_t) lwe_key[i] << (32 - (z + 1) * TF_bg);
+        if (y == 0) a[0] = (int32_t) ((uint32_t) a[0] + mu);
+        else b[0] = (int32_t) ((uint32_t) b[0] + mu);
+        o_tfhe_to_ntt(c, a, boot_key + row * 2 * TF_N);
+        o_tfhe_to_ntt(c, b, boot_key + row * 2 * TF_N + TF_N);
+    }
+    const int mask = (1 << TF_ksb) - 1;
+    const u64 rows = (u64) TF_N * TF_ksl * mask;
+    for (u64 s = 0; s < rows; s++) {
+        const u64 v = s % mask + 1, j = (s / mask) % TF_ksl, i = s / ((u64) mask * TF_ksl);
+        const uint32_t m = (uint32_t) tlwe_key[i] * (uint32_t) v * (1u << (32 - (j + 1) * TF_ksb));
+        lwe_encrypt(lwe_key, s, m, ks_a + s * TF_n, ks_b + s, ck, r->seed, s0 + 2, s0 + 3);
+    }
+}
+
+void o_tfhe_encrypt(orng_t* r, const int32_t* lwe_key, const int32_t* messages, int shape, int32_t* a, int32_t* b)
+{
+    u64 s0 = r->stream;
+    r->stream += 2;
+    for (int s = 0; s < shape; s++)
+        lwe_encrypt(lwe_key, (u64) s, (uint32_t) messages[s], a + (u64) s * TF_n, b + s, KS_STDEV / IH, r->seed, s0, s0 + 1);
+}
+
+void o_tfhe_phase(const int32_t* lwe_key, const int32_t* a, const int32_t* b, int shape, int32_t* phase)
+{
+    for (int s = 0; s < shape; s++) {
+        uint32_t acc = 0;
+        for (int j = 0; j < TF_n; j++) acc += (uint32_t) a[(u64) s * TF_n + j] * (uint32_t) lwe_key[j];
+        phase[s] = (int32_t) ((uint32_t) b[s] - acc);
+    }
+}

@@ -98,3 +98,47 @@ def test_not_gate(hg, setup):
     torch.cuda.synchronize()
     assert np.array_equal(out_a.cpu().numpy(), (-a.astype(np.int64)).astype(np.int32))
     assert np.array_equal(out_b.cpu().numpy(), (-b.astype(np.int64)).astype(np.int32))
+
+
+def test_front_end_keys_encryption_and_gates(hg, oracle):
+    """TFHE front end: generated keys, bit encryption and the decryption phase are bit-identical
+    to the oracle for the same DRBG seed; with the GPU-generated key all gates incl. MUX give
+    their truth tables (reference test/test_tfhe_gate_boot.cpp:64-86), FP64 blind rotate."""
+    import torch
+    t = hg.TfheContext()
+    o = oracle.OracleTfhe()
+    rg, ro = hg.Rng(77), oracle.ORng(77)
+    lwe, tlwe = t.generate_secret_key(rg)
+    lwe_o, tlwe_o = o.gen_secret(ro)
+    assert np.array_equal(lwe.cpu().numpy(), lwe_o) and np.array_equal(tlwe.cpu().numpy(), tlwe_o)
+    bk, ks_a, ks_b = t.generate_bootstrapping_key(rg, lwe, tlwe)
+    bk_o, ksa_o, ksb_o = o.gen_bootkey(ro, lwe_o, tlwe_o)
+    assert np.array_equal(bk.cpu().numpy().view(np.uint64), bk_o), "boot key"
+    assert np.array_equal(ks_a.cpu().numpy(), ksa_o) and np.array_equal(ks_b.cpu().numpy(), ksb_o), "key-switch key"
+    prepared = t.prepare_bootkey(bk)
+    assert t.prepared_is_fp64(prepared), "a generated key has torus32 coefficients"
+    mu = 1 << 29
+    xs = np.array([0, 0, 1, 1, 0, 0, 1, 1])
+    ys = np.array([0, 1, 0, 1, 0, 1, 0, 1])
+    cs = np.array([0, 0, 0, 0, 1, 1, 1, 1])
+    enc = lambda bits: torch.from_numpy(np.where(bits == 1, mu, -mu).astype(np.int32)).cuda()
+    a1, b1 = t.encrypt(rg, lwe, enc(xs))
+    a1o, b1o = o.encrypt(ro, lwe_o, np.where(xs == 1, mu, -mu))
+    assert np.array_equal(a1.cpu().numpy(), a1o) and np.array_equal(b1.cpu().numpy(), b1o), "encryption"
+    a2, b2 = t.encrypt(rg, lwe, enc(ys))
+    ac, bc = t.encrypt(rg, lwe, enc(cs))
+    ph = t.decrypt_phase(lwe, a1, b1).cpu().numpy()
+    assert np.array_equal(ph, o.phase(lwe_o, a1o, b1o)) and np.array_equal((ph > 0).astype(int), xs)
+    S = len(xs)
+    out_a = torch.empty(S * 512, dtype=torch.int32, device="cuda")
+    out_b = torch.empty(S, dtype=torch.int32, device="cuda")
+    ws = torch.empty((512 + 1 + 2 * (1024 + 1)) * S, dtype=torch.int32, device="cuda")
+    truth = {hg.GATE_NAND: 1 - (xs & ys), hg.GATE_AND: xs & ys, hg.GATE_NOR: 1 - (xs | ys), hg.GATE_OR: xs | ys,
+             hg.GATE_XNOR: 1 - (xs ^ ys), hg.GATE_XOR: xs ^ ys}
+    for gate, want in truth.items():
+        t.gate(gate, a1, b1, a2, b2, out_a, out_b, prepared, ks_a, ks_b, S, ws)
+        got = (t.decrypt_phase(lwe, out_a, out_b).cpu().numpy() > 0).astype(int)
+        assert np.array_equal(got, want), f"gate {gate}"
+    t.mux(a1, b1, a2, b2, ac, bc, out_a, out_b, prepared, ks_a, ks_b, S, ws)
+    got = (t.decrypt_phase(lwe, out_a, out_b).cpu().numpy() > 0).astype(int)
+    assert np.array_equal(got, np.where(cs == 1, xs, ys)), "MUX(in1, in2, control) = control ? in1 : in2"

@@ -77,3 +77,24 @@ def test_gate_truth_table(keys, gate):
     oa, ob_ = o.gate(gate, a1, b1, a2, b2, bk, ks_a, ks_b)
     got = decrypt_bits(s, oa, ob_)
     assert got == [TRUTH[gate](x, y) for x, y in zip(xs, ys)]
+
+
+def test_generated_keys_reproduce_truth_tables(oracle):
+    """keys from the oracle's own generator (oracle/o_keygen.c: binary keys, TGSW boot key,
+    key-switch key, Irwin-Hall torus noise) drive the gate path to the truth tables"""
+    o = oracle.OracleTfhe()
+    rng = oracle.ORng(2026)
+    lwe, tlwe = o.gen_secret(rng)
+    assert set(np.unique(lwe)) <= {0, 1} and 150 < lwe.sum() < 362
+    bk, ks_a, ks_b = o.gen_bootkey(rng, lwe, tlwe)
+    xs, ys = [0, 0, 1, 1], [0, 1, 0, 1]
+    mu = 1 << 29
+    a1, b1 = o.encrypt(rng, lwe, [mu if x else -mu for x in xs])
+    a2, b2 = o.encrypt(rng, lwe, [mu if y else -mu for y in ys])
+    ph = o.phase(lwe, a1, b1)
+    assert [int(p > 0) for p in ph] == xs
+    assert np.max(np.abs(ph.astype(np.int64) - np.array([mu if x else -mu for x in xs]))) < 1 << 22
+    for gate in (0, 4, 6):  # NAND, OR, XOR
+        oa, ob_ = o.gate(gate, a1, b1, a2, b2, bk, ks_a, ks_b)
+        got = [int(p > 0) for p in o.phase(lwe, oa, ob_)]
+        assert got == [TRUTH[gate](x, y) for x, y in zip(xs, ys)], gate
