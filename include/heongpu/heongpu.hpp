@@ -157,8 +157,7 @@ template <typename T> class DeviceVector {
 template <typename T> using HostVector = std::vector<T>; // util/hostvector.cuh:17-31 (pinned there)
 
 // ------------------------------------------------------------------ context
-template <Scheme S> class HEContextImpl {
-    static_assert(S == Scheme::BFV || S == Scheme::CKKS, "use the C ABI (hegpu_tfhe_*) for TFHE");
+template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation is at the end of this file
 
   public:
     explicit HEContextImpl(sec_level_type sec = sec_level_type::sec128) : sec_level_(sec) {}
@@ -1045,6 +1044,258 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         }
         if (&a != &out) copy_meta(a, out);
         out.memory_set(std::move(m));
+    }
+    HEContext<S> context_;
+};
+
+// ------------------------------------------------------------------ TFHE (host/tfhe/*.cuh)
+// Fixed parameter set (tfhe/context.cu:15-57).  Ciphertexts are LWE samples a [shape][n], b [shape]
+// on the 32-bit torus; a bit is +-1/8.
+template <> class HEContextImpl<Scheme::TFHE> {
+  public:
+    explicit HEContextImpl(sec_level_type = sec_level_type::sec128)
+    {
+        detail::check(hegpu_tfhe_context_create(&h_));
+        n_ = (int) hegpu_tfhe_context_int(h_, "n");
+        N_ = (int) hegpu_tfhe_context_int(h_, "N");
+        k_ = (int) hegpu_tfhe_context_int(h_, "k");
+    }
+    ~HEContextImpl() { if (h_) hegpu_tfhe_context_destroy(h_); }
+    HEContextImpl(const HEContextImpl&) = delete;
+    hegpu_tfhe_context* handle() const { return h_; }
+    long elems(const char* what) const { return hegpu_tfhe_context_int(h_, what); }
+    int n_ = 0, N_ = 0, k_ = 0;
+    bool context_generated_ = true;
+
+  private:
+    hegpu_tfhe_context* h_ = nullptr;
+};
+
+template <> class Ciphertext<Scheme::TFHE> {
+  public:
+    explicit Ciphertext(HEContext<Scheme::TFHE> context, const ExecutionOptions& = ExecutionOptions())
+    {
+        if (!context) throw std::invalid_argument("HEContext is not generated!");
+        n_ = context->n_;
+    }
+    DeviceVector<int32_t> a_device_location_, b_device_location_;
+    int n_ = 0, shape_ = 0;
+    bool ciphertext_generated_ = false;
+};
+
+template <> class Secretkey<Scheme::TFHE> {
+  public:
+    explicit Secretkey(HEContext<Scheme::TFHE> context) : context_(std::move(context))
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+    }
+    DeviceVector<int32_t> lwe_key_device_location_, tlwe_key_device_location_;
+    bool secret_key_generated_ = false;
+
+  private:
+    HEContext<Scheme::TFHE> context_;
+};
+
+template <Scheme S> class Bootstrappingkey;
+template <> class Bootstrappingkey<Scheme::TFHE> { // boot key (prepared for the blind rotate) + key-switch key
+  public:
+    explicit Bootstrappingkey(HEContext<Scheme::TFHE> context) : context_(std::move(context))
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+    }
+    DeviceVector<Data64> boot_key_device_location_;  // reference layout [n][k+1][l][k+1][N], NTT domain
+    DeviceVector<Data64> prepared_;                  // hegpu_tfhe_prepare_bootkey
+    DeviceVector<int32_t> switch_key_device_location_a_, switch_key_device_location_b_;
+    bool boot_key_generated_ = false;
+
+  private:
+    HEContext<Scheme::TFHE> context_;
+};
+
+template <> class HEKeyGenerator<Scheme::TFHE> { // host/tfhe/keygenerator.cuh
+    static constexpr Scheme S = Scheme::TFHE;
+
+  public:
+    explicit HEKeyGenerator(HEContext<S> context) : HEKeyGenerator(std::move(context), std::random_device{}()) {}
+    HEKeyGenerator(HEContext<S> context, std::uint64_t seed) : context_(std::move(context))
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+        detail::check(hegpu_rng_create(seed, &rng_));
+    }
+    ~HEKeyGenerator() { hegpu_rng_destroy(rng_); }
+    HEKeyGenerator(const HEKeyGenerator&) = delete;
+    HEKeyGenerator& operator=(const HEKeyGenerator&) = delete;
+
+    void generate_secret_key(Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (sk.secret_key_generated_) throw std::logic_error("Secretkey is already generated!");
+        sk.lwe_key_device_location_ = DeviceVector<int32_t>((size_t) context_->n_, o.stream_);
+        sk.tlwe_key_device_location_ = DeviceVector<int32_t>((size_t) context_->k_ * context_->N_, o.stream_);
+        detail::check(hegpu_tfhe_generate_secret_key(context_->handle(), rng_, sk.lwe_key_device_location_.data(),
+                                                     sk.tlwe_key_device_location_.data(), o.stream_));
+        sk.secret_key_generated_ = true;
+    }
+    void generate_bootstrapping_key(Bootstrappingkey<S>& bk, Secretkey<S>& sk,
+                                    const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        if (bk.boot_key_generated_) throw std::logic_error("Bootstrappingkey is already generated!");
+        bk.boot_key_device_location_ = DeviceVector<Data64>((size_t) context_->elems("bootkey_elems"), o.stream_);
+        bk.switch_key_device_location_a_ = DeviceVector<int32_t>((size_t) context_->elems("kskey_a_elems"), o.stream_);
+        bk.switch_key_device_location_b_ = DeviceVector<int32_t>((size_t) context_->elems("kskey_b_elems"), o.stream_);
+        DeviceVector<Data64> ws((size_t) context_->N_, o.stream_);
+        detail::check(hegpu_tfhe_generate_bootstrapping_key(
+            context_->handle(), rng_, sk.lwe_key_device_location_.data(), sk.tlwe_key_device_location_.data(),
+            (uint64_t*) bk.boot_key_device_location_.data(), bk.switch_key_device_location_a_.data(),
+            bk.switch_key_device_location_b_.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        bk.prepared_ = DeviceVector<Data64>((size_t) context_->elems("prepared_bootkey_elems"), o.stream_);
+        detail::check(hegpu_tfhe_prepare_bootkey(context_->handle(), (const uint64_t*) bk.boot_key_device_location_.data(),
+                                                 (uint64_t*) bk.prepared_.data(), o.stream_));
+        bk.boot_key_generated_ = true;
+    }
+
+  private:
+    HEContext<S> context_;
+    hegpu_rng* rng_ = nullptr;
+};
+
+template <> class HEEncryptor<Scheme::TFHE> { // host/tfhe/encryptor.cuh: symmetric LWE encryption of bits
+    static constexpr Scheme S = Scheme::TFHE;
+
+  public:
+    HEEncryptor(HEContext<S> context, Secretkey<S>& sk) : context_(std::move(context)), sk_(&sk)
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        detail::check(hegpu_rng_create(std::random_device{}(), &rng_));
+    }
+    ~HEEncryptor() { hegpu_rng_destroy(rng_); }
+    HEEncryptor(const HEEncryptor&) = delete;
+    HEEncryptor& operator=(const HEEncryptor&) = delete;
+
+    void encrypt(Ciphertext<S>& ct, const std::vector<bool>& messages, const ExecutionOptions& o = ExecutionOptions())
+    {
+        const int shape = (int) messages.size();
+        std::vector<int32_t> enc(messages.size());
+        for (size_t i = 0; i < messages.size(); i++) enc[i] = messages[i] ? (1 << 29) : -(1 << 29); // +-1/8
+        DeviceVector<int32_t> msg(enc, o.stream_);
+        ct.a_device_location_ = DeviceVector<int32_t>((size_t) shape * context_->n_, o.stream_);
+        ct.b_device_location_ = DeviceVector<int32_t>((size_t) shape, o.stream_);
+        detail::check(hegpu_tfhe_encrypt(context_->handle(), rng_, sk_->lwe_key_device_location_.data(), msg.data(),
+                                         shape, ct.a_device_location_.data(), ct.b_device_location_.data(), o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+        ct.shape_ = shape;
+        ct.ciphertext_generated_ = true;
+    }
+
+  private:
+    HEContext<S> context_;
+    Secretkey<S>* sk_;
+    hegpu_rng* rng_ = nullptr;
+};
+
+template <> class HEDecryptor<Scheme::TFHE> { // host/tfhe/decryptor.cuh
+    static constexpr Scheme S = Scheme::TFHE;
+
+  public:
+    HEDecryptor(HEContext<S> context, Secretkey<S>& sk) : context_(std::move(context)), sk_(&sk)
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+        if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+    }
+    void decrypt(Ciphertext<S>& ct, std::vector<bool>& messages, const ExecutionOptions& o = ExecutionOptions())
+    {
+        DeviceVector<int32_t> phase((size_t) ct.shape_, o.stream_);
+        detail::check(hegpu_tfhe_decrypt_phase(context_->handle(), sk_->lwe_key_device_location_.data(),
+                                               ct.a_device_location_.data(), ct.b_device_location_.data(), ct.shape_,
+                                               phase.data(), o.stream_));
+        std::vector<int32_t> h((size_t) ct.shape_);
+        detail::hip(hipMemcpyAsync(h.data(), phase.data(), h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+        messages.resize(h.size());
+        for (size_t i = 0; i < h.size(); i++) messages[i] = h[i] > 0;
+    }
+
+  private:
+    HEContext<S> context_;
+    Secretkey<S>* sk_;
+};
+
+template <Scheme S> class HELogicOperator;
+template <> class HELogicOperator<Scheme::TFHE> { // host/tfhe/operator.cuh: bootstrapped binary gates
+    static constexpr Scheme S = Scheme::TFHE;
+
+  public:
+    explicit HELogicOperator(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+    }
+#define HEONGPU_TFHE_GATE(NAME, ID)                                                                              \
+    void NAME(Ciphertext<S>& in1, Ciphertext<S>& in2, Ciphertext<S>& out, Bootstrappingkey<S>& bk,               \
+              const ExecutionOptions& o = ExecutionOptions())                                                    \
+    {                                                                                                            \
+        gate(ID, in1, in2, out, bk, o);                                                                          \
+    }
+    HEONGPU_TFHE_GATE(NAND, HEGPU_GATE_NAND)
+    HEONGPU_TFHE_GATE(AND, HEGPU_GATE_AND)
+    HEONGPU_TFHE_GATE(NOR, HEGPU_GATE_NOR)
+    HEONGPU_TFHE_GATE(OR, HEGPU_GATE_OR)
+    HEONGPU_TFHE_GATE(XNOR, HEGPU_GATE_XNOR)
+    HEONGPU_TFHE_GATE(XOR, HEGPU_GATE_XOR)
+#undef HEONGPU_TFHE_GATE
+    void NOT(Ciphertext<S>& in, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!in.ciphertext_generated_) throw std::runtime_error("Input is not generated!");
+        DeviceVector<int32_t> a((size_t) in.shape_ * context_->n_, o.stream_), b((size_t) in.shape_, o.stream_);
+        detail::check(hegpu_tfhe_gate_precompute(context_->handle(), HEGPU_GATE_NOT, a.data(), b.data(),
+                                                 in.a_device_location_.data(), in.b_device_location_.data(), nullptr,
+                                                 nullptr, in.shape_, o.stream_));
+        finish(out, in.shape_, std::move(a), std::move(b));
+    }
+    void MUX(Ciphertext<S>& in1, Ciphertext<S>& in2, Ciphertext<S>& control, Ciphertext<S>& out,
+             Bootstrappingkey<S>& bk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (in1.shape_ != in2.shape_ || in1.shape_ != control.shape_)
+            throw std::runtime_error("Ciphertexts size should be equal!");
+        if (!(in1.ciphertext_generated_ && in2.ciphertext_generated_)) throw std::runtime_error("One or the inputs are generated!");
+        const int shape = in1.shape_;
+        DeviceVector<int32_t> a((size_t) shape * context_->n_, o.stream_), b((size_t) shape, o.stream_);
+        DeviceVector<int32_t> ws(((size_t) context_->n_ + 1 + 2 * ((size_t) context_->k_ * context_->N_ + 1)) * shape,
+                                 o.stream_);
+        detail::check(hegpu_tfhe_mux(context_->handle(), in1.a_device_location_.data(), in1.b_device_location_.data(),
+                                     in2.a_device_location_.data(), in2.b_device_location_.data(),
+                                     control.a_device_location_.data(), control.b_device_location_.data(), a.data(),
+                                     b.data(), (const uint64_t*) bk.prepared_.data(),
+                                     bk.switch_key_device_location_a_.data(), bk.switch_key_device_location_b_.data(),
+                                     shape, ws.data(), ws.size() * sizeof(int32_t), o.stream_));
+        finish(out, shape, std::move(a), std::move(b));
+    }
+
+  private:
+    void gate(int id, Ciphertext<S>& in1, Ciphertext<S>& in2, Ciphertext<S>& out, Bootstrappingkey<S>& bk,
+              const ExecutionOptions& o)
+    {
+        if (in1.shape_ != in2.shape_) throw std::runtime_error("Ciphertexts size should be equal!");
+        if (!(in1.ciphertext_generated_ && in2.ciphertext_generated_)) throw std::runtime_error("One or the inputs are generated!");
+        if (!bk.boot_key_generated_) throw std::runtime_error("Bootstrappingkey is not generated!");
+        const int shape = in1.shape_;
+        DeviceVector<int32_t> a((size_t) shape * context_->n_, o.stream_), b((size_t) shape, o.stream_);
+        DeviceVector<int32_t> ws(((size_t) context_->n_ + (size_t) context_->k_ * context_->N_ + 2) * shape, o.stream_);
+        detail::check(hegpu_tfhe_gate(context_->handle(), id, in1.a_device_location_.data(),
+                                      in1.b_device_location_.data(), in2.a_device_location_.data(),
+                                      in2.b_device_location_.data(), a.data(), b.data(),
+                                      (const uint64_t*) bk.prepared_.data(), bk.switch_key_device_location_a_.data(),
+                                      bk.switch_key_device_location_b_.data(), shape, ws.data(),
+                                      ws.size() * sizeof(int32_t), o.stream_));
+        finish(out, shape, std::move(a), std::move(b));
+    }
+    void finish(Ciphertext<S>& out, int shape, DeviceVector<int32_t>&& a, DeviceVector<int32_t>&& b)
+    {
+        out.a_device_location_ = std::move(a);
+        out.b_device_location_ = std::move(b);
+        out.shape_ = shape;
+        out.n_ = context_->n_;
+        out.ciphertext_generated_ = true;
     }
     HEContext<S> context_;
 };

@@ -456,6 +456,42 @@ static void serializer_round_trip()
     EXPECT(thrown, "a BFV-tagged binary is rejected by a CKKS ciphertext");
 }
 
+// TFHE through the class layer (reference test/test_tfhe_gate_boot.cpp:64-86): all gates and MUX
+static void tfhe_gates()
+{
+    constexpr auto S = Scheme::TFHE;
+    HEContext<S> ctx = GenHEContext<S>();
+    HEKeyGenerator<S> keygen(ctx, 9);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Bootstrappingkey<S> bk(ctx);
+    keygen.generate_bootstrapping_key(bk, sk);
+    HEEncryptor<S> enc(ctx, sk);
+    HEDecryptor<S> dec(ctx, sk);
+    HELogicOperator<S> logic(ctx);
+    std::vector<bool> x = {0, 0, 1, 1, 0, 0, 1, 1}, y = {0, 1, 0, 1, 0, 1, 0, 1}, c = {0, 0, 0, 0, 1, 1, 1, 1}, got;
+    Ciphertext<S> cx(ctx), cy(ctx), cc(ctx), r(ctx);
+    enc.encrypt(cx, x);
+    enc.encrypt(cy, y);
+    enc.encrypt(cc, c);
+    dec.decrypt(cx, got);
+    EXPECT(got == x, "tfhe decrypt(encrypt(bits)) == bits");
+    auto check = [&](const char* name, auto f) {
+        dec.decrypt(r, got);
+        bool ok = got.size() == x.size();
+        for (size_t i = 0; ok && i < x.size(); i++) ok = got[i] == f(x[i], y[i], c[i]);
+        EXPECT(ok, name);
+    };
+    logic.NAND(cx, cy, r, bk); check("tfhe NAND", [](bool a, bool b, bool) { return !(a && b); });
+    logic.AND(cx, cy, r, bk);  check("tfhe AND", [](bool a, bool b, bool) { return a && b; });
+    logic.NOR(cx, cy, r, bk);  check("tfhe NOR", [](bool a, bool b, bool) { return !(a || b); });
+    logic.OR(cx, cy, r, bk);   check("tfhe OR", [](bool a, bool b, bool) { return a || b; });
+    logic.XNOR(cx, cy, r, bk); check("tfhe XNOR", [](bool a, bool b, bool) { return a == b; });
+    logic.XOR(cx, cy, r, bk);  check("tfhe XOR", [](bool a, bool b, bool) { return a != b; });
+    logic.NOT(cx, r);          check("tfhe NOT", [](bool a, bool, bool) { return !a; });
+    logic.MUX(cx, cy, cc, r, bk); check("tfhe MUX", [](bool a, bool b, bool s) { return s ? a : b; });
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -475,6 +511,7 @@ int main()
     bfv_pipeline();
     ckks_encoder_flow();
     serializer_round_trip();
+    tfhe_gates();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }

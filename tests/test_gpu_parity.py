@@ -414,7 +414,7 @@ def test_cpp_class_layer(torch):
     assert "PASSED" in r.stdout
 
 
-@pytest.mark.parametrize("name", ["ckks", "bfv"])
+@pytest.mark.parametrize("name", ["ckks", "bfv", "tfhe"])
 def test_reference_benchmark_runs_unchanged(torch, name):
     """benchmark/benchmark_{ckks,bfv}.cpp of the reference, compiled unchanged against the class
     layer by __graft_entry__.build() (where the reference tree is available), run to completion."""
@@ -427,4 +427,7 @@ def test_reference_benchmark_runs_unchanged(torch, name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     print(r.stdout[-2500:], r.stderr[-500:])
     assert r.returncode == 0
-    assert r.stdout.count("Average multiplication timing") >= 4
+    if name == "tfhe":
+        assert "[NAND] Avg Time" in r.stdout and "[MUX] Avg Time" in r.stdout
+    else:
+        assert r.stdout.count("Average multiplication timing") >= 4
