@@ -60,11 +60,13 @@ SIGNATURES = [
     ("hegpu_generate_secret_key", c_int, [voidp, voidp, c_int, u64p, voidp, c_size_t, voidp]),
     ("hegpu_generate_public_key", c_int, [voidp, voidp, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_generate_relin_key", c_int, [voidp, voidp, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_generate_switch_key", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_generate_galois_key", c_int, [voidp, voidp, u64p, c_int, u64p, voidp, c_size_t, voidp]),
     ("hegpu_ckks_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_ckks_decrypt", c_int, [voidp, u64p, u64p, c_int, u64p, voidp]),
     ("hegpu_bfv_encrypt", c_int, [voidp, voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_bfv_decrypt", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_bfv_noise_rns", c_int, [voidp, u64p, u64p, u64p, voidp]),
     ("hegpu_cipherplain_multiplication", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),
     ("hegpu_bfv_plain_addsub", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),
     ("hegpu_bfv_multiply_plain", c_int, [voidp, u64p, u64p, u64p, voidp, c_size_t, voidp]),

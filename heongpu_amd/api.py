@@ -264,18 +264,36 @@ class Context:
                                                    stream if stream is not None else _stream()))
         return pk
 
+    def switch_key_digits(self):
+        """digits of a key-switching key: Q (method I) or the depth-0 partition of method II
+        (digits of 2 primes for BFV, of P_size primes for CKKS; contextpool.cpp:161-438)"""
+        if self.P_size == 1:
+            return self.Q_size
+        m = 2 if self.int("scheme") == BFV else self.P_size
+        return -(-self.Q_size // m)
+
     def generate_relin_key(self, rng, sk, stream=None):
         import torch
-        rk = torch.empty(self.Q_size * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        rk = torch.empty(self.switch_key_digits() * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
         ws = self._kg_ws(OP_KEYGEN_SWITCH)
         _check(self._lib.hegpu_generate_relin_key(self._h, rng._h, _ptr(sk), _ptr(rk), _ptr(ws),
                                                   ws.numel() * ws.element_size(),
                                                   stream if stream is not None else _stream()))
         return rk
 
+    def generate_switch_key(self, rng, new_sk, old_sk, stream=None):
+        """HEKeyGenerator::generate_switch_key (ckks/keygenerator.cu:996-1095): key under new_sk carrying old_sk."""
+        import torch
+        swk = torch.empty(self.switch_key_digits() * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        ws = self._kg_ws(OP_KEYGEN_SWITCH)
+        _check(self._lib.hegpu_generate_switch_key(self._h, rng._h, _ptr(new_sk), _ptr(old_sk), _ptr(swk), _ptr(ws),
+                                                   ws.numel() * ws.element_size(),
+                                                   stream if stream is not None else _stream()))
+        return swk
+
     def generate_galois_key(self, rng, sk, galois_elt, stream=None):
         import torch
-        gk = torch.empty(self.Q_size * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
+        gk = torch.empty(self.switch_key_digits() * 2 * self.Q_prime_size * self.n, dtype=torch.int64, device="cuda")
         ws = self._kg_ws(OP_KEYGEN_SWITCH)
         _check(self._lib.hegpu_generate_galois_key(self._h, rng._h, _ptr(sk), galois_elt, _ptr(gk), _ptr(ws),
                                                    ws.numel() * ws.element_size(),

@@ -193,6 +193,7 @@ long hegpu_context_int(const hegpu_context* ctx, const char* name)
     if (!strcmp(name, "Q_prime_size")) return c.Qp_size;
     if (!strcmp(name, "bsk_modulus")) return c.bsk_size;
     if (!strcmp(name, "scheme")) return c.scheme;
+    if (!strcmp(name, "max_logq_128")) return host::max_logq_128((int) c.n); // util/secstdparams.h
     return -1;
 }
 
@@ -525,9 +526,20 @@ int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t*
 {
     NEED_CTX(ctx);
     CHECK_KG(ctx, rng, OP_KEYGEN_SWITCH, ws, ws_bytes);
-    if (ctx->c.P_size != 1) return fail(HEGPU_E_LOGIC, "key generation implements key-switching method I (P_size == 1)");
-    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, 0, (u64*) rk, (u64*) ws, (hipStream_t) stream),
+    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, 0, nullptr, (u64*) rk, (u64*) ws,
+                                     (hipStream_t) stream),
                    "hegpu_generate_relin_key");
+}
+
+int hegpu_generate_switch_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* new_sk, const uint64_t* old_sk,
+                              uint64_t* swk, void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_KG(ctx, rng, OP_KEYGEN_SWITCH, ws, ws_bytes);
+    if (!old_sk) return fail(HEGPU_E_INVALID, "null old secret key");
+    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) new_sk, 0, (const u64*) old_sk, (u64*) swk, (u64*) ws,
+                                     (hipStream_t) stream),
+                   "hegpu_generate_switch_key");
 }
 
 int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, int galois_elt, uint64_t* gk,
@@ -535,10 +547,9 @@ int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t
 {
     NEED_CTX(ctx);
     CHECK_KG(ctx, rng, OP_KEYGEN_SWITCH, ws, ws_bytes);
-    if (ctx->c.P_size != 1) return fail(HEGPU_E_LOGIC, "key generation implements key-switching method I (P_size == 1)");
     if (!(galois_elt & 1) || galois_elt <= 0 || galois_elt >= (int) (2 * ctx->c.n))
         return fail(HEGPU_E_INVALID, "galois element must be odd and below 2N");
-    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, galois_elt, (u64*) gk, (u64*) ws,
+    return hip_ret(op_gen_switch_key(ctx->c, rng->r, (const u64*) sk, galois_elt, nullptr, (u64*) gk, (u64*) ws,
                                      (hipStream_t) stream),
                    "hegpu_generate_galois_key");
 }
@@ -642,6 +653,14 @@ int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, doub
         return fail(HEGPU_E_INVALID, "workspace too small");
     return hip_ret(op_ckks_decode(ctx->c, (const u64*) plain, depth, scale, message, (u64*) ws, (hipStream_t) stream),
                    "hegpu_ckks_decode");
+}
+
+int hegpu_bfv_noise_rns(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* out, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    return hip_ret(op_bfv_noise_rns(ctx->c, (const u64*) ct, (const u64*) sk, (u64*) out, (hipStream_t) stream),
+                   "hegpu_bfv_noise_rns");
 }
 
 // ---- ciphertext (x) plaintext operations

@@ -111,26 +111,37 @@ __device__ __forceinline__ u32 ntt_permutation(u32 index, u32 galois_elt, int n_
     return bitrev(raw, n_power);
 }
 
+// One kernel for the six generators of the reference (keygeneration.cu relinkey_gen_kernel :145,
+// relinkey_gen_II_kernel :584, galoiskey_gen_kernel :757, galoiskey_gen_II_kernel :807,
+// switchkey_gen_kernel :896, switchkey_gen_II_kernel :941).  Digit i of the key is
+//   ( -(s' * a_i + e_i) + [limb y belongs to digit i] * carried * P  ,  a_i )   over the Q' limbs,
+// with (s', carried) = (s, s^2) relinearisation, (s o g^-1, s) Galois, (s_new, s_old) switch key.
+// Method I: digits = Q, digit_width = 1, P = the one special prime; method II: digits of
+// digit_width primes (Sk_pair = y / width; special limbs belong to no digit), P = product of the
+// special primes, multiplied in one factor at a time like the reference.
 __global__ __launch_bounds__(KG_THREADS) void k_kg_switchkey(u64* __restrict__ key, const u64* __restrict__ sk,
                                                              const u64* __restrict__ e, const u64* __restrict__ a,
                                                              const Mod* __restrict__ mods,
                                                              const u64* __restrict__ factor, int galois_elt,
-                                                             int n_power, int limbs)
+                                                             const u64* __restrict__ old_sk, int n_power, int limbs,
+                                                             int digits, int digit_width, int q_size, int p_size)
 {
     const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
     const int y = blockIdx.y;
     const Mod m = mods[y];
     const u64 s = sk[idx + ((u64) y << n_power)];
-    // secret the key is encrypted under / polynomial it carries
     const u64 sp = galois_elt ? sk[((u64) y << n_power) + ntt_permutation(idx, (u32) galois_elt, n_power)] : s;
-    const u64 carried = galois_elt ? s : mul_barrett(s, s, m);
-    for (int i = 0; i < limbs - 1; i++) {
+    u64 carried = old_sk ? old_sk[idx + ((u64) y << n_power)] : (galois_elt ? s : mul_barrett(s, s, m));
+    const int own = (y < q_size) ? y / digit_width : -1;
+    if (own >= 0)
+        for (int j = 0; j < p_size; j++) carried = mul_barrett(carried, factor[j * q_size + y], m);
+    for (int i = 0; i < digits; i++) {
         const u64 src = idx + ((u64) y << n_power) + ((u64) (limbs * i) << n_power);
         const u64 av = a[src];
         u64 k0 = mul_barrett(sp, av, m);
         k0 = add_mod(k0, e[src], m.q);
         k0 = sub_mod(0, k0, m.q);
-        if (i == y) k0 = add_mod(k0, mul_barrett(carried, factor[y], m), m.q);
+        if (i == own) k0 = add_mod(k0, carried, m.q);
         const u64 dst = idx + ((u64) y << n_power) + ((u64) (limbs * i) << (n_power + 1));
         key[dst] = k0;
         key[dst + ((u64) limbs << n_power)] = av;
@@ -138,10 +149,11 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_switchkey(u64* __restrict__ k
 }
 
 hipError_t kg_switchkey(u64* key, const u64* sk, const u64* e, const u64* a, const Mod* mods, const u64* factor,
-                        int galois_elt, int n_power, int limbs, hipStream_t st)
+                        int galois_elt, const u64* old_sk, int n_power, int limbs, int digits, int digit_width,
+                        int q_size, int p_size, hipStream_t st)
 {
     hipLaunchKernelGGL(k_kg_switchkey, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, key, sk, e,
-                       a, mods, factor, galois_elt, n_power, limbs);
+                       a, mods, factor, galois_elt, old_sk, n_power, limbs, digits, digit_width, q_size, p_size);
     return hipGetLastError();
 }
 
@@ -285,6 +297,23 @@ hipError_t kg_sk_multiplication(const u64* in, const u64* sk, u64* out, const Mo
 {
     hipLaunchKernelGGL(k_kg_sk_mul, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, in, sk, out,
                        mods, n_power);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(KG_THREADS) void k_kg_coeff_multadd(const u64* __restrict__ ct0, const u64* __restrict__ x,
+                                                                 u64* __restrict__ out, u64 t,
+                                                                 const Mod* __restrict__ mods, int n_power)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power);
+    const Mod m = mods[blockIdx.y];
+    out[loc] = mul_barrett(add_mod(ct0[loc], x[loc], m.q), reduce64(t, m), m);
+}
+
+hipError_t kg_coeff_multadd(const u64* ct0, const u64* x, u64* out, u64 t, const Mod* mods, int n_power, int limbs,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_coeff_multadd, dim3((1u << n_power) / KG_THREADS, limbs), dim3(KG_THREADS), 0, st, ct0, x,
+                       out, t, mods, n_power);
     return hipGetLastError();
 }
 

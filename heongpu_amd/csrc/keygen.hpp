@@ -25,7 +25,8 @@ hipError_t kg_publickey(u64* pk, const u64* sk, const u64* e, const u64* a, cons
 // key[d][0][j] = -(s'_j * a_dj + e_dj) + (d == j) * factor_j * t_j,  key[d][1][j] = a_dj with
 // (s', t) = (s, s*s) for relinearisation, (sigma_g(s), s) for a Galois key (galois_elt != 0)
 hipError_t kg_switchkey(u64* key, const u64* sk, const u64* e, const u64* a, const Mod* mods, const u64* factor,
-                        int galois_elt, int n_power, int limbs, hipStream_t st);
+                        int galois_elt, const u64* old_sk, int n_power, int limbs, int digits, int digit_width,
+                        int q_size, int p_size, hipStream_t st);
 // pk_u_kernel (encryption.cu:10-26): out[z][j] = pk[z][j] * u[j]
 hipError_t kg_pk_u(const u64* pk, const u64* u, u64* out, const Mod* mods, int n_power, int limbs, hipStream_t st);
 // cipher_message_add_kernel (encryption.cu:254-267): ct[0][j] += plain[j]
@@ -49,6 +50,9 @@ hipError_t kg_bfv_threshold(const u64* plain, u64* out, const Mod* mods, const u
 // sk_multiplication (decryption.cu:10-23): out[j] = in[j] * sk[j]
 hipError_t kg_sk_multiplication(const u64* in, const u64* sk, u64* out, const Mod* mods, int n_power, int limbs,
                                 hipStream_t st);
+// coeff_multadd (decryption.cu, noise budget path): out[j] = (ct0[j] + x[j]) * t mod q_j
+hipError_t kg_coeff_multadd(const u64* ct0, const u64* x, u64* out, u64 t, const Mod* mods, int n_power, int limbs,
+                            hipStream_t st);
 struct BfvDecryptDev {
     Mod plain, gamma;
     const u64 *Qi_t, *Qi_gamma, *Qi_inverse;

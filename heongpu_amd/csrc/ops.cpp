@@ -486,20 +486,24 @@ hipError_t op_gen_public_key(const Context& c, Rng& r, const u64* sk, u64* pk, u
     return kg_publickey(pk, sk, e, av, c.plan_qp.mods, c.n_power, Qp, st);
 }
 
-hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, u64* key, u64* ws,
-                             hipStream_t st)
+hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, const u64* old_sk, u64* key,
+                             u64* ws, hipStream_t st)
 {
-    if (c.P_size != 1) return hipErrorNotSupported; // method I keys only
     const int Q = c.Q_size, Qp = c.Qp_size;
+    // method I: one digit per ciphertext prime; method II: the depth-0 digit partition
+    // (ckks/keygenerator.cu:326-414 uses d_leveled[0] and Sk_pair_leveled[0])
+    const int d = c.P_size == 1 ? Q : c.m2_levels[0].d;
+    const int width = c.P_size == 1 ? 1 : c.m2_width;
     u64* e = ws;
-    u64* av = ws + (u64) Q * Qp * c.n;
-    TRY(kg_uniform(av, c.plan_qp.mods, c.n_power, Qp, Q, r.seed, r.stream++, st));
-    TRY(kg_gaussian(e, c.plan_qp.mods, c.n_power, Qp, Q, r.seed, r.stream++, c.gauss_cdt, st));
+    u64* av = ws + (u64) d * Qp * c.n;
+    TRY(kg_uniform(av, c.plan_qp.mods, c.n_power, Qp, d, r.seed, r.stream++, st));
+    TRY(kg_gaussian(e, c.plan_qp.mods, c.n_power, Qp, d, r.seed, r.stream++, c.gauss_cdt, st));
     NttArgs a = c.ntt_args(0);
     a.in = e; a.out = e; a.mod_count = Qp;
-    TRY(ntt_launch(a, Q * Qp, false, st));
+    TRY(ntt_launch(a, d * Qp, false, st));
     const int inv = galois_elt ? (int) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0; // keygenerator.cu:474
-    return kg_switchkey(key, sk, e, av, c.plan_qp.mods, c.d64("factor"), inv, c.n_power, Qp, st);
+    return kg_switchkey(key, sk, e, av, c.plan_qp.mods, c.d64("factor"), inv, old_sk, c.n_power, Qp, d, width, Q,
+                        c.P_size, st);
 }
 
 // (pk*u + e) / P with rounding: the common front of both encryptions (encryptor.cu:52-100)
@@ -561,6 +565,18 @@ hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* p
     d.mulq_inv_gamma = c.h64("mulq_inv_gamma")[0];
     d.inv_gamma = c.h64("inv_gamma")[0];
     return kg_bfv_decryption(ct, t1, plain, c.plan_qp.mods, d, np, Q, st);                 // :107
+}
+
+hipError_t op_bfv_noise_rns(const Context& c, const u64* ct, const u64* sk, u64* out, hipStream_t st)
+{
+    const int np = c.n_power, Q = c.Q_size;
+    NttArgs a = c.ntt_args(0);
+    a.in = ct + ((u64) Q << np); a.out = out; a.mod_count = Q;
+    TRY(ntt_launch(a, Q, false, st));
+    TRY(kg_sk_multiplication(out, sk, out, c.plan_qp.mods, np, Q, st));
+    a.in = out; a.out = out;
+    TRY(ntt_launch(a, Q, true, st));
+    return kg_coeff_multadd(ct, out, out, c.plain_modulus, c.plan_qp.mods, np, Q, st);
 }
 
 hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st)

@@ -47,9 +47,10 @@ hipError_t op_gen_secret_key(const Context& c, Rng& r, int hamming_weight, u64* 
 // generate_public_key (ckks/keygenerator.cu:167-240); pk [2][Q'][N]
 hipError_t op_gen_public_key(const Context& c, Rng& r, const u64* sk, u64* pk, u64* ws, hipStream_t st);
 // generate_relin_key_method_I (:242-324) / generate_galois_key_method_I (:415-560); key [Q][2][Q'][N];
-// galois_elt == 0: relinearisation key
-hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, u64* key, u64* ws,
-                             hipStream_t st);
+// galois_elt == 0: relinearisation key; old_sk != nullptr (galois_elt == 0): generate_switch_key_method_I
+// (:996-1095), the key under `sk` that carries old_sk
+hipError_t op_gen_switch_key(const Context& c, Rng& r, const u64* sk, int galois_elt, const u64* old_sk, u64* key,
+                             u64* ws, hipStream_t st);
 // HEEncryptor<CKKS>::encrypt_ckks (ckks/encryptor.cu:36-110); plain [Q][N] NTT domain, ct [2][Q][N]
 hipError_t op_ckks_encrypt(const Context& c, Rng& r, const u64* pk, const u64* plain, u64* ct, u64* ws,
                            hipStream_t st);
@@ -60,6 +61,9 @@ hipError_t op_bfv_encrypt(const Context& c, Rng& r, const u64* pk, const u64* pl
                           hipStream_t st);
 // HEDecryptor<BFV>::decrypt_bfv (bfv/decryptor.cu:36-120), coefficient-domain ciphertext; plain [N]
 hipError_t op_bfv_decrypt(const Context& c, const u64* ct, const u64* sk, u64* plain, u64* ws, hipStream_t st);
+// first half of HEDecryptor<BFV>::noise_budget_calculation (bfv/decryptor.cu:170-225):
+// out [Q][N] = t * (c0 + c1*s) mod q_j, coefficient domain (the caller composes and takes the norm)
+hipError_t op_bfv_noise_rns(const Context& c, const u64* ct, const u64* sk, u64* out, hipStream_t st);
 // HEEncoder<BFV>::encode_bfv / decode_bfv (bfv/encoder.cu:48-95, 213-249): message [size <= N]
 // int64 (negative values wrap mod t) -> plain [N]; plain [N] -> message [N].  ws: N words (decode).
 hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st);

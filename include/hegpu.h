@@ -205,6 +205,10 @@ int hegpu_generate_public_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t
 int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* rk, void* ws,
                              size_t ws_bytes, hegpu_stream stream);
 /* generate_galois_key_method_I, one element (keygenerator.cu:415-560, keygeneration.cu:742-805) */
+/* HEKeyGenerator::generate_switch_key (ckks/keygenerator.cu:996-1095, switchkey_gen_kernel
+ * keygeneration.cu:896-939): key under new_sk that carries old_sk; layout of a relinearisation key */
+int hegpu_generate_switch_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* new_sk, const uint64_t* old_sk,
+                              uint64_t* swk, void* ws, size_t ws_bytes, hegpu_stream stream);
 int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, int galois_elt, uint64_t* gk,
                               void* ws, size_t ws_bytes, hegpu_stream stream);
 /* HEEncryptor<CKKS>::encrypt_ckks (src/lib/host/ckks/encryptor.cu:36-110); plain [Q][N], ct [2][Q][N] */
@@ -241,6 +245,11 @@ int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_siz
                       void* ws, size_t ws_bytes, hegpu_stream stream);
 int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
                       size_t ws_bytes, hegpu_stream stream);
+
+/* HEDecryptor<BFV>::remainder_noise_budget, device part (src/lib/host/bfv/decryptor.cu:170-225):
+ * out [Q][N] = t * (c0 + c1*s) mod q_j in the coefficient domain; the CRT composition and the
+ * infinity norm are host work (include/heongpu/heongpu.hpp) */
+int hegpu_bfv_noise_rns(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* out, hegpu_stream stream);
 
 /* ---- ciphertext (x) plaintext
  * cipherplain_kernel (src/lib/kernel/multiplication.cu:298-311): out[z][j] = ct[z][j] * plain[j] for the

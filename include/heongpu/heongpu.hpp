@@ -10,10 +10,10 @@
 // util/storagemanager.cuh:23-97, util/devicevector.cuh:17-173,
 // host/{bfv,ckks}/{context,ciphertext,evaluationkey,operator}.cuh.
 //
-// What is NOT here yet: key generation, encryption /
-// decryption, encoders.  Until then keys and ciphertexts are filled through
-// the `load()` members with data produced elsewhere (tests: seeded synthetic
-// data / python big-int key generation in the reference's layouts).
+// Also here: key generation, encryption / decryption, the encoders and the
+// reference's serialization format (save/load of every object, util/serializer.h).
+// Objects can alternatively be filled through the `load(std::vector)` members with
+// data produced elsewhere (tests: seeded synthetic data in the reference's layouts).
 //
 // Header-only; link against heongpu_amd/lib/libhegpu.so and the HIP runtime.
 #pragma once
@@ -38,6 +38,8 @@
 #include <sstream>
 #include <random>
 #include <memory>
+#include <optional>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -48,9 +50,20 @@ namespace heongpu {
 typedef unsigned long long Data64;
 
 enum class Scheme { BFV = 1, CKKS = 2, TFHE = 3 };                           // util/schemes.h:15-20
-enum class sec_level_type { none = 0, sec128 = 128, sec192 = 192, sec256 = 256 };
+enum class scheme_type : std::uint8_t { none = 0x0, bfv = 0x1, ckks = 0x2, bgv = 0x3, tfhe = 0x4 }; // util/schemes.h:70-86
+enum class sec_level_type : std::uint8_t { none = 0x0, sec128 = 0x1, sec192 = 0x2, sec256 = 0x3 }; // :88-104
 enum class storage_type : std::uint8_t { HOST = 0x1, DEVICE = 0x2 };        // util/storagemanager.cuh:23-27
-enum class keyswitching_type { NONE = 0, KEYSWITCHING_METHOD_I = 1, KEYSWITCHING_METHOD_II = 2 };
+enum class keyswitching_type : std::uint8_t { NONE = 0x0, KEYSWITCHING_METHOD_I = 0x1, KEYSWITCHING_METHOD_II = 0x2 };
+enum class encoding : std::uint8_t { SLOT = 0x0, COEFFICIENT = 0x1 };        // util/schemes.h:129-133
+struct Modulus64 { // GPU-NTT's record as the reference serializes it: value, bit length, Barrett mu
+    Data64 value = 0, bit = 0, mu = 0;
+    Modulus64() = default;
+    explicit Modulus64(Data64 q) : value(q)
+    {
+        while ((q >> bit) != 0) bit++;
+        mu = q ? (Data64) ((((unsigned __int128) 1) << (2 * bit + 1)) / q) : 0;
+    }
+};
 
 // util/storagemanager.cuh:34-97
 struct ExecutionOptions {
@@ -83,21 +96,100 @@ inline void hip(hipError_t e)
 {
     if (e != hipSuccess) throw HipException(hipGetErrorString(e));
 }
-// one stream-ordered pool per device, never trimmed (the reference's RMM
-// pool_memory_resource, util/memorypool.cuh:56-117)
-inline void init_pool()
-{
-    static bool done = false;
-    if (done) return;
-    int dev = 0;
-    hip(hipGetDevice(&dev));
-    hipMemPool_t pool;
-    hip(hipDeviceGetDefaultMemPool(&pool, dev));
-    uint64_t keep = UINT64_MAX;
-    hip(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    done = true;
-}
 } // namespace detail
+
+// ------------------------------------------------------------------ memory pool
+// util/memorypool.cuh:38-117.  The reference builds RMM pools; here the device side is HIP's
+// stream-ordered allocator (hipMallocAsync on the device's default pool): `max` becomes the
+// pool's release threshold (memory above it goes back to the driver at the next
+// synchronisation), `initial` is reserved once so that the first operations do not pay for
+// growing the pool.  The host-side fields are accepted and ignored: nothing is parked in host
+// memory (see Ciphertext::store_in_host).
+struct MemoryPoolConfig {
+    std::optional<float> initial_device_fraction, max_device_fraction;
+    std::optional<size_t> initial_device_bytes, max_device_bytes;
+    std::optional<float> initial_host_fraction, max_host_fraction;
+    std::optional<size_t> initial_host_bytes, max_host_bytes;
+    bool use_memory_pool = true;
+    static MemoryPoolConfig Defaults() { return MemoryPoolConfig(); }
+};
+
+class MemoryPool {
+  public:
+    static MemoryPool& instance()
+    {
+        static MemoryPool pool;
+        return pool;
+    }
+    void initialize() { initialize(MemoryPoolConfig::Defaults()); }
+    void initialize(const MemoryPoolConfig& config) // the first call wins, like the reference
+    {
+        if (initialized_) return;
+        initialized_ = true;
+        use_pool_ = config.use_memory_pool;
+        if (!use_pool_) return;
+        int dev = 0;
+        detail::hip(hipGetDevice(&dev));
+        detail::hip(hipDeviceGetDefaultMemPool(&pool_, dev));
+        size_t free_b = 0, total_b = 0;
+        detail::hip(hipMemGetInfo(&free_b, &total_b));
+        auto bytes = [&](const std::optional<float>& frac, const std::optional<size_t>& abs, size_t dflt) {
+            if (abs) return *abs;
+            if (frac) return (size_t) ((double) free_b * (*frac > 1.0f ? *frac / 100.0 : *frac));
+            return dflt;
+        };
+        uint64_t keep = bytes(config.max_device_fraction, config.max_device_bytes, (size_t) UINT64_MAX);
+        detail::hip(hipMemPoolSetAttribute(pool_, hipMemPoolAttrReleaseThreshold, &keep));
+        const size_t initial = bytes(config.initial_device_fraction, config.initial_device_bytes, 0);
+        if (initial) { // reserve once: allocate and hand back to the pool
+            void* warm = nullptr;
+            if (hipMallocAsync(&warm, initial, nullptr) == hipSuccess) (void) hipFreeAsync(warm, nullptr);
+            else (void) hipGetLastError();
+            detail::hip(hipStreamSynchronize(nullptr));
+        }
+    }
+    void use_memory_pool(bool use) { use_pool_ = use; }
+    void* allocate(size_t size, hipStream_t stream = nullptr)
+    {
+        if (!initialized_) initialize();
+        void* p = nullptr;
+        if (use_pool_) detail::hip(hipMallocAsync(&p, size, stream));
+        else detail::hip(hipMalloc(&p, size));
+        return p;
+    }
+    void deallocate(void* p, size_t, hipStream_t stream = nullptr)
+    {
+        if (!p) return;
+        if (use_pool_) (void) hipFreeAsync(p, stream);
+        else (void) hipFree(p);
+    }
+    void* host_allocate(size_t size)
+    {
+        void* p = nullptr;
+        detail::hip(hipHostMalloc(&p, size, hipHostMallocDefault));
+        return p;
+    }
+    void host_deallocate(void* p, size_t) { if (p) (void) hipHostFree(p); }
+    void print_memory_pool_status() const
+    {
+        uint64_t used = 0, reserved = 0;
+        if (use_pool_ && pool_) {
+            (void) hipMemPoolGetAttribute(pool_, hipMemPoolAttrUsedMemCurrent, &used);
+            (void) hipMemPoolGetAttribute(pool_, hipMemPoolAttrReservedMemCurrent, &reserved);
+        }
+        size_t free_b = 0, total_b = 0;
+        (void) hipMemGetInfo(&free_b, &total_b);
+        const double mb = 1024.0 * 1024.0;
+        std::cout << "Device Memory Pool: " << (use_pool_ ? "stream-ordered HIP pool" : "disabled (hipMalloc)") << std::endl;
+        std::cout << "-->   in use: " << used / mb << " MB, reserved: " << reserved / mb << " MB" << std::endl;
+        std::cout << "-->   device free: " << free_b / mb << " MB of " << total_b / mb << " MB" << std::endl;
+    }
+
+  private:
+    MemoryPool() = default;
+    bool initialized_ = false, use_pool_ = true;
+    hipMemPool_t pool_ = nullptr;
+};
 
 // util/devicevector.cuh:17-173: stream-ordered device buffer
 template <typename T> class DeviceVector {
@@ -127,10 +219,7 @@ template <typename T> class DeviceVector {
         release();
         s_ = s;
         n_ = n;
-        if (n) {
-            detail::init_pool();
-            detail::hip(hipMallocAsync((void**) &p_, n * sizeof(T), s));
-        }
+        if (n) p_ = (T*) MemoryPool::instance().allocate(n * sizeof(T), s);
     }
     T* data() const { return p_; }
     size_t size() const { return n_; }
@@ -140,7 +229,7 @@ template <typename T> class DeviceVector {
   private:
     void release()
     {
-        if (p_) (void) hipFreeAsync(p_, s_);
+        if (p_) MemoryPool::instance().deallocate(p_, n_ * sizeof(T), s_);
         p_ = nullptr;
         n_ = 0;
     }
@@ -164,80 +253,202 @@ template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation
     ~HEContextImpl() { if (h_) hegpu_context_destroy(h_); }
     HEContextImpl(const HEContextImpl&) = delete;
 
-    void set_poly_modulus_degree(size_t n) // ckks/context.cu:24-52
+    void set_poly_modulus_degree(size_t degree) // ckks/context.cu:24-52
     {
         if (coeff_modulus_specified_ || poly_modulus_degree_specified_)
             throw std::logic_error("Poly modulus degree cannot be changed after the coeff_modulus is specified!");
-        if (n == 0 || (n & (n - 1))) throw std::logic_error("Poly modulus degree have to be power of two");
-        if (n > 65536 || n < 4096) throw std::logic_error("Poly modulus degree is not supported");
-        n_ = n;
+        if (degree == 0 || (degree & (degree - 1))) throw std::logic_error("Poly modulus degree have to be power of two");
+        if (degree > 65536 || degree < 4096) throw std::logic_error("Poly modulus degree is not supported");
+        n = (int) degree;
+        n_power = 0;
+        while ((1 << n_power) < n) n_power++;
         poly_modulus_degree_specified_ = true;
     }
+    // The chain is fixed here (not in generate()), as in the reference: save() works on a
+    // context that has its parameters but no device tables yet (example 13_bfv_serialization).
     void set_coeff_modulus_bit_sizes(const std::vector<int>& q, const std::vector<int>& p) // :54-147
     {
         if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
             throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
         if (p.empty()) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
-        q_bits_ = q;
-        p_bits_ = p;
-        use_default_ = false;
-        coeff_modulus_specified_ = true;
+        hegpu_context* chain = nullptr; // prime search + validation; the scheme tables are built in generate()
+        detail::check(hegpu_context_create(HEGPU_CKKS, n, q.data(), (int) q.size(), p.data(), (int) p.size(), 0,
+                                           sec_abi(), &chain));
+        adopt_chain(chain);
+        Q_mod_bit_sizes_ = q;
+        P_mod_bit_sizes_ = p;
+        Qprime_mod_bit_sizes_ = q;
+        Qprime_mod_bit_sizes_.insert(Qprime_mod_bit_sizes_.end(), p.begin(), p.end());
+        total_coeff_bit_count = 0;
+        for (int b : Qprime_mod_bit_sizes_) total_coeff_bit_count += b;
     }
     void set_coeff_modulus_default_values(int p_count) // bfv/context.cu:267-374
     {
         if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
             throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
         if (p_count < 1) throw std::logic_error("P_modulus_size cannot be lower than 1!");
-        default_p_ = p_count;
-        use_default_ = true;
-        coeff_modulus_specified_ = true;
+        if (sec_level_ != sec_level_type::sec128)
+            throw std::runtime_error("Invalid security level"); // only the 128-bit table is carried so far
+        hegpu_context* chain = nullptr;
+        detail::check(hegpu_context_create_default(HEGPU_CKKS, n, p_count, 0, sec_abi(), &chain));
+        total_coeff_bit_count = (int) hegpu_context_int(chain, "max_logq_128");
+        adopt_chain(chain);
+        for (int i = 0; i < Q_size; i++) Q_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
+        for (int i = Q_size; i < Q_prime_size; i++) P_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
     }
-    void set_plain_modulus(int t) { plain_modulus_ = (uint64_t) t; } // bfv/context.cu:376-389
+    void set_plain_modulus(int t) // bfv/context.cu:376-389
+    {
+        static_assert(S == Scheme::BFV || S == Scheme::CKKS, "");
+        if (context_generated_) throw std::logic_error("Plain modulus cannot be changed after the context is generated!");
+        plain_modulus_ = Modulus64((Data64) t);
+        plain_modulus_specified_ = true;
+    }
     void generate()
     {
         if (context_generated_ || !poly_modulus_degree_specified_ || !coeff_modulus_specified_)
             throw std::logic_error("Context is already generated or parameters are missing!");
-        const int sec = (sec_level_ == sec_level_type::none) ? HEGPU_SEC_NONE : (int) sec_level_;
-        if (sec_level_ == sec_level_type::sec192 || sec_level_ == sec_level_type::sec256)
-            throw std::runtime_error("Invalid security level"); // only the 128-bit table is carried so far
-        if (use_default_)
-            detail::check(hegpu_context_create_default((int) S, (int) n_, default_p_, plain_modulus_, sec, &h_));
-        else
-            detail::check(hegpu_context_create((int) S, (int) n_, q_bits_.data(), (int) q_bits_.size(), p_bits_.data(),
-                                               (int) p_bits_.size(), plain_modulus_, sec, &h_));
+        std::vector<uint64_t> primes;
+        for (const Modulus64& m : prime_vector_) primes.push_back(m.value);
+        detail::check(hegpu_context_create_from_primes((int) S, n, primes.data(), Q_size, P_size, plain_modulus_.value, &h_));
+        MemoryPool::instance().initialize();
         detail::check(hegpu_context_upload(h_));
-        n_power = (int) hegpu_context_int(h_, "n_power");
-        Q_size = (int) hegpu_context_int(h_, "Q_size");
-        P_size = (int) hegpu_context_int(h_, "P_size");
-        Q_prime_size = (int) hegpu_context_int(h_, "Q_prime_size");
-        n = (int) n_;
-        keyswitching_type_ = P_size == 1 ? keyswitching_type::KEYSWITCHING_METHOD_I
-                                         : keyswitching_type::KEYSWITCHING_METHOD_II;
-        prime_vector_.resize(Q_prime_size);
-        hegpu_context_get(h_, "modulus", (uint64_t*) prime_vector_.data(), Q_prime_size);
         context_generated_ = true;
     }
+    void generate(const MemoryPoolConfig& config) // */context.cu generate(const MemoryPoolConfig&)
+    {
+        MemoryPool::instance().initialize(config);
+        generate();
+    }
+    void print_parameters() const // */context.cu print_parameters
+    {
+        if (!context_generated_) { std::cout << "Parameters is not generated yet!" << std::endl; return; }
+        std::cout << "==== HEonGPU a GPU Based Homomorphic Encryption Library ====\n" << std::endl;
+        std::cout << "Encryption parameters:" << std::endl;
+        std::cout << "-->   scheme: " << (S == Scheme::BFV ? "BFV" : "CKKS") << std::endl;
+        std::cout << "-->   poly_modulus_degree: " << n << std::endl;
+        std::cout << "-->   Q_tilta size: Q( ";
+        for (int i = 0; i < Q_size; i++) std::cout << prime_vector_[i].bit << (i + 1 < Q_size ? " + " : "");
+        std::cout << " ) + P( ";
+        for (int i = Q_size; i < Q_prime_size; i++) std::cout << prime_vector_[i].bit << (i + 1 < Q_prime_size ? " + " : "");
+        std::cout << " ) bits" << std::endl;
+        if (S == Scheme::BFV) std::cout << "-->   plain_modulus: " << plain_modulus_.value << std::endl;
+        std::cout << std::endl;
+    }
+
+    // Wire format of */context.cu save/load (bfv :804-930, ckks :576-700): scheme, security
+    // level, key-switching type (u8 each), n, n_power, coeff_modulus, total_coeff_bit_count,
+    // Q'/Q/P counts (int), then counted arrays: primes (Modulus64), base_q (u64), the three
+    // bit-size lists (int); BFV appends the plain modulus (Modulus64).
+    void save(std::ostream& os) const
+    {
+        if (!poly_modulus_degree_specified_ || !coeff_modulus_specified_ || (S == Scheme::BFV && !plain_modulus_specified_))
+            throw std::runtime_error("Context has no enough parameters to serialize!");
+        const scheme_type scheme = (S == Scheme::BFV) ? scheme_type::bfv : scheme_type::ckks;
+        os.write((const char*) &scheme, sizeof(scheme));
+        os.write((const char*) &sec_level_, sizeof(sec_level_));
+        os.write((const char*) &keyswitching_type_, sizeof(keyswitching_type_));
+        os.write((const char*) &n, sizeof(n));
+        os.write((const char*) &n_power, sizeof(n_power));
+        const int coeff_modulus = Q_prime_size;
+        os.write((const char*) &coeff_modulus, sizeof(int));
+        os.write((const char*) &total_coeff_bit_count, sizeof(int));
+        os.write((const char*) &Q_prime_size, sizeof(int));
+        os.write((const char*) &Q_size, sizeof(int));
+        os.write((const char*) &P_size, sizeof(int));
+        write_counted(os, prime_vector_);
+        std::vector<Data64> base_q;
+        for (const Modulus64& m : prime_vector_) base_q.push_back(m.value);
+        write_counted(os, base_q);
+        write_counted(os, Qprime_mod_bit_sizes_);
+        write_counted(os, Q_mod_bit_sizes_);
+        write_counted(os, P_mod_bit_sizes_);
+        if (S == Scheme::BFV) os.write((const char*) &plain_modulus_, sizeof(plain_modulus_));
+    }
+    void load(std::istream& is)
+    {
+        if (context_generated_ || h_) throw std::runtime_error("Context has been already exist!");
+        scheme_type scheme = scheme_type::none;
+        is.read((char*) &scheme, sizeof(scheme));
+        if (scheme != ((S == Scheme::BFV) ? scheme_type::bfv : scheme_type::ckks)) throw std::runtime_error("Invalid scheme binary!");
+        is.read((char*) &sec_level_, sizeof(sec_level_));
+        is.read((char*) &keyswitching_type_, sizeof(keyswitching_type_));
+        is.read((char*) &n, sizeof(n));
+        is.read((char*) &n_power, sizeof(n_power));
+        int coeff_modulus = 0;
+        is.read((char*) &coeff_modulus, sizeof(int));
+        is.read((char*) &total_coeff_bit_count, sizeof(int));
+        is.read((char*) &Q_prime_size, sizeof(int));
+        is.read((char*) &Q_size, sizeof(int));
+        is.read((char*) &P_size, sizeof(int));
+        std::vector<Data64> base_q;
+        read_counted(is, prime_vector_);
+        read_counted(is, base_q);
+        read_counted(is, Qprime_mod_bit_sizes_);
+        read_counted(is, Q_mod_bit_sizes_);
+        read_counted(is, P_mod_bit_sizes_);
+        if (S == Scheme::BFV) is.read((char*) &plain_modulus_, sizeof(plain_modulus_));
+        if (!is || (int) prime_vector_.size() != Q_prime_size || Q_size + P_size != Q_prime_size || n != (1 << n_power))
+            throw std::runtime_error("Context binary is not consistent!");
+        poly_modulus_degree_specified_ = true;
+        coeff_modulus_specified_ = true;
+        plain_modulus_specified_ = true;
+        this->generate();
+    }
+
     inline int get_poly_modulus_degree() const noexcept { return n; }
     inline int get_ciphertext_modulus_count() const noexcept { return Q_size; }
     inline int get_key_modulus_count() const noexcept { return Q_prime_size; }
-    inline std::vector<Data64> get_key_modulus() const noexcept { return prime_vector_; }
+    inline std::vector<Data64> get_key_modulus() const
+    {
+        std::vector<Data64> v;
+        for (const Modulus64& m : prime_vector_) v.push_back(m.value);
+        return v;
+    }
     inline int get_log_poly_modulus_degree() const noexcept { return n_power; }
-    inline uint64_t get_plain_modulus() const noexcept { return plain_modulus_; }
+    inline uint64_t get_plain_modulus() const noexcept { return plain_modulus_.value; }
     hegpu_context* handle() const { return h_; }
 
     int n = 0, n_power = 0, Q_size = 0, P_size = 0, Q_prime_size = 0;
+    int total_coeff_bit_count = 0;
     bool context_generated_ = false;
     keyswitching_type keyswitching_type_ = keyswitching_type::NONE;
-    std::vector<Data64> prime_vector_;
+    std::vector<Modulus64> prime_vector_;
 
   private:
+    int sec_abi() const { return sec_level_ == sec_level_type::none ? HEGPU_SEC_NONE : sec_level_ == sec_level_type::sec128 ? HEGPU_SEC_128 : -1; }
+    void adopt_chain(hegpu_context* c) // counts and primes of a host-only context, which is then dropped
+    {
+        Q_size = (int) hegpu_context_int(c, "Q_size");
+        P_size = (int) hegpu_context_int(c, "P_size");
+        Q_prime_size = (int) hegpu_context_int(c, "Q_prime_size");
+        keyswitching_type_ = P_size == 1 ? keyswitching_type::KEYSWITCHING_METHOD_I
+                                         : keyswitching_type::KEYSWITCHING_METHOD_II;
+        std::vector<uint64_t> q(Q_prime_size);
+        hegpu_context_get(c, "modulus", q.data(), Q_prime_size);
+        hegpu_context_destroy(c);
+        prime_vector_.clear();
+        for (uint64_t v : q) prime_vector_.push_back(Modulus64(v));
+        coeff_modulus_specified_ = true;
+    }
+    template <typename T> static void write_counted(std::ostream& os, const std::vector<T>& v)
+    {
+        const std::uint32_t count = (std::uint32_t) v.size();
+        os.write((const char*) &count, sizeof(count));
+        os.write((const char*) v.data(), sizeof(T) * count);
+    }
+    template <typename T> static void read_counted(std::istream& is, std::vector<T>& v)
+    {
+        std::uint32_t count = 0;
+        is.read((char*) &count, sizeof(count));
+        if (!is || count > (1u << 20)) throw std::runtime_error("Context binary is not consistent!");
+        v.resize(count);
+        is.read((char*) v.data(), sizeof(T) * count);
+    }
     hegpu_context* h_ = nullptr;
     sec_level_type sec_level_;
-    size_t n_ = 0;
-    uint64_t plain_modulus_ = 0;
-    std::vector<int> q_bits_, p_bits_;
-    int default_p_ = 1;
-    bool use_default_ = false, poly_modulus_degree_specified_ = false, coeff_modulus_specified_ = false;
+    Modulus64 plain_modulus_;
+    std::vector<int> Qprime_mod_bit_sizes_, Q_mod_bit_sizes_, P_mod_bit_sizes_;
+    bool poly_modulus_degree_specified_ = false, coeff_modulus_specified_ = false, plain_modulus_specified_ = false;
 };
 
 template <Scheme S> using HEContext = std::shared_ptr<HEContextImpl<S>>;
@@ -253,6 +464,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     friend class HEArithmeticOperator<S>;
 
   public:
+    Ciphertext() = default; // filled by load(std::istream&) or by an operator
     explicit Ciphertext(HEContext<S> context, const ExecutionOptions& options = ExecutionOptions())
     {
         if (!context || !context->context_generated_) throw std::invalid_argument("HEContext is not generated!");
@@ -270,6 +482,10 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     void switch_stream(hipStream_t s) { device_locations_.set_stream(s); }
     hipStream_t stream() const noexcept { return device_locations_.stream(); }
     bool is_on_device() const noexcept { return storage_type_ == storage_type::DEVICE; }
+    // The reference can park objects in host memory (storage manager); here the residues always
+    // stay in HBM (288 GB) and these calls only keep the caller's bookkeeping consistent.
+    void store_in_device(hipStream_t = nullptr) { storage_type_ = storage_type::DEVICE; }
+    void store_in_host(hipStream_t = nullptr) { storage_type_ = storage_type::DEVICE; }
     inline int ring_size() const noexcept { return ring_size_; }
     inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
     inline int size() const noexcept { return cipher_size_; }
@@ -347,6 +563,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         int ring = 0, count_mod = 0;
         is.read((char*) &ring, sizeof(int));
         is.read((char*) &count_mod, sizeof(int));
+        if (ring_size_ == 0) { ring_size_ = ring; coeff_modulus_count_ = count_mod; } // default-constructed
         if (ring != ring_size_ || count_mod != coeff_modulus_count_)
             throw std::runtime_error("Ciphertext binary does not match the context!");
         is.read((char*) &cipher_size_, sizeof(int));
@@ -385,19 +602,50 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     DeviceVector<Data64> device_locations_;
 };
 
+namespace detail {
+inline std::vector<Data64> to_host(const Data64* dev, size_t count)
+{
+    std::vector<Data64> h(count);
+    if (count) hip(hipMemcpy(h.data(), dev, count * sizeof(Data64), hipMemcpyDeviceToHost));
+    return h;
+}
+template <typename T> void put(std::ostream& os, const T& v) { os.write((const char*) &v, sizeof(T)); }
+template <typename T> void get(std::istream& is, T& v) { is.read((char*) &v, sizeof(T)); }
+template <Scheme S> constexpr scheme_type wire_scheme() { return S == Scheme::BFV ? scheme_type::bfv : scheme_type::ckks; }
+template <Scheme S> void check_scheme(std::istream& is)
+{
+    scheme_type sc = scheme_type::none;
+    get(is, sc);
+    if (sc != wire_scheme<S>()) throw std::runtime_error("Invalid scheme binary!");
+}
+inline DeviceVector<Data64> read_payload(std::istream& is, size_t count, const char* what)
+{
+    std::vector<Data64> h(count);
+    is.read((char*) h.data(), sizeof(Data64) * count);
+    if (!is) throw std::runtime_error(std::string(what) + " binary is truncated!");
+    DeviceVector<Data64> d(h);
+    hip(hipStreamSynchronize(nullptr));
+    return d;
+}
+} // namespace detail
+
 // ------------------------------------------------------------------ keys
 template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N (evaluationkey.cu:30-36)
   public:
+    Relinkey() = default;
     explicit Relinkey(HEContext<S> context) : context_(std::move(context))
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
         const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
+        ring_size = context_->n;
+        Q_prime_size_ = context_->Q_prime_size;
+        Q_size_ = context_->Q_size;
         d_ = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
-        relinkey_size_ = (size_t) 2 * d_ * context_->Q_prime_size * context_->n;
-        key_type = context_->P_size == 1 ? 1 : 2;
+        relinkey_size_ = (Data64) 2 * d_ * Q_prime_size_ * ring_size;
+        key_type = context_->keyswitching_type_;
     }
     Data64* data() { return device_location_.data(); }
-    size_t size() const { return relinkey_size_; }
+    size_t size() const { return (size_t) relinkey_size_; }
     void load(const std::vector<Data64>& host, hipStream_t s = nullptr) // a key produced elsewhere
     {
         if (host.size() != relinkey_size_) throw std::invalid_argument("Invalid relinkey size!");
@@ -405,88 +653,378 @@ template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N 
         relin_key_generated_ = true;
     }
     void memory_set(DeviceVector<Data64>&& m) { device_location_ = std::move(m); }
-    int key_type = 1;
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {} // keys stay in HBM (see Ciphertext::store_in_host)
+    // */evaluationkey.cu Relinkey::save/load (bfv :91-200): scheme, key type (u8), ring size, Q', Q,
+    // d, d_tilda, r_prime (int), storage (u8), generated (bool), element count (u64), the key
+    void save(std::ostream& os) const
+    {
+        if (!relin_key_generated_) throw std::runtime_error("Relinkey is not generated so can not be serialized!");
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, key_type);
+        detail::put(os, ring_size); detail::put(os, Q_prime_size_); detail::put(os, Q_size_);
+        detail::put(os, d_); detail::put(os, d_tilda_); detail::put(os, r_prime_);
+        detail::put(os, storage_type::DEVICE);
+        detail::put(os, relin_key_generated_);
+        detail::put(os, relinkey_size_);
+        const std::vector<Data64> h = detail::to_host(device_location_.data(), (size_t) relinkey_size_);
+        os.write((const char*) h.data(), sizeof(Data64) * h.size());
+    }
+    void load(std::istream& is)
+    {
+        if (relin_key_generated_) throw std::runtime_error("Relinkey has been already exist!");
+        detail::check_scheme<S>(is);
+        storage_type st;
+        detail::get(is, key_type);
+        detail::get(is, ring_size); detail::get(is, Q_prime_size_); detail::get(is, Q_size_);
+        detail::get(is, d_); detail::get(is, d_tilda_); detail::get(is, r_prime_);
+        detail::get(is, st);
+        detail::get(is, relin_key_generated_);
+        detail::get(is, relinkey_size_);
+        if (!is || relinkey_size_ > ((Data64) 1 << 36)) throw std::runtime_error("Invalid relinkey size!");
+        device_location_ = detail::read_payload(is, (size_t) relinkey_size_, "Relinkey");
+        relin_key_generated_ = true;
+    }
+    keyswitching_type key_type = keyswitching_type::KEYSWITCHING_METHOD_I;
     bool relin_key_generated_ = false;
 
   private:
     HEContext<S> context_;
-    int d_ = 0;
-    size_t relinkey_size_ = 0;
+    int ring_size = 0, Q_prime_size_ = 0, Q_size_ = 0, d_ = 0, d_tilda_ = 0, r_prime_ = 0;
+    Data64 relinkey_size_ = 0;
+    DeviceVector<Data64> device_location_;
+};
+
+// A key that moves a ciphertext from one secret key to another (host/*/evaluationkey.cuh
+// Switchkey; generated by HEKeyGenerator::generate_switch_key, used by keyswitch())
+template <Scheme S> class Switchkey {
+  public:
+    Switchkey() = default;
+    explicit Switchkey(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
+        ring_size = context_->n;
+        Q_prime_size_ = context_->Q_prime_size;
+        Q_size_ = context_->Q_size;
+        d_ = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
+        switchkey_size_ = (Data64) 2 * d_ * Q_prime_size_ * ring_size;
+        key_type = context_->keyswitching_type_;
+    }
+    Data64* data() { return device_location_.data(); }
+    size_t size() const { return (size_t) switchkey_size_; }
+    void memory_set(DeviceVector<Data64>&& m) { device_location_ = std::move(m); }
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {}
+    void save(std::ostream& os) const // */evaluationkey.cu Switchkey::save (bfv :835-882)
+    {
+        if (!switch_key_generated_) throw std::runtime_error("Switchkey is not generated so can not be serialized!");
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, key_type);
+        detail::put(os, ring_size); detail::put(os, Q_prime_size_); detail::put(os, Q_size_); detail::put(os, d_);
+        detail::put(os, storage_type::DEVICE);
+        detail::put(os, switch_key_generated_);
+        detail::put(os, switchkey_size_);
+        const std::vector<Data64> h = detail::to_host(device_location_.data(), (size_t) switchkey_size_);
+        os.write((const char*) h.data(), sizeof(Data64) * h.size());
+    }
+    void load(std::istream& is)
+    {
+        if (switch_key_generated_) throw std::runtime_error("Switchkey has been already exist!");
+        detail::check_scheme<S>(is);
+        storage_type st;
+        detail::get(is, key_type);
+        detail::get(is, ring_size); detail::get(is, Q_prime_size_); detail::get(is, Q_size_); detail::get(is, d_);
+        detail::get(is, st);
+        detail::get(is, switch_key_generated_);
+        detail::get(is, switchkey_size_);
+        if (!is || switchkey_size_ > ((Data64) 1 << 36)) throw std::runtime_error("Invalid switchkey size!");
+        device_location_ = detail::read_payload(is, (size_t) switchkey_size_, "Switchkey");
+        switch_key_generated_ = true;
+    }
+    keyswitching_type key_type = keyswitching_type::KEYSWITCHING_METHOD_I;
+    bool switch_key_generated_ = false;
+
+  private:
+    HEContext<S> context_;
+    int ring_size = 0, Q_prime_size_ = 0, Q_size_ = 0, d_ = 0;
+    Data64 switchkey_size_ = 0;
     DeviceVector<Data64> device_location_;
 };
 
 template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration.cu:684-728
   public:
+    Galoiskey() = default;
+    // power-of-two shifts in both directions (evaluationkey.cu:291-345, MAX_SHIFT = 8)
+    explicit Galoiskey(HEContext<S> context) : Galoiskey(context, default_shifts()) {}
+    static std::vector<int> default_shifts()
+    {
+        std::vector<int> v;
+        for (int i = 0; i < 8; i++) { v.push_back(1 << i); v.push_back(-(1 << i)); }
+        return v;
+    }
     Galoiskey(HEContext<S> context, const std::vector<int>& shifts) : context_(std::move(context))
     {
-        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
-        group_order_ = (S == Scheme::BFV) ? 3 : 5; // bfv/evaluationkey.cu:308, ckks/evaluationkey.cu:408
+        init_sizes();
         for (int sh : shifts) galois_elt[sh] = hegpu_steps_to_galois_elt(sh, context_->n, group_order_);
-        galois_elt_zero = hegpu_steps_to_galois_elt(0, context_->n, group_order_); // column rotation / conjugation
-        const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
-        const int d = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
-        galoiskey_size_ = (size_t) 2 * d * context_->Q_prime_size * context_->n;
     }
-    size_t size() const { return galoiskey_size_; }
+    // keys for explicit Galois elements (evaluationkey.cu:347-375)
+    Galoiskey(HEContext<S> context, const std::vector<uint32_t>& galois_elts) : context_(std::move(context))
+    {
+        init_sizes();
+        customized = true;
+        custom_galois_elt = galois_elts;
+    }
+    size_t size() const { return (size_t) galoiskey_size_; }
     void load(int galois_element, const std::vector<Data64>& host, hipStream_t s = nullptr)
     {
         if (host.size() != galoiskey_size_) throw std::invalid_argument("Invalid galoiskey size!");
         device_location_[galois_element] = DeviceVector<Data64>(host, s);
     }
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {}
+    // */evaluationkey.cu Galoiskey::save/load (bfv :540-760): header as Relinkey up to d, then
+    // customized (bool), group order (int), storage (u8), generated (bool); the element table
+    // (u32 list when customized, else (shift, element) int pairs); galois_elt_zero (int), key
+    // size (u64), key count (u32), then (element (int), key) per key, and last the key of
+    // galois_elt_zero.  The reference keeps that one apart (zero_device_location_); here it sits
+    // in the map under its element and is written in the reference's position.
+    void save(std::ostream& os) const
+    {
+        if (!galois_key_generated_) throw std::runtime_error("Galoiskey is not generated so can not be serialized!");
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, key_type);
+        detail::put(os, ring_size); detail::put(os, Q_prime_size_); detail::put(os, Q_size_); detail::put(os, d_);
+        detail::put(os, customized);
+        detail::put(os, group_order_);
+        detail::put(os, storage_type::DEVICE);
+        detail::put(os, galois_key_generated_);
+        if (customized) {
+            detail::put(os, (std::uint32_t) custom_galois_elt.size());
+            os.write((const char*) custom_galois_elt.data(), sizeof(std::uint32_t) * custom_galois_elt.size());
+        } else {
+            detail::put(os, (std::uint32_t) galois_elt.size());
+            for (const auto& g : galois_elt) { detail::put(os, g.first); detail::put(os, g.second); }
+        }
+        detail::put(os, galois_elt_zero);
+        detail::put(os, galoiskey_size_);
+        // a shift whose element equals galois_elt_zero cannot occur (the latter is 2N-1 / 2N-1)
+        std::uint32_t key_count = 0;
+        for (const auto& k : device_location_) if (k.first != galois_elt_zero) key_count++;
+        detail::put(os, key_count);
+        for (const auto& k : device_location_) {
+            if (k.first == galois_elt_zero) continue;
+            detail::put(os, k.first);
+            const std::vector<Data64> h = detail::to_host(k.second.data(), (size_t) galoiskey_size_);
+            os.write((const char*) h.data(), sizeof(Data64) * h.size());
+        }
+        const auto zero = device_location_.find(galois_elt_zero);
+        if (zero == device_location_.end()) throw std::runtime_error("Galoiskey has no column-rotation key!");
+        const std::vector<Data64> h = detail::to_host(zero->second.data(), (size_t) galoiskey_size_);
+        os.write((const char*) h.data(), sizeof(Data64) * h.size());
+    }
+    void load(std::istream& is)
+    {
+        if (galois_key_generated_) throw std::runtime_error("Galoiskey has been already exist!");
+        detail::check_scheme<S>(is);
+        storage_type st;
+        detail::get(is, key_type);
+        detail::get(is, ring_size); detail::get(is, Q_prime_size_); detail::get(is, Q_size_); detail::get(is, d_);
+        detail::get(is, customized);
+        detail::get(is, group_order_);
+        detail::get(is, st);
+        detail::get(is, galois_key_generated_);
+        std::uint32_t count = 0;
+        detail::get(is, count);
+        if (!is || count > (1u << 20)) throw std::runtime_error("Invalid galoiskey binary!");
+        galois_elt.clear();
+        custom_galois_elt.clear();
+        if (customized) {
+            custom_galois_elt.resize(count);
+            is.read((char*) custom_galois_elt.data(), sizeof(std::uint32_t) * count);
+        } else {
+            for (std::uint32_t i = 0; i < count; i++) {
+                int shift = 0, elt = 0;
+                detail::get(is, shift); detail::get(is, elt);
+                galois_elt[shift] = elt;
+            }
+        }
+        detail::get(is, galois_elt_zero);
+        detail::get(is, galoiskey_size_);
+        std::uint32_t key_count = 0;
+        detail::get(is, key_count);
+        if (!is || galoiskey_size_ > ((Data64) 1 << 36) || key_count > (1u << 20)) throw std::runtime_error("Invalid galoiskey size!");
+        device_location_.clear();
+        for (std::uint32_t i = 0; i < key_count; i++) {
+            int elt = 0;
+            detail::get(is, elt);
+            device_location_[elt] = detail::read_payload(is, (size_t) galoiskey_size_, "Galoiskey");
+        }
+        device_location_[galois_elt_zero] = detail::read_payload(is, (size_t) galoiskey_size_, "Galoiskey");
+        galois_key_generated_ = true;
+    }
     bool galois_key_generated_ = false;
+    bool customized = false;
     int galois_elt_zero = 0;
     std::map<int, int> galois_elt;                           // shift -> Galois element
+    std::vector<std::uint32_t> custom_galois_elt;            // customized == true
     std::map<int, DeviceVector<Data64>> device_location_;    // Galois element -> key
     int group_order_ = 5;
+    keyswitching_type key_type = keyswitching_type::KEYSWITCHING_METHOD_I;
 
   private:
+    void init_sizes()
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        group_order_ = (S == Scheme::BFV) ? 3 : 5; // bfv/evaluationkey.cu:308, ckks/evaluationkey.cu:408
+        galois_elt_zero = hegpu_steps_to_galois_elt(0, context_->n, group_order_); // column rotation / conjugation
+        const int m = (S == Scheme::BFV) ? 2 : context_->P_size;
+        ring_size = context_->n;
+        Q_prime_size_ = context_->Q_prime_size;
+        Q_size_ = context_->Q_size;
+        d_ = context_->P_size == 1 ? context_->Q_size : (context_->Q_size + m - 1) / m;
+        galoiskey_size_ = (Data64) 2 * d_ * Q_prime_size_ * ring_size;
+        key_type = context_->keyswitching_type_;
+    }
     HEContext<S> context_;
-    size_t galoiskey_size_ = 0;
+    int ring_size = 0, Q_prime_size_ = 0, Q_size_ = 0, d_ = 0;
+    Data64 galoiskey_size_ = 0;
 };
 
 // ------------------------------------------------------------------ secret / public key, plaintext
 template <Scheme S> class Secretkey { // host/*/secretkey.cuh; [Q'][N], NTT domain
   public:
+    Secretkey() = default;
     explicit Secretkey(HEContext<S> context) : context_(std::move(context))
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        ring_size_ = context_->n;
+        coeff_modulus_count_ = context_->Q_prime_size;
+        n_power_ = context_->n_power;
         hamming_weight_ = context_->n >> 1; // secretkey.cu:23
     }
     Secretkey(HEContext<S> context, int hamming_weight) : Secretkey(std::move(context))
     {
-        if (hamming_weight <= 0 || hamming_weight > context_->n)
+        if (hamming_weight <= 0 || hamming_weight > ring_size_)
             throw std::invalid_argument("hamming weight has to be in range 0 to ring size."); // secretkey.cu:43
         hamming_weight_ = hamming_weight;
     }
     Data64* data() { return device_locations_.data(); }
     const Data64* data() const { return device_locations_.data(); }
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {}
+    inline int ring_size() const noexcept { return ring_size_; }
+    inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
+    // */secretkey.cu:235-345: scheme (u8), ring size, modulus count, n_power, hamming weight (int),
+    // ntt flag, generated flag (bool), storage (u8), element count (u32), residues
+    void save(std::ostream& os) const
+    {
+        if (!secret_key_generated_) throw std::runtime_error("Secretkey is not generated so can not be serialized!");
+        const bool ntt = true;
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, ring_size_); detail::put(os, coeff_modulus_count_); detail::put(os, n_power_);
+        detail::put(os, hamming_weight_);
+        detail::put(os, ntt);
+        detail::put(os, secret_key_generated_);
+        detail::put(os, storage_type::DEVICE);
+        const std::uint32_t count = (std::uint32_t) ((size_t) coeff_modulus_count_ * ring_size_);
+        detail::put(os, count);
+        const std::vector<Data64> h = detail::to_host(device_locations_.data(), count);
+        os.write((const char*) h.data(), sizeof(Data64) * count);
+    }
+    void load(std::istream& is)
+    {
+        if (secret_key_generated_) throw std::runtime_error("Secretkey has been already exist!");
+        detail::check_scheme<S>(is);
+        bool ntt = false;
+        storage_type st;
+        detail::get(is, ring_size_); detail::get(is, coeff_modulus_count_); detail::get(is, n_power_);
+        detail::get(is, hamming_weight_);
+        detail::get(is, ntt);
+        detail::get(is, secret_key_generated_);
+        detail::get(is, st);
+        std::uint32_t count = 0;
+        detail::get(is, count);
+        if (!is || ring_size_ <= 0 || coeff_modulus_count_ <= 0 || count != (std::uint32_t) ((size_t) ring_size_ * coeff_modulus_count_))
+            throw std::runtime_error("Invalid secretkey size!");
+        device_locations_ = detail::read_payload(is, count, "Secretkey");
+        secret_key_generated_ = true;
+    }
     int hamming_weight_ = 0;
     bool secret_key_generated_ = false;
 
   private:
     HEContext<S> context_;
+    int ring_size_ = 0, coeff_modulus_count_ = 0, n_power_ = 0;
     DeviceVector<Data64> device_locations_;
 };
 
 template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT domain
   public:
+    Publickey() = default;
     explicit Publickey(HEContext<S> context) : context_(std::move(context))
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        ring_size_ = context_->n;
+        coeff_modulus_count_ = context_->Q_prime_size;
     }
     Data64* data() { return device_locations_.data(); }
     const Data64* data() const { return device_locations_.data(); }
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {}
+    inline int ring_size() const noexcept { return ring_size_; }
+    inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
+    // */publickey.cu:92-200: scheme (u8), ring size, modulus count (int), ntt flag, generated flag
+    // (bool), storage (u8), element count (u32), residues
+    void save(std::ostream& os) const
+    {
+        if (!public_key_generated_) throw std::runtime_error("Publickey is not generated so can not be serialized!");
+        const bool ntt = true;
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, ring_size_); detail::put(os, coeff_modulus_count_);
+        detail::put(os, ntt);
+        detail::put(os, public_key_generated_);
+        detail::put(os, storage_type::DEVICE);
+        const std::uint32_t count = (std::uint32_t) ((size_t) 2 * coeff_modulus_count_ * ring_size_);
+        detail::put(os, count);
+        const std::vector<Data64> h = detail::to_host(device_locations_.data(), count);
+        os.write((const char*) h.data(), sizeof(Data64) * count);
+    }
+    void load(std::istream& is)
+    {
+        if (public_key_generated_) throw std::runtime_error("Publickey has been already exist!");
+        detail::check_scheme<S>(is);
+        bool ntt = false;
+        storage_type st;
+        detail::get(is, ring_size_); detail::get(is, coeff_modulus_count_);
+        detail::get(is, ntt);
+        detail::get(is, public_key_generated_);
+        detail::get(is, st);
+        std::uint32_t count = 0;
+        detail::get(is, count);
+        if (!is || ring_size_ <= 0 || coeff_modulus_count_ <= 0 || count != (std::uint32_t) ((size_t) 2 * ring_size_ * coeff_modulus_count_))
+            throw std::runtime_error("Invalid publickey size!");
+        device_locations_ = detail::read_payload(is, count, "Publickey");
+        public_key_generated_ = true;
+    }
     bool public_key_generated_ = false;
 
   private:
     HEContext<S> context_;
+    int ring_size_ = 0, coeff_modulus_count_ = 0;
     DeviceVector<Data64> device_locations_;
 };
 
 template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - depth][N] NTT domain (+ depth, scale); BFV: [N] mod t
   public:
+    Plaintext() = default;
     explicit Plaintext(HEContext<S> context, const ExecutionOptions& options = ExecutionOptions())
         : context_(std::move(context))
     {
@@ -497,7 +1035,8 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
     const Data64* data() const { return device_locations_.data(); }
     size_t size() const { return device_locations_.size(); }
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
-    // until the encoders exist: residues [Q - depth][N] of the scaled message, NTT domain
+    void set_context(HEContext<S> context) { context_ = std::move(context); }
+    // residues produced elsewhere: [Q - depth][N] of the scaled message, NTT domain (CKKS) / [N] mod t (BFV)
     void load(const std::vector<Data64>& host, int depth, double scale, hipStream_t s = nullptr)
     {
         const size_t want = (S == Scheme::CKKS) ? (size_t) (context_->Q_size - depth) * context_->n : (size_t) context_->n;
@@ -514,8 +1053,51 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
                                    hipMemcpyDeviceToHost, s));
         detail::hip(hipStreamSynchronize(s));
     }
+    // */plaintext.cu (bfv :88-180, ckks :91-200): scheme (u8), size (int) [, depth (int), scale
+    // (double)], ntt flag (bool) [, encoding (u8)], generated flag (bool), storage (u8), size again
+    // (int), coefficients
+    void save(std::ostream& os) const
+    {
+        if (!plaintext_generated_) throw std::runtime_error("Plaintext is not generated so can not be serialized!");
+        const int plain_size = (int) device_locations_.size();
+        const bool ntt = (S == Scheme::CKKS);
+        detail::put(os, detail::wire_scheme<S>());
+        detail::put(os, plain_size);
+        if (S == Scheme::CKKS) { detail::put(os, depth_); detail::put(os, scale_); }
+        detail::put(os, ntt);
+        if (S == Scheme::CKKS) detail::put(os, encoding_);
+        detail::put(os, plaintext_generated_);
+        detail::put(os, storage_type::DEVICE);
+        detail::put(os, plain_size);
+        const std::vector<Data64> h = detail::to_host(device_locations_.data(), (size_t) plain_size);
+        os.write((const char*) h.data(), sizeof(Data64) * h.size());
+    }
+    void load(std::istream& is)
+    {
+        if (plaintext_generated_) throw std::runtime_error("Plaintext has been already exist!");
+        detail::check_scheme<S>(is);
+        int plain_size = 0, again = 0;
+        bool ntt = false;
+        storage_type st;
+        detail::get(is, plain_size);
+        if (S == Scheme::CKKS) { detail::get(is, depth_); detail::get(is, scale_); }
+        detail::get(is, ntt);
+        if (S == Scheme::CKKS) detail::get(is, encoding_);
+        detail::get(is, plaintext_generated_);
+        detail::get(is, st);
+        detail::get(is, again);
+        if (!is || plain_size <= 0 || again != plain_size) throw std::runtime_error("Invalid plaintext size!");
+        device_locations_ = detail::read_payload(is, (size_t) plain_size, "Plaintext");
+        plaintext_generated_ = true;
+    }
+    void store_in_device(hipStream_t = nullptr) {}
+    void store_in_host(hipStream_t = nullptr) {}
+    inline int depth() const noexcept { return depth_; }
+    inline double scale() const noexcept { return scale_; }
+    inline encoding encoding_type() const noexcept { return encoding_; }
     int depth_ = 0;
     double scale_ = 0;
+    encoding encoding_ = encoding::SLOT;
     bool plaintext_generated_ = false;
 
   private:
@@ -571,17 +1153,35 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
         rk.memory_set(std::move(out));
         rk.relin_key_generated_ = true;
     }
+    // key under new_sk that carries old_sk (ckks/keygenerator.cu:996-1095)
+    void generate_switch_key(Switchkey<S>& swk, Secretkey<S>& new_sk, Secretkey<S>& old_sk,
+                             const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!old_sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
+        if (!new_sk.secret_key_generated_) throw std::logic_error("Ner Secretkey is not generated!");
+        if (swk.switch_key_generated_) throw std::logic_error("Switchkey is already generated!");
+        DeviceVector<Data64> out(swk.size(), o.stream_);
+        Workspace ws(context_, HEGPU_OP_KEYGEN_SWITCH, o.stream_);
+        detail::check(hegpu_generate_switch_key(context_->handle(), rng_, (const uint64_t*) new_sk.data(),
+                                                (const uint64_t*) old_sk.data(), (uint64_t*) out.data(), ws.p(),
+                                                ws.bytes(), o.stream_));
+        swk.memory_set(std::move(out));
+        swk.switch_key_generated_ = true;
+    }
     void generate_galois_key(Galoiskey<S>& gk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (gk.galois_key_generated_) throw std::logic_error("Galoiskey is already generated!");
         Workspace ws(context_, HEGPU_OP_KEYGEN_SWITCH, o.stream_);
-        for (auto& g : gk.galois_elt) {
-            if (gk.device_location_.count(g.second)) continue;
+        std::vector<int> elements;
+        if (gk.customized) for (std::uint32_t e : gk.custom_galois_elt) elements.push_back((int) e);
+        else for (auto& g : gk.galois_elt) elements.push_back(g.second);
+        for (int elt : elements) {
+            if (gk.device_location_.count(elt)) continue;
             DeviceVector<Data64> out(gk.size(), o.stream_);
-            detail::check(hegpu_generate_galois_key(context_->handle(), rng_, (const uint64_t*) sk.data(), g.second,
+            detail::check(hegpu_generate_galois_key(context_->handle(), rng_, (const uint64_t*) sk.data(), elt,
                                                     (uint64_t*) out.data(), ws.p(), ws.bytes(), o.stream_));
-            gk.device_location_[g.second] = std::move(out);
+            gk.device_location_[elt] = std::move(out);
         }
         if (!gk.device_location_.count(gk.galois_elt_zero)) { // "Columns Rotate" key (keygenerator.cu:508-560)
             DeviceVector<Data64> out(gk.size(), o.stream_);
@@ -670,6 +1270,73 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
         pt.depth_ = ct.depth();
         pt.scale_ = ct.scale();
         pt.plaintext_generated_ = true;
+    }
+
+    // BFV invariant noise budget in bits: log2(Q) - log2(|t * (c0 + c1 s) mod Q|_inf) - 1
+    // (bfv/decryptor.cu:170-300); the residues come from the device, the CRT composition and the
+    // norm are done here on the host with multi-word integers
+    int remainder_noise_budget(Ciphertext<S>& ct, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::BFV, "the noise budget is defined for BFV");
+        const int Q = context_->Q_size;
+        const size_t n = context_->n;
+        DeviceVector<Data64> out((size_t) Q * n, o.stream_);
+        detail::check(hegpu_bfv_noise_rns(context_->handle(), (const uint64_t*) ct.data(), (const uint64_t*) sk_->data(),
+                                          (uint64_t*) out.data(), o.stream_));
+        std::vector<Data64> h((size_t) Q * n);
+        detail::hip(hipMemcpyAsync(h.data(), out.data(), h.size() * sizeof(Data64), hipMemcpyDeviceToHost, o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+        typedef unsigned __int128 u128;
+        const std::vector<Data64> q = context_->get_key_modulus();
+        auto mul_word = [](std::vector<Data64>& big, Data64 f) {
+            u128 carry = 0;
+            for (Data64& w : big) { u128 v = (u128) w * f + carry; w = (Data64) v; carry = v >> 64; }
+            big.push_back((Data64) carry);
+        };
+        std::vector<Data64> M{1};
+        for (int j = 0; j < Q; j++) mul_word(M, q[j]);
+        M.resize(Q + 1, 0);
+        std::vector<std::vector<Data64>> Mi(Q);
+        std::vector<Data64> Mi_inv(Q);
+        auto mulmod = [](Data64 a, Data64 b, Data64 m) { return (Data64) ((u128) a * b % m); };
+        auto powmod = [&](Data64 a, Data64 e, Data64 m) { Data64 r = 1; while (e) { if (e & 1) r = mulmod(r, a, m); a = mulmod(a, a, m); e >>= 1; } return r; };
+        for (int i = 0; i < Q; i++) {
+            Mi[i] = {1};
+            Data64 m = 1;
+            for (int j = 0; j < Q; j++)
+                if (j != i) { mul_word(Mi[i], q[j]); m = mulmod(m, q[j] % q[i], q[i]); }
+            Mi[i].resize(Q + 1, 0);
+            Mi_inv[i] = powmod(m, q[i] - 2, q[i]);
+        }
+        auto geq = [&](const std::vector<Data64>& a, const std::vector<Data64>& b) {
+            for (int k = Q; k >= 0; k--) if (a[k] != b[k]) return a[k] > b[k];
+            return true;
+        };
+        auto sub = [&](std::vector<Data64>& a, const std::vector<Data64>& b) {
+            Data64 borrow = 0;
+            for (int k = 0; k <= Q; k++) { u128 d = (u128) a[k] - b[k] - borrow; a[k] = (Data64) d; borrow = (Data64) (d >> 64) & 1; }
+        };
+        std::vector<Data64> half = M; // M >> 1
+        for (int k = 0; k <= Q; k++) half[k] = (M[k] >> 1) | (k < Q ? (M[k + 1] << 63) : 0);
+        auto bit_length = [&](const std::vector<Data64>& a) {
+            for (int k = Q; k >= 0; k--) if (a[k]) { int b = 0; Data64 v = a[k]; while (v) { b++; v >>= 1; } return 64 * k + b; }
+            return 0;
+        };
+        int norm_bits = 0;
+        std::vector<Data64> acc(Q + 1), term(Q + 1);
+        for (size_t c = 0; c < n; c++) {
+            std::fill(acc.begin(), acc.end(), 0);
+            for (int i = 0; i < Q; i++) {
+                const Data64 t = mulmod(h[(size_t) i * n + c], Mi_inv[i], q[i]);
+                u128 carry = 0;
+                for (int k = 0; k <= Q; k++) { u128 v = (u128) Mi[i][k] * t + acc[k] + carry; acc[k] = (Data64) v; carry = v >> 64; }
+                if (geq(acc, M)) sub(acc, M);
+            }
+            if (geq(acc, half)) { term = M; sub(term, acc); norm_bits = std::max(norm_bits, bit_length(term)); }
+            else norm_bits = std::max(norm_bits, bit_length(acc));
+        }
+        const int budget = bit_length(M) - norm_bits - 1;
+        return budget < 0 ? 0 : budget;
     }
 
   private:
@@ -884,7 +1551,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         detail::check(hegpu_ckks_rescale_inplace(context_->handle(), (uint64_t*) a.data(),
                                                  (uint64_t) 2 * l * context_->n, a.depth_, 1, ws.data(), wsb,
                                                  o.stream_));
-        a.scale_ = a.scale_ / (double) context_->prime_vector_[l - 1]; // ckks/operator.cu:1235-1241
+        a.scale_ = a.scale_ / (double) context_->prime_vector_[l - 1].value; // ckks/operator.cu:1235-1241
         a.depth_++;
         a.rescale_required_ = false;
     }
@@ -920,11 +1587,24 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         Ciphertext<S> tmp(a);
         rotate_rows(tmp, a, gk, shift, o);
     }
+    // Move a ciphertext to the secret key the switch key was generated for (*/operator.cuh
+    // keyswitch; switchkey_*_method_I is the Galois path with the identity permutation).
+    void keyswitch(Ciphertext<S>& in, Ciphertext<S>& out, Switchkey<S>& swk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (!swk.switch_key_generated_) throw std::logic_error("Switchkey is not generated!");
+        apply_key(in, out, swk.data(), 1, o);
+    }
     void apply_galois(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, int galois_elt,
                       const ExecutionOptions& o = ExecutionOptions())
     {
         auto it = gk.device_location_.find(galois_elt);
         if (it == gk.device_location_.end()) throw std::logic_error("Galois key not present!");
+        apply_key(in, out, it->second.data(), galois_elt, o);
+    }
+
+  private:
+    void apply_key(Ciphertext<S>& in, Ciphertext<S>& out, const Data64* key, int galois_elt, const ExecutionOptions& o)
+    {
         if (in.relinearization_required_) throw std::invalid_argument("Ciphertext should be relinearized first!");
         const int l = limbs(in);
         const size_t n = context_->n;
@@ -934,14 +1614,47 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         DeviceVector<Data64> ws(wsb / 8, o.stream_);
         if (S == Scheme::CKKS)
             detail::check(hegpu_ckks_apply_galois(context_->handle(), (const uint64_t*) in.data(), 0,
-                                                  (uint64_t*) m.data(), 0, (const uint64_t*) it->second.data(),
-                                                  galois_elt, in.depth_, 1, ws.data(), wsb, o.stream_));
+                                                  (uint64_t*) m.data(), 0, (const uint64_t*) key, galois_elt,
+                                                  in.depth_, 1, ws.data(), wsb, o.stream_));
         else
             detail::check(hegpu_bfv_apply_galois(context_->handle(), (const uint64_t*) in.data(), 0,
-                                                 (uint64_t*) m.data(), 0, (const uint64_t*) it->second.data(),
-                                                 galois_elt, 1, ws.data(), wsb, o.stream_));
+                                                 (uint64_t*) m.data(), 0, (const uint64_t*) key, galois_elt, 1,
+                                                 ws.data(), wsb, o.stream_));
         if (&in != &out) copy_meta(in, out);
         out.memory_set(std::move(m));
+    }
+
+  public:
+
+    void add_inplace(Ciphertext<S>& a, Ciphertext<S>& b, const ExecutionOptions& o = ExecutionOptions()) { binary(a, b, a, 0, o); }
+    void sub_inplace(Ciphertext<S>& a, Ciphertext<S>& b, const ExecutionOptions& o = ExecutionOptions()) { binary(a, b, a, 1, o); }
+    void negate_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { negate(a, a, o); }
+    // CKKS: drop the last limb without dividing (ckks/operator.cuh mod_drop*)
+    void mod_drop(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::CKKS, "mod_drop is a CKKS operation");
+        const int l = limbs(a);
+        if (l < 2) throw std::logic_error("Ciphertext modulus can not be reducible, since there is only one modulus");
+        const size_t n = context_->n;
+        DeviceVector<Data64> m((size_t) a.cipher_size_ * (l - 1) * n, o.stream_);
+        for (int p = 0; p < a.cipher_size_; p++)
+            detail::hip(hipMemcpyAsync(m.data() + (size_t) p * (l - 1) * n, a.data() + (size_t) p * l * n,
+                                       (size_t) (l - 1) * n * sizeof(Data64), hipMemcpyDeviceToDevice, o.stream_));
+        const int depth = a.depth_ + 1;
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
+        out.depth_ = depth;
+    }
+    void mod_drop_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { mod_drop(a, a, o); }
+    void mod_drop_inplace(Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::CKKS, "mod_drop is a CKKS operation");
+        const int l = context_->Q_size - p.depth_;
+        if (l < 2) throw std::logic_error("Plaintext modulus can not be reducible, since there is only one modulus");
+        DeviceVector<Data64> m((size_t) (l - 1) * context_->n, o.stream_);
+        detail::hip(hipMemcpyAsync(m.data(), p.data(), m.size() * sizeof(Data64), hipMemcpyDeviceToDevice, o.stream_));
+        p.memory_set(std::move(m));
+        p.depth_++;
     }
 
     // ---- ciphertext (+,-,*) plaintext (host/*/operator.cuh add_plain / sub_plain / multiply_plain)
@@ -1350,6 +2063,13 @@ template <typename T> void deserialize(T& obj, const std::vector<std::uint8_t>& 
     from_buffer(ss, decompress(buffer));
     obj.load(ss);
 }
+// reference signature (util/serializer.h:86): objects that can be default-constructed
+template <typename T> T deserialize(const std::vector<std::uint8_t>& buffer)
+{
+    T obj;
+    deserialize(obj, buffer);
+    return obj;
+}
 template <typename T> void save_to_file(const T& obj, const std::string& filename)
 {
     const std::vector<std::uint8_t> data = serialize(obj);
@@ -1369,6 +2089,12 @@ template <typename T> void load_from_file(T& obj, const std::string& filename)
     ifs.read((char*) buffer.data(), (std::streamsize) size);
     if (!ifs) throw std::runtime_error("File is truncated: " + filename);
     deserialize(obj, buffer);
+}
+template <typename T> T load_from_file(const std::string& filename) // util/serializer.h:115
+{
+    T obj;
+    load_from_file(obj, filename);
+    return obj;
 }
 #endif // HEONGPU_WITH_ZLIB
 } // namespace serializer

@@ -82,6 +82,7 @@ def lib():
     L.o_gen_secret_key.argtypes = [vp, vp, ci, vp]
     L.o_gen_public_key.argtypes = [vp, vp, vp, vp]
     L.o_gen_switch_key.argtypes = [vp, vp, vp, ci, vp]
+    L.o_gen_switch_key_new_old.argtypes = [vp, vp, vp, vp, vp]
     L.o_ckks_encrypt.argtypes = [vp, vp, vp, vp, vp]
     L.o_ckks_decrypt.argtypes = [vp, vp, vp, ci, vp]
     L.o_bfv_encrypt.argtypes = [vp, vp, vp, vp, vp]
@@ -235,9 +236,18 @@ class OracleContext:
         self.L.o_gen_public_key(self.h, ctypes.byref(rng), _p(sk), _p(pk))
         return pk
 
+    def switch_key_digits(self):
+        """digits of a key-switching key: Q (method I) or the depth-0 partition (method II)"""
+        return self.Q if self.P == 1 else -(-self.Q // (2 if self.scheme == BFV else self.P))
+
     def gen_switch_key(self, rng, sk, galois_elt=0):
-        key = np.zeros(self.Q * 2 * self.Qp * self.n, dtype=np.uint64)
+        key = np.zeros(self.switch_key_digits() * 2 * self.Qp * self.n, dtype=np.uint64)
         self.L.o_gen_switch_key(self.h, ctypes.byref(rng), _p(sk), galois_elt, _p(key))
+        return key
+
+    def gen_switch_key_new_old(self, rng, new_sk, old_sk):
+        key = np.zeros(self.switch_key_digits() * 2 * self.Qp * self.n, dtype=np.uint64)
+        self.L.o_gen_switch_key_new_old(self.h, ctypes.byref(rng), _p(new_sk), _p(old_sk), _p(key))
         return key
 
     def ckks_encrypt(self, rng, pk, plain):

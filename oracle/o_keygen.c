@@ -185,28 +185,54 @@ static u64 modinv_2n(u64 g, u64 two_n)
 /* generate_relin_key_method_I (ckks/keygenerator.cu:242-324, relinkey_gen_kernel
  * keygeneration.cu:145-185) when galois_elt == 0, else generate_galois_key_method_I for
  * one element (keygenerator.cu:415-500, galoiskey_gen_kernel keygeneration.cu:757-805). */
+static void gen_switch_key(const octx_t* c, orng_t* r, const u64* sk, int galois_elt, const u64* old_sk, u64* key);
 void o_gen_switch_key(const octx_t* c, orng_t* r, const u64* sk, int galois_elt, u64* key)
 {
-    const int Q = c->Q_size, Qp = c->Qp_size, np = c->n_power;
-    const u64 sz = ((u64) Q * Qp) << np;
+    gen_switch_key(c, r, sk, galois_elt, NULL, key);
+}
+/* generate_switch_key_method_I (ckks/keygenerator.cu:996-1095, switchkey_gen_kernel
+ * keygeneration.cu:896-939): same sampling order, the diagonal carries old_sk */
+void o_gen_switch_key_new_old(const octx_t* c, orng_t* r, const u64* new_sk, const u64* old_sk, u64* key)
+{
+    gen_switch_key(c, r, new_sk, 0, old_sk, key);
+}
+static void gen_switch_key(const octx_t* c, orng_t* r, const u64* sk, int galois_elt, const u64* old_sk, u64* key)
+{
+    const int Q = c->Q_size, Qp = c->Qp_size, P = c->P_size, np = c->n_power;
+    /* method I: Q digits, limb y carries the payload in digit y (i == block_y, keygeneration.cu:166).
+     * method II (relinkey_gen_II_kernel :584-629, galoiskey_gen_II_kernel :807-858,
+     * switchkey_gen_II_kernel :941-989): d = d_leveled[0] digits, Sk_pair from
+     * sk_pair_counter (contextpool.cpp:48-66): the digit index repeated I_j times, INT32_MAX for
+     * the special limbs; the payload is multiplied by every special prime in turn. */
+    const int d = (P == 1) ? Q : c->m2->lv[0].d;
+    int sk_pair[64];
+    if (P == 1) {
+        for (int y = 0; y < Qp; y++) sk_pair[y] = y; /* y == Q never equals i < Q */
+    } else {
+        int k = 0;
+        for (int l = 0; l < d; l++)
+            for (int t = 0; t < c->m2->lv[0].I_j[l]; t++) sk_pair[k++] = l;
+        for (int t = 0; t < P; t++) sk_pair[k++] = 0x7fffffff;
+    }
+    const u64 sz = ((u64) d * Qp) << np;
     u64* e = (u64*) malloc(2 * sz * sizeof(u64));
     u64* a = e + sz;
-    fill_uniform(c, r, a, Qp, Q);
-    fill_gaussian(c, r, e, Qp, Q);
-    o_gpu_ntt(e, e, c->ntt_table, c->mod, np, Q * Qp, Qp);
+    fill_uniform(c, r, a, Qp, d);
+    fill_gaussian(c, r, e, Qp, d);
+    o_gpu_ntt(e, e, c->ntt_table, c->mod, np, d * Qp, Qp);
     const int inv = galois_elt ? (int) modinv_2n((u64) galois_elt, 2 * c->n) : 0;
     for (int y = 0; y < Qp; y++)
         for (int idx = 0; idx < (int) c->n; idx++) {
             u64 s = sk[idx + ((u64) y << np)];
             u64 sp = galois_elt ? sk[((u64) y << np) + permutation(idx, inv, (int) c->n, np)] : s;
-            for (int i = 0; i < Qp - 1; i++) {
+            for (int i = 0; i < d; i++) {
                 u64 src = idx + ((u64) y << np) + ((u64) (Qp * i) << np);
                 u64 k0 = o_mult(sp, a[src], &c->mod[y]);
                 k0 = o_add(k0, e[src], &c->mod[y]);
                 k0 = o_sub(0, k0, &c->mod[y]);
-                if (i == y) {
-                    u64 t = galois_elt ? s : o_mult(s, s, &c->mod[y]);
-                    t = o_mult(t, c->factor[y], &c->mod[y]);
+                if (i == sk_pair[y]) {
+                    u64 t = old_sk ? old_sk[idx + ((u64) y << np)] : (galois_elt ? s : o_mult(s, s, &c->mod[y]));
+                    for (int j = 0; j < P; j++) t = o_mult(t, c->factor[j * Q + y], &c->mod[y]);
                     k0 = o_add(k0, t, &c->mod[y]);
                 }
                 u64 dst = idx + ((u64) y << np) + ((u64) (Qp * i) << (np + 1));

@@ -456,6 +456,152 @@ static void serializer_round_trip()
     EXPECT(thrown, "a BFV-tagged binary is rejected by a CKKS ciphertext");
 }
 
+// Every serializable object of the reference (example/basic/13_bfv_serialization.cpp,
+// 14_ckks_serialization.cpp): byte layout of the headers (field order and widths of
+// */context.cu, secretkey.cu, publickey.cu, evaluationkey.cu, plaintext.cu save()), round trips
+// through default-constructed objects, and the loaded objects keep working.
+static void serialize_all_objects()
+{
+    constexpr auto S = Scheme::BFV;
+    const int n = 4096;
+    HEContext<S> ctx0 = GenHEContext<S>();
+    ctx0->set_poly_modulus_degree(n);
+    ctx0->set_coeff_modulus_default_values(1);
+    ctx0->set_plain_modulus(1032193);
+    std::stringstream cs;
+    ctx0->save(cs); // before generate(), like the example
+    // u8 x3 | int x7 | u32 + 3 x Modulus64(24 B) | u32 + 3 x u64 | u32 (empty) | u32 + 2 int | u32 + 1 int | Modulus64
+    EXPECT(cs.str().size() == 3 + 7 * 4 + (4 + 3 * 24) + (4 + 3 * 8) + 4 + (4 + 2 * 4) + (4 + 4) + 24, "BFV context wire size");
+    EXPECT((unsigned char) cs.str()[0] == 1 && (unsigned char) cs.str()[1] == 1 && (unsigned char) cs.str()[2] == 1,
+           "context tags: bfv, sec128, method I");
+    HEContext<S> ctx = GenHEContext<S>();
+    ctx->load(cs);
+    EXPECT(ctx->context_generated_ && ctx->n == n && ctx->Q_size == 2 && ctx->get_plain_modulus() == 1032193 &&
+               ctx->get_key_modulus() == ctx0->get_key_modulus(), "context load -> generated context with the same chain");
+
+    HEKeyGenerator<S> keygen(ctx, 1);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    std::stringstream ss;
+    sk.save(ss);
+    EXPECT(ss.str().size() == 1 + 4 * 4 + 1 + 1 + 1 + 4 + (size_t) 3 * n * 8, "secret key wire size");
+    auto sk2 = serializer::deserialize<Secretkey<S>>(serializer::serialize(sk));
+    EXPECT(sk2.secret_key_generated_ && sk2.ring_size() == n && sk2.coeff_modulus_count() == 3, "secret key zlib round trip");
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk2);
+    serializer::save_to_file(pk, "/tmp/hegpu_pk.bin");
+    auto pk2 = serializer::load_from_file<Publickey<S>>("/tmp/hegpu_pk.bin");
+    Relinkey<S> rk(ctx);
+    keygen.generate_relin_key(rk, sk2);
+    std::stringstream rs;
+    rk.save(rs);
+    EXPECT(rs.str().size() == 1 + 1 + 6 * 4 + 1 + 1 + 8 + rk.size() * 8, "relin key wire size");
+    Relinkey<S> rk2;
+    rk2.load(rs);
+    std::vector<int> shifts = {1, 3};
+    Galoiskey<S> gk(ctx, shifts);
+    keygen.generate_galois_key(gk, sk2);
+    std::stringstream gs;
+    gk.save(gs);
+    // header 1+1+4*4+1+4+1+1 | u32 + 2 pairs | int zero | u64 size | u32 count | 2 x (int + key) | zero key
+    EXPECT(gs.str().size() == 25 + 4 + 2 * 8 + 4 + 8 + 4 + 2 * (4 + gk.size() * 8) + gk.size() * 8, "galois key wire size");
+    Galoiskey<S> gk2;
+    gk2.load(gs);
+    EXPECT(gk2.galois_elt == gk.galois_elt && gk2.galois_elt_zero == gk.galois_elt_zero && gk2.device_location_.size() == 3,
+           "galois key table after load");
+
+    HEEncoder<S> encoder(ctx);
+    HEEncryptor<S> encryptor(ctx, pk2, 2);
+    HEDecryptor<S> decryptor(ctx, sk2);
+    HEArithmeticOperator<S> op(ctx, encoder);
+    std::vector<uint64_t> message(n, 8ULL);
+    message[0] = 1; message[1] = 12; message[2] = 23; message[n / 2] = 7;
+    Plaintext<S> p1(ctx);
+    encoder.encode(p1, message);
+    std::stringstream ps;
+    p1.save(ps);
+    EXPECT(ps.str().size() == 1 + 4 + 1 + 1 + 1 + 4 + (size_t) n * 8, "BFV plaintext wire size");
+    Plaintext<S> p2;
+    p2.load(ps);
+    Ciphertext<S> c1(ctx);
+    encryptor.encrypt(c1, p2);
+    std::stringstream ts;
+    c1.save(ts);
+    Ciphertext<S> c2;
+    c2.load(ts);
+    op.multiply_inplace(c2, c2);
+    op.relinearize_inplace(c2, rk2);
+    op.rotate_rows_inplace(c2, gk2, 3);
+    Plaintext<S> pr(ctx);
+    decryptor.decrypt(pr, c2);
+    std::vector<uint64_t> result;
+    encoder.decode(result, pr);
+    // row 0: [1,144,529,64,...] rotated left by 3
+    EXPECT(result[0] == 64 && result[n / 2 - 3] == 1 && result[n / 2 - 2] == 144 && result[n / 2 - 1] == 529 &&
+               result[n - 3] == 49, "loaded objects: encrypt -> square -> relinearize -> rotate -> decrypt");
+    bool thrown = false;
+    try { Relinkey<S> again; std::stringstream r2(rs.str()); again.load(r2); again.load(r2); } catch (const std::runtime_error&) { thrown = true; }
+    EXPECT(thrown, "loading into a generated key is refused");
+}
+
+// Key-switching method II end to end with generated keys (two special primes), and the
+// secret-key switch (example/basic/5_switchkey_methods_ckks.cpp).
+static void method_II_and_switch_key()
+{
+    constexpr auto S = Scheme::CKKS;
+    const size_t n = 8192;
+    HEContext<S> ctx = GenHEContext<S>(sec_level_type::none);
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_bit_sizes({60, 40, 40, 40, 40}, {60, 60});
+    ctx->generate();
+    EXPECT(ctx->keyswitching_type_ == keyswitching_type::KEYSWITCHING_METHOD_II, "two special primes select method II");
+    HEKeyGenerator<S> keygen(ctx, 3);
+    Secretkey<S> sk(ctx), sk2(ctx);
+    keygen.generate_secret_key(sk);
+    keygen.generate_secret_key(sk2);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk(ctx);
+    keygen.generate_relin_key(rk, sk);
+    EXPECT(rk.size() == (size_t) 2 * 3 * 7 * n, "method II relin key: 3 digits of 2 primes over 7 limbs");
+    Galoiskey<S> gk(ctx, std::vector<int>{2});
+    keygen.generate_galois_key(gk, sk);
+    Switchkey<S> swk(ctx);
+    keygen.generate_switch_key(swk, sk2, sk);
+    HEEncoder<S> encoder(ctx);
+    HEEncryptor<S> encryptor(ctx, pk, 4);
+    HEDecryptor<S> dec1(ctx, sk), dec2(ctx, sk2);
+    HEArithmeticOperator<S> op(ctx, encoder);
+    const double scale = std::pow(2.0, 40);
+    std::vector<double> m(n / 2);
+    for (size_t i = 0; i < m.size(); i++) m[i] = 0.001 * (double) (i % 1000) - 0.3;
+    Plaintext<S> p(ctx);
+    encoder.encode(p, m, scale);
+    Ciphertext<S> c(ctx);
+    encryptor.encrypt(c, p);
+    op.multiply_inplace(c, c);
+    op.relinearize_inplace(c, rk);
+    op.rescale_inplace(c);
+    op.rotate_rows_inplace(c, gk, 2);
+    Plaintext<S> out(ctx);
+    std::vector<double> got;
+    dec1.decrypt(out, c);
+    encoder.decode(got, out);
+    double err = 0;
+    for (size_t i = 0; i < m.size(); i++) err = std::max(err, std::fabs(got[i] - m[(i + 2) % m.size()] * m[(i + 2) % m.size()]));
+    EXPECT(err < 1e-6, "method II: square -> relinearize -> rescale -> rotate under generated keys");
+    op.keyswitch(c, c, swk);
+    Plaintext<S> out2(ctx);
+    dec2.decrypt(out2, c);
+    encoder.decode(got, out2);
+    err = 0;
+    for (size_t i = 0; i < m.size(); i++) err = std::max(err, std::fabs(got[i] - m[(i + 2) % m.size()] * m[(i + 2) % m.size()]));
+    EXPECT(err < 1e-6, "keyswitch moves the ciphertext to the second secret key");
+    std::stringstream ws;
+    swk.save(ws);
+    EXPECT(ws.str().size() == 1 + 1 + 4 * 4 + 1 + 1 + 8 + swk.size() * 8, "switch key wire size");
+}
+
 // TFHE through the class layer (reference test/test_tfhe_gate_boot.cpp:64-86): all gates and MUX
 static void tfhe_gates()
 {
@@ -500,9 +646,8 @@ int main()
         EXPECT(throws_logic([&] { bad->set_poly_modulus_degree(1000); }), "degree must be a power of two");
         auto sec = GenHEContext<Scheme::CKKS>();
         sec->set_poly_modulus_degree(4096);
-        sec->set_coeff_modulus_bit_sizes({40, 30, 30}, {40});
-        bool thrown = false;
-        try { sec->generate(); } catch (const std::runtime_error&) { thrown = true; }
+        bool thrown = false; // thrown where the reference throws it (ckks/context.cu:95-117)
+        try { sec->set_coeff_modulus_bit_sizes({40, 30, 30}, {40}); } catch (const std::runtime_error&) { thrown = true; }
         EXPECT(thrown, "140-bit chain at N=4096 violates the 128-bit security table");
     }
     ckks();
@@ -511,6 +656,8 @@ int main()
     bfv_pipeline();
     ckks_encoder_flow();
     serializer_round_trip();
+    serialize_all_objects();
+    method_II_and_switch_key();
     tfhe_gates();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;

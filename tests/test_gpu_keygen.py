@@ -170,3 +170,78 @@ def test_bfv_batch_encoder_bit_exact(hg, oracle, torch, n, t):
         full = np.zeros(n, dtype=np.int64)
         full[:len(msg)] = msg
         assert np.array_equal(hg.to_host(dec), (full % t).astype(np.uint64)), "decode(encode(m)) = m mod t"
+
+
+def test_switch_key_bit_exact_and_keyswitch(hg, oracle, torch):
+    """generate_switch_key (ckks/keygenerator.cu:996-1095) against the oracle, then keyswitch
+    (= the Galois path with the identity permutation, operator.cu switchkey_ckks_method_I) on the
+    GPU against the oracle, and decryption under the new secret."""
+    n = 4096
+    c, o, primes = _pair(hg, oracle, n, [50, 30, 30, 30], [50])
+    Q = 4
+    rg, ro = hg.Rng(99), oracle.ORng(99)
+    sk, sk_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    sk2, sk2_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    pk, pk_o = c.generate_public_key(rg, sk), o.gen_public_key(ro, sk_o)
+    swk = c.generate_switch_key(rg, sk2, sk)
+    swk_o = o.gen_switch_key_new_old(ro, sk2_o, sk_o)
+    assert np.array_equal(hg.to_host(swk), swk_o), "switch key"
+    he = RLWE(o, seed=1)
+    scale = 1 << 30
+    m = np.random.default_rng(4).integers(-50, 51, n)
+    plain = he.to_ntt([int(v) * scale for v in m], range(Q)).reshape(-1)
+    ct = c.ckks_encrypt(rg, pk, hg.to_device(plain))
+    moved = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(ct, 2 * Q * n, moved, 2 * Q * n, swk, 1, 0, 1, c.workspace(hg.OP_CKKS_GALOIS, 0, 1))
+    want = o.ckks_apply_galois(hg.to_host(ct), swk_o, 1, 0)
+    assert np.array_equal(hg.to_host(moved), want), "keyswitch"
+    dec = hg.to_host(c.ckks_decrypt(moved, sk2, 0))
+    coeff = he.ntt_limbs(dec.reshape(Q, n), list(range(Q)), inverse=True)
+    x = he.crt_centered(coeff, list(range(Q)))[0]
+    assert max(abs(int(a) - int(b) * scale) for a, b in zip(x, m)) < 1 << 20
+
+
+@pytest.mark.parametrize("scheme_name", ["ckks", "bfv"])
+def test_method_II_key_generation_bit_exact(hg, oracle, torch, scheme_name):
+    """relinkey_gen_II / galoiskey_gen_II / switchkey_gen_II (keygeneration.cu:584-629, :807-858,
+    :941-989) with two special primes against the oracle; the generated relinearisation key then
+    drives the method II relinearisation on both sides."""
+    n = 4096
+    if scheme_name == "ckks":
+        c = hg.Context.from_bit_sizes(hg.CKKS, n, [50, 36, 36, 36, 36], [50, 50], sec=hg.SEC_NONE)
+        sch = oracle.CKKS
+    else:
+        c = hg.Context.from_bit_sizes(hg.BFV, n, [40, 40, 40], [41, 41], plain_modulus=65537, sec=hg.SEC_NONE)
+        sch = oracle.BFV
+    primes = [int(x) for x in c.table("modulus")]
+    Q, P = c.Q_size, c.P_size
+    o = oracle.OracleContext(sch, c.n_power, primes, Q, P, 65537 if scheme_name == "bfv" else 0)
+    c.upload()
+    assert c.switch_key_digits() == o.switch_key_digits() == (3 if scheme_name == "ckks" else 2)
+    rg, ro = hg.Rng(5150), oracle.ORng(5150)
+    sk, sk_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    assert np.array_equal(hg.to_host(sk), sk_o)
+    rk, rk_o = c.generate_relin_key(rg, sk), o.gen_switch_key(ro, sk_o, 0)
+    assert np.array_equal(hg.to_host(rk), rk_o), "relinearisation key (method II)"
+    gal = hg.steps_to_galois_elt(1, n, 5 if scheme_name == "ckks" else 3)
+    gk, gk_o = c.generate_galois_key(rg, sk, gal), o.gen_switch_key(ro, sk_o, gal)
+    assert np.array_equal(hg.to_host(gk), gk_o), "galois key (method II)"
+    sk2, sk2_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    swk, swk_o = c.generate_switch_key(rg, sk2, sk), o.gen_switch_key_new_old(ro, sk2_o, sk_o)
+    assert np.array_equal(hg.to_host(swk), swk_o), "switch key (method II)"
+    pk, pk_o = c.generate_public_key(rg, sk), o.gen_public_key(ro, sk_o)
+    assert np.array_equal(hg.to_host(pk), pk_o), "public key over two special primes"
+    if scheme_name == "ckks":
+        plain = np.concatenate([oracle.fill_poly(3, j, n, primes[j]) for j in range(Q)])
+        ct = c.ckks_encrypt(rg, pk, hg.to_device(plain))
+        ct_o = o.ckks_encrypt(ro, pk_o, plain)
+        assert np.array_equal(hg.to_host(ct), ct_o), "encryption with P_size = 2"
+        out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+        c.ckks_multiply(ct, 2 * Q * n, ct, 2 * Q * n, out, 3 * Q * n, 0, 1)
+        c.ckks_relinearize_inplace(out, 3 * Q * n, rk, 0, 1, c.workspace(hg.OP_CKKS_RELIN, 0, 1))
+        ct3 = o.ckks_multiply(ct_o, ct_o, 0)
+        o.ckks_relinearize_II(ct3, rk_o, 0)
+        assert np.array_equal(hg.to_host(out)[:2 * Q * n], ct3[:2 * Q * n]), "relinearize with the generated key"
+        rot = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+        c.ckks_apply_galois(ct, 2 * Q * n, rot, 2 * Q * n, gk, gal, 0, 1, c.workspace(hg.OP_CKKS_GALOIS, 0, 1))
+        assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois_II(ct_o, gk_o, gal, 0)), "rotate with the generated key"

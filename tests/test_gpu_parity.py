@@ -431,3 +431,58 @@ def test_reference_benchmark_runs_unchanged(torch, name):
         assert "[NAND] Avg Time" in r.stdout and "[MUX] Avg Time" in r.stdout
     else:
         assert r.stdout.count("Average multiplication timing") >= 4
+
+
+# what each of the reference's example programs must print (from the expected-result comments in
+# example/basic/*.cpp); values are matched without the column padding of display_matrix/vector
+_EXAMPLE_EXPECT = {
+    "1_basic_bfv": ["[1,144,529,961,64,...,64,64,64,64,64]", "[49,2916,36,10000,64,...,64,64,64,64,64]",
+                    "[6,864,3174,5766,384,...,384,384,384,384,384]", "[294,17496,216,60000,384,...,384,384,384,384,384]"],
+    "2_basic_ckks": ["[100.000,400.000,900.000,1600.000,...,9.000,9.000,9.000,9.000]",
+                     "[50.000,200.000,450.000,800.000,...,4.500,4.500,4.500,4.500]"],
+    "3_basic_memorypool_config": ["Q_tiltasize:Q(60+30+30+30)+P(60)bits", "DeviceMemoryPool"],
+    "4_switchkey_methods_bfv": ["Checkresult4:[10000,64,64,64,64,...,64,64,49,2916,36][961,64,64,64,64,...,64,64,1,144,529]"],
+    "5_switchkey_methods_ckks": ["Checkcheck3:[1600.000,0.250,9.000,9.000,...,9.000,100.000,400.000,900.000]"],
+    "8_default_stream_usage": ["Done."],
+    "9_multi_stream_usage_way1": ["Done."],
+    "10_multi_stream_usage_way2": ["Done."],
+    "13_bfv_serialization": ["[961,64,64,64,64,...,64,64,1,144,529][10000,64,64,64,64,...,64,64,49,2916,36]"],
+    "14_ckks_serialization": ["[1600.000,0.250,9.000,9.000,...,9.000,100.00", ",400.000,900.000]"],
+    "15_basic_tfhe": None,
+}
+
+
+@pytest.mark.parametrize("name", sorted(_EXAMPLE_EXPECT))
+def test_reference_example_runs_unchanged(torch, name):
+    """example/basic/<name>.cpp of the reference, compiled UNCHANGED against the class layer by
+    __graft_entry__.build() (where the reference tree is available), must run and print the results
+    its own comments announce."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "heongpu_amd", "lib", "ref_example_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("reference example binary not built (no /root/reference at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd="/tmp")
+    print(r.stdout[-2500:], r.stderr[-500:])
+    assert r.returncode == 0
+    flat = re.sub(r"\s+", "", r.stdout)
+    if name == "15_basic_tfhe":
+        def bits(label):
+            m = re.search(r"^" + re.escape(label) + r"\s*([01, ]+)$", r.stdout, re.M)
+            assert m, label
+            return [int(v) for v in re.findall(r"[01]", m.group(1))]
+        a, b, c = bits("Input1:"), bits("Input2:"), bits("Input3(control input of MUX):")
+        assert len(a) == len(b) == len(c) == 8
+        assert bits("NAND (Decrypted):") == [1 - (x & y) for x, y in zip(a, b)]
+        assert bits("AND (Decrypted):") == [x & y for x, y in zip(a, b)]
+        assert bits("NOR (Decrypted):") == [1 - (x | y) for x, y in zip(a, b)]
+        assert bits("OR (Decrypted):") == [x | y for x, y in zip(a, b)]
+        assert bits("XNOR (Decrypted):") == [1 - (x ^ y) for x, y in zip(a, b)]
+        assert bits("XOR (Decrypted):") == [x ^ y for x, y in zip(a, b)]
+        assert bits("NOT input1 (Decrypted):") == [1 - x for x in a]
+        assert bits("MUX (Decrypted):") == [x if s else y for x, y, s in zip(a, b, c)]
+        return
+    for want in _EXAMPLE_EXPECT[name]:
+        assert want in flat, want

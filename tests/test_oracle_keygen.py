@@ -105,6 +105,87 @@ def test_generated_galois_key_works(setup, oracle):
     assert err < scale // 2 ** 8
 
 
+def _adopt(he_cls, o, sk, primes):
+    """RLWE helper whose secret is a generated key (coefficients from the inverse NTT of limb 0)"""
+    he = he_cls(o, seed=1)
+    s0 = np.ascontiguousarray(sk.reshape(o.Qp, o.n)[0].copy())
+    o.ntt(s0, 1, 1, mod_offset=0, inverse=True)
+    q0 = primes[0]
+    he.s = np.array([int(v) - q0 if int(v) > q0 // 2 else int(v) for v in s0])
+    he.s_ntt = sk.reshape(o.Qp, o.n).copy()
+    return he
+
+
+def test_generated_switch_key_moves_ciphertext_to_the_new_secret(setup, oracle):
+    """generate_switch_key + keyswitch (ckks/keygenerator.cu:996-1095, operator.cu
+    switchkey_ckks_method_I = the Galois path with the identity permutation): a ciphertext under
+    sk decrypts under sk2 after the switch, and no longer under sk."""
+    o, he, rng, sk, primes = setup
+    n, Q = o.n, o.Q
+    sk2 = o.gen_secret_key(rng)
+    he2 = _adopt(RLWE, o, sk2, primes)
+    swk = o.gen_switch_key_new_old(rng, sk2, sk)
+    scale = 1 << 30
+    m = np.random.default_rng(8).integers(-50, 51, n)
+    ct = he.encrypt([int(v) * scale for v in m], Q, ntt_domain=True)
+    moved = o.ckks_apply_galois(ct, swk, 1, 0)
+    x, M = he2.decrypt(moved, Q, 2, ntt_domain=True)
+    assert max(abs(int(a) - int(b) * scale) for a, b in zip(x, m)) < scale // 2 ** 8
+    y, M = he.decrypt(moved, Q, 2, ntt_domain=True)
+    assert max(abs(int(a) - int(b) * scale) for a, b in zip(y, m)) > scale * 2 ** 8
+
+
+@pytest.fixture(scope="module")
+def setup_m2(oracle):
+    import ctypes
+    n_power = 10
+    n = 1 << n_power
+    bits = [40, 30, 30, 30, 30]
+    arr = (ctypes.c_int * 7)(*(bits + [40, 40]))
+    out = (ctypes.c_uint64 * 7)()
+    assert oracle.lib().o_generate_primes(n, arr, 7, out) == 0
+    primes = [int(v) for v in out]
+    o = oracle.OracleContext(oracle.CKKS, n_power, primes, len(bits), 2)
+    rng = oracle.ORng(31337)
+    sk = o.gen_secret_key(rng)
+    return o, _adopt(RLWE, o, sk, primes), rng, sk, primes
+
+
+def test_method_II_generated_keys_work(setup_m2, oracle):
+    """relinkey_gen_II_kernel / galoiskey_gen_II_kernel (keygeneration.cu:584-629, :807-858) with
+    two special primes: 3 digits of 2 primes for Q = 5; the keys drive the method II operators."""
+    o, he, rng, sk, primes = setup_m2
+    n, Q = o.n, o.Q
+    assert o.switch_key_digits() == 3
+    rk = o.gen_switch_key(rng, sk, 0)
+    assert rk.size == 3 * 2 * o.Qp * n
+    scale = 1 << 25
+    g = np.random.default_rng(15)
+    m1, m2 = g.integers(-8, 9, n), g.integers(-8, 9, n)
+    ct1 = he.encrypt([int(v) * scale for v in m1], Q, ntt_domain=True)
+    ct2 = he.encrypt([int(v) * scale for v in m2], Q, ntt_domain=True)
+    ct3 = o.ckks_multiply(ct1, ct2, 0)
+    o.ckks_relinearize_II(ct3, rk, 0)
+    x, M = he.decrypt(ct3[:2 * Q * n], Q, 2, ntt_domain=True)
+    prod = negacyclic_mul(m1, m2)
+    assert max(abs(int(a) - int(b) * scale * scale) for a, b in zip(x, prod)) < scale * scale // 2 ** 10
+    gal = oracle.lib().o_steps_to_galois_elt(2, n, 5)
+    gk = o.gen_switch_key(rng, sk, gal)
+    sc = 1 << 30
+    ct = he.encrypt([int(v) * sc for v in m1], Q, ntt_domain=True)
+    rot = o.ckks_apply_galois_II(ct, gk, gal, 0)
+    x, M = he.decrypt(rot, Q, 2, ntt_domain=True)
+    want = he.apply_galois_poly(np.array([int(v) * sc for v in m1], dtype=object), gal)
+    assert max(abs(int(a) - int(b)) for a, b in zip(x, want)) < sc // 2 ** 8
+    # switch key, method II
+    sk2 = o.gen_secret_key(rng)
+    he2 = _adopt(RLWE, o, sk2, primes)
+    swk = o.gen_switch_key_new_old(rng, sk2, sk)
+    moved = o.ckks_apply_galois_II(ct, swk, 1, 0)
+    x, M = he2.decrypt(moved, Q, 2, ntt_domain=True)
+    assert max(abs(int(a) - int(b) * sc) for a, b in zip(x, m1)) < sc // 2 ** 8
+
+
 def test_streams_are_reproducible(setup, oracle):
     o, he, rng, sk, primes = setup
     a = o.gen_secret_key(oracle.ORng(77))
