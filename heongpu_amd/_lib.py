@@ -73,6 +73,11 @@ SIGNATURES = [
     ("hegpu_bfv_encode", c_int, [voidp, voidp, c_int, u64p, voidp]),
     ("hegpu_ckks_encode", c_int, [voidp, voidp, c_int, ctypes.c_double, u64p, voidp, c_size_t, voidp]),
     ("hegpu_ckks_decode", c_int, [voidp, u64p, c_int, ctypes.c_double, voidp, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_encode_complex", c_int, [voidp, voidp, c_int, ctypes.c_double, u64p, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_decode_complex", c_int, [voidp, u64p, c_int, ctypes.c_double, voidp, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_encode_coeff", c_int, [voidp, voidp, c_int, ctypes.c_double, u64p, voidp]),
+    ("hegpu_ckks_decode_coeff", c_int, [voidp, u64p, c_int, ctypes.c_double, voidp, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_encode_scalar", c_int, [voidp, ctypes.c_double, ctypes.c_double, u64p, voidp]),
     ("hegpu_bfv_decode", c_int, [voidp, u64p, u64p, voidp, c_size_t, voidp]),
     ("hegpu_tfhe_context_create", c_int, [ctypes.POINTER(voidp)]),
     ("hegpu_tfhe_context_destroy", None, [voidp]),

@@ -362,6 +362,38 @@ class Context:
                                            stream if stream is not None else _stream()))
         return out
 
+    def ckks_encode_ex(self, mode, message, scale, stream=None):
+        """The other encodings of HEEncoder<CKKS> (ckks/encoder.cu:222-446).  mode 1: complex128 device
+        tensor (<= N/2) into the slots; mode 2: float64 device tensor (<= N) as polynomial coefficients;
+        mode 3: `message` is one Python number placed in every slot."""
+        import torch
+        st = stream if stream is not None else _stream()
+        plain = torch.empty(self.Q_size * self.n, dtype=torch.int64, device="cuda")
+        if mode == 3:
+            _check(self._lib.hegpu_ckks_encode_scalar(self._h, float(message), float(scale), _ptr(plain), st))
+        elif mode == 2:
+            _check(self._lib.hegpu_ckks_encode_coeff(self._h, _ptr(message), message.numel(), float(scale), _ptr(plain), st))
+        else:
+            assert mode == 1 and message.dtype == torch.complex128
+            ws = self._kg_ws(OP_CKKS_ENCODE)
+            _check(self._lib.hegpu_ckks_encode_complex(self._h, _ptr(message), message.numel(), float(scale),
+                                                       _ptr(plain), _ptr(ws), ws.numel() * ws.element_size(), st))
+        return plain
+
+    def ckks_decode_ex(self, mode, plain, scale, depth=0, stream=None):
+        """mode 1: the N/2 complex slots; mode 2: the N polynomial coefficients"""
+        import torch
+        st = stream if stream is not None else _stream()
+        ws = self.workspace(OP_CKKS_DECODE, depth, 1)
+        if mode == 1:
+            out = torch.empty(self.n // 2, dtype=torch.complex128, device="cuda")
+            fn = self._lib.hegpu_ckks_decode_complex
+        else:
+            out = torch.empty(self.n, dtype=torch.float64, device="cuda")
+            fn = self._lib.hegpu_ckks_decode_coeff
+        _check(fn(self._h, _ptr(plain), depth, float(scale), _ptr(out), _ptr(ws), ws.numel() * ws.element_size(), st))
+        return out
+
     def ckks_decrypt(self, ct, sk, depth=0, stream=None):
         import torch
         plain = torch.empty((self.Q_size - depth) * self.n, dtype=torch.int64, device="cuda")

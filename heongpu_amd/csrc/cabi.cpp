@@ -628,22 +628,48 @@ int hegpu_bfv_decode(hegpu_context* ctx, const uint64_t* plain, uint64_t* messag
                    "hegpu_bfv_decode");
 }
 
-int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
-                      void* ws, size_t ws_bytes, hegpu_stream stream)
+static int ckks_encode_any(hegpu_context* ctx, int mode, const double* message, int message_size, double scalar,
+                           double scale, uint64_t* plain, void* ws, size_t ws_bytes, hegpu_stream stream, const char* who)
 {
     NEED_CTX(ctx);
     if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
-    if (message_size < 0 || message_size > (int) (ctx->c.n >> 1))
-        return fail(HEGPU_E_INVALID, "Vector size can not be higher than slot count!"); // ckks/encoder.cuh:74
-    if (!(scale > 0.0)) return fail(HEGPU_E_INVALID, "scale must be positive");
-    if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_CKKS_ENCODE, 0, 1))
+    if (mode == 2) {
+        if (message_size < 0 || message_size > (int) ctx->c.n)
+            return fail(HEGPU_E_INVALID, "Vector size can not be higher than polynomial degree!"); // ckks/encoder.cuh:80
+    } else if (mode != 3 && (message_size < 0 || message_size > (int) (ctx->c.n >> 1))) {
+        return fail(HEGPU_E_INVALID, "Vector size can not be higher than slot count!");            // :74
+    }
+    if (!(scale > 0.0)) return fail(HEGPU_E_INVALID, "Scale out of bounds");                       // :63
+    if (mode < 2 && (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_CKKS_ENCODE, 0, 1)))
         return fail(HEGPU_E_INVALID, "workspace too small");
-    return hip_ret(op_ckks_encode(ctx->c, message, message_size, scale, (u64*) plain, (u64*) ws, (hipStream_t) stream),
-                   "hegpu_ckks_encode");
+    return hip_ret(op_ckks_encode(ctx->c, mode, message, message_size, scalar, scale, (u64*) plain, (u64*) ws,
+                                  (hipStream_t) stream), who);
 }
 
-int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
-                      size_t ws_bytes, hegpu_stream stream)
+int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
+                      void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    return ckks_encode_any(ctx, 0, message, message_size, 0.0, scale, plain, ws, ws_bytes, stream, "hegpu_ckks_encode");
+}
+int hegpu_ckks_encode_complex(hegpu_context* ctx, const double* message, int message_size, double scale,
+                              uint64_t* plain, void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    return ckks_encode_any(ctx, 1, message, message_size, 0.0, scale, plain, ws, ws_bytes, stream,
+                           "hegpu_ckks_encode_complex");
+}
+int hegpu_ckks_encode_coeff(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
+                            hegpu_stream stream)
+{
+    return ckks_encode_any(ctx, 2, message, message_size, 0.0, scale, plain, nullptr, 0, stream,
+                           "hegpu_ckks_encode_coeff");
+}
+int hegpu_ckks_encode_scalar(hegpu_context* ctx, double value, double scale, uint64_t* plain, hegpu_stream stream)
+{
+    return ckks_encode_any(ctx, 3, nullptr, 0, value, scale, plain, nullptr, 0, stream, "hegpu_ckks_encode_scalar");
+}
+
+static int ckks_decode_any(hegpu_context* ctx, int mode, const uint64_t* plain, int depth, double scale, double* message,
+                           void* ws, size_t ws_bytes, hegpu_stream stream, const char* who)
 {
     NEED_CTX(ctx);
     if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
@@ -651,8 +677,24 @@ int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, doub
     if (!(scale > 0.0)) return fail(HEGPU_E_INVALID, "scale must be positive");
     if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_CKKS_DECODE, depth, 1))
         return fail(HEGPU_E_INVALID, "workspace too small");
-    return hip_ret(op_ckks_decode(ctx->c, (const u64*) plain, depth, scale, message, (u64*) ws, (hipStream_t) stream),
-                   "hegpu_ckks_decode");
+    return hip_ret(op_ckks_decode(ctx->c, mode, (const u64*) plain, depth, scale, message, (u64*) ws,
+                                  (hipStream_t) stream), who);
+}
+
+int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
+                      size_t ws_bytes, hegpu_stream stream)
+{
+    return ckks_decode_any(ctx, 0, plain, depth, scale, message, ws, ws_bytes, stream, "hegpu_ckks_decode");
+}
+int hegpu_ckks_decode_complex(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message,
+                              void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    return ckks_decode_any(ctx, 1, plain, depth, scale, message, ws, ws_bytes, stream, "hegpu_ckks_decode_complex");
+}
+int hegpu_ckks_decode_coeff(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message,
+                            void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    return ckks_decode_any(ctx, 2, plain, depth, scale, message, ws, ws_bytes, stream, "hegpu_ckks_decode_coeff");
 }
 
 int hegpu_bfv_noise_rns(hegpu_context* ctx, const uint64_t* ct, const uint64_t* sk, uint64_t* out, hegpu_stream stream)

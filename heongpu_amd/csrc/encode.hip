@@ -18,18 +18,20 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.i
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub_(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 
-// message [size] -> (message, 0) padded with zeros to `slots`
+// message [size] -> (message, 0) padded with zeros to `slots`; complex input: (re, im) pairs
 __global__ __launch_bounds__(EN_THREADS) void k_en_double_to_complex(const double* __restrict__ in, int size,
-                                                                     cplx* __restrict__ out)
+                                                                     cplx* __restrict__ out, int complex_in)
 {
     const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    out[idx] = {idx < size ? in[idx] : 0.0, 0.0};
+    if (complex_in) out[idx] = idx < size ? ((const cplx*) in)[idx] : cplx{0.0, 0.0};
+    else out[idx] = {idx < size ? in[idx] : 0.0, 0.0};
 }
 __global__ __launch_bounds__(EN_THREADS) void k_en_complex_to_double(const cplx* __restrict__ in,
-                                                                     double* __restrict__ out)
+                                                                     double* __restrict__ out, int complex_out)
 {
     const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    out[idx] = in[idx].re;
+    if (complex_out) ((cplx*) out)[idx] = in[idx];
+    else out[idx] = in[idx].re;
 }
 
 // One butterfly stage with block length len = 2*lenh; thread = one butterfly.
@@ -78,14 +80,16 @@ hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inv
     return hipGetLastError();
 }
 
-hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, hipStream_t st)
+hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, bool complex_in, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_en_double_to_complex, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, in, size, (cplx*) out);
+    hipLaunchKernelGGL(k_en_double_to_complex, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, in, size, (cplx*) out,
+                       (int) complex_in);
     return hipGetLastError();
 }
-hipError_t en_complex_to_double(const void* in, double* out, int slots, hipStream_t st)
+hipError_t en_complex_to_double(const void* in, double* out, int slots, bool complex_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_en_complex_to_double, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, (const cplx*) in, out);
+    hipLaunchKernelGGL(k_en_complex_to_double, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, (const cplx*) in, out,
+                       (int) complex_out);
     return hipGetLastError();
 }
 
@@ -120,6 +124,26 @@ hipError_t en_conversion(u64* plain, const void* msg, const Mod* mods, int limbs
 {
     hipLaunchKernelGGL(k_en_conversion, dim3((1u << (n_power - 1)) / EN_THREADS), dim3(EN_THREADS), 0, st, plain,
                        (const cplx*) msg, mods, limbs, reverse_order, n_power);
+    return hipGetLastError();
+}
+
+// encode_kernel_coeff_ckks_conversion (encoding.cu:106-137): coefficient idx = round(message[idx] * scale);
+// encode_kernel_double_ckks_conversion (:43-77): every entry = round(value) (message == nullptr)
+__global__ __launch_bounds__(EN_THREADS) void k_en_coeff_conversion(u64* __restrict__ plain,
+                                                                    const double* __restrict__ message, int size,
+                                                                    double scale_or_value, const Mod* __restrict__ mods,
+                                                                    int limbs, int n_power)
+{
+    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
+    const double v = message ? (idx < size ? message[idx] : 0.0) * scale_or_value : scale_or_value;
+    en_store_rns(plain, (u64) idx, v, mods, limbs, n_power);
+}
+
+hipError_t en_coeff_conversion(u64* plain, const double* message, int size, double scale_or_value, const Mod* mods,
+                               int limbs, int n_power, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_en_coeff_conversion, dim3((1u << n_power) / EN_THREADS), dim3(EN_THREADS), 0, st, plain, message,
+                       size, scale_or_value, mods, limbs, n_power);
     return hipGetLastError();
 }
 
@@ -211,6 +235,29 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
     if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_en_compose, dim3((1u << (n_power - 1)) / EN_THREADS), dim3(EN_THREADS), 0, st, (cplx*) msg,
                        plain, mods, Mi_inv, Mi, upper_half, M, l, scale, reverse_order, n_power);
+    return hipGetLastError();
+}
+
+// decode_kernel_coeff_ckks_compose (encoding.cu:387-464): one real value per coefficient
+__global__ __launch_bounds__(EN_THREADS) void k_en_coeff_compose(double* __restrict__ message,
+                                                                 const u64* __restrict__ plain,
+                                                                 const Mod* __restrict__ mods,
+                                                                 const u64* __restrict__ Mi_inv,
+                                                                 const u64* __restrict__ Mi,
+                                                                 const u64* __restrict__ upper_half,
+                                                                 const u64* __restrict__ M, int l, double scale,
+                                                                 int n_power)
+{
+    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
+    message[idx] = en_compose_one(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, 1.0 / scale, n_power);
+}
+
+hipError_t en_coeff_compose(double* message, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
+                            const u64* upper_half, const u64* M, int l, double scale, int n_power, hipStream_t st)
+{
+    if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_en_coeff_compose, dim3((1u << n_power) / EN_THREADS), dim3(EN_THREADS), 0, st, message, plain,
+                       mods, Mi_inv, Mi, upper_half, M, l, scale, n_power);
     return hipGetLastError();
 }
 

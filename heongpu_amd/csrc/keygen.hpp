@@ -71,8 +71,13 @@ hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location
 // special FFT over `1 << log_slots` complex doubles in place; roots: the rotation-group-ordered
 // table; inverse: scaled by `fix`
 hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st);
-hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, hipStream_t st);
-hipError_t en_complex_to_double(const void* in, double* out, int slots, hipStream_t st);
+hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, bool complex_in, hipStream_t st);
+hipError_t en_complex_to_double(const void* in, double* out, int slots, bool complex_out, hipStream_t st);
+// message == nullptr: the constant round(scale_or_value) everywhere
+hipError_t en_coeff_conversion(u64* plain, const double* message, int size, double scale_or_value, const Mod* mods,
+                               int limbs, int n_power, hipStream_t st);
+hipError_t en_coeff_compose(double* message, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
+                            const u64* upper_half, const u64* M, int l, double scale, int n_power, hipStream_t st);
 hipError_t en_conversion(u64* plain, const void* msg, const Mod* mods, int limbs, const int* reverse_order, int n_power,
                          hipStream_t st);
 hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,

@@ -622,23 +622,33 @@ static int log2i(u64 v)
     return r;
 }
 
-hipError_t op_ckks_encode(const Context& c, const double* message, int message_size, double scale, u64* plain,
-                          u64* ws, hipStream_t st)
+// mode: 0 real slots, 1 complex slots ((re, im) pairs), 2 polynomial coefficients, 3 one value in every slot
+// (message == host pointer to that value is NOT used: the value comes in `scalar`)
+hipError_t op_ckks_encode(const Context& c, int mode, const double* message, int message_size, double scalar,
+                          double scale, u64* plain, u64* ws, hipStream_t st)
 {
     const int slots = (int) (c.n >> 1), Q = c.Q_size;
+    if (mode == 3)                                                                         // encoder.cu:412-446
+        return en_coeff_conversion(plain, nullptr, 0, scalar * scale, c.plan_qp.mods, Q, c.n_power, st);
+    NttArgs a = c.ntt_args(0);
+    a.in = plain; a.out = plain; a.mod_count = Q;
+    if (mode == 2) {                                                                       // :222-261
+        if (message_size < 0 || message_size > (int) c.n) return hipErrorInvalidValue;
+        TRY(en_coeff_conversion(plain, message, message_size, scale, c.plan_qp.mods, Q, c.n_power, st));
+        return ntt_launch(a, Q, false, st);
+    }
     if (message_size < 0 || message_size > slots) return hipErrorInvalidValue;
     void* cbuf = ws; // slots complex doubles = N words
-    TRY(en_double_to_complex(message, message_size, cbuf, slots, st));                     // :120
+    TRY(en_double_to_complex(message, message_size, cbuf, slots, mode == 1, st));          // :120
     const double fix = scale / (double) slots;                                             // :127
     TRY(en_special_fft(cbuf, c.d64("special_ifft_roots_table"), log2i(slots), true, fix, st));
     TRY(en_conversion(plain, cbuf, c.plan_qp.mods, Q, c.d32("reverse_order"), c.n_power, st)); // :138
-    NttArgs a = c.ntt_args(0);
-    a.in = plain; a.out = plain; a.mod_count = Q;
     return ntt_launch(a, Q, false, st);                                                    // :153
 }
 
-hipError_t op_ckks_decode(const Context& c, const u64* plain, int depth, double scale, double* message, u64* ws,
-                          hipStream_t st)
+// mode: 0 the N/2 real parts, 1 the N/2 complex slots, 2 the N coefficients
+hipError_t op_ckks_decode(const Context& c, int mode, const u64* plain, int depth, double scale, double* message,
+                          u64* ws, hipStream_t st)
 {
     const int slots = (int) (c.n >> 1), l = c.Q_size - depth;
     if (l < 1) return hipErrorInvalidValue;
@@ -649,11 +659,15 @@ hipError_t op_ckks_decode(const Context& c, const u64* plain, int depth, double 
     TRY(ntt_launch(a, l, true, st));                                                       // :469
     int counter = c.Q_size, loc1 = 0, loc2 = 0;                                            // :474-482
     for (int i = 0; i < depth; i++) { loc1 += counter; loc2 += counter * counter; counter--; }
+    if (mode == 2)                                                                         // :586-635
+        return en_coeff_compose(message, coeff, c.plan_qp.mods, c.d64("Mi_inv") + loc1, c.d64("Mi") + loc2,
+                                c.d64("upper_half_threshold") + loc1, c.d64("decryption_modulus") + loc1, l, scale,
+                                c.n_power, st);
     TRY(en_compose(cbuf, coeff, c.plan_qp.mods, c.d64("Mi_inv") + loc1, c.d64("Mi") + loc2,
                    c.d64("upper_half_threshold") + loc1, c.d64("decryption_modulus") + loc1, l, scale,
                    c.d32("reverse_order"), c.n_power, st));                                // :485
     TRY(en_special_fft(cbuf, c.d64("special_fft_roots_table"), log2i(slots), false, 1.0, st)); // :502
-    return en_complex_to_double(cbuf, message, slots, st);                                 // :505
+    return en_complex_to_double(cbuf, message, slots, mode == 1, st);                      // :505
 }
 
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)

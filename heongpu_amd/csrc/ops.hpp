@@ -70,11 +70,13 @@ hipError_t op_bfv_encode(const Context& c, const long long* message, int message
 hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* ws, hipStream_t st);
 // HEOperator<BFV>::multiply_plain_bfv, coefficient-domain ciphertext (bfv/operator.cu:432-503)
 hipError_t op_bfv_multiply_plain(const Context& c, const u64* ct, const u64* plain, u64* out, u64* ws, hipStream_t st);
-// HEEncoder<CKKS>::encode_ckks / decode_ckks, real vectors (ckks/encoder.cu:100-160, 449-513):
-// message: device doubles (size <= N/2 slots); plain [Q - depth][N] NTT domain
-hipError_t op_ckks_encode(const Context& c, const double* message, int message_size, double scale, u64* plain,
+// HEEncoder<CKKS>::encode_ckks / encode_ckks_coeff / decode_ckks / decode_ckks_coeff (ckks/encoder.cu:100-690).
+// encode mode: 0 real slots, 1 complex slots ((re, im) pairs), 2 coefficients (<= N), 3 `scalar` in every slot;
+// decode mode: 0 real parts [N/2], 1 complex slots [N/2 pairs], 2 coefficients [N].
+// message: device doubles; plain [Q - depth][N] NTT domain
+hipError_t op_ckks_encode(const Context& c, int mode, const double* message, int message_size, double scalar,
+                          double scale, u64* plain, u64* ws, hipStream_t st);
+hipError_t op_ckks_decode(const Context& c, int mode, const u64* plain, int depth, double scale, double* message,
                           u64* ws, hipStream_t st);
-hipError_t op_ckks_decode(const Context& c, const u64* plain, int depth, double scale, double* message, u64* ws,
-                          hipStream_t st);
 
 } // namespace hegpu

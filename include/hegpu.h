@@ -245,6 +245,23 @@ int hegpu_ckks_encode(hegpu_context* ctx, const double* message, int message_siz
                       void* ws, size_t ws_bytes, hegpu_stream stream);
 int hegpu_ckks_decode(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message, void* ws,
                       size_t ws_bytes, hegpu_stream stream);
+/* The other encodings of HEEncoder<CKKS> (ckks/encoder.cu):
+ *  _complex: vector<Complex64> into / out of the slots (:294-352, :515-584); message = N/2 (re, im) pairs
+ *  _coeff:   encoding::COEFFICIENT -- the message is the polynomial itself, round(m_i * scale), at most N
+ *            values (:222-261, encode_kernel_coeff_ckks_conversion encoding.cu:106-137); decoding returns the
+ *            N coefficients (:586-635, decode_kernel_coeff_ckks_compose encoding.cu:387-464)
+ *  _scalar:  one double (or an int64 cast to double) in every slot: the constant polynomial
+ *            round(value * scale), written directly in the NTT domain (:412-446,
+ *            encode_kernel_double_ckks_conversion encoding.cu:43-77) */
+int hegpu_ckks_encode_complex(hegpu_context* ctx, const double* message, int message_size, double scale,
+                              uint64_t* plain, void* ws, size_t ws_bytes, hegpu_stream stream);
+int hegpu_ckks_decode_complex(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message,
+                              void* ws, size_t ws_bytes, hegpu_stream stream);
+int hegpu_ckks_encode_coeff(hegpu_context* ctx, const double* message, int message_size, double scale, uint64_t* plain,
+                            hegpu_stream stream);
+int hegpu_ckks_decode_coeff(hegpu_context* ctx, const uint64_t* plain, int depth, double scale, double* message,
+                            void* ws, size_t ws_bytes, hegpu_stream stream);
+int hegpu_ckks_encode_scalar(hegpu_context* ctx, double value, double scale, uint64_t* plain, hegpu_stream stream);
 
 /* HEDecryptor<BFV>::remainder_noise_budget, device part (src/lib/host/bfv/decryptor.cu:170-225):
  * out [Q][N] = t * (c0 + c1*s) mod q_j in the coefficient domain; the CRT composition and the

@@ -27,6 +27,7 @@
 #endif
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <algorithm>
 #include <complex>
 #include <fstream>
@@ -38,6 +39,7 @@
 #include <sstream>
 #include <random>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <unordered_map>
 #include <stdexcept>
@@ -45,9 +47,40 @@
 #include <utility>
 #include <vector>
 
+// Names that the reference's public headers bring into the global namespace from GPU-NTT /
+// GPU-FFT (thirdparty, unvendored) and that its consumers use unqualified (test/test_bfv_*.cpp:
+// Data64, Modulus64, OPERATOR64::mult).
+typedef unsigned long long Data64;
+typedef std::complex<double> Complex64;
+struct Modulus64 { // value, bit length, Barrett constant mu = floor(2^(2 bit + 1) / value)
+    Data64 value = 0, bit = 0, mu = 0;
+    Modulus64() = default;
+    Modulus64(Data64 q) : value(q)
+    {
+        while ((q >> bit) != 0) bit++;
+        mu = q ? (Data64) ((((unsigned __int128) 1) << (2 * bit + 1)) / q) : 0;
+    }
+};
+namespace OPERATOR64 { // host-side modular arithmetic on canonical residues
+inline Data64 add(Data64 a, Data64 b, const Modulus64& m) { const Data64 s = a + b; return s >= m.value ? s - m.value : s; }
+inline Data64 sub(Data64 a, Data64 b, const Modulus64& m) { const Data64 d = a + m.value - b; return d >= m.value ? d - m.value : d; }
+inline Data64 mult(Data64 a, Data64 b, const Modulus64& m) { return (Data64) ((unsigned __int128) a * b % m.value); }
+inline Data64 reduce(Data64 a, const Modulus64& m) { return a % m.value; }
+inline Data64 exp(Data64 base, Data64 e, const Modulus64& m)
+{
+    Data64 r = 1 % m.value;
+    base %= m.value;
+    while (e) { if (e & 1) r = mult(r, base, m); base = mult(base, base, m); e >>= 1; }
+    return r;
+}
+inline Data64 modinv(Data64 a, const Modulus64& m) { return exp(a, m.value - 2, m); } // prime moduli
+} // namespace OPERATOR64
+
 namespace heongpu {
 
-typedef unsigned long long Data64;
+using ::Data64;
+using ::Modulus64;
+using ::Complex64;
 
 enum class Scheme { BFV = 1, CKKS = 2, TFHE = 3 };                           // util/schemes.h:15-20
 enum class scheme_type : std::uint8_t { none = 0x0, bfv = 0x1, ckks = 0x2, bgv = 0x3, tfhe = 0x4 }; // util/schemes.h:70-86
@@ -55,15 +88,6 @@ enum class sec_level_type : std::uint8_t { none = 0x0, sec128 = 0x1, sec192 = 0x
 enum class storage_type : std::uint8_t { HOST = 0x1, DEVICE = 0x2 };        // util/storagemanager.cuh:23-27
 enum class keyswitching_type : std::uint8_t { NONE = 0x0, KEYSWITCHING_METHOD_I = 0x1, KEYSWITCHING_METHOD_II = 0x2 };
 enum class encoding : std::uint8_t { SLOT = 0x0, COEFFICIENT = 0x1 };        // util/schemes.h:129-133
-struct Modulus64 { // GPU-NTT's record as the reference serializes it: value, bit length, Barrett mu
-    Data64 value = 0, bit = 0, mu = 0;
-    Modulus64() = default;
-    explicit Modulus64(Data64 q) : value(q)
-    {
-        while ((q >> bit) != 0) bit++;
-        mu = q ? (Data64) ((((unsigned __int128) 1) << (2 * bit + 1)) / q) : 0;
-    }
-};
 
 // util/storagemanager.cuh:34-97
 struct ExecutionOptions {
@@ -99,12 +123,15 @@ inline void hip(hipError_t e)
 } // namespace detail
 
 // ------------------------------------------------------------------ memory pool
-// util/memorypool.cuh:38-117.  The reference builds RMM pools; here the device side is HIP's
-// stream-ordered allocator (hipMallocAsync on the device's default pool): `max` becomes the
-// pool's release threshold (memory above it goes back to the driver at the next
-// synchronisation), `initial` is reserved once so that the first operations do not pay for
-// growing the pool.  The host-side fields are accepted and ignored: nothing is parked in host
-// memory (see Ciphertext::store_in_host).
+// util/memorypool.cuh:38-117.  The reference builds RMM pool_memory_resources; here MemoryPool is a
+// caching allocator over hipMalloc: freed blocks go to size-ordered free lists together with the
+// stream they were last used on and an event recorded at the free, and are handed out again
+// without touching the driver (same stream: stream order is enough; other stream: the new
+// stream waits for that event).  hipMallocAsync is deliberately NOT used: on this ROCm the
+// default stream-ordered pool returns overlapping buffers (tools/hip_pool_repro.cpp,
+// profiles/r1h_hip_pool/repro.txt).  `max` caps what the cache keeps, `initial` is reserved
+// up front.  The host-side fields are accepted and ignored: nothing is parked in host memory
+// (see Ciphertext::store_in_host).
 struct MemoryPoolConfig {
     std::optional<float> initial_device_fraction, max_device_fraction;
     std::optional<size_t> initial_device_bytes, max_device_bytes;
@@ -124,13 +151,11 @@ class MemoryPool {
     void initialize() { initialize(MemoryPoolConfig::Defaults()); }
     void initialize(const MemoryPoolConfig& config) // the first call wins, like the reference
     {
+        std::lock_guard<std::mutex> lock(mu_);
         if (initialized_) return;
         initialized_ = true;
         use_pool_ = config.use_memory_pool;
         if (!use_pool_) return;
-        int dev = 0;
-        detail::hip(hipGetDevice(&dev));
-        detail::hip(hipDeviceGetDefaultMemPool(&pool_, dev));
         size_t free_b = 0, total_b = 0;
         detail::hip(hipMemGetInfo(&free_b, &total_b));
         auto bytes = [&](const std::optional<float>& frac, const std::optional<size_t>& abs, size_t dflt) {
@@ -138,30 +163,45 @@ class MemoryPool {
             if (frac) return (size_t) ((double) free_b * (*frac > 1.0f ? *frac / 100.0 : *frac));
             return dflt;
         };
-        uint64_t keep = bytes(config.max_device_fraction, config.max_device_bytes, (size_t) UINT64_MAX);
-        detail::hip(hipMemPoolSetAttribute(pool_, hipMemPoolAttrReleaseThreshold, &keep));
-        const size_t initial = bytes(config.initial_device_fraction, config.initial_device_bytes, 0);
-        if (initial) { // reserve once: allocate and hand back to the pool
-            void* warm = nullptr;
-            if (hipMallocAsync(&warm, initial, nullptr) == hipSuccess) (void) hipFreeAsync(warm, nullptr);
-            else (void) hipGetLastError();
-            detail::hip(hipStreamSynchronize(nullptr));
+        max_cached_ = bytes(config.max_device_fraction, config.max_device_bytes, (size_t) -1);
+        const size_t initial = std::min(bytes(config.initial_device_fraction, config.initial_device_bytes, 0), max_cached_);
+        if (initial) { // one block that later requests are carved from by best fit
+            Block b;
+            b.bytes = round_up(initial);
+            b.arena = true;
+            if (hipMalloc((void**) &b.p, b.bytes) == hipSuccess) {
+                reserved_ += b.bytes;
+                free_.insert({b.bytes, b});
+            } else {
+                (void) hipGetLastError();
+            }
         }
     }
     void use_memory_pool(bool use) { use_pool_ = use; }
+
     void* allocate(size_t size, hipStream_t stream = nullptr)
     {
         if (!initialized_) initialize();
-        void* p = nullptr;
-        if (use_pool_) detail::hip(hipMallocAsync(&p, size, stream));
-        else detail::hip(hipMalloc(&p, size));
-        return p;
+        const size_t g = guard();
+        char* p = raw_allocate(size + 2 * g, stream);
+        if (g) { // HEGPU_POOL_GUARD=<bytes>: canaries around every buffer, checked when it is freed
+            detail::hip(hipMemsetAsync(p, 0xA5, g, stream));
+            detail::hip(hipMemsetAsync(p + g + size, 0xA5, g, stream));
+            std::lock_guard<std::mutex> lock(mu_);
+            guarded_[p + g] = size;
+        }
+        return p + g;
     }
-    void deallocate(void* p, size_t, hipStream_t stream = nullptr)
+    void deallocate(void* ptr, size_t size, hipStream_t stream = nullptr)
     {
-        if (!p) return;
-        if (use_pool_) (void) hipFreeAsync(p, stream);
-        else (void) hipFree(p);
+        if (!ptr) return;
+        const size_t g = guard();
+        if (g) {
+            check_one((char*) ptr, size, "free");
+            std::lock_guard<std::mutex> lock(mu_);
+            guarded_.erase((char*) ptr);
+        }
+        raw_deallocate((char*) ptr - g, stream);
     }
     void* host_allocate(size_t size)
     {
@@ -172,23 +212,140 @@ class MemoryPool {
     void host_deallocate(void* p, size_t) { if (p) (void) hipHostFree(p); }
     void print_memory_pool_status() const
     {
-        uint64_t used = 0, reserved = 0;
-        if (use_pool_ && pool_) {
-            (void) hipMemPoolGetAttribute(pool_, hipMemPoolAttrUsedMemCurrent, &used);
-            (void) hipMemPoolGetAttribute(pool_, hipMemPoolAttrReservedMemCurrent, &reserved);
-        }
         size_t free_b = 0, total_b = 0;
         (void) hipMemGetInfo(&free_b, &total_b);
         const double mb = 1024.0 * 1024.0;
-        std::cout << "Device Memory Pool: " << (use_pool_ ? "stream-ordered HIP pool" : "disabled (hipMalloc)") << std::endl;
-        std::cout << "-->   in use: " << used / mb << " MB, reserved: " << reserved / mb << " MB" << std::endl;
+        std::cout << "Device Memory Pool: " << (use_pool_ ? "caching allocator over hipMalloc" : "disabled (hipMalloc)") << std::endl;
+        std::cout << "-->   in use: " << in_use_ / mb << " MB, reserved: " << reserved_ / mb << " MB" << std::endl;
         std::cout << "-->   device free: " << free_b / mb << " MB of " << total_b / mb << " MB" << std::endl;
+    }
+    // give every cached block back to the driver (after the work that last used it has finished)
+    void release_cached()
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        release_cached_locked();
+    }
+    // debug (HEGPU_POOL_GUARD): verify the canaries of every live buffer
+    void check_all(const char* when)
+    {
+        std::map<char*, size_t> snapshot;
+        { std::lock_guard<std::mutex> lock(mu_); snapshot = guarded_; }
+        for (const auto& a : snapshot) check_one(a.first, a.second, when);
     }
 
   private:
+    struct Block {
+        char* p = nullptr;
+        size_t bytes = 0;
+        hipStream_t stream = nullptr; // stream of the last use
+        hipEvent_t freed = nullptr;   // recorded on `stream` when the block was given back
+        bool arena = false;           // piece of the initial reservation (never returned to the driver)
+    };
     MemoryPool() = default;
+    static size_t round_up(size_t b) // 512 B granules below 1 MiB, 2 MiB granules above
+    {
+        if (b == 0) b = 1;
+        return b <= (1u << 20) ? (b + 511) & ~(size_t) 511 : (b + (2u << 20) - 1) & ~(size_t) ((2u << 20) - 1);
+    }
+    char* raw_allocate(size_t size, hipStream_t stream)
+    {
+        if (!use_pool_) {
+            char* p = nullptr;
+            detail::hip(hipMalloc((void**) &p, size));
+            return p;
+        }
+        const size_t want = round_up(size);
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = free_.lower_bound(want);
+        // near fit only (at most 1.25x, or anything up to 2 MiB), so that the repeating request
+        // sizes of HE pipelines find their own blocks again; pieces of the initial reservation
+        // are carved by best fit
+        while (it != free_.end() && !(it->first <= want + want / 4 || it->first <= 2 * (1u << 20) || it->second.arena)) ++it;
+        Block b;
+        if (it != free_.end()) {
+            b = it->second;
+            free_.erase(it);
+            if (b.arena && b.bytes - want >= (2u << 20)) { // split: the tail stays cached
+                Block tail = b;
+                tail.p = b.p + want;
+                tail.bytes = b.bytes - want;
+                tail.freed = nullptr;
+                if (b.freed) { // the tail was freed with the same work
+                    detail::hip(hipEventCreateWithFlags(&tail.freed, hipEventDisableTiming));
+                    detail::hip(hipEventRecord(tail.freed, b.stream));
+                }
+                free_.insert({tail.bytes, tail});
+                b.bytes = want;
+            }
+            if (b.freed && b.stream != stream) detail::hip(hipStreamWaitEvent(stream, b.freed, 0));
+        } else {
+            hipError_t e = hipMalloc((void**) &b.p, want);
+            if (e != hipSuccess) { // out of memory: drop the cache and try once more
+                (void) hipGetLastError();
+                release_cached_locked();
+                detail::hip(hipMalloc((void**) &b.p, want));
+            }
+            b.bytes = want;
+            reserved_ += want;
+        }
+        in_use_ += b.bytes;
+        live_[b.p] = b;
+        return b.p;
+    }
+    void raw_deallocate(char* p, hipStream_t stream)
+    {
+        if (!use_pool_) { (void) hipFree(p); return; }
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end()) { (void) hipFree(p); return; } // allocated before the pool was switched on
+        Block b = it->second;
+        live_.erase(it);
+        in_use_ -= b.bytes;
+        b.stream = stream;
+        if (!b.freed) (void) hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
+        (void) hipEventRecord(b.freed, stream);
+        free_.insert({b.bytes, b});
+        if (reserved_ > max_cached_) release_cached_locked();
+    }
+    void release_cached_locked()
+    {
+        (void) hipDeviceSynchronize();
+        for (auto it = free_.begin(); it != free_.end();) {
+            Block& b = it->second;
+            if (b.arena) { ++it; continue; } // pieces of the initial reservation stay
+            if (b.freed) (void) hipEventDestroy(b.freed);
+            (void) hipFree(b.p);
+            reserved_ -= b.bytes;
+            it = free_.erase(it);
+        }
+    }
+    void check_one(char* ptr, size_t size, const char* when)
+    {
+        const size_t g = guard();
+        std::vector<unsigned char> h(2 * g);
+        (void) hipDeviceSynchronize();
+        (void) hipMemcpy(h.data(), ptr - g, g, hipMemcpyDeviceToHost);
+        (void) hipMemcpy(h.data() + g, ptr + size, g, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < 2 * g; i++)
+            if (h[i] != 0xA5) {
+                size_t bad = 0;
+                for (size_t k = 0; k < 2 * g; k++) bad += h[k] != 0xA5;
+                std::cerr << "MemoryPool guard [" << when << "]: buffer of " << size << " bytes was written "
+                          << (i < g ? "before its start" : "past its end") << " (" << bad << " canary bytes differ)" << std::endl;
+                break;
+            }
+    }
+    static size_t guard()
+    {
+        static const size_t g = [] { const char* e = getenv("HEGPU_POOL_GUARD"); return e ? (size_t) atol(e) : (size_t) 0; }();
+        return g;
+    }
     bool initialized_ = false, use_pool_ = true;
-    hipMemPool_t pool_ = nullptr;
+    std::mutex mu_;
+    std::multimap<size_t, Block> free_;        // cached blocks by size
+    std::unordered_map<char*, Block> live_;    // blocks handed out
+    std::map<char*, size_t> guarded_;          // only with HEGPU_POOL_GUARD
+    size_t reserved_ = 0, in_use_ = 0, max_cached_ = (size_t) -1;
 };
 
 // util/devicevector.cuh:17-173: stream-ordered device buffer
@@ -494,6 +651,8 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     inline bool in_ntt_domain() const noexcept { return in_ntt_domain_; }
     inline bool rescale_required() const noexcept { return rescale_required_; }
     inline bool relinearization_required() const noexcept { return relinearization_required_; }
+    inline encoding encoding_type() const noexcept { return encoding_; } // CKKS: slots or coefficients
+    encoding encoding_ = encoding::SLOT;
     void get_data(std::vector<Data64>& out, hipStream_t s = nullptr) const
     {
         out.resize(device_locations_.size());
@@ -532,7 +691,8 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     void save(std::ostream& os) const
     {
         if (!ciphertext_generated_) throw std::runtime_error("Ciphertext is not generated so can not be serialized!");
-        const std::uint8_t scheme = (std::uint8_t) S, storage = (std::uint8_t) storage_type::DEVICE, enc = 0;
+        const std::uint8_t scheme = (std::uint8_t) S, storage = (std::uint8_t) storage_type::DEVICE;
+        const std::uint8_t enc = (std::uint8_t) encoding_;
         os.write((const char*) &scheme, 1);
         os.write((const char*) &ring_size_, sizeof(int));
         os.write((const char*) &coeff_modulus_count_, sizeof(int));
@@ -574,6 +734,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         if (S == Scheme::CKKS) {
             is.read((char*) &scale_, sizeof(double));
             is.read((char*) &enc, 1);
+            encoding_ = (encoding) enc;
             is.read((char*) &rescale_required_, sizeof(bool));
         }
         is.read((char*) &relinearization_required_, sizeof(bool));
@@ -1235,6 +1396,7 @@ template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key e
                                             (const uint64_t*) pt.data(), (uint64_t*) out.data(), ws.data(),
                                             ws.size() * sizeof(Data64), o.stream_));
         ct.adopt(std::move(out), 2, 0, pt.scale_);
+        ct.encoding_ = pt.encoding_; // ckks/encryptor.cuh:84
     }
 
   private:
@@ -1269,6 +1431,7 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
         pt.memory_set(std::move(out));
         pt.depth_ = ct.depth();
         pt.scale_ = ct.scale();
+        pt.encoding_ = ct.encoding_; // ckks/decryptor.cuh:81
         pt.plaintext_generated_ = true;
     }
 
@@ -1402,7 +1565,7 @@ template <> class HEEncoder<Scheme::BFV> { // host/bfv/encoder.cuh: batching ove
     HEContext<S> context_;
 };
 
-template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 complex slots, real vectors here
+template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 complex slots or N coefficients
     static constexpr Scheme S = Scheme::CKKS;
 
   public:
@@ -1412,40 +1575,105 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     }
     inline int slot_count() const noexcept { return context_->n >> 1; }
 
+    // real vector into the slots, or (encoding::COEFFICIENT) as the polynomial itself (encoder.cuh:56-115)
     void encode(Plaintext<S>& plain, const std::vector<double>& message, double scale,
-                const ExecutionOptions& o = ExecutionOptions())
+                const ExecutionOptions& o = ExecutionOptions(), encoding type = encoding::SLOT)
     {
-        if ((int) message.size() > slot_count())
-            throw std::invalid_argument("Vector size can not be higher than slot count!"); // ckks/encoder.cuh:74
+        check_scale(scale);
+        if (type == encoding::SLOT && (int) message.size() > slot_count())
+            throw std::invalid_argument("Vector size can not be higher than slot count!");        // :74
+        if (type != encoding::SLOT && message.size() > (size_t) context_->n)
+            throw std::invalid_argument("Vector size can not be higher than polynomial degree!"); // :80
         DeviceVector<Data64> msg(message.size() ? message.size() : 1, o.stream_);
         if (!message.empty())
             detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(double),
                                        hipMemcpyHostToDevice, o.stream_));
         DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
-        DeviceVector<Data64> ws((hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_ENCODE, 0, 1) + 7) / 8,
-                                o.stream_);
-        detail::check(hegpu_ckks_encode(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
-                                        (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
-        detail::hip(hipStreamSynchronize(o.stream_));
-        plain.memory_set(std::move(out));
-        plain.depth_ = 0;
-        plain.scale_ = scale;
-        plain.plaintext_generated_ = true;
+        if (type == encoding::SLOT) {
+            DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_ENCODE, 0), o.stream_);
+            detail::check(hegpu_ckks_encode(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
+                                            (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        } else {
+            detail::check(hegpu_ckks_encode_coeff(context_->handle(), (const double*) msg.data(), (int) message.size(),
+                                                  scale, (uint64_t*) out.data(), o.stream_));
+        }
+        finish(plain, std::move(out), scale, type, o);
     }
+    // complex vector into the slots (encoder.cuh:188-235)
+    void encode(Plaintext<S>& plain, const std::vector<Complex64>& message, double scale,
+                const ExecutionOptions& o = ExecutionOptions())
+    {
+        check_scale(scale);
+        if ((int) message.size() > slot_count())
+            throw std::invalid_argument("Vector size can not be higher than slot count!");
+        DeviceVector<Data64> msg(message.size() ? 2 * message.size() : 1, o.stream_);
+        if (!message.empty())
+            detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(Complex64),
+                                       hipMemcpyHostToDevice, o.stream_));
+        DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
+        DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_ENCODE, 0), o.stream_);
+        detail::check(hegpu_ckks_encode_complex(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
+                                                (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        finish(plain, std::move(out), scale, encoding::SLOT, o);
+    }
+    // one number in every slot (encoder.cuh:290-370)
+    void encode(Plaintext<S>& plain, const double& message, double scale, const ExecutionOptions& o = ExecutionOptions())
+    {
+        check_scale(scale);
+        DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
+        detail::check(hegpu_ckks_encode_scalar(context_->handle(), message, scale, (uint64_t*) out.data(), o.stream_));
+        finish(plain, std::move(out), scale, encoding::SLOT, o);
+    }
+    void encode(Plaintext<S>& plain, const std::int64_t& message, double scale,
+                const ExecutionOptions& o = ExecutionOptions())
+    {
+        encode(plain, static_cast<double>(message), scale, o); // encoder.cu:437
+    }
+
     void decode(std::vector<double>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
-        DeviceVector<Data64> out((size_t) slot_count(), o.stream_);
-        DeviceVector<Data64> ws(
-            (hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_DECODE, plain.depth_, 1) + 7) / 8, o.stream_);
-        detail::check(hegpu_ckks_decode(context_->handle(), (const uint64_t*) plain.data(), plain.depth_, plain.scale_,
-                                        (double*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        const bool coeff = plain.encoding_ == encoding::COEFFICIENT; // encoder.cuh:383
+        const size_t count = coeff ? (size_t) context_->n : (size_t) slot_count();
+        DeviceVector<Data64> out(count, o.stream_);
+        DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_DECODE, plain.depth_), o.stream_);
+        detail::check((coeff ? hegpu_ckks_decode_coeff : hegpu_ckks_decode)(
+            context_->handle(), (const uint64_t*) plain.data(), plain.depth_, plain.scale_, (double*) out.data(),
+            ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        message.resize(count);
+        detail::hip(hipMemcpyAsync(message.data(), out.data(), count * sizeof(double), hipMemcpyDeviceToHost, o.stream_));
+        detail::hip(hipStreamSynchronize(o.stream_));
+    }
+    void decode(std::vector<Complex64>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (plain.encoding_ == encoding::COEFFICIENT)
+            throw std::invalid_argument("Coefficient encoded CKKS plaintext can not be decoded to complex slots."); // :438
+        DeviceVector<Data64> out((size_t) 2 * slot_count(), o.stream_);
+        DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_DECODE, plain.depth_), o.stream_);
+        detail::check(hegpu_ckks_decode_complex(context_->handle(), (const uint64_t*) plain.data(), plain.depth_,
+                                                plain.scale_, (double*) out.data(), ws.data(),
+                                                ws.size() * sizeof(Data64), o.stream_));
         message.resize(slot_count());
-        detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(double), hipMemcpyDeviceToHost,
+        detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(Complex64), hipMemcpyDeviceToHost,
                                    o.stream_));
         detail::hip(hipStreamSynchronize(o.stream_));
     }
 
   private:
+    void check_scale(double scale) const // encoder.cuh:60-65
+    {
+        if (scale <= 0 || static_cast<int>(std::log2(scale)) >= context_->total_coeff_bit_count)
+            throw std::invalid_argument("Scale out of bounds");
+    }
+    size_t ws_words(int op, int depth) const { return (hegpu_workspace_bytes(context_->handle(), op, depth, 1) + 7) / 8; }
+    void finish(Plaintext<S>& plain, DeviceVector<Data64>&& out, double scale, encoding type, const ExecutionOptions& o)
+    {
+        detail::hip(hipStreamSynchronize(o.stream_)); // the staging buffer of the message dies with the caller
+        plain.memory_set(std::move(out));
+        plain.depth_ = 0;
+        plain.scale_ = scale;
+        plain.encoding_ = type;
+        plain.plaintext_generated_ = true;
+    }
     HEContext<S> context_;
 };
 

@@ -94,6 +94,8 @@ def lib():
     L.o_tfhe_phase.argtypes = [vp, vp, vp, ci, vp]
     L.o_ckks_encode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_decode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
+    L.o_ckks_encode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
+    L.o_ckks_decode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
     L.o_bfv_decode.argtypes = [vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
     L.o_fast_floor.argtypes = [vp, vp, vp]
@@ -293,6 +295,19 @@ class OracleContext:
         out = np.zeros(self.n // 2, dtype=np.float64)
         self.L.o_ckks_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), depth, float(scale), _p(out))
         return out
+
+    # mode: 0 real slots, 1 complex slots, 2 coefficients, 3 one scalar in every slot
+    def ckks_encode_ex(self, mode, message, scale):
+        m = np.ascontiguousarray(message, dtype=np.complex128 if mode == 1 else np.float64).reshape(-1)
+        plain = np.zeros(self.Q * self.n, dtype=np.uint64)
+        self.L.o_ckks_encode_ex(self.h, mode, _p(m.view(np.float64)), len(m), float(scale), _p(plain))
+        return plain
+
+    def ckks_decode_ex(self, mode, plain, scale, depth=0):
+        out = np.zeros(self.n if mode else self.n // 2, dtype=np.float64)
+        self.L.o_ckks_decode_ex(self.h, mode, _p(np.ascontiguousarray(plain, dtype=np.uint64)), depth, float(scale),
+                                _p(out))
+        return out.view(np.complex128) if mode == 1 else out
 
     # key-switching method II (P_size > 1)
     def ckks_relinearize_II(self, ct3, key, depth=0):

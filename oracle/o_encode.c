@@ -94,17 +94,38 @@ static void store_rns(const octx_t* c, u64* plain, u64 at, double value, int lim
     }
 }
 
-/* HEEncoder<CKKS>::encode_ckks(vector<double>) (ckks/encoder.cu:100-160); plain [Q][N] NTT domain */
-void o_ckks_encode(const octx_t* c, const double* message, int message_size, double scale, u64* plain)
+/* HEEncoder<CKKS>::encode_ckks / encode_ckks_coeff (ckks/encoder.cu:100-446); plain [Q][N], NTT domain.
+ *   mode 0: vector<double> into the slots (:100-160)
+ *   mode 1: vector<Complex64> into the slots, message = (re, im) pairs (:294-352)
+ *   mode 2: vector<double> as polynomial coefficients, at most N of them (:222-261,
+ *           encode_kernel_coeff_ckks_conversion encoding.cu:106-137)
+ *   mode 3: one double (or int64 cast to double) in every slot = the constant polynomial,
+ *           written straight into the NTT domain (:412-446, encode_kernel_double_ckks_conversion
+ *           encoding.cu:43-77) */
+void o_ckks_encode_ex(const octx_t* c, int mode, const double* message, int message_size, double scale, u64* plain)
 {
     const u64 slots = c->n >> 1;
+    if (mode == 3) {
+        for (u64 idx = 0; idx < c->n; idx++) store_rns(c, plain, idx, message[0] * scale, c->Q_size);
+        return;
+    }
+    if (mode == 2) {
+        for (u64 idx = 0; idx < c->n; idx++)
+            store_rns(c, plain, idx, ((int) idx < message_size ? message[idx] : 0.0) * scale, c->Q_size);
+        o_gpu_ntt(plain, plain, c->ntt_table, c->mod, c->n_power, c->Q_size, c->Q_size);
+        return;
+    }
     cx* fwd = (cx*) malloc(sizeof(cx) * slots);
     cx* inv = (cx*) malloc(sizeof(cx) * slots);
     int* rev = (int*) malloc(sizeof(int) * slots);
     cx* v = (cx*) malloc(sizeof(cx) * slots);
     int log_slots;
     tables(c, fwd, inv, rev, &log_slots);
-    for (u64 i = 0; i < slots; i++) { v[i].re = (int) i < message_size ? message[i] : 0.0; v[i].im = 0.0; }
+    for (u64 i = 0; i < slots; i++) {
+        const int in = (int) i < message_size;
+        v[i].re = in ? message[mode == 1 ? 2 * i : i] : 0.0;
+        v[i].im = (in && mode == 1) ? message[2 * i + 1] : 0.0;
+    }
     special_ifft(v, inv, slots, scale / (double) slots);
     for (u64 idx = 0; idx < slots; idx++) {
         cx z = v[rev[idx]];
@@ -113,6 +134,10 @@ void o_ckks_encode(const octx_t* c, const double* message, int message_size, dou
     }
     o_gpu_ntt(plain, plain, c->ntt_table, c->mod, c->n_power, c->Q_size, c->Q_size);
     free(fwd); free(inv); free(rev); free(v);
+}
+void o_ckks_encode(const octx_t* c, const double* message, int message_size, double scale, u64* plain)
+{
+    o_ckks_encode_ex(c, 0, message, message_size, scale, plain);
 }
 
 /* one coefficient of encode_kernel_compose (encoding.cu:246-312): CRT composition with
@@ -158,8 +183,15 @@ static double compose_one(const octx_t* c, const u64* coeff, u64 at, int l, cons
     return result;
 }
 
-/* HEEncoder<CKKS>::decode_ckks(vector<double>) (ckks/encoder.cu:449-513); plain [Q - depth][N] */
+/* HEEncoder<CKKS>::decode_ckks / decode_ckks_coeff (ckks/encoder.cu:449-690); plain [Q - depth][N]
+ *   mode 0: N/2 real parts of the slots; mode 1: N/2 complex slots as (re, im) pairs;
+ *   mode 2: the N polynomial coefficients (decode_kernel_coeff_ckks_compose encoding.cu:387-464) */
+void o_ckks_decode_ex(const octx_t* c, int mode, const u64* plain, int depth, double scale, double* message);
 void o_ckks_decode(const octx_t* c, const u64* plain, int depth, double scale, double* message)
+{
+    o_ckks_decode_ex(c, 0, plain, depth, scale, message);
+}
+void o_ckks_decode_ex(const octx_t* c, int mode, const u64* plain, int depth, double scale, double* message)
 {
     const int l = c->Q_size - depth, np = c->n_power;
     const u64 slots = c->n >> 1;
@@ -197,13 +229,18 @@ void o_ckks_decode(const octx_t* c, const u64* plain, int depth, double scale, d
         for (int k = 0; k <= l; k++) if (++t[k]) break;
         for (int k = 0; k <= l; k++) half[k] = (t[k] >> 1) | (t[k + 1] << 63);
     }
+    const double inv_scale = 1.0 / scale;
+    if (mode == 2) {
+        for (u64 idx = 0; idx < c->n; idx++) message[idx] = compose_one(c, coeff, idx, l, Mi, Mi_inv, M, half, inv_scale);
+        free(coeff); free(Mi);
+        return;
+    }
     cx* fwd = (cx*) malloc(sizeof(cx) * slots);
     cx* inv = (cx*) malloc(sizeof(cx) * slots);
     int* rev = (int*) malloc(sizeof(int) * slots);
     cx* v = (cx*) malloc(sizeof(cx) * slots);
     int log_slots;
     tables(c, fwd, inv, rev, &log_slots);
-    const double inv_scale = 1.0 / scale;
     for (u64 idx = 0; idx < slots; idx++) {
         cx z;
         z.re = compose_one(c, coeff, idx, l, Mi, Mi_inv, M, half, inv_scale);
@@ -211,6 +248,9 @@ void o_ckks_decode(const octx_t* c, const u64* plain, int depth, double scale, d
         v[rev[idx]] = z;
     }
     special_fft(v, fwd, slots);
-    for (u64 i = 0; i < slots; i++) message[i] = v[i].re;
+    for (u64 i = 0; i < slots; i++) {
+        if (mode == 1) { message[2 * i] = v[i].re; message[2 * i + 1] = v[i].im; }
+        else message[i] = v[i].re;
+    }
     free(coeff); free(Mi); free(fwd); free(inv); free(rev); free(v);
 }

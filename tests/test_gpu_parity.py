@@ -486,3 +486,44 @@ def test_reference_example_runs_unchanged(torch, name):
         return
     for want in _EXAMPLE_EXPECT[name]:
         assert want in flat, want
+
+
+_REFERENCE_TESTS = ["test_bfv_addition", "test_bfv_encoding", "test_bfv_encryption", "test_bfv_multiplication",
+                    "test_bfv_relinearization", "test_bfv_rotation_method_1", "test_bfv_rotation_method_2",
+                    "test_ckks_addition", "test_ckks_encoding", "test_ckks_encryption", "test_ckks_multiplication",
+                    "test_ckks_relinearization", "test_ckks_rotation_method_1", "test_ckks_rotation_method_2",
+                    "test_tfhe_gate_boot"]
+
+
+@pytest.mark.parametrize("name", _REFERENCE_TESTS)
+def test_reference_own_test_passes(torch, name):
+    """test/<name>.cpp of the reference -- its own encrypt -> operate -> decrypt checks over all its
+    parameter sets (N = 2^12 .. 2^16, up to 37 primes, key-switching methods I and II) -- compiled
+    UNCHANGED against the class layer (GoogleTest's TEST/EXPECT_EQ come from tests/cpp/gtest/gtest.h)
+    by __graft_entry__.build(), must pass on this backend."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "heongpu_amd", "lib", "ref_" + name)
+    if not os.path.exists(exe):
+        pytest.skip("reference test binary not built (no /root/reference at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1500, cwd="/tmp")
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0
+    assert "[  FAILED  ]" not in r.stdout and r.stdout.count("[       OK ]") >= 1
+
+
+def test_cpp_api_writes_inside_its_buffers(torch):
+    """tests/cpp/test_api.cpp again with 64 KiB canaries around every device buffer of the class layer
+    (HEGPU_POOL_GUARD): no kernel may write outside the buffer it was given."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "heongpu_amd", "lib", "test_cpp_api")
+    if not os.path.exists(exe):
+        pytest.skip("test_cpp_api not built")
+    env = dict(os.environ, HEGPU_POOL_GUARD="65536")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1500, env=env)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "PASSED" in r.stdout
+    assert "MemoryPool guard" not in r.stderr
