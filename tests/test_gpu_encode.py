@@ -75,3 +75,38 @@ def test_basic_ckks_flow_on_gpu(hg, oracle, torch):
     c.ckks_apply_galois(cx, 2 * Q * n, rot, 2 * Q * n, gk, gal, 0, 1, c.workspace(hg.OP_CKKS_GALOIS, 0, 1))
     r = c.ckks_decode(c.ckks_decrypt(rot, sk, 0), scale).cpu().numpy()
     assert np.max(np.abs(r - np.roll(x, -1))) < 1e-6, "rotate_rows(1)"
+
+
+@pytest.mark.parametrize("n,log_q", [(4096, [50, 40, 40]), (32768, [59, 45, 45, 45, 45, 45])])
+def test_other_encodings_match_oracle(hg, oracle, torch, n, log_q):
+    """complex-slot, coefficient and scalar encodings (ckks/encoder.cu:222-446, :515-690) against the
+    oracle: residues identical, decoded doubles identical."""
+    c, o, primes = _pair(hg, oracle, n, log_q, [60])
+    slots = n // 2
+    g = np.random.default_rng(n + 1)
+    scale = 2.0 ** 42
+    z = g.uniform(-50, 50, slots) + 1j * g.uniform(-50, 50, slots)
+    for msg in (z, z[:9]):
+        plain = c.ckks_encode_ex(1, torch.from_numpy(np.ascontiguousarray(msg)).cuda(), scale)
+        want = o.ckks_encode_ex(1, msg, scale)
+        assert np.array_equal(hg.to_host(plain), want), "complex encode"
+        for depth in (0, len(log_q) - 1):
+            l = len(log_q) - depth
+            sub = np.ascontiguousarray(want.reshape(len(log_q), n)[:l].reshape(-1))
+            dec = c.ckks_decode_ex(1, hg.to_device(sub), scale, depth).cpu().numpy()
+            assert np.array_equal(dec.view(np.float64), o.ckks_decode_ex(1, sub, scale, depth).view(np.float64)), "complex decode"
+    m = g.uniform(-1000, 1000, n)
+    for msg in (m, m[:5], -np.abs(m)):
+        plain = c.ckks_encode_ex(2, torch.from_numpy(np.ascontiguousarray(msg)).cuda(), scale)
+        want = o.ckks_encode_ex(2, msg, scale)
+        assert np.array_equal(hg.to_host(plain), want), "coefficient encode"
+        for depth in (0, 1):
+            l = len(log_q) - depth
+            sub = np.ascontiguousarray(want.reshape(len(log_q), n)[:l].reshape(-1))
+            dec = c.ckks_decode_ex(2, hg.to_device(sub), scale, depth).cpu().numpy()
+            assert np.array_equal(dec, o.ckks_decode_ex(2, sub, scale, depth)), "coefficient decode"
+    for v in (3.141592653589793, -2.5e6, 0.0, -0.0, 1e-30):
+        plain = c.ckks_encode_ex(3, v, scale)
+        assert np.array_equal(hg.to_host(plain), o.ckks_encode_ex(3, [v], scale)), "scalar encode"
+    with pytest.raises(hg.HEError):
+        c.ckks_encode_ex(2, torch.zeros(n + 1, dtype=torch.float64, device="cuda"), scale)

@@ -73,3 +73,39 @@ def test_galois_5_rotates_slots(ctx):
     back = he.ntt_limbs(rot, ids).reshape(-1)
     got = o.ckks_decode(back, scale)
     assert np.max(np.abs(got - np.roll(x, -1))) < 1e-7
+
+
+def test_other_encodings(ctx):
+    """complex slots, coefficient encoding and the scalar shortcut (ckks/encoder.cu:222-446),
+    pinned by their meaning: complex decode inverts complex encode and its product is slot-wise;
+    the coefficient encoding IS the polynomial (INTT of the plaintext = round(m * scale), negacyclic
+    products); a scalar equals the constant vector."""
+    o, primes = ctx
+    n, slots = o.n, o.n // 2
+    g = np.random.default_rng(4)
+    scale = 2.0 ** 35
+    z = g.uniform(-4, 4, slots) + 1j * g.uniform(-4, 4, slots)
+    w = g.uniform(-4, 4, slots) + 1j * g.uniform(-4, 4, slots)
+    pz, pw = o.ckks_encode_ex(1, z, scale), o.ckks_encode_ex(1, w, scale)
+    assert np.max(np.abs(o.ckks_decode_ex(1, pz, scale) - z)) < 1e-6
+    he = RLWE(o, seed=2)
+    prod = np.concatenate([he.mulmod(pz.reshape(o.Q, n)[j], pw.reshape(o.Q, n)[j], primes[j]) for j in range(o.Q)])
+    assert np.max(np.abs(o.ckks_decode_ex(1, prod, scale * scale) - z * w)) < 1e-5
+    # a real vector is the complex vector with zero imaginary parts
+    x = g.uniform(-4, 4, slots)
+    assert np.array_equal(o.ckks_encode_ex(1, x + 0j, scale), o.ckks_encode(x, scale))
+    # coefficient encoding
+    m = g.uniform(-8, 8, n)
+    pm = o.ckks_encode_ex(2, m, scale)
+    coeff = he.ntt_limbs(pm.reshape(o.Q, n), list(range(o.Q)), inverse=True)
+    for j in range(o.Q):
+        want = np.array([int(round(v * scale)) % primes[j] for v in m], dtype=np.uint64)
+        assert np.array_equal(coeff[j], want)
+    assert np.max(np.abs(o.ckks_decode_ex(2, pm, scale) - m)) < 1e-9
+    short = o.ckks_decode_ex(2, o.ckks_encode_ex(2, m[:3], scale), scale)
+    assert np.max(np.abs(short[:3] - m[:3])) < 1e-9 and np.max(np.abs(short[3:])) == 0.0
+    # scalar
+    for v in (2.75, -1.5, 0.0):
+        ps = o.ckks_encode_ex(3, [v], scale)
+        assert np.array_equal(ps, o.ckks_encode(np.full(slots, v), scale))
+        assert np.max(np.abs(o.ckks_decode(ps, scale) - v)) < 1e-9
