@@ -53,6 +53,8 @@ for prefix in ("void hegpu::ntt_fwd_col<8, false>", "hegpu::ntt_fwd_row"):
                          "write_KiB": per.get(("WRITE_SIZE", k, g)), "bytes": by}
     total += by
 res["bytes_per_launch"] = total
+res["limb_ntts_per_launch"] = 17408  # bench.py default workload: 64 pairs x 16 digits x 17 limbs
+res["source"] = "profiles/$TAG (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bench.py --no-cpu-baseline $*)"
 json.dump(res, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(res)[:400])
 PY
