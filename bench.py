@@ -140,6 +140,23 @@ def main():
     fwd_gbps = ntt_bytes / (ntt_ms[False] * 1e-3) / 1e9
     inv_gbps = ntt_bytes / (ntt_ms[True] * 1e-3) / 1e9
 
+    # ---- the two operators of a step on their own (HIP events on the launch stream), against
+    # their algorithmic bytes: multiply reads 4l and writes 3l limbs per pair, the
+    # rest of (6 l^2 + 32 l + 8) W belongs to relinearize_inplace
+    op_ms = {}
+    for name, fn in (("ckks_multiply", lambda: ctx.ckks_multiply(ct1, ct_elems, ct2, ct_elems, out, out_elems, 0, B,
+                                                                 stream=stream)),
+                     ("ckks_relinearize_inplace", lambda: ctx.ckks_relinearize_inplace(out, out_elems, key, 0, B, ws,
+                                                                                       stream=stream))):
+        fn()
+        for i in range(reps):
+            e0[i].record()
+            fn()
+            e1[i].record()
+        torch.cuda.synchronize()
+        op_ms[name] = sum(a.elapsed_time(b) for a, b in zip(e0, e1)) / reps
+    op_bytes = {"ckks_multiply": 7 * l * W * B, "ckks_relinearize_inplace": (6 * l * l + 25 * l + 8) * W * B}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -184,6 +201,11 @@ def main():
             "algorithmic_bytes_per_launch": ntt_bytes,
         },
         "ntt": {"forward_GBps": fwd_gbps, "inverse_GBps": inv_gbps, "n": N, "limbs": polys},
+        # per operator: SURVEY 8d bytes = what the reference's kernel sequence for that operator reads and
+        # writes; the fused kernels here move fewer bytes, so this is "reference-equivalent" bandwidth
+        "operators": {k: {"ms_per_launch": op_ms[k], "reference_sequence_bytes_per_launch": op_bytes[k],
+                          "reference_equivalent_GBps": op_bytes[k] / (op_ms[k] * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": op_bytes[k] / (op_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k in op_ms},
         "hbm_fraction_end_to_end": ((6 * l * l + 32 * l + 8) * W * value / world) / 1e9 / HBM_PEAK_GBPS,
     }
     # HBM traffic of the same launch from the PMC counters (separate rocprofv3

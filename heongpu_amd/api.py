@@ -362,6 +362,23 @@ class Context:
                                            stream if stream is not None else _stream()))
         return out
 
+    def ckks_constant_op(self, op, ct, value, limbs, parts=2, out=None, stream=None):
+        """op 0/1/2 = add / subtract / multiply by round(value) (value = constant * scale); NTT-domain ciphertext"""
+        import torch
+        if out is None:
+            out = torch.empty(parts * limbs * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_ckks_constant_op(self._h, op, _ptr(ct), float(value), _ptr(out), limbs, parts,
+                                                stream if stream is not None else _stream()))
+        return out
+
+    def ckks_mult_i(self, ct, limbs, parts=2, divide=False, out=None, stream=None):
+        import torch
+        if out is None:
+            out = torch.empty(parts * limbs * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_ckks_mult_i(self._h, _ptr(ct), _ptr(out), limbs, parts, int(divide),
+                                           stream if stream is not None else _stream()))
+        return out
+
     def ckks_encode_ex(self, mode, message, scale, stream=None):
         """The other encodings of HEEncoder<CKKS> (ckks/encoder.cu:222-446).  mode 1: complex128 device
         tensor (<= N/2) into the slots; mode 2: float64 device tensor (<= N) as polynomial coefficients;

@@ -716,6 +716,32 @@ int hegpu_cipherplain_multiplication(hegpu_context* ctx, const uint64_t* ct, con
                    "hegpu_cipherplain_multiplication");
 }
 
+int hegpu_ckks_constant_op(hegpu_context* ctx, int op, const uint64_t* ct, double value, uint64_t* out, int limbs,
+                           int parts, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (op < 0 || op > 2) return fail(HEGPU_E_INVALID, "unknown constant operation");
+    if (limbs <= 0 || limbs > ctx->c.Q_size || parts < 2 || parts > 3) return fail(HEGPU_E_INVALID, "bad ciphertext shape");
+    if (!(value == value) || value >= 3.4e38 || value <= -3.4e38) return fail(HEGPU_E_INVALID, "constant out of range");
+    return hip_ret(kg_ckks_constant((const u64*) ct, value, (u64*) out, ctx->c.plan_qp.mods, ctx->c.n_power, limbs, parts,
+                                    op, (hipStream_t) stream),
+                   "hegpu_ckks_constant_op");
+}
+
+int hegpu_ckks_mult_i(hegpu_context* ctx, const uint64_t* ct, uint64_t* out, int limbs, int parts, int divide,
+                      hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (limbs <= 0 || limbs > ctx->c.Q_size || parts < 2 || parts > 3) return fail(HEGPU_E_INVALID, "bad ciphertext shape");
+    return guarded([&]() -> int {
+        return hip_ret(kg_ckks_mult_i((const u64*) ct, (u64*) out, ctx->c.d64("psi_half"), ctx->c.plan_qp.mods,
+                                      ctx->c.n_power, limbs, parts, divide, (hipStream_t) stream),
+                       "hegpu_ckks_mult_i");
+    });
+}
+
 int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, int sub,
                            hegpu_stream stream)
 {

@@ -37,6 +37,11 @@ void Context::build_host()
     host["psi"] = psi;
     host["n_inverse"] = ninv;
     host["ntt_table"] = fwd;
+    { // psi^(N/2) per modulus = entry 1 of the bit-reversed forward table (the "i" of mult_i / div_i)
+        vec ph;
+        for (int j = 0; j < Qp; j++) ph.push_back(fwd[(size_t) j * n + 1]);
+        host["psi_half"] = ph;
+    }
     host["intt_table"] = inv;
 
     // mod-down by the special primes, last P prime first (util.cu:701-767)
@@ -497,7 +502,8 @@ hipError_t Context::upload()
     if ((e = build_plan(plan_qp, host["modulus"], host["ntt_table"], host["intt_table"], host["n_inverse"],
                         n_power)) != hipSuccess)
         return e;
-    static const char* u64_tables[] = {"last_q_modinv",
+    static const char* u64_tables[] = {"psi_half",
+                                       "last_q_modinv",
                                        "half",
                                        "half_mod",
                                        "factor",

@@ -400,4 +400,59 @@ hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location
     return hipGetLastError();
 }
 
+// ---- CKKS ciphertext (+,-,*) one real constant, and multiplication / division by the imaginary unit
+// addition_constant_plain_ckks_poly / substraction_constant_plain_ckks_poly (addition.cu:219-300): part 0
+// gets +-round(value) mod q_j, the other parts are copied; cipher_constant_plain_multiplication_kernel
+// (multiplication.cu:333-372): every part times round(value) mod q_j.  |value| < 2^128.
+__global__ __launch_bounds__(KG_THREADS) void k_kg_ckks_constant(const u64* __restrict__ ct, double value,
+                                                                 u64* __restrict__ out, const Mod* __restrict__ mods,
+                                                                 int n_power, int op)
+{
+    const u64 loc = (u64) blockIdx.x * KG_THREADS + threadIdx.x + ((u64) blockIdx.y << n_power) +
+                    (((u64) gridDim.y * blockIdx.z) << n_power);
+    const u64 x = ct[loc];
+    if (op != 2 && blockIdx.z != 0) { out[loc] = x; return; }
+    const Mod m = mods[blockIdx.y];
+    double c = round(value);
+    const bool neg = signbit(c);
+    c = fabs(c);
+    const double two64 = 18446744073709551616.0;
+    const u64 lo = (u64) fmod(c, two64), hi = (u64) (c / two64);
+    u64 pt = reduce128(hi, lo, m);
+    if (neg) pt = sub_mod(m.q, pt, m.q); // sub(q, 0) == q is the reference's
+    out[loc] = op == 0 ? add_mod(x, pt, m.q) : op == 1 ? sub_mod(x, pt, m.q) : mul_barrett(x, pt, m);
+}
+
+hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mods, int n_power, int limbs, int parts,
+                            int op, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_ckks_constant, dim3((1u << n_power) / KG_THREADS, limbs, parts), dim3(KG_THREADS), 0, st,
+                       ct, value, out, mods, n_power, op);
+    return hipGetLastError();
+}
+
+// cipher_mult_by_i_kernel / cipher_div_by_i_kernel (multiplication.cu:441-495): in the NTT domain the
+// monomial X^(N/2) (= i in every slot) is +psi^(N/2) on the first half of the positions and -psi^(N/2) on
+// the second; psi_half[j] = forward table entry 1 of modulus j
+__global__ __launch_bounds__(KG_THREADS) void k_kg_ckks_mult_i(const u64* __restrict__ ct, u64* __restrict__ out,
+                                                               const u64* __restrict__ psi_half,
+                                                               const Mod* __restrict__ mods, int n_power, int divide)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const u64 loc = idx + ((u64) blockIdx.y << n_power) + (((u64) gridDim.y * blockIdx.z) << n_power);
+    const Mod m = mods[blockIdx.y];
+    const u64 psi = psi_half[blockIdx.y];
+    const bool first = idx < (1u << (n_power - 1));
+    const u64 w = (first != (divide != 0)) ? psi : sub_mod(0, psi, m.q);
+    out[loc] = mul_barrett(ct[loc], w, m);
+}
+
+hipError_t kg_ckks_mult_i(const u64* ct, u64* out, const u64* psi_half, const Mod* mods, int n_power, int limbs,
+                          int parts, int divide, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_ckks_mult_i, dim3((1u << n_power) / KG_THREADS, limbs, parts), dim3(KG_THREADS), 0, st, ct,
+                       out, psi_half, mods, n_power, divide);
+    return hipGetLastError();
+}
+
 } // namespace hegpu

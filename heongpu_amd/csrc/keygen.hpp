@@ -84,4 +84,10 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
                       const u64* upper_half, const u64* M, int l, double scale, const int* reverse_order, int n_power,
                       hipStream_t st);
 
+// CKKS ciphertext with one constant: op 0 add, 1 subtract (part 0 only), 2 multiply (all parts)
+hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mods, int n_power, int limbs, int parts,
+                            int op, hipStream_t st);
+hipError_t kg_ckks_mult_i(const u64* ct, u64* out, const u64* psi_half, const Mod* mods, int n_power, int limbs,
+                          int parts, int divide, hipStream_t st);
+
 } // namespace hegpu

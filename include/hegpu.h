@@ -274,6 +274,18 @@ int hegpu_bfv_noise_rns(hegpu_context* ctx, const uint64_t* ct, const uint64_t* 
  * ckks/operator.cu multiply_plain_ckks).  CKKS add/sub of a plaintext is hegpu_addition on part 0. */
 int hegpu_cipherplain_multiplication(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out,
                                      int limbs, hegpu_stream stream);
+/* CKKS ciphertext with one real constant (HEArithmeticOperator::add_plain / sub_plain / multiply_plain with a
+ * double, ckks/operator.cuh:312-390, :507-585, :812-925): value = constant * scale, rounded to the
+ * nearest integer.  op 0: part 0 += value (addition_constant_plain_ckks_poly, addition.cu:219-258), 1: part 0
+ * -= value (:260-300), 2: every part *= value (cipher_constant_plain_multiplication_kernel,
+ * multiplication.cu:333-372).  ct, out: [parts][limbs][N], NTT domain; in place allowed. */
+enum { HEGPU_CONST_ADD = 0, HEGPU_CONST_SUB = 1, HEGPU_CONST_MUL = 2 };
+int hegpu_ckks_constant_op(hegpu_context* ctx, int op, const uint64_t* ct, double value, uint64_t* out, int limbs,
+                           int parts, hegpu_stream stream);
+/* HEArithmeticOperator::mult_i / div_i (cipher_mult_by_i_kernel / cipher_div_by_i_kernel,
+ * multiplication.cu:441-495): every slot times +-i, no level consumed */
+int hegpu_ckks_mult_i(hegpu_context* ctx, const uint64_t* ct, uint64_t* out, int limbs, int parts, int divide,
+                      hegpu_stream stream);
 /* addition_plain_bfv_poly / substraction_plain_bfv_poly (src/lib/kernel/addition.cu:50-176): part 0 gets
  * +-(floor(Q/t)*m + fix), part 1 is copied; plain [N] mod t, coefficient-domain ciphertext */
 int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, int sub,

@@ -1934,6 +1934,55 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     {
         multiply_plain(a, p, a, o);
     }
+
+    // ---- CKKS: one real constant in every slot (ckks/operator.cuh:312-390, :507-585, :812-925), +-i, conjugation
+    void add_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (a.relinearization_required_)
+            throw std::invalid_argument("Ciphertext and Plaintext can not be added because ciphertext has non-linear partl!");
+        constant_op(HEGPU_CONST_ADD, a, c * a.scale_, out, o);
+    }
+    void add_plain_inplace(Ciphertext<S>& a, double c, const ExecutionOptions& o = ExecutionOptions()) { add_plain(a, c, a, o); }
+    void sub_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (a.relinearization_required_)
+            throw std::invalid_argument("Ciphertext and Plaintext can not be added because ciphertext has non-linear partl!");
+        constant_op(HEGPU_CONST_SUB, a, c * a.scale_, out, o);
+    }
+    void sub_plain_inplace(Ciphertext<S>& a, double c, const ExecutionOptions& o = ExecutionOptions()) { sub_plain(a, c, a, o); }
+    void multiply_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, double scale,
+                        const ExecutionOptions& o = ExecutionOptions())
+    {
+        if (a.relinearization_required_)
+            throw std::invalid_argument("Ciphertext and Plaintext can not be multiplied because of the non-linear part! "
+                                        "Please use relinearization operation!");
+        const double in_scale = a.scale_;
+        constant_op(HEGPU_CONST_MUL, a, c * scale, out, o);
+        out.scale_ = in_scale * scale; // multiply_const_plain_ckks, operator.cu:893
+        out.rescale_required_ = true;
+    }
+    void multiply_plain_inplace(Ciphertext<S>& a, double c, double scale, const ExecutionOptions& o = ExecutionOptions())
+    {
+        multiply_plain(a, c, a, scale, o);
+    }
+    void mult_i(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions()) { times_i(a, out, 0, o); }
+    void div_i(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions()) { times_i(a, out, 1, o); }
+    // complex conjugate of every slot: the Galois element 2N - 1 (conjugate_ckks_method_I/II)
+    void conjugate(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::CKKS, "conjugate is a CKKS operation");
+        apply_galois(in, out, gk, gk.galois_elt_zero, o);
+    }
+    void apply_galois_inplace(Ciphertext<S>& a, Galoiskey<S>& gk, int galois_elt, const ExecutionOptions& o = ExecutionOptions())
+    {
+        Ciphertext<S> tmp(a);
+        apply_galois(tmp, a, gk, galois_elt, o);
+    }
+    void mod_drop(Plaintext<S>& p, Plaintext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        out = p;
+        mod_drop_inplace(out, o);
+    }
     // BFV: swap the two rows of the slot matrix (Galois element 2N - 1, bfv/operator.cu:975-1068)
     void rotate_columns(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk,
                         const ExecutionOptions& o = ExecutionOptions())
@@ -1964,6 +2013,28 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), (const uint64_t*) b.data(),
                                      (uint64_t*) m.data(), l, a.cipher_size_, 1, op, o.stream_));
         copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+    void constant_op(int op, Ciphertext<S>& a, double value, Ciphertext<S>& out, const ExecutionOptions& o)
+    {
+        static_assert(S == Scheme::CKKS, "constants are CKKS operations");
+        const int l = limbs(a), parts = a.relinearization_required_ ? 3 : 2;
+        if (a.memory_size() < (size_t) parts * l * context_->n) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) parts * l * context_->n, o.stream_);
+        detail::check(hegpu_ckks_constant_op(context_->handle(), op, (const uint64_t*) a.data(), value,
+                                             (uint64_t*) m.data(), l, parts, o.stream_));
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+    void times_i(Ciphertext<S>& a, Ciphertext<S>& out, int divide, const ExecutionOptions& o)
+    {
+        static_assert(S == Scheme::CKKS, "mult_i / div_i are CKKS operations");
+        const int l = limbs(a), parts = a.relinearization_required_ ? 3 : 2;
+        if (a.memory_size() < (size_t) parts * l * context_->n) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) parts * l * context_->n, o.stream_);
+        detail::check(hegpu_ckks_mult_i(context_->handle(), (const uint64_t*) a.data(), (uint64_t*) m.data(), l, parts,
+                                        divide, o.stream_));
+        if (&a != &out) copy_meta(a, out);
         out.memory_set(std::move(m));
     }
     void plain_addsub(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, int sub, const ExecutionOptions& o)

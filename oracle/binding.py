@@ -95,6 +95,8 @@ def lib():
     L.o_ckks_encode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_decode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_encode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
+    L.o_ckks_constant_op.argtypes = [vp, ci, vp, ctypes.c_double, vp, ci, ci]
+    L.o_ckks_mult_i.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_ckks_decode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
     L.o_bfv_decode.argtypes = [vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
@@ -294,6 +296,17 @@ class OracleContext:
     def ckks_decode(self, plain, scale, depth=0):
         out = np.zeros(self.n // 2, dtype=np.float64)
         self.L.o_ckks_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), depth, float(scale), _p(out))
+        return out
+
+    def ckks_constant_op(self, op, ct, value, limbs, parts=2):
+        out = np.zeros(parts * limbs * self.n, dtype=np.uint64)
+        self.L.o_ckks_constant_op(self.h, op, _p(np.ascontiguousarray(ct, dtype=np.uint64)), float(value), _p(out),
+                                  limbs, parts)
+        return out
+
+    def ckks_mult_i(self, ct, limbs, parts=2, divide=False):
+        out = np.zeros(parts * limbs * self.n, dtype=np.uint64)
+        self.L.o_ckks_mult_i(self.h, _p(np.ascontiguousarray(ct, dtype=np.uint64)), _p(out), limbs, parts, int(divide))
         return out
 
     # mode: 0 real slots, 1 complex slots, 2 coefficients, 3 one scalar in every slot

@@ -254,3 +254,42 @@ void o_ckks_decode_ex(const octx_t* c, int mode, const u64* plain, int depth, do
     }
     free(coeff); free(Mi); free(fwd); free(inv); free(rev); free(v);
 }
+
+/* addition_constant_plain_ckks_poly / substraction_constant_plain_ckks_poly (addition.cu:219-300) and
+ * cipher_constant_plain_multiplication_kernel (multiplication.cu:333-372); op 0 add, 1 sub, 2 multiply.
+ * ct, out [parts][limbs][N] */
+void o_ckks_constant_op(const octx_t* c, int op, const u64* ct, double value, u64* out, int limbs, int parts)
+{
+    double v = round(value);
+    const int neg = signbit(v) != 0;
+    v = fabs(v);
+    const double two64 = 18446744073709551616.0;
+    const u128 wide = ((u128) (u64) (v / two64) << 64) | (u64) fmod(v, two64);
+    for (int z = 0; z < parts; z++)
+        for (int y = 0; y < limbs; y++) {
+            u64 pt = (u64) (wide % c->mod[y].value);
+            if (neg) pt = o_sub(c->mod[y].value, pt, &c->mod[y]);
+            for (u64 i = 0; i < c->n; i++) {
+                const u64 loc = i + ((u64) y << c->n_power) + (((u64) limbs * z) << c->n_power);
+                if (op == 2) out[loc] = o_mult(ct[loc], pt, &c->mod[y]);
+                else if (z != 0) out[loc] = ct[loc];
+                else out[loc] = op == 0 ? o_add(ct[loc], pt, &c->mod[y]) : o_sub(ct[loc], pt, &c->mod[y]);
+            }
+        }
+}
+
+/* cipher_mult_by_i_kernel / cipher_div_by_i_kernel (multiplication.cu:441-495) */
+void o_ckks_mult_i(const octx_t* c, const u64* ct, u64* out, int limbs, int parts, int divide)
+{
+    for (int z = 0; z < parts; z++)
+        for (int y = 0; y < limbs; y++) {
+            const u64 psi = c->ntt_table[1 + ((u64) y << c->n_power)];
+            const u64 neg_psi = o_sub(0, psi, &c->mod[y]);
+            for (u64 i = 0; i < c->n; i++) {
+                const u64 loc = i + ((u64) y << c->n_power) + (((u64) limbs * z) << c->n_power);
+                const int first = i < (c->n >> 1);
+                const u64 w = divide ? (first ? neg_psi : psi) : (first ? psi : neg_psi);
+                out[loc] = o_mult(ct[loc], w, &c->mod[y]);
+            }
+        }
+}

@@ -590,6 +590,35 @@ static void method_II_and_switch_key()
     double err = 0;
     for (size_t i = 0; i < m.size(); i++) err = std::max(err, std::fabs(got[i] - m[(i + 2) % m.size()] * m[(i + 2) % m.size()]));
     EXPECT(err < 1e-6, "method II: square -> relinearize -> rescale -> rotate under generated keys");
+    { // constants, +-i, conjugation (ckks/operator.cuh:312-390, :812-925, :969-1050, :1353-1420) on a fresh ciphertext
+        std::vector<Complex64> z(n / 2), zg;
+        for (size_t i = 0; i < z.size(); i++) z[i] = Complex64(0.01 * (double) (i % 50), -0.02 * (double) (i % 31));
+        Plaintext<S> pz(ctx);
+        encoder.encode(pz, z, scale);
+        Ciphertext<S> cz(ctx), t(ctx);
+        encryptor.encrypt(cz, pz);
+        auto worst = [&](Ciphertext<S>& ct, auto want) {
+            Plaintext<S> q(ctx);
+            dec1.decrypt(q, ct);
+            encoder.decode(zg, q);
+            double e = 0;
+            for (size_t i = 0; i < z.size(); i++) e = std::max(e, std::abs(zg[i] - want(z[i])));
+            return e;
+        };
+        op.add_plain(cz, 1.5, t);
+        EXPECT(worst(t, [](Complex64 v) { return v + 1.5; }) < 1e-6, "ciphertext + constant");
+        op.sub_plain(cz, 0.25, t);
+        EXPECT(worst(t, [](Complex64 v) { return v - 0.25; }) < 1e-6, "ciphertext - constant");
+        op.multiply_plain(cz, -3.0, t, scale);
+        op.rescale_inplace(t);
+        EXPECT(worst(t, [](Complex64 v) { return v * -3.0; }) < 1e-6, "ciphertext * constant, rescaled");
+        op.mult_i(cz, t);
+        EXPECT(worst(t, [](Complex64 v) { return v * Complex64(0, 1); }) < 1e-6, "mult_i");
+        op.div_i(cz, t);
+        EXPECT(worst(t, [](Complex64 v) { return v / Complex64(0, 1); }) < 1e-6, "div_i");
+        op.conjugate(cz, t, gk);
+        EXPECT(worst(t, [](Complex64 v) { return std::conj(v); }) < 1e-6, "conjugate (method II key for 2N-1)");
+    }
     op.keyswitch(c, c, swk);
     Plaintext<S> out2(ctx);
     dec2.decrypt(out2, c);

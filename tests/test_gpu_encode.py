@@ -110,3 +110,24 @@ def test_other_encodings_match_oracle(hg, oracle, torch, n, log_q):
         assert np.array_equal(hg.to_host(plain), o.ckks_encode_ex(3, [v], scale)), "scalar encode"
     with pytest.raises(hg.HEError):
         c.ckks_encode_ex(2, torch.zeros(n + 1, dtype=torch.float64, device="cuda"), scale)
+
+
+def test_constant_operations_and_mult_i_match_oracle(hg, oracle, torch):
+    """addition_constant_plain_ckks_poly / substraction_... / cipher_constant_plain_multiplication_kernel /
+    cipher_{mult,div}_by_i_kernel against the oracle, 2- and 3-part ciphertexts, two levels."""
+    n = 8192
+    c, o, primes = _pair(hg, oracle, n, [59, 45, 45, 45], [59])
+    Q = 4
+    for parts, l in ((2, Q), (3, Q - 1), (2, 1)):
+        ct = np.concatenate([oracle.fill_poly(20 + p, j, n, primes[j]) for p in range(parts) for j in range(l)])
+        d = hg.to_device(ct)
+        for op in (0, 1, 2):
+            for v in (1234567.25 * 2.0 ** 40, -9.75 * 2.0 ** 45, 0.0, -0.4, 2.0 ** 100):
+                got = hg.to_host(c.ckks_constant_op(op, d, v, l, parts))
+                assert np.array_equal(got, o.ckks_constant_op(op, ct, v, l, parts)), (op, v, parts, l)
+        for div in (False, True):
+            assert np.array_equal(hg.to_host(c.ckks_mult_i(d, l, parts, div)), o.ckks_mult_i(ct, l, parts, div))
+        # in place
+        e = d.clone()
+        c.ckks_constant_op(2, e, 3.0 * 2.0 ** 30, l, parts, out=e)
+        assert np.array_equal(hg.to_host(e), o.ckks_constant_op(2, ct, 3.0 * 2.0 ** 30, l, parts))

@@ -109,3 +109,33 @@ def test_other_encodings(ctx):
         ps = o.ckks_encode_ex(3, [v], scale)
         assert np.array_equal(ps, o.ckks_encode(np.full(slots, v), scale))
         assert np.max(np.abs(o.ckks_decode(ps, scale) - v)) < 1e-9
+
+
+def test_constant_operations_and_mult_i(ctx):
+    """add / sub / multiply by a real constant and multiplication / division by i
+    (ckks/operator.cuh:312-390, :812-925, :969-1050), pinned by their meaning on a trivial ciphertext
+    (c0 = plaintext, c1 = 0): slots + c, slots - c, slots * c at scale^2, and i * slots."""
+    o, primes = ctx
+    n, slots, Q = o.n, o.n // 2, o.Q
+    g = np.random.default_rng(6)
+    scale = 2.0 ** 35
+    z = g.uniform(-4, 4, slots) + 1j * g.uniform(-4, 4, slots)
+    ct = np.concatenate([o.ckks_encode_ex(1, z, scale), np.zeros(Q * n, dtype=np.uint64)])
+    for c in (2.5, -1.75, 0.0):
+        add = o.ckks_constant_op(0, ct, c * scale, Q)
+        assert np.max(np.abs(o.ckks_decode_ex(1, add[:Q * n], scale) - (z + c))) < 1e-6
+        assert np.array_equal(add[Q * n:], ct[Q * n:])
+        sub = o.ckks_constant_op(1, ct, c * scale, Q)
+        assert np.max(np.abs(o.ckks_decode_ex(1, sub[:Q * n], scale) - (z - c))) < 1e-6
+        mul = o.ckks_constant_op(2, ct, c * scale, Q)
+        assert np.max(np.abs(o.ckks_decode_ex(1, mul[:Q * n], scale * scale) - z * c)) < 1e-5
+    # at a lower level only the first l limbs take part
+    l = Q - 1
+    sub_ct = np.concatenate([ct[:l * n], ct[Q * n:Q * n + l * n]])
+    add = o.ckks_constant_op(0, sub_ct, 3.0 * scale, l)
+    assert np.max(np.abs(o.ckks_decode_ex(1, add[:l * n], scale, depth=1) - (z + 3.0))) < 1e-6
+    mi = o.ckks_mult_i(ct, Q)
+    assert np.max(np.abs(o.ckks_decode_ex(1, mi[:Q * n], scale) - 1j * z)) < 1e-6
+    di = o.ckks_mult_i(ct, Q, divide=True)
+    assert np.max(np.abs(o.ckks_decode_ex(1, di[:Q * n], scale) + 1j * z)) < 1e-6
+    assert np.array_equal(o.ckks_mult_i(mi, Q, divide=True), ct)
