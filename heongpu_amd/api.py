@@ -17,6 +17,7 @@ TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
 OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE = 7, 8, 9, 10, 11, 12, 13
 OP_CKKS_ENCODE, OP_CKKS_DECODE = 14, 15
+OP_BFV_MULTIPLY_PLAIN = 16
 TABLES_PLAIN = 2
 
 E_INVALID, E_LOGIC, E_RUNTIME, E_NODEVICE = 10001, 10002, 10003, 10004
@@ -360,6 +361,19 @@ class Context:
         _check(self._lib.hegpu_ckks_decode(self._h, _ptr(plain), depth, float(scale), _ptr(out), _ptr(ws),
                                            ws.numel() * ws.element_size(),
                                            stream if stream is not None else _stream()))
+        return out
+
+    def bfv_plain_to_ntt(self, plain, stream=None):
+        import torch
+        out = torch.empty(self.Q_size * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_bfv_plain_to_ntt(self._h, _ptr(plain), _ptr(out), stream if stream is not None else _stream()))
+        return out
+
+    def negacyclic_shift(self, ct, shift, limbs, parts=2, stream=None):
+        import torch
+        out = torch.empty(parts * limbs * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_negacyclic_shift(self._h, _ptr(ct), _ptr(out), shift, limbs, parts,
+                                                stream if stream is not None else _stream()))
         return out
 
     def ckks_constant_op(self, op, ct, value, limbs, parts=2, out=None, stream=None):

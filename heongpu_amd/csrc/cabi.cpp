@@ -757,6 +757,28 @@ int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_
     });
 }
 
+int hegpu_bfv_plain_to_ntt(hegpu_context* ctx, const uint64_t* plain, uint64_t* out, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    return guarded([&]() -> int {
+        return hip_ret(op_bfv_plain_to_ntt(ctx->c, (const u64*) plain, (u64*) out, (hipStream_t) stream),
+                       "hegpu_bfv_plain_to_ntt");
+    });
+}
+
+int hegpu_negacyclic_shift(hegpu_context* ctx, const uint64_t* in, uint64_t* out, int shift, int limbs, int parts,
+                           hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if ((const void*) in == (const void*) out) return fail(HEGPU_E_INVALID, "negacyclic shift: out must not alias in");
+    if (limbs <= 0 || limbs > ctx->c.Qp_size || parts < 1 || parts > 3) return fail(HEGPU_E_INVALID, "bad ciphertext shape");
+    if (shift < 0 || shift >= (int) (2 * ctx->c.n)) return fail(HEGPU_E_INVALID, "shift must be in [0, 2N)");
+    return hip_ret(kg_negacyclic_shift((const u64*) in, (u64*) out, ctx->c.plan_qp.mods, shift, ctx->c.n_power, limbs,
+                                       parts, (hipStream_t) stream),
+                   "hegpu_negacyclic_shift");
+}
+
 int hegpu_bfv_multiply_plain(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, void* ws,
                              size_t ws_bytes, hegpu_stream stream)
 {

@@ -455,4 +455,26 @@ hipError_t kg_ckks_mult_i(const u64* ct, u64* out, const u64* psi_half, const Mo
     return hipGetLastError();
 }
 
+// negacyclic_shift_poly_coeffmod_kernel (switchkey.cu:1433-1457): multiplication by X^shift in the coefficient
+// domain; the wrapped coefficients are stored as q - x without a zero test, as the reference does
+__global__ __launch_bounds__(KG_THREADS) void k_kg_negacyclic_shift(const u64* __restrict__ in, u64* __restrict__ out,
+                                                                    const Mod* __restrict__ mods, int shift,
+                                                                    int n_power)
+{
+    const int idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const u64 base = ((u64) blockIdx.y << n_power) + (((u64) gridDim.y << n_power) * blockIdx.z);
+    const int raw = idx + shift;
+    u64 v = in[idx + base];
+    if ((raw >> n_power) & 1) v = mods[blockIdx.y].q - v;
+    out[(raw & ((1 << n_power) - 1)) + base] = v;
+}
+
+hipError_t kg_negacyclic_shift(const u64* in, u64* out, const Mod* mods, int shift, int n_power, int limbs, int parts,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_negacyclic_shift, dim3((1u << n_power) / KG_THREADS, limbs, parts), dim3(KG_THREADS), 0, st,
+                       in, out, mods, shift, n_power);
+    return hipGetLastError();
+}
+
 } // namespace hegpu

@@ -90,4 +90,7 @@ hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mo
 hipError_t kg_ckks_mult_i(const u64* ct, u64* out, const u64* psi_half, const Mod* mods, int n_power, int limbs,
                           int parts, int divide, hipStream_t st);
 
+hipError_t kg_negacyclic_shift(const u64* in, u64* out, const Mod* mods, int shift, int n_power, int limbs, int parts,
+                               hipStream_t st);
+
 } // namespace hegpu

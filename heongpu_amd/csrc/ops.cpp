@@ -615,6 +615,16 @@ hipError_t op_bfv_multiply_plain(const Context& c, const u64* ct, const u64* pla
     return ntt_launch(a, 2 * Q, true, st);                                                 // :496
 }
 
+// HEOperator<BFV>::transform_to_ntt_bfv_plain (bfv/operator.cu:1398-1431): threshold lift mod every q_j, forward NTT
+hipError_t op_bfv_plain_to_ntt(const Context& c, const u64* plain, u64* out, hipStream_t st)
+{
+    TRY(kg_bfv_threshold(plain, out, c.plan_qp.mods, c.d64("upper_halfincrement"), c.h64("upper_threshold")[0],
+                         c.n_power, c.Q_size, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = out; a.out = out; a.mod_count = c.Q_size;
+    return ntt_launch(a, c.Q_size, false, st);
+}
+
 static int log2i(u64 v)
 {
     int r = 0;

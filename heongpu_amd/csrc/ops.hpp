@@ -69,6 +69,7 @@ hipError_t op_bfv_noise_rns(const Context& c, const u64* ct, const u64* sk, u64*
 hipError_t op_bfv_encode(const Context& c, const long long* message, int message_size, u64* plain, hipStream_t st);
 hipError_t op_bfv_decode(const Context& c, const u64* plain, u64* message, u64* ws, hipStream_t st);
 // HEOperator<BFV>::multiply_plain_bfv, coefficient-domain ciphertext (bfv/operator.cu:432-503)
+hipError_t op_bfv_plain_to_ntt(const Context& c, const u64* plain, u64* out, hipStream_t st);
 hipError_t op_bfv_multiply_plain(const Context& c, const u64* ct, const u64* plain, u64* out, u64* ws, hipStream_t st);
 // HEEncoder<CKKS>::encode_ckks / encode_ckks_coeff / decode_ckks / decode_ckks_coeff (ckks/encoder.cu:100-690).
 // encode mode: 0 real slots, 1 complex slots ((re, im) pairs), 2 coefficients (<= N), 3 `scalar` in every slot;

@@ -292,6 +292,14 @@ int hegpu_bfv_plain_addsub(hegpu_context* ctx, const uint64_t* ct, const uint64_
                            hegpu_stream stream);
 /* HEOperator<BFV>::multiply_plain_bfv (src/lib/host/bfv/operator.cu:432-503): threshold lift, NTT,
  * cipherplain product, INTT.  Workspace HEGPU_OP_BFV_MULTIPLY_PLAIN. */
+/* HEArithmeticOperator<BFV>::transform_to_ntt(Plaintext) (bfv/operator.cu:1398-1431): plain [N] mod t -> [Q][N],
+ * threshold lift (multiplication.cu:274-296) + forward NTT; such a plaintext multiplies an NTT-domain
+ * ciphertext with hegpu_cipherplain_multiplication.  (Ciphertexts change domain with hegpu_ntt.) */
+int hegpu_bfv_plain_to_ntt(hegpu_context* ctx, const uint64_t* plain, uint64_t* out, hegpu_stream stream);
+/* HEArithmeticOperator<BFV>::multiply_power_of_X (negacyclic_shift_poly_coeffmod_kernel, switchkey.cu:1433-1457):
+ * out = in * X^shift in the coefficient domain, [parts][limbs][N]; out must not alias in */
+int hegpu_negacyclic_shift(hegpu_context* ctx, const uint64_t* in, uint64_t* out, int shift, int limbs, int parts,
+                           hegpu_stream stream);
 int hegpu_bfv_multiply_plain(hegpu_context* ctx, const uint64_t* ct, const uint64_t* plain, uint64_t* out, void* ws,
                              size_t ws_bytes, hegpu_stream stream);
 

@@ -1221,7 +1221,7 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
     {
         if (!plaintext_generated_) throw std::runtime_error("Plaintext is not generated so can not be serialized!");
         const int plain_size = (int) device_locations_.size();
-        const bool ntt = (S == Scheme::CKKS);
+        const bool ntt = (S == Scheme::CKKS) || in_ntt_domain_;
         detail::put(os, detail::wire_scheme<S>());
         detail::put(os, plain_size);
         if (S == Scheme::CKKS) { detail::put(os, depth_); detail::put(os, scale_); }
@@ -1243,6 +1243,7 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
         detail::get(is, plain_size);
         if (S == Scheme::CKKS) { detail::get(is, depth_); detail::get(is, scale_); }
         detail::get(is, ntt);
+        in_ntt_domain_ = (S == Scheme::BFV) && ntt;
         if (S == Scheme::CKKS) detail::get(is, encoding_);
         detail::get(is, plaintext_generated_);
         detail::get(is, st);
@@ -1259,6 +1260,7 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
     int depth_ = 0;
     double scale_ = 0;
     encoding encoding_ = encoding::SLOT;
+    bool in_ntt_domain_ = false; // BFV: after transform_to_ntt ([Q][N] residues instead of [N] mod t)
     bool plaintext_generated_ = false;
 
   private:
@@ -1915,6 +1917,12 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
             detail::check(hegpu_cipherplain_multiplication(context_->handle(), (const uint64_t*) a.data(),
                                                            (const uint64_t*) p.data(), (uint64_t*) m.data(), l,
                                                            o.stream_));
+        } else if (a.in_ntt_domain_ != p.in_ntt_domain_) {
+            throw std::logic_error("BFV ciphertext or plaintext should be not in same domain"); // bfv/operator.cuh:447
+        } else if (a.in_ntt_domain_) { // both transformed: one pointwise product (bfv/operator.cu:441-449)
+            detail::check(hegpu_cipherplain_multiplication(context_->handle(), (const uint64_t*) a.data(),
+                                                           (const uint64_t*) p.data(), (uint64_t*) m.data(), l,
+                                                           o.stream_));
         } else {
             const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_BFV_MULTIPLY_PLAIN, 0, 1);
             DeviceVector<Data64> ws(wsb / 8, o.stream_);
@@ -1933,6 +1941,46 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void multiply_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
     {
         multiply_plain(a, p, a, o);
+    }
+
+    // ---- BFV: domain changes and X^k (bfv/operator.cuh:884-1110)
+    void transform_to_ntt(Plaintext<S>& p, Plaintext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::BFV, "BFV operation");
+        if (p.in_ntt_domain_) { if (&p != &out) out = p; return; }
+        if (p.size() < (size_t) context_->n) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) context_->Q_size * context_->n, o.stream_);
+        detail::check(hegpu_bfv_plain_to_ntt(context_->handle(), (const uint64_t*) p.data(), (uint64_t*) m.data(), o.stream_));
+        if (&p != &out) out = p;
+        out.memory_set(std::move(m));
+        out.in_ntt_domain_ = true;
+    }
+    void transform_to_ntt_inplace(Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions()) { transform_to_ntt(p, p, o); }
+    void transform_to_ntt(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::BFV, "BFV operation");
+        if (a.relinearization_required_) throw std::invalid_argument("Ciphertexts can not be transformed to NTT!");
+        change_domain(a, out, false, o);
+    }
+    void transform_to_ntt_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { transform_to_ntt(a, a, o); }
+    void transform_from_ntt(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::BFV, "BFV operation");
+        if (a.relinearization_required_) throw std::invalid_argument("Ciphertexts can not be transformed from NTT!");
+        change_domain(a, out, true, o);
+    }
+    void transform_from_ntt_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { transform_from_ntt(a, a, o); }
+    void multiply_power_of_X(Ciphertext<S>& a, Ciphertext<S>& out, int index, const ExecutionOptions& o = ExecutionOptions())
+    {
+        static_assert(S == Scheme::BFV, "BFV operation");
+        if (index == 0) return; // the reference leaves `out` untouched (bfv/operator.cuh:889)
+        if (a.in_ntt_domain_) throw std::invalid_argument("Ciphertext should be in intt domain");
+        if (a.memory_size() < (size_t) 2 * context_->n * context_->Q_size) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) 2 * context_->Q_size * context_->n, o.stream_);
+        detail::check(hegpu_negacyclic_shift(context_->handle(), (const uint64_t*) a.data(), (uint64_t*) m.data(), index,
+                                             context_->Q_size, 2, o.stream_));
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
     }
 
     // ---- CKKS: one real constant in every slot (ckks/operator.cuh:312-390, :507-585, :812-925), +-i, conjugation
@@ -2014,6 +2062,18 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
                                      (uint64_t*) m.data(), l, a.cipher_size_, 1, op, o.stream_));
         copy_meta(a, out);
         out.memory_set(std::move(m));
+    }
+    void change_domain(Ciphertext<S>& a, Ciphertext<S>& out, bool inverse, const ExecutionOptions& o)
+    {
+        if (a.in_ntt_domain_ == !inverse) { if (&a != &out) out = a; return; } // already there
+        const int Q = context_->Q_size;
+        if (a.memory_size() < (size_t) 2 * context_->n * Q) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) 2 * Q * context_->n, o.stream_);
+        detail::check(hegpu_ntt(context_->handle(), HEGPU_TABLES_QP, (const uint64_t*) a.data(), (uint64_t*) m.data(),
+                                inverse ? 1 : 0, 2 * Q, Q, 0, nullptr, nullptr, o.stream_));
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
+        out.in_ntt_domain_ = !inverse;
     }
     void constant_op(int op, Ciphertext<S>& a, double value, Ciphertext<S>& out, const ExecutionOptions& o)
     {

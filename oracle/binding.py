@@ -95,6 +95,9 @@ def lib():
     L.o_ckks_encode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_decode.argtypes = [vp, vp, ci, ctypes.c_double, vp]
     L.o_ckks_encode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
+    L.o_bfv_plain_to_ntt.argtypes = [vp, vp, vp]
+    L.o_bfv_multiply_plain.argtypes = [vp, vp, vp, vp]
+    L.o_negacyclic_shift.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_ckks_constant_op.argtypes = [vp, ci, vp, ctypes.c_double, vp, ci, ci]
     L.o_ckks_mult_i.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_ckks_decode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
@@ -296,6 +299,22 @@ class OracleContext:
     def ckks_decode(self, plain, scale, depth=0):
         out = np.zeros(self.n // 2, dtype=np.float64)
         self.L.o_ckks_decode(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), depth, float(scale), _p(out))
+        return out
+
+    def bfv_plain_to_ntt(self, plain):
+        out = np.zeros(self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_plain_to_ntt(self.h, _p(np.ascontiguousarray(plain, dtype=np.uint64)), _p(out))
+        return out
+
+    def bfv_multiply_plain(self, ct, plain):
+        out = np.zeros(2 * self.Q * self.n, dtype=np.uint64)
+        self.L.o_bfv_multiply_plain(self.h, _p(np.ascontiguousarray(ct, dtype=np.uint64)),
+                                    _p(np.ascontiguousarray(plain, dtype=np.uint64)), _p(out))
+        return out
+
+    def negacyclic_shift(self, ct, shift, limbs, parts=2):
+        out = np.zeros(parts * limbs * self.n, dtype=np.uint64)
+        self.L.o_negacyclic_shift(self.h, _p(np.ascontiguousarray(ct, dtype=np.uint64)), _p(out), shift, limbs, parts)
         return out
 
     def ckks_constant_op(self, op, ct, value, limbs, parts=2):

@@ -628,3 +628,53 @@ void o_tfhe_phase(const int32_t* lwe_key, const int32_t* a, const int32_t* b, in
         phase[s] = (int32_t) ((uint32_t) b[s] - acc);
     }
 }
+
+/* ---- BFV plaintext lift and ciphertext (x) plaintext
+ * threshold_kernel (multiplication.cu:274-296) with upper_halfincrement = q_j - t and
+ * upper_threshold = (t + 1) >> 1 (bfv/context.cu:501-508), forward NTT:
+ * HEOperator<BFV>::transform_to_ntt_bfv_plain (bfv/operator.cu:1398-1431); out [Q][N] */
+void o_bfv_plain_to_ntt(const octx_t* c, const u64* plain, u64* out)
+{
+    const int Q = c->Q_size, np = c->n_power;
+    const u64 t = c->plain_mod.value, thr = (t + 1) >> 1;
+    for (int y = 0; y < Q; y++)
+        for (u64 i = 0; i < c->n; i++) {
+            const u64 v = plain[i];
+            out[i + ((u64) y << np)] = (v >= thr) ? o_add(v, c->mod[y].value - t, &c->mod[y]) : v;
+        }
+    o_gpu_ntt(out, out, c->ntt_table, c->mod, np, Q, Q);
+}
+
+/* HEOperator<BFV>::multiply_plain_bfv, coefficient-domain ciphertext (bfv/operator.cu:432-503):
+ * lift + NTT of the plaintext, NTT of both parts, cipherplain_kernel (multiplication.cu:298-311), INTT */
+void o_bfv_multiply_plain(const octx_t* c, const u64* ct, const u64* plain, u64* out)
+{
+    const int Q = c->Q_size, np = c->n_power;
+    u64* pl = (u64*) malloc(sizeof(u64) * ((u64) Q << np));
+    o_bfv_plain_to_ntt(c, plain, pl);
+    o_gpu_ntt(ct, out, c->ntt_table, c->mod, np, 2 * Q, Q);
+    for (int z = 0; z < 2; z++)
+        for (int y = 0; y < Q; y++)
+            for (u64 i = 0; i < c->n; i++) {
+                const u64 a = i + ((u64) y << np), b = a + (((u64) Q << np) * z);
+                out[b] = o_mult(out[b], pl[a], &c->mod[y]);
+            }
+    o_gpu_intt(out, out, c->intt_table, c->mod, c->n_inv, np, 2 * Q, Q);
+    free(pl);
+}
+
+/* negacyclic_shift_poly_coeffmod_kernel (switchkey.cu:1433-1457); in, out [parts][limbs][N] */
+void o_negacyclic_shift(const octx_t* c, const u64* in, u64* out, int shift, int limbs, int parts)
+{
+    const int np = c->n_power;
+    const int mask = (1 << np) - 1;
+    for (int z = 0; z < parts; z++)
+        for (int y = 0; y < limbs; y++)
+            for (int idx = 0; idx < (int) c->n; idx++) {
+                const u64 base = ((u64) y << np) + (((u64) limbs << np) * z);
+                const int raw = idx + shift;
+                u64 v = in[idx + base];
+                if ((raw >> np) & 1) v = c->mod[y].value - v;
+                out[(raw & mask) + base] = v;
+            }
+}

@@ -460,6 +460,65 @@ static void serializer_round_trip()
 // 14_ckks_serialization.cpp): byte layout of the headers (field order and widths of
 // */context.cu, secretkey.cu, publickey.cu, evaluationkey.cu, plaintext.cu save()), round trips
 // through default-constructed objects, and the loaded objects keep working.
+// BFV in the NTT domain (bfv/operator.cuh:884-1110): transform_to_ntt of ciphertext and plaintext,
+// pointwise multiply_plain, transform_from_ntt; multiply_power_of_X
+static void bfv_ntt_domain_and_shift()
+{
+    constexpr auto S = Scheme::BFV;
+    const int n = 8192, t = 65537;
+    HEContext<S> ctx = GenHEContext<S>();
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_default_values(1);
+    ctx->set_plain_modulus(t);
+    ctx->generate();
+    HEKeyGenerator<S> keygen(ctx, 6);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    HEEncoder<S> encoder(ctx);
+    HEEncryptor<S> encryptor(ctx, pk, 7);
+    HEDecryptor<S> decryptor(ctx, sk);
+    HEArithmeticOperator<S> op(ctx, encoder);
+    std::vector<uint64_t> m1(n), m2(n), got;
+    for (int i = 0; i < n; i++) { m1[i] = (uint64_t) (i * 7 + 1) % t; m2[i] = (uint64_t) (i * 13 + 5) % t; }
+    Plaintext<S> p1(ctx), p2(ctx), pr(ctx);
+    encoder.encode(p1, m1);
+    encoder.encode(p2, m2);
+    Ciphertext<S> c1(ctx), direct(ctx), viaNtt(ctx);
+    encryptor.encrypt(c1, p1);
+    op.multiply_plain(c1, p2, direct);
+    Ciphertext<S> cn(ctx);
+    op.transform_to_ntt(c1, cn);
+    EXPECT(cn.in_ntt_domain() && !c1.in_ntt_domain(), "transform_to_ntt sets the domain flag");
+    bool thrown = false;
+    try { op.multiply_plain(cn, p2, viaNtt); } catch (const std::logic_error&) { thrown = true; }
+    EXPECT(thrown, "NTT ciphertext x coefficient plaintext is refused");
+    op.transform_to_ntt_inplace(p2);
+    op.multiply_plain(cn, p2, viaNtt);
+    op.transform_from_ntt_inplace(viaNtt);
+    Vec a, b;
+    direct.get_data(a);
+    viaNtt.get_data(b);
+    EXPECT(a == b, "multiply_plain through the NTT domain == direct multiply_plain, bit for bit");
+    decryptor.decrypt(pr, viaNtt);
+    encoder.decode(got, pr);
+    bool ok = true;
+    for (int i = 0; i < n; i++) ok = ok && got[i] == m1[i] * m2[i] % t;
+    EXPECT(ok, "and decrypts to the slot-wise product");
+    // X^k on an un-batched message: coefficients move up by k with a sign flip on wrap-around
+    Plaintext<S> raw(ctx);
+    std::vector<Data64> poly(n, 0);
+    poly[0] = 5; poly[n - 1] = 9;
+    raw.load(poly, 0, 0);
+    Ciphertext<S> cx(ctx), sh(ctx);
+    encryptor.encrypt(cx, raw);
+    op.multiply_power_of_X(cx, sh, 3);
+    decryptor.decrypt(pr, sh);
+    pr.get_data(a);
+    EXPECT(a[3] == 5 && a[2] == (Data64) t - 9 && a[0] == 0, "multiply_power_of_X: 5 + 9 X^(N-1) -> 5 X^3 - 9 X^2");
+}
+
 static void serialize_all_objects()
 {
     constexpr auto S = Scheme::BFV;
@@ -686,6 +745,7 @@ int main()
     ckks_encoder_flow();
     serializer_round_trip();
     serialize_all_objects();
+    bfv_ntt_domain_and_shift();
     method_II_and_switch_key();
     tfhe_gates();
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);

@@ -245,3 +245,31 @@ def test_method_II_key_generation_bit_exact(hg, oracle, torch, scheme_name):
         rot = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
         c.ckks_apply_galois(ct, 2 * Q * n, rot, 2 * Q * n, gk, gal, 0, 1, c.workspace(hg.OP_CKKS_GALOIS, 0, 1))
         assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois_II(ct_o, gk_o, gal, 0)), "rotate with the generated key"
+
+
+def test_bfv_plain_ops_bit_exact(hg, oracle, torch):
+    """multiply_plain (bfv/operator.cu:432-503), transform_to_ntt of a plaintext (:1398-1431) and
+    multiply_power_of_X (switchkey.cu:1433-1457) against the oracle."""
+    n, t = 8192, 65537
+    c = hg.Context.from_bit_sizes(hg.BFV, n, [54, 54, 54], [55], plain_modulus=t, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    Q = 3
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, Q, 1, t)
+    c.upload()
+    g = np.random.default_rng(2)
+    plain = g.integers(0, t, n).astype(np.uint64)
+    plain[:4] = [0, t - 1, (t + 1) // 2, (t + 1) // 2 - 1]       # both sides of the threshold
+    ct = np.concatenate([oracle.fill_poly(40 + p, j, n, primes[j]) for p in range(2) for j in range(Q)])
+    assert np.array_equal(hg.to_host(c.bfv_plain_to_ntt(hg.to_device(plain))), o.bfv_plain_to_ntt(plain))
+    out = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    ws = c.workspace(hg.OP_BFV_MULTIPLY_PLAIN, 0, 1)
+    d_ct, d_plain = hg.to_device(ct), hg.to_device(plain)
+    rc = hg._lib.load().hegpu_bfv_multiply_plain(c._h, d_ct.data_ptr(), d_plain.data_ptr(), out.data_ptr(),
+                                                 ws.data_ptr(), ws.numel() * 8, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.array_equal(hg.to_host(out), o.bfv_multiply_plain(ct, plain))
+    for k in (0, 1, 100, n - 1, n, 2 * n - 1):
+        for parts, l in ((2, Q), (3, Q), (1, 2)):
+            sub = ct[:parts * l * n] if parts * l * n <= ct.size else np.concatenate([ct, ct[:Q * n]])
+            got = hg.to_host(c.negacyclic_shift(hg.to_device(sub), k, l, parts))
+            assert np.array_equal(got, o.negacyclic_shift(sub, k, l, parts)), (k, parts, l)

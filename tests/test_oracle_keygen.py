@@ -268,3 +268,41 @@ def test_bfv_batch_encoder_semantics(bfv):
     # end to end with encryption: encode -> encrypt -> decrypt -> decode
     ct = o.bfv_encrypt(rng, pk, pa)
     assert np.array_equal(o.bfv_decode(o.bfv_decrypt(ct, sk)), a.astype(np.uint64))
+
+
+def test_bfv_multiply_plain_and_power_of_x(bfv):
+    """multiply_plain (bfv/operator.cu:432-503), transform_to_ntt of a plaintext (:1398-1431) and
+    multiply_power_of_X (switchkey.cu:1433-1457), pinned by decryption: Enc(m) * p decrypts to the
+    negacyclic product mod t (centred lift of p), the NTT-domain route gives the same ciphertext, and
+    X^k shifts the message polynomial negacyclically."""
+    o, rng, sk, pk, t = bfv
+    n, Q = o.n, o.Q
+    g = np.random.default_rng(21)
+    m = g.integers(0, t, n).astype(np.uint64)
+    p = np.zeros(n, dtype=np.uint64)
+    p[0], p[1], p[5] = 3, t - 2, 7          # 3 - 2X + 7X^5
+    ct = o.bfv_encrypt(rng, pk, m)
+    prod = o.bfv_multiply_plain(ct, p)
+    want = np.array([(3 * int(m[i]) - 2 * (int(m[i - 1]) if i >= 1 else -int(m[n - 1]))
+                      + 7 * (int(m[i - 5]) if i >= 5 else -int(m[n + i - 5]))) % t for i in range(n)], dtype=np.uint64)
+    assert np.array_equal(o.bfv_decrypt(prod, sk), want)
+    # NTT-domain route: transform both, multiply pointwise, transform back
+    pn = o.bfv_plain_to_ntt(p)
+    ctn = ct.copy()
+    o.ntt(ctn, 2 * Q, Q)
+    primes = o.primes
+    for z in range(2):
+        for j in range(Q):
+            seg = slice((z * Q + j) * n, (z * Q + j + 1) * n)
+            ctn[seg] = np.array([(int(a) * int(b)) % primes[j] for a, b in zip(ctn[seg], pn[j * n:(j + 1) * n])],
+                                dtype=np.uint64)
+    o.ntt(ctn, 2 * Q, Q, inverse=True)
+    assert np.array_equal(ctn, prod)
+    for k in (1, 17, n - 1, n + 3):
+        sh = o.negacyclic_shift(ct, k, Q)
+        dec = o.bfv_decrypt(sh, sk)
+        want = np.zeros(n, dtype=np.uint64)
+        for i in range(n):
+            r = i + k
+            want[r % n] = m[i] if (r // n) % 2 == 0 else (t - int(m[i])) % t
+        assert np.array_equal(dec, want), k
