@@ -527,3 +527,51 @@ def test_cpp_api_writes_inside_its_buffers(torch):
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and "PASSED" in r.stdout
     assert "MemoryPool guard" not in r.stderr
+
+
+def test_operator_sequence_replays_from_a_hip_graph(hg, oracle, torch):
+    """The operator entry points neither allocate nor synchronise (caller workspace, caller stream), so a
+    fixed sequence is capturable: multiply -> relinearize -> rescale -> rotate recorded once into a hipGraph
+    (torch.cuda.CUDAGraph) and replayed on new inputs gives the oracle's results bit for bit (config C2
+    shapes; the reference's multi-stream manager, util/storagemanager.cuh, reimplemented on HIP streams)."""
+    n = 16384
+    c, o, primes = _ckks_pair(hg, oracle, n, [50] + [40] * 7, [50])
+    Q, Qp = 8, 9
+    key = synth_key(primes, Q, Qp, n, 3)
+    gal = hg.steps_to_galois_elt(1, n, 5)
+    gkey = synth_key(primes, Q, Qp, n, 4)
+    dkey, dgkey = hg.to_device(key), hg.to_device(gkey)
+    d1 = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    d2 = torch.empty_like(d1)
+    out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+    rot = torch.empty(2 * (Q - 1) * n, dtype=torch.int64, device="cuda")
+    ws_relin = c.workspace(hg.OP_CKKS_RELIN, 0, 1)
+    ws_resc = c.workspace(hg.OP_CKKS_RESCALE, 0, 1)
+    ws_gal = c.workspace(hg.OP_CKKS_GALOIS, 1, 1)
+
+    def sequence():
+        c.ckks_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, 0, 1)
+        c.ckks_relinearize_inplace(out, 3 * Q * n, dkey, 0, 1, ws_relin)
+        c.ckks_rescale_inplace(out, 3 * Q * n, 0, 1, ws_resc)
+        c.ckks_apply_galois(out, 2 * (Q - 1) * n, rot, 2 * (Q - 1) * n, dgkey, gal, 1, 1, ws_gal)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):   # warm up outside the capture (lazy module loading)
+        d1.zero_(); d2.zero_()
+        sequence()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequence()
+    for seed in (1, 5):
+        ct1 = synth_ct(primes, range(Q), 2, n, seed)
+        ct2 = synth_ct(primes, range(Q), 2, n, seed + 1)
+        d1.copy_(hg.to_device(ct1)); d2.copy_(hg.to_device(ct2))
+        graph.replay()
+        torch.cuda.synchronize()
+        w = o.ckks_multiply(ct1, ct2, 0)
+        o.ckks_relinearize(w, key, 0)
+        w = o.ckks_rescale(w[:2 * Q * n].copy(), 0)[:2 * (Q - 1) * n]
+        assert np.array_equal(hg.to_host(out)[:2 * (Q - 1) * n], w), "graph replay: multiply+relinearize+rescale"
+        assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois(w, gkey, gal, 1)), "graph replay: rotate"
