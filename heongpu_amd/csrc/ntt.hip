@@ -289,16 +289,22 @@ struct PolySel {
     int item, j;         // ciphertext of the batch, polynomial index inside it
 };
 
+// x / d for x < 2^16 with the host's magic = ceil(2^32 / d) (0: d == 1); scalar-ALU work
+__device__ __forceinline__ int udiv16(int x, unsigned magic)
+{
+    return magic ? (int) __umulhi((unsigned) x, magic) : x;
+}
+
 __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
 {
     PolySel s;
     if (a.group_span) {
         // modulus-major walk: grid index = k * span + r  ->  r-th polynomial
         // (in item-major order) among those with modulus slot k
-        const int k = poly / a.group_span, r = poly - k * a.group_span;
+        const int k = udiv16(poly, a.mg_group_span), r = poly - k * a.group_span;
         if (a.polys_per_item) {
-            const int per_item = a.polys_per_item / a.mod_count; // digits per item
-            const int it = r / per_item, d = r - it * per_item;
+            const int per_item = udiv16(a.polys_per_item, a.mg_mod_count); // digits per item
+            const int it = udiv16(r, a.mg_per_item), d = r - it * per_item;
             poly = it * a.polys_per_item + d * a.mod_count + k;
         } else {
             poly = r * a.mod_count + k;
@@ -306,14 +312,14 @@ __device__ __forceinline__ PolySel select_poly(const NttArgs& a, int poly)
     }
     int item = 0, j = poly;
     if (a.polys_per_item) {
-        item = poly / a.polys_per_item;
+        item = udiv16(poly, a.mg_polys_per_item);
         j = poly - item * a.polys_per_item;
     }
-    int k = j % a.mod_count;
+    int k = j - udiv16(j, a.mg_mod_count) * a.mod_count;
     if (a.mod_order) k = a.mod_order[k];
     s.mod = a.mod_offset + k;
     u64 slot = a.poly_order ? (u64) a.poly_order[j] : (u64) j;
-    s.digit = a.decomp_mods ? j / a.decomp_mods : -1;
+    s.digit = a.decomp_mods ? udiv16(j, a.mg_decomp_mods) : -1;
     u64 in_slot = a.decomp_mods ? (u64) s.digit * (a.decomp_in_mul ? a.decomp_in_mul : 1) + a.decomp_in_add : slot;
     s.in_off = (u64) item * a.in_item_stride + (in_slot << a.n_power);
     s.out_off = (u64) item * a.out_item_stride + (slot << a.n_power);
@@ -493,7 +499,7 @@ __device__ __forceinline__ void row_store(const NttArgs& a, const PolySel& ps, c
         return;
     }
     const NttEpilogue& ep = a.epi;
-    const int part = ps.j / ep.limbs, limb = ps.j - part * ep.limbs;
+    const int part = udiv16(ps.j, ep.mg_limbs), limb = ps.j - part * ep.limbs;
     const u64 ks = ep.ks[ep.ks_item_stride * ps.item + ((u64) (part * ep.ks_part_limbs + limb) << a.n_power) + e];
     const u64 off = ((u64) (part * ep.limbs + limb) << a.n_power) + e;
     u64 r = mul_barrett(sub_mod(ks, x, md.q), ep.inv[ps.mod], md);
@@ -948,6 +954,18 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
     hipLaunchKernelGGL(ntt_inv_col<S1>, dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, b);
 }
 
+static unsigned magic16(int d) { return d <= 1 ? 0u : (unsigned) ((0x100000000ull + (unsigned) d - 1) / (unsigned) d); }
+// divisors of select_poly; every dividend is a grid index (< 65536) or polys_per_item (<= batch)
+static void fill_magics(NttArgs& g)
+{
+    g.mg_group_span = magic16(g.group_span);
+    g.mg_mod_count = magic16(g.mod_count);
+    g.mg_per_item = magic16(g.mod_count ? g.polys_per_item / g.mod_count : 0);
+    g.mg_polys_per_item = magic16(g.polys_per_item);
+    g.mg_decomp_mods = magic16(g.decomp_mods);
+    g.epi.mg_limbs = magic16(g.epi.limbs);
+}
+
 hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
@@ -956,6 +974,7 @@ hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st)
     g.group_span = 0;
     if (a.mod_count > 1 && batch % a.mod_count == 0 && (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
         g.group_span = batch / a.mod_count;
+    fill_magics(g);
     switch (a.n_power - 8) {
         case 4: launch_fwd_col_only<4>(g, batch, st); break;
         case 5: launch_fwd_col_only<5>(g, batch, st); break;
@@ -1001,6 +1020,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (!a.poly_order && a.mod_count > 1 && batch % a.mod_count == 0 &&
         (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
         g.group_span = batch / a.mod_count;
+    fill_magics(g);
     switch (a.n_power - 8) {
 #define CASE(S)                                   \
     case S:                                       \

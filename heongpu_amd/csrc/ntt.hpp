@@ -24,6 +24,7 @@ struct NttEpilogue {
     const u64* inv;     // per-modulus P^-1
     int limbs;
     int on;
+    unsigned mg_limbs; // set by ntt_launch: ceil(2^32 / limbs), see NttArgs::mg_*
 };
 
 struct NttArgs {
@@ -67,6 +68,11 @@ struct NttArgs {
     // (all polynomials of one modulus back to back) so that concurrently
     // running workgroups share one modulus' twiddle table in L2.
     int group_span; // polynomials per modulus class = batch / mod_count
+    // Set by ntt_launch: ceil(2^32 / d) for the wave-uniform divisions of select_poly (dividends are
+    // below 2^16 -- gridDim.y -- so mulhi(x, magic) == x / d exactly; 0 stands for d == 1).  The
+    // compiler's own expansion of an integer division runs on the vector ALU even for uniform
+    // operands: ~20 instructions each, 12 % of the FP64 column pass.
+    unsigned mg_group_span, mg_per_item, mg_polys_per_item, mg_mod_count, mg_decomp_mods;
     NttEpilogue epi; // forward only, needs polys_per_item
     // Decomposing launches read digit d from input slot d * decomp_in_mul + decomp_in_add
     // (0 means 1 / 0).  half_on: the loaded residue v of modulus `half_src_mod` becomes

@@ -438,16 +438,16 @@ def test_reference_benchmark_runs_unchanged(torch, name):
 _EXAMPLE_EXPECT = {
     "1_basic_bfv": ["[1,144,529,961,64,...,64,64,64,64,64]", "[49,2916,36,10000,64,...,64,64,64,64,64]",
                     "[6,864,3174,5766,384,...,384,384,384,384,384]", "[294,17496,216,60000,384,...,384,384,384,384,384]"],
-    "2_basic_ckks": ["[100.000,400.000,900.000,1600.000,...,9.000,9.000,9.000,9.000]",
-                     "[50.000,200.000,450.000,800.000,...,4.500,4.500,4.500,4.500]"],
+    "2_basic_ckks": [(100.0, 400.0, 900.0, 1600.0, 9.0, 9.0, 9.0, 9.0), (50.0, 200.0, 450.0, 800.0, 4.5, 4.5, 4.5, 4.5)],
     "3_basic_memorypool_config": ["Q_tiltasize:Q(60+30+30+30)+P(60)bits", "DeviceMemoryPool"],
     "4_switchkey_methods_bfv": ["Checkresult4:[10000,64,64,64,64,...,64,64,49,2916,36][961,64,64,64,64,...,64,64,1,144,529]"],
-    "5_switchkey_methods_ckks": ["Checkcheck3:[1600.000,0.250,9.000,9.000,...,9.000,100.000,400.000,900.000]"],
+    "5_switchkey_methods_ckks": ["Checkcheck3:", (1600.0, 0.25, 9.0, 9.0, 9.0, 100.0, 400.0, 900.0)],
     "8_default_stream_usage": ["Done."],
     "9_multi_stream_usage_way1": ["Done."],
     "10_multi_stream_usage_way2": ["Done."],
     "13_bfv_serialization": ["[961,64,64,64,64,...,64,64,1,144,529][10000,64,64,64,64,...,64,64,49,2916,36]"],
-    "14_ckks_serialization": ["[1600.000,0.250,9.000,9.000,...,9.000,100.00", ",400.000,900.000]"],
+    # scale 2^30: the third decimal depends on the encryption noise -> compared numerically below
+    "14_ckks_serialization": [(1600.0, 0.25, 9.0, 9.0, 9.0, 100.0, 400.0, 900.0)],
     "15_basic_tfhe": None,
 }
 
@@ -485,7 +485,11 @@ def test_reference_example_runs_unchanged(torch, name):
         assert bits("MUX (Decrypted):") == [x if s else y for x, y, s in zip(a, b, c)]
         return
     for want in _EXAMPLE_EXPECT[name]:
-        assert want in flat, want
+        if isinstance(want, tuple):   # a displayed vector of doubles, to 0.01
+            rows = [[float(v) for v in re.findall(r"-?\d+\.\d+", m)] for m in re.findall(r"\[([^\]]*)\]", r.stdout)]
+            assert any(len(row) == len(want) and all(abs(a - b) < 1e-2 for a, b in zip(row, want)) for row in rows), rows
+        else:
+            assert want in flat, want
 
 
 _REFERENCE_TESTS = ["test_bfv_addition", "test_bfv_encoding", "test_bfv_encryption", "test_bfv_multiplication",
