@@ -104,3 +104,27 @@ dt = timeit(bm, max(3, args.reps // 4))
 print(f"   BFV N=2^15 multiply+relinearize, {B} ciphertexts: {dt*1e3:.2f} ms  ({B/dt:.0f} op/s)")
 dtm = timeit(lambda: ctx.bfv_multiply(ct, 2 * Q * n, ct2, 2 * Q * n, o3, 3 * Q * n, B, wsm), max(3, args.reps // 4))
 print(f"   (multiply alone: {dtm*1e3:.2f} ms)")
+ctx.close()
+del ct, ct2, out, o3, key, ws, wsm, wsr
+
+# ---- north_star's second target: BFV N=2^14 (default 128-bit chain) homomorphic multiplications per second
+n, t, B = 1 << 14, 786433, 256
+ctx = hg.Context.from_default(hg.BFV, n, 1, plain_modulus=t)
+ctx.upload()
+Q, Qp = ctx.Q_size, ctx.Q_prime_size
+ct, ct2 = rnd(2 * Q * n * B), rnd(2 * Q * n * B)
+o3 = torch.empty(3 * Q * n * B, dtype=torch.int64, device="cuda")
+key = rnd(Q * 2 * Qp * n)
+wsm = ctx.workspace(hg.OP_BFV_MULTIPLY, 0, B)
+wsr = ctx.workspace(hg.OP_BFV_RELIN, 0, B)
+
+
+def bm14():
+    ctx.bfv_multiply(ct, 2 * Q * n, ct2, 2 * Q * n, o3, 3 * Q * n, B, wsm)
+    ctx.bfv_relinearize_inplace(o3, 3 * Q * n, key, B, wsr)
+
+
+dt = timeit(bm14, max(3, args.reps // 4))
+print(f"BFV N=2^14 Q={Q} P=1 multiply+relinearize, {B} ciphertexts: {dt*1e3:.2f} ms  ({B/dt:.0f} op/s)")
+dtm = timeit(lambda: ctx.bfv_multiply(ct, 2 * Q * n, ct2, 2 * Q * n, o3, 3 * Q * n, B, wsm), max(3, args.reps // 4))
+print(f"   (multiply alone: {dtm*1e3:.2f} ms = {B/dtm:.0f} mult/s)")
