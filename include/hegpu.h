@@ -201,7 +201,9 @@ int hegpu_generate_secret_key(hegpu_context* ctx, hegpu_rng* rng, int hamming_we
 /* generate_public_key (keygenerator.cu:167-240, kernel/keygeneration.cu:93-116); pk [2][Q'][N] */
 int hegpu_generate_public_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* pk, void* ws,
                               size_t ws_bytes, hegpu_stream stream);
-/* generate_relin_key_method_I (keygenerator.cu:242-324, keygeneration.cu:145-185); rk [Q][2][Q'][N] */
+/* generate_relin_key_method_I / _II (keygenerator.cu:242-414, keygeneration.cu:145-185, 584-629);
+ * rk [d][2][Q'][N], d = Q (method I, P_size == 1) or the number of digits of the depth-0 partition
+ * (method II: ceil(Q / P_size) for CKKS, ceil(Q / 2) for BFV) */
 int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* rk, void* ws,
                              size_t ws_bytes, hegpu_stream stream);
 /* generate_galois_key_method_I, one element (keygenerator.cu:415-560, keygeneration.cu:742-805) */

@@ -1269,7 +1269,7 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
 };
 
 // ------------------------------------------------------------------ key generator / encryptor / decryptor
-// Key-switching method I (P_size == 1).  Random values come from the backend's DRBG
+// Key-switching methods I and II (one or several special primes).  Random values come from the backend's DRBG
 // (csrc/drbg.hpp); like the reference's generator it is seeded from std::random_device unless
 // a seed is given.
 template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
