@@ -206,11 +206,13 @@ int hegpu_generate_public_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t
  * (method II: ceil(Q / P_size) for CKKS, ceil(Q / 2) for BFV) */
 int hegpu_generate_relin_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, uint64_t* rk, void* ws,
                              size_t ws_bytes, hegpu_stream stream);
-/* generate_galois_key_method_I, one element (keygenerator.cu:415-560, keygeneration.cu:742-805) */
-/* HEKeyGenerator::generate_switch_key (ckks/keygenerator.cu:996-1095, switchkey_gen_kernel
- * keygeneration.cu:896-939): key under new_sk that carries old_sk; layout of a relinearisation key */
+/* HEKeyGenerator::generate_switch_key (ckks/keygenerator.cu:996-1250, switchkey_gen_kernel /
+ * switchkey_gen_II_kernel keygeneration.cu:896-989): key under new_sk that carries old_sk; layout of a
+ * relinearisation key */
 int hegpu_generate_switch_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* new_sk, const uint64_t* old_sk,
                               uint64_t* swk, void* ws, size_t ws_bytes, hegpu_stream stream);
+/* generate_galois_key_method_I / _II, one element (keygenerator.cu:415-990, galoiskey_gen_kernel /
+ * galoiskey_gen_II_kernel keygeneration.cu:742-858) */
 int hegpu_generate_galois_key(hegpu_context* ctx, hegpu_rng* rng, const uint64_t* sk, int galois_elt, uint64_t* gk,
                               void* ws, size_t ws_bytes, hegpu_stream stream);
 /* HEEncryptor<CKKS>::encrypt_ckks (src/lib/host/ckks/encryptor.cu:36-110); plain [Q][N], ct [2][Q][N] */
