@@ -579,3 +579,55 @@ def test_operator_sequence_replays_from_a_hip_graph(hg, oracle, torch):
         w = o.ckks_rescale(w[:2 * Q * n].copy(), 0)[:2 * (Q - 1) * n]
         assert np.array_equal(hg.to_host(out)[:2 * (Q - 1) * n], w), "graph replay: multiply+relinearize+rescale"
         assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois(w, gkey, gal, 1)), "graph replay: rotate"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_parameter_sets(hg, oracle, torch, seed):
+    """Seeded random CKKS parameter sets -- degree, number of primes, prime widths on both sides of the
+    FP64 / integer split (2^50) and of the lazy-butterfly split (2^57), key-switching method, depth,
+    batch -- through multiply -> relinearize -> rescale -> rotate, bit for bit against the oracle."""
+    g = np.random.default_rng(1000 + seed)
+    n = int(g.choice([4096, 8192, 16384]))
+    Q = int(g.integers(2, 9))
+    P = 1 if seed % 3 else 2
+    widths = [30, 36, 40, 45, 49, 50, 51, 53, 57, 58, 60]
+    log_q = [int(g.choice(widths)) for _ in range(Q)]
+    log_p = [max(log_q)] * P if P == 1 else [max(max(log_q), 45)] * P
+    log_p = [min(60, b + (1 if P == 1 else 0)) for b in log_p]
+    try:
+        c, o, primes = _ckks_pair(hg, oracle, n, log_q, log_p, sec=hg.SEC_NONE)
+    except hg.HEError as e:            # "P should be bigger than Q pairs" for some draws
+        pytest.skip(str(e))
+    Qp = Q + P
+    depth = int(g.integers(0, max(1, Q - 1)))
+    l = Q - depth
+    batch = int(g.integers(1, 4))
+    rg, ro = hg.Rng(seed), oracle.ORng(seed)
+    sk, sk_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    rk, rk_o = c.generate_relin_key(rg, sk), o.gen_switch_key(ro, sk_o, 0)
+    gal = hg.steps_to_galois_elt(int(g.integers(1, 9)), n, 5)
+    gk, gk_o = c.generate_galois_key(rg, sk, gal), o.gen_switch_key(ro, sk_o, gal)
+    assert np.array_equal(hg.to_host(rk), rk_o) and np.array_equal(hg.to_host(gk), gk_o)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b + seed) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b + seed) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * l * n, d2, 2 * l * n, out, 3 * l * n, depth, batch)
+    c.ckks_relinearize_inplace(out, 3 * l * n, rk, depth, batch, c.workspace(hg.OP_CKKS_RELIN, depth, batch))
+    relin_o = o.ckks_relinearize if P == 1 else o.ckks_relinearize_II
+    galois_o = o.ckks_apply_galois if P == 1 else o.ckks_apply_galois_II
+    want = [relin_o(o.ckks_multiply(ct1[b], ct2[b], depth), rk_o, depth)[:2 * l * n] for b in range(batch)]
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b][:2 * l * n], want[b]), ("relinearize", n, log_q, log_p, depth, b)
+    rot = torch.empty(batch * 2 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(d1, 2 * l * n, rot, 2 * l * n, gk, gal, depth, batch, c.workspace(hg.OP_CKKS_GALOIS, depth, batch))
+    got = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], galois_o(ct1[b], gk_o, gal, depth)), ("rotate", n, log_q, log_p, depth, b)
+    if l >= 2:
+        c.ckks_rescale_inplace(out, 3 * l * n, depth, batch, c.workspace(hg.OP_CKKS_RESCALE, depth, batch))
+        got = hg.to_host(out).reshape(batch, -1)
+        for b in range(batch):
+            w = o.ckks_rescale(want[b].copy(), depth)
+            assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), ("rescale", n, log_q, log_p, depth)
