@@ -631,3 +631,51 @@ def test_random_parameter_sets(hg, oracle, torch, seed):
         for b in range(batch):
             w = o.ckks_rescale(want[b].copy(), depth)
             assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), ("rescale", n, log_q, log_p, depth)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_bfv_parameter_sets(hg, oracle, torch, seed):
+    """Seeded random BFV parameter sets (degree, prime count and widths, plain modulus, key-switching method,
+    batch) through multiply (BEHZ) -> relinearize -> rotate, bit for bit against the oracle."""
+    g = np.random.default_rng(2000 + seed)
+    n = int(g.choice([4096, 8192, 16384]))
+    Q = int(g.integers(2, 7))
+    P = 1 if seed % 2 else 2
+    w = int(g.choice([36, 40, 45, 50, 54, 58, 59]))
+    log_q = [w] * Q
+    log_p = [min(60, w + 1)] * P
+    t = int(g.choice([65537, 786433, 1032193]))
+    try:
+        c = hg.Context.from_bit_sizes(hg.BFV, n, log_q, log_p, plain_modulus=t, sec=hg.SEC_NONE)
+    except hg.HEError as e:
+        pytest.skip(str(e))
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, Q, P, t)
+    c.upload()
+    Qp = Q + P
+    batch = int(g.integers(1, 4))
+    rg, ro = hg.Rng(50 + seed), oracle.ORng(50 + seed)
+    sk, sk_o = c.generate_secret_key(rg), o.gen_secret_key(ro)
+    rk, rk_o = c.generate_relin_key(rg, sk), o.gen_switch_key(ro, sk_o, 0)
+    gal = hg.steps_to_galois_elt(int(g.integers(1, 9)), n, 3)
+    gk, gk_o = c.generate_galois_key(rg, sk, gal), o.gen_switch_key(ro, sk_o, gal)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 3 + 10 * b + seed) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 4 + 10 * b + seed) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+    want = [o.bfv_multiply(ct1[b], ct2[b]) for b in range(batch)]
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], want[b]), ("multiply", n, log_q, log_p, t, b)
+    c.bfv_relinearize_inplace(out, 3 * Q * n, rk, batch, c.workspace(hg.OP_BFV_RELIN, 0, batch))
+    relin_o = o.bfv_relinearize if P == 1 else o.bfv_relinearize_II
+    galois_o = o.bfv_apply_galois if P == 1 else o.bfv_apply_galois_II
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b][:2 * Q * n], relin_o(want[b].copy(), rk_o)[:2 * Q * n]), ("relinearize", n, log_q, log_p)
+    rot = torch.empty(batch * 2 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_apply_galois(d1, 2 * Q * n, rot, 2 * Q * n, gk, gal, batch, c.workspace(hg.OP_BFV_GALOIS, 0, batch))
+    got = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], galois_o(ct1[b], gk_o, gal)), ("rotate", n, log_q, log_p)
