@@ -30,3 +30,17 @@ for mib in (512, 8704):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print("sum  %5d MiB: %7.3f ms  %6.0f GB/s (read only)" % (mib, ms, n * 8 / (ms * 1e-3) / 1e9))
+# write-only stream
+for mib in (512, 8704):
+    n = mib * (1 << 20) // 8
+    dst = torch.empty(n, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        dst.fill_(7)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.fill_(7)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("fill %5d MiB: %7.3f ms  %6.0f GB/s (write only)" % (mib, ms, n * 8 / (ms * 1e-3) / 1e9))
