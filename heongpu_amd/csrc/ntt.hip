@@ -736,6 +736,25 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
     const u64 dig_off = (u64) a.rc << a.n_power;
     const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
 
+    // The 30 twiddles a lane needs do not depend on the digit.  Fetched from the tables inside the
+    // loop they cost ~25 exposed L2 latencies per digit (the table slice of a workgroup, 65 KiB, does
+    // not fit the 32 KiB L1) and the SIMDs issued only 48 % of the time; 120 more registers are not
+    // available.  So they are parked in LDS once per workgroup: the 15 of the last four stages are
+    // private to the lane (slot k at [k][t]), the 15 of the first four are shared by the 16 lanes of
+    // a row ([k][row], written by lane i0 == k).  Only w is kept; its companion RN(w/q) is
+    // recomputed as w * RN(1/q) when the twiddle is used (one multiply per twiddle; the quotient
+    // estimate stays within 0.63 of the exact one, so |x| <= 4.1 q < 2^53 after four stages).
+    __shared__ double twl[15 * 256 + 15 * 16];
+#pragma unroll
+    for (int k = 0; k < 15; k++) twl[k * 256 + t] = as_f64(tb[k * 16].x);
+    if (i0 < 15) {
+        // slot i0 = (1 << s) - 1 + b of local stage s
+        const int s = (i0 >= 7) ? 3 : (i0 >= 3) ? 2 : (i0 >= 1) ? 1 : 0;
+        const int b = i0 - ((1 << s) - 1);
+        twl[15 * 256 + i0 * 16 + row] = as_f64(tw[((((u32) 1 << s1) + crow) << s) + b].x);
+    }
+    wave_lds_fence(); // every value is read back by the wavefront that wrote it
+
     double a0[16], a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a0[k] = a1[k] = 0.0;
@@ -760,7 +779,19 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);
-            fp_ct_radix<4>(x, tw, (1u << s1) + crow, fc);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int half = 8 >> s;
+#pragma unroll
+                for (int b = 0; b < (1 << s); b++) {
+                    const double w = twl[15 * 256 + ((1 << s) - 1 + b) * 16 + row];
+                    const ulonglong2 wp = make_ulonglong2(as_bits(w), as_bits(w * fc.qi));
+#pragma unroll
+                    for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
             wave_lds_fence();
@@ -776,7 +807,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
                 const int half = 8 >> s;
 #pragma unroll
                 for (int b = 0; b < (1 << s); b++) {
-                    const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+                    const double wd = twl[((1 << s) - 1 + b) * 256 + t];
+                    const ulonglong2 w = make_ulonglong2(as_bits(wd), as_bits(wd * fc.qi));
 #pragma unroll
                     for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
                 }
