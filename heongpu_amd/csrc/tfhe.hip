@@ -359,8 +359,10 @@ __device__ __forceinline__ void f_gs(double& x, double& y, ulonglong2 w, const F
 // |x| <= p'.  Out: x[k] = slot 16*lane + k, centred (|x| <= p'/2).  Magnitudes
 // grow by at most 0.51 p' per stage (10 stages: < 7 p' < 2^47): no reduction
 // before the end.
+// `twl`: the same table for the lane-dependent twiddles (stages 4..9); the blind rotate passes an LDS copy
+// (the 27 per-lane loads of every transform are loop-invariant and otherwise come from L2 630 times)
 __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const ulonglong2* __restrict__ tw,
-                                              const FC& c, int lane)
+                                              const ulonglong2* twl, const FC& c, int lane)
 {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -383,7 +385,7 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
         const int half = 8 >> s;
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
-            const ulonglong2 w = tw[((16 + b) << s) + bb];
+            const ulonglong2 w = twl[((16 + b) << s) + bb];
 #pragma unroll
             for (int j = 0; j < half; j++) f_ct(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
         }
@@ -396,10 +398,10 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
     for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(16 * lane + k)]);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const ulonglong2 w8 = tw[256 + 4 * lane + g];
+        const ulonglong2 w8 = twl[256 + 4 * lane + g];
         f_ct(x[4 * g + 0], x[4 * g + 2], w8, c);
         f_ct(x[4 * g + 1], x[4 * g + 3], w8, c);
-        const ulonglong2 w9a = tw[512 + 8 * lane + 2 * g], w9b = tw[512 + 8 * lane + 2 * g + 1];
+        const ulonglong2 w9a = twl[512 + 8 * lane + 2 * g], w9b = twl[512 + 8 * lane + 2 * g + 1];
         f_ct(x[4 * g + 0], x[4 * g + 1], w9a, c);
         f_ct(x[4 * g + 2], x[4 * g + 3], w9b, c);
     }
@@ -414,14 +416,15 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
 // applied.  The un-multiplied outputs double per stage: 2.2 p' -> 141 p' < 2^52
 // after six stages, one centred reduction, then 8 p' before the last stage.
 __device__ __forceinline__ void fwave_intt1024(double (&x)[16], u64* buf, const ulonglong2* __restrict__ itw,
-                                               ulonglong2 ninv, ulonglong2 w1ninv, const FC& c, int lane)
+                                               const ulonglong2* itwl, ulonglong2 ninv, ulonglong2 w1ninv,
+                                               const FC& c, int lane)
 {
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const ulonglong2 w9a = itw[512 + 8 * lane + 2 * g], w9b = itw[512 + 8 * lane + 2 * g + 1];
+        const ulonglong2 w9a = itwl[512 + 8 * lane + 2 * g], w9b = itwl[512 + 8 * lane + 2 * g + 1];
         f_gs(x[4 * g + 0], x[4 * g + 1], w9a, c);
         f_gs(x[4 * g + 2], x[4 * g + 3], w9b, c);
-        const ulonglong2 w8 = itw[256 + 4 * lane + g];
+        const ulonglong2 w8 = itwl[256 + 4 * lane + g];
         f_gs(x[4 * g + 0], x[4 * g + 2], w8, c);
         f_gs(x[4 * g + 1], x[4 * g + 3], w8, c);
     }
@@ -436,7 +439,7 @@ __device__ __forceinline__ void fwave_intt1024(double (&x)[16], u64* buf, const 
         const int half = 8 >> s;
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
-            const ulonglong2 w = itw[((16 + b) << s) + bb];
+            const ulonglong2 w = itwl[((16 + b) << s) + bb];
 #pragma unroll
             for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
         }
@@ -506,8 +509,8 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
         hi[k] = (double) (vi >> 16);
     }
     if (oob) atomicOr(bad, 1);
-    fwave_ntt1024(lo, buf, p.ftw, fc, lane);
-    fwave_ntt1024(hi, buf, p.ftw, fc, lane);
+    fwave_ntt1024(lo, buf, p.ftw, p.ftw, fc, lane);
+    fwave_ntt1024(hi, buf, p.ftw, p.ftw, fc, lane);
     u64* d = dst + pi * 2 * TF_N;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -535,8 +538,16 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
     __shared__ int acc[TF_G][2][TF_N];
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
+    // lane-dependent twiddles of both transforms (entries 16..1023; (w, companion) pairs, 2 x 16 KiB)
+    constexpr bool TW_LDS = (TF_G == 1); // the experimental multi-gate variant has no LDS left for them
+    __shared__ ulonglong2 twf[TW_LDS ? TF_N : 1], twi[TW_LDS ? TF_N : 1];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int y = wv >> 1, z = wv & 1;
+    if (TW_LDS)
+        for (int j = t; j < TF_N; j += TF_THREADS) {
+            twf[j] = p.ftw[j];
+            twi[j] = p.fitw[j];
+        }
     const int g0 = blockIdx.x * TF_G;
     const int ng = (shape - g0 < TF_G) ? shape - g0 : TF_G;
     const int n = p.n;
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
                 x[k] = (double) d;
             }
-            fwave_ntt1024(x, buf[wv], p.ftw, fc, lane);
+            fwave_ntt1024(x, buf[wv], p.ftw, TW_LDS ? twf : p.ftw, fc, lane);
             // x is the "twiddle" of the products: companion RN(x/p') ~ x * RN(1/p'), recomputed
             // per product (one multiply) rather than held in 32 more registers
             // own output first (plain store into the own staging area, free after the transform)
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = as_f64(buf[wv][k * 64 + lane]);
             wave_fence();
-            fwave_intt1024(x, buf[wv], p.fitw, p.fninv, p.fw1ninv, fc, lane);
+            fwave_intt1024(x, buf[wv], p.fitw, TW_LDS ? twi : p.fitw, p.fninv, p.fw1ninv, fc, lane);
             // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
 #pragma unroll
             for (int k = 0; k < 16; k++)
