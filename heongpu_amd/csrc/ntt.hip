@@ -413,7 +413,8 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
 // FP64 column pass (Mod::fp).  Output: centred residues as raw doubles -- the
 // row pass of the same modulus consumes them as such.
 template <int S1, bool DECOMP, bool WIDE>
-__device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
+__device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds,
+                                                ulonglong2* twl)
 {
     constexpr int R = 1 << S1;
     constexpr int CT = 4096 / R;
@@ -451,6 +452,11 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     double x[16];
     const int col = t % CT, r1 = t / CT;
     if constexpr (NSA > 0) {
+        // The second register round needs tw[((RA + r1) << s) + b], s < 4: 15 entries per lane, all inside
+        // tw[RA .. 16 RA).  One coalesced 16-byte load per thread, issued with the coefficients and handed
+        // over through LDS at the barrier the exchange needs anyway, replaces 15 dependent L2 round trips.
+        // (indices stay below 16 RA <= 256 for every S1)
+        const ulonglong2 mine = tw[t];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int L = t + NTT_THREADS * g;
@@ -462,14 +468,16 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
         }
+        twl[t] = mine;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = as_f64(lds[col_phys((16 * r1 + k) * CT + col)]);
+        fp_ct_radix<4>(x, twl, (u32) (RA + r1), fc);
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = load(&src[(u64) k * 256 + col]);
+        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
     }
-    fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(u64) (16 * r1 + k) * 256 + col] = as_bits(x[k]);
 }
@@ -478,13 +486,14 @@ template <int S1, bool DECOMP>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
 {
     __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
+    __shared__ ulonglong2 twl[(S1 > 4) ? 256 : 1]; // second-round twiddles of the FP64 path
     const PolySel ps = select_poly(a, blockIdx.y);
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.fp) {
         if (DECOMP && a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52)
-            fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds);
-        else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds);
+            fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds, twl);
+        else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds, twl);
     } else if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
