@@ -630,12 +630,22 @@ __device__ __forceinline__ void acc128(u64& hi, u64& lo, u64 a, u64 b)
 
 template <bool LAZY>
 __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict__ p, u64* lds,
-                                             const ulonglong2* __restrict__ tw, const ulonglong2* __restrict__ tb,
-                                             u32 root_a, const QC& qc, const Mod& md, int row, int i0)
+                                             const ulonglong2* twa, const ulonglong2* __restrict__ tb,
+                                             const QC& qc, const Mod& md, int row, int i0)
 {
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = gld(&p[row * 256 + i0 + 16 * k]);
-    ct_radix<4, LAZY>(x, tw, root_a, qc);
+    // first four stages: the row's 15 twiddles from LDS (slot (1 << s) - 1 + b at [slot][row])
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = twa[((1 << s) - 1 + b) * 16 + row];
+#pragma unroll
+            for (int j = 0; j < half; j++) ct_bfly<LAZY>(x[b * 2 * half + j], x[b * 2 * half + j + half], w, qc);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = x[k];
     wave_lds_fence();
@@ -687,6 +697,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
     const u64 dig_off = (u64) a.rc << a.n_power;
     const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
     const bool lazy = md.bit <= NTT_LAZY_BITS;
+    // digit-invariant twiddles of the first four stages, shared by the 16 lanes of a row (see
+    // ks_row_mac_fp; the per-lane ones of the last four stages would need 61 KiB as pairs)
+    __shared__ ulonglong2 twa[15 * 16];
+    if (i0 < 15) {
+        const int s = (i0 >= 7) ? 3 : (i0 >= 3) ? 2 : (i0 >= 1) ? 1 : 0;
+        twa[i0 * 16 + row] = tw[((((u32) 1 << s1) + crow) << s) + (i0 - ((1 << s) - 1))];
+    }
+    wave_lds_fence();
 
     u64 h0[16], l0[16], h1[16], l1[16];
 #pragma unroll
@@ -699,9 +717,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = gld(&pi[row * 256 + i0 + 16 * k]);
         } else if (lazy) {
-            ks_row_digit<true>(x, p, lds, tw, tb, (1u << s1) + crow, qc, md, row, i0);
+            ks_row_digit<true>(x, p, lds, twa, tb, qc, md, row, i0);
         } else {
-            ks_row_digit<false>(x, p, lds, tw, tb, (1u << s1) + crow, qc, md, row, i0);
+            ks_row_digit<false>(x, p, lds, twa, tb, qc, md, row, i0);
         }
         const u64* k0 = pk + key_off2 * i;
         const u64* k1 = k0 + key_off1;
