@@ -456,6 +456,60 @@ static void serializer_round_trip()
     EXPECT(thrown, "a BFV-tagged binary is rejected by a CKKS ciphertext");
 }
 
+// MemoryPool (the class layer's caching allocator, util/memorypool.cuh in the reference): blocks are reused,
+// a block freed on one stream and taken on another is ordered by its event, and the cache can be dropped.
+__global__ void fill_pattern(unsigned long long* p, size_t n, unsigned long long v)
+{
+    const size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v + i;
+}
+static void memory_pool()
+{
+    MemoryPool& pool = MemoryPool::instance();
+    hipStream_t s1, s2;
+    hipStreamCreate(&s1);
+    hipStreamCreate(&s2);
+    const size_t n = (size_t) 3 << 20; // 24 MiB
+    void* a = pool.allocate(n * 8, s1);
+    pool.deallocate(a, n * 8, s1);
+    void* b = pool.allocate(n * 8, s1);
+    EXPECT(a == b, "a freed block is handed out again for the same size");
+    pool.deallocate(b, n * 8, s1);
+    // cross-stream reuse: a long kernel on s1 writes the block, it is freed on s1 and taken on s2, whose
+    // kernel must run after the first one (the second pattern survives)
+    bool ok = true;
+    std::vector<unsigned long long> h(n);
+    for (int round = 0; round < 8 && ok; round++) {
+        unsigned long long* x = (unsigned long long*) pool.allocate(n * 8, s1);
+        for (int rep = 0; rep < 20; rep++) fill_pattern<<<(unsigned) ((n + 255) / 256), 256, 0, s1>>>(x, n, 1000 + rep);
+        pool.deallocate(x, n * 8, s1);
+        unsigned long long* y = (unsigned long long*) pool.allocate(n * 8, s2);
+        fill_pattern<<<(unsigned) ((n + 255) / 256), 256, 0, s2>>>(y, n, 7);
+        hipMemcpyAsync(h.data(), y, n * 8, hipMemcpyDeviceToHost, s2);
+        hipStreamSynchronize(s2);
+        ok = ok && (x == y) && h[0] == 7 && h[n - 1] == 7 + n - 1 && h[n / 2] == 7 + n / 2;
+        pool.deallocate(y, n * 8, s2);
+    }
+    EXPECT(ok, "block freed on one stream and reused on another: the later kernel wins");
+    // different sizes get different live blocks, nothing overlaps
+    std::vector<std::pair<char*, size_t>> live;
+    for (size_t sz : {(size_t) 11010048, (size_t) 22020096, (size_t) 33030144, (size_t) 11534336, (size_t) 512, (size_t) 4096})
+        live.push_back({(char*) pool.allocate(sz, s1), sz});
+    bool disjoint = true;
+    for (size_t i = 0; i < live.size(); i++)
+        for (size_t j = i + 1; j < live.size(); j++)
+            disjoint = disjoint && (live[i].first + live[i].second <= live[j].first || live[j].first + live[j].second <= live[i].first);
+    EXPECT(disjoint, "live buffers do not overlap (the ROCm stream-ordered pool's failure, tools/hip_pool_repro.cpp)");
+    for (auto& l : live) pool.deallocate(l.first, l.second, s1);
+    hipDeviceSynchronize();
+    pool.release_cached();
+    void* c = pool.allocate(n * 8, s1);
+    EXPECT(c != nullptr, "allocation after the cache was released");
+    pool.deallocate(c, n * 8, s1);
+    hipStreamDestroy(s1);
+    hipStreamDestroy(s2);
+}
+
 // Every serializable object of the reference (example/basic/13_bfv_serialization.cpp,
 // 14_ckks_serialization.cpp): byte layout of the headers (field order and widths of
 // */context.cu, secretkey.cu, publickey.cu, evaluationkey.cu, plaintext.cu save()), round trips
@@ -743,6 +797,7 @@ int main()
     ckks_pipeline();
     bfv_pipeline();
     ckks_encoder_flow();
+    memory_pool();
     serializer_round_trip();
     serialize_all_objects();
     bfv_ntt_domain_and_shift();
