@@ -305,6 +305,21 @@ void Context::build_host()
         host["inv_punctured_prod_mod_B_array"] = inv_punct_B;
         host["inv_prod_B_mod_m_sk"] = vec{inv_mod_prime(prod_B_msk, msk)};
         host["prod_B_mod_q"] = prod_B_q;
+        // Products of constants that the reference multiplies in one after the other
+        // (multiplication.cu:37-41, 160-164, 196-205): one Barrett product per coefficient instead of two.
+        // The values are canonical residues either way, so the kernels' outputs do not change.
+        {
+            vec fc_in, ff_in, ff_mid;
+            const u64 mt = ((u64) 1) << 32; // m_tilde
+            for (int i = 0; i < Q; i++) {
+                fc_in.push_back(mul_mod(mt % primes[i], inv_punct[i], primes[i]));
+                ff_in.push_back(mul_mod(plain_modulus % primes[i], inv_punct[i], primes[i]));
+            }
+            for (int i = 0; i < bsk - 1; i++) ff_mid.push_back(mul_mod(inv_prod_q_B[i], inv_punct_B[i], B[i]));
+            host["behz_mtilde_inv_punct"] = fc_in;
+            host["behz_t_inv_punct"] = ff_in;
+            host["behz_invq_inv_punct_B"] = ff_mid;
+        }
 
         // merged base [q | Bsk] with its NTT tables (bfv/context.cu:1210-1241)
         vec mm(primes.begin(), primes.begin() + Q), mpsi(psi.begin(), psi.begin() + Q), mfwd, minv, mninv;
@@ -519,6 +534,9 @@ hipError_t Context::upload()
                                        "base_change_matrix_q",
                                        "base_change_matrix_msk",
                                        "inv_punctured_prod_mod_B_array",
+                                       "behz_mtilde_inv_punct",
+                                       "behz_t_inv_punct",
+                                       "behz_invq_inv_punct_B",
                                        "prod_B_mod_q",
                                        "Mi",
                                        "Mi_inv",
@@ -574,6 +592,9 @@ hipError_t Context::upload()
         behz.base_change_matrix_q = d64("base_change_matrix_q");
         behz.base_change_matrix_msk = d64("base_change_matrix_msk");
         behz.prod_B_mod_q = d64("prod_B_mod_q");
+        behz.mtilde_inv_punct = d64("behz_mtilde_inv_punct");
+        behz.t_inv_punct = d64("behz_t_inv_punct");
+        behz.invq_inv_punct_B = d64("behz_invq_inv_punct_B");
         behz.ibase_size = Q_size;
         behz.obase_size = bsk_size;
     }

@@ -578,8 +578,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
             const Mod mi = b.ibase[i];
             u64 v = input[location + ((u64) i << n_power)];
             po[(u64) i << n_power] = v;
-            v = mul_barrett(v, b.m_tilde.q, mi);
-            temp[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+            temp[i] = mul_barrett(v, b.mtilde_inv_punct[i], mi); // x * m_tilde * (q/q_i)^-1, one product
         }
     }
     // m_tilde channel
@@ -646,8 +645,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
         reg_q[i] = 0;
         if (i < ib) {
             const Mod mi = b.ibase[i];
-            u64 v = mul_barrett(pq[(u64) i << n_power], t, mi);
-            reg_q[i] = mul_barrett(v, b.inv_punctured_prod_mod_base_array[i], mi);
+            reg_q[i] = mul_barrett(pq[(u64) i << n_power], b.t_inv_punct[i], mi); // x * t * (q/q_i)^-1
         }
     }
     u64 reg_Bsk_last = 0;
@@ -665,9 +663,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
             u64 tmp = reduce128(hi, lo, mo);
             u64 t2 = sub_mod(mo.q, tmp, mo.q);
             t2 = add_mod(t2, rb, mo.q);
-            rb = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
-            if (i < ob - 1) temp3[i] = mul_barrett(rb, b.inv_punctured_prod_mod_B_array[i], mo);
-            else reg_Bsk_last = rb;
+            if (i < ob - 1) temp3[i] = mul_barrett(t2, b.invq_inv_punct_B[i], mo); // * q^-1 * (B/b_i)^-1
+            else reg_Bsk_last = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
         }
     }
     const Mod msk = b.obase[ob - 1];

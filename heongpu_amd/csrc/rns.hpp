@@ -104,6 +104,11 @@ struct BehzDev {
     const u64* base_change_matrix_q;
     const u64* base_change_matrix_msk;
     const u64* prod_B_mod_q;
+    // merged constants (context.cpp): m_tilde * inv_punct_q[i], t * inv_punct_q[i] mod q_i;
+    // inv_prod_q_mod_Bsk[i] * inv_punct_B[i] mod Bsk_i
+    const u64* mtilde_inv_punct;
+    const u64* t_inv_punct;
+    const u64* invq_inv_punct_B;
     int ibase_size, obase_size;
 };
 
