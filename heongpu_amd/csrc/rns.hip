@@ -581,18 +581,14 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
             temp[i] = mul_barrett(v, b.mtilde_inv_punct[i], mi); // x * m_tilde * (q/q_i)^-1, one product
         }
     }
-    // m_tilde channel
-    u64 acc_mt = 0;
+    // m_tilde channel: m_tilde = 2^32, so reduction, product and sum modulo it are plain 32-bit
+    // arithmetic (the same canonical values as the Barrett routines of the reference, multiplication.cu:44-60)
+    u32 acc_mt32 = 0;
 #pragma unroll
-    for (int j = 0; j < MAXB; j++) {
-        if (j < ib) {
-            u64 ti = reduce64(temp[j], b.m_tilde);
-            u64 mu = mul_barrett(ti, b.base_change_matrix_m_tilde[j], b.m_tilde);
-            acc_mt = add_mod(acc_mt, mu, b.m_tilde.q);
-        }
-    }
+    for (int j = 0; j < MAXB; j++)
+        if (j < ib) acc_mt32 += (u32) temp[j] * (u32) b.base_change_matrix_m_tilde[j];
     const u64 mt = b.m_tilde.q;
-    u64 r_mt = mul_barrett(acc_mt, b.inv_prod_q_mod_m_tilde, b.m_tilde);
+    u64 r_mt = (u64) (u32) (acc_mt32 * (u32) b.inv_prod_q_mod_m_tilde);
     r_mt = mt - r_mt;
     for (int i = 0; i < ob; i++) {
         const Mod mo = b.obase[i];
