@@ -319,6 +319,9 @@ void Context::build_host()
             host["behz_mtilde_inv_punct"] = fc_in;
             host["behz_t_inv_punct"] = ff_in;
             host["behz_invq_inv_punct_B"] = ff_mid;
+            vec msk_q;
+            for (int i = 0; i < Q; i++) msk_q.push_back(msk % primes[i]);
+            host["behz_msk_mod_q"] = msk_q;
         }
 
         // merged base [q | Bsk] with its NTT tables (bfv/context.cu:1210-1241)
@@ -537,6 +540,7 @@ hipError_t Context::upload()
                                        "behz_mtilde_inv_punct",
                                        "behz_t_inv_punct",
                                        "behz_invq_inv_punct_B",
+                                       "behz_msk_mod_q",
                                        "prod_B_mod_q",
                                        "Mi",
                                        "Mi_inv",
@@ -595,6 +599,7 @@ hipError_t Context::upload()
         behz.mtilde_inv_punct = d64("behz_mtilde_inv_punct");
         behz.t_inv_punct = d64("behz_t_inv_punct");
         behz.invq_inv_punct_B = d64("behz_invq_inv_punct_B");
+        behz.msk_mod_q = d64("behz_msk_mod_q");
         behz.ibase_size = Q_size;
         behz.obase_size = bsk_size;
     }

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
         for (int j = 0; j < MAXB; j++)
             if (j < ob - 1) acc_mad(h2, l2, temp3[j], row[j]); // un-reduced: < 2^61 * 2^61 * 40 terms fits 128 bits
         u64 t4 = reduce128(h2, l2, mi);
-        u64 obase_ = reduce64(msk.q, mi);
+        u64 obase_ = b.msk_mod_q[i];
         u64 alpha_ = reduce64(alpha_sk, mi);
         u64 inner;
         if (neg) {

@@ -109,6 +109,7 @@ struct BehzDev {
     const u64* mtilde_inv_punct;
     const u64* t_inv_punct;
     const u64* invq_inv_punct_B;
+    const u64* msk_mod_q; // m_sk mod q_i
     int ibase_size, obase_size;
 };
 

@@ -184,6 +184,9 @@ class MemoryPool {
         if (!initialized_) initialize();
         const size_t g = guard();
         char* p = raw_allocate(size + 2 * g, stream);
+        // HEGPU_POOL_POISON=<byte>: fill every new buffer, to expose reads of memory nobody wrote
+        static const int poison = [] { const char* e = getenv("HEGPU_POOL_POISON"); return e ? atoi(e) : -1; }();
+        if (poison >= 0) detail::hip(hipMemsetAsync(p, poison, size + 2 * g, stream));
         if (g) { // HEGPU_POOL_GUARD=<bytes>: canaries around every buffer, checked when it is freed
             detail::hip(hipMemsetAsync(p, 0xA5, g, stream));
             detail::hip(hipMemsetAsync(p + g + size, 0xA5, g, stream));
