@@ -467,8 +467,8 @@ static void memory_pool()
 {
     MemoryPool& pool = MemoryPool::instance();
     hipStream_t s1, s2;
-    hipStreamCreate(&s1);
-    hipStreamCreate(&s2);
+    (void) hipStreamCreate(&s1);
+    (void) hipStreamCreate(&s2);
     const size_t n = (size_t) 3 << 20; // 24 MiB
     void* a = pool.allocate(n * 8, s1);
     pool.deallocate(a, n * 8, s1);
@@ -485,8 +485,8 @@ static void memory_pool()
         pool.deallocate(x, n * 8, s1);
         unsigned long long* y = (unsigned long long*) pool.allocate(n * 8, s2);
         fill_pattern<<<(unsigned) ((n + 255) / 256), 256, 0, s2>>>(y, n, 7);
-        hipMemcpyAsync(h.data(), y, n * 8, hipMemcpyDeviceToHost, s2);
-        hipStreamSynchronize(s2);
+        (void) hipMemcpyAsync(h.data(), y, n * 8, hipMemcpyDeviceToHost, s2);
+        (void) hipStreamSynchronize(s2);
         ok = ok && (x == y) && h[0] == 7 && h[n - 1] == 7 + n - 1 && h[n / 2] == 7 + n / 2;
         pool.deallocate(y, n * 8, s2);
     }
@@ -501,13 +501,13 @@ static void memory_pool()
             disjoint = disjoint && (live[i].first + live[i].second <= live[j].first || live[j].first + live[j].second <= live[i].first);
     EXPECT(disjoint, "live buffers do not overlap (the ROCm stream-ordered pool's failure, tools/hip_pool_repro.cpp)");
     for (auto& l : live) pool.deallocate(l.first, l.second, s1);
-    hipDeviceSynchronize();
+    (void) hipDeviceSynchronize();
     pool.release_cached();
     void* c = pool.allocate(n * 8, s1);
     EXPECT(c != nullptr, "allocation after the cache was released");
     pool.deallocate(c, n * 8, s1);
-    hipStreamDestroy(s1);
-    hipStreamDestroy(s2);
+    (void) hipStreamDestroy(s1);
+    (void) hipStreamDestroy(s2);
 }
 
 // Every serializable object of the reference (example/basic/13_bfv_serialization.cpp,
