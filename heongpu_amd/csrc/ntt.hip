@@ -788,8 +788,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
     for (int i = 0; i < a.digits; i++) {
         double x[16];
         const u64* p = pin + dig_off * i;
-        // key tile of this digit: requested before the transform so that the
-        // loads are in flight while the butterflies run
+        // The digit first, then the key tile of this digit: vmcnt counts in order, so the wait for the
+        // coefficients leaves the 32 key loads in flight while the butterflies run (issued the other way
+        // round, the first use of a coefficient would wait for the key as well).  The identity digit is the
+        // NTT-domain limb (canonical u64) of the decomposed polynomial itself.
+        const bool ident = a.skip_identity && i == midx;
+        const u64* px = ident ? a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096 : p;
+        u64 xr[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) xr[k] = px[row * 256 + i0 + 16 * k];
         const u64* k0 = pk + key_off2 * i;
         const u64* k1 = k0 + key_off1;
         u64 kv0[16], kv1[16];
@@ -798,14 +805,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
             kv0[k] = k0[16 * k];
             kv1[k] = k1[16 * k];
         }
-        if (a.skip_identity && i == midx) {
-            // NTT-domain limb (canonical u64) of the decomposed polynomial itself
-            const u64* pi = a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096;
+        if (ident) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(pi[row * 256 + i0 + 16 * k]), fc);
+            for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(xr[k]), fc);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);
+            for (int k = 0; k < 16; k++) x[k] = as_f64(xr[k]);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int half = 8 >> s;
