@@ -675,13 +675,32 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
     wave_lds_fence();
 }
 
-// grid = (items, N/4096, rc): ciphertext fastest so the workgroups that share
-// a key tile run back to back
+// One-dimensional grid of 8 * ceil(groups / 8) * items workgroups, group = (tile, limb slot).  The
+// `items` workgroups of a group share the key tiles of that group (1 MiB at 16 digits) and nothing
+// else is re-used, so they are placed on ONE XCD (workgroup b runs on XCD b % 8): group g goes to XCD
+// g % 8 and its ciphertexts run there back to back -- one L2 instead of eight fetches every key tile.
+struct KsIdx { int item, tile, slot; bool valid; };
+__device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
+{
+    const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    const unsigned gi = j / (unsigned) a.items, item = j - gi * (unsigned) a.items;
+    const unsigned g = gi * 8u + xcd;
+    const unsigned tiles = 1u << (a.n_power - 12);
+    KsIdx r;
+    r.item = (int) item;
+    r.slot = (int) (g >> (a.n_power - 12));
+    r.tile = (int) (g & (tiles - 1));
+    r.valid = r.slot < a.rc;
+    return r;
+}
+
 __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const int item = blockIdx.x, tile = blockIdx.y, slot = blockIdx.z;
+    const KsIdx ki = ks_index(a);
+    if (!ki.valid) return;
+    const int item = ki.item, tile = ki.tile, slot = ki.slot;
     const int midx = a.mod_order ? a.mod_order[slot] : slot;
     const Mod md = a.mods[midx];
     if (md.fp) return; // FP64 moduli are handled by ks_row_mac_fp
@@ -748,7 +767,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const int item = blockIdx.x, tile = blockIdx.y, slot = blockIdx.z;
+    const KsIdx ki = ks_index(a);
+    if (!ki.valid) return;
+    const int item = ki.item, tile = ki.tile, slot = ki.slot;
     const int midx = a.mod_order ? a.mod_order[slot] : slot;
     const Mod md = a.mods[midx];
     if (!md.fp) return; // integer moduli are handled by ks_row_mac
@@ -883,10 +904,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
 
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
 {
-    if (a.digits > 64) return hipErrorInvalidValue;
+    if (a.digits > 64 || items <= 0) return hipErrorInvalidValue;
+    KsMacArgs k = a;
+    k.items = items;
+    const unsigned groups = ((1u << a.n_power) / 4096) * (unsigned) a.rc;
+    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned) items;
     // both kernels cover the whole grid; each exits at once on the other's moduli
-    hipLaunchKernelGGL(ks_row_mac_fp, dim3(items, (1u << a.n_power) / 4096, a.rc), dim3(NTT_THREADS), 0, st, a);
-    hipLaunchKernelGGL(ks_row_mac, dim3(items, (1u << a.n_power) / 4096, a.rc), dim3(NTT_THREADS), 0, st, a);
+    hipLaunchKernelGGL(ks_row_mac_fp, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+    hipLaunchKernelGGL(ks_row_mac, dim3(grid), dim3(NTT_THREADS), 0, st, k);
     return hipGetLastError();
 }
 
@@ -996,9 +1021,12 @@ template <int S1>
 static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
-    if (a.decomp_mods)
-        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
-    else
+    if (a.decomp_mods) {
+        NttArgs c = a; // natural order for the decomposing column pass (see ntt_launch_fwd_col)
+        c.group_span = 0;
+        c.mg_group_span = 0;
+        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, c);
+    } else
         hipLaunchKernelGGL((ntt_fwd_col<S1, false>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
     NttArgs b = a;
     b.in = a.out;
@@ -1036,7 +1064,14 @@ hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st)
     if (a.n_power < 12 || a.n_power > 16 || batch > 65535 || a.poly_order) return hipErrorInvalidValue;
     NttArgs g = a;
     g.group_span = 0;
-    if (a.mod_count > 1 && batch % a.mod_count == 0 && (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
+    // A decomposing launch walks the polynomials in their natural order (item, digit, modulus slot):
+    // the rc consumers of one source limb are then dispatched back to back -- tile x of all of them on
+    // XCD x % 8 -- and all but the first read it from that XCD's L2.  (The modulus-major walk of the
+    // plain transform would put them batch / rc polynomials apart: rc reads of every source limb from
+    // HBM, 8.6 GB instead of 0.5 GB per 64-ciphertext launch at C4.)  The column pass only touches the
+    // first 256 twiddles of a modulus, 4 KiB, so it has no table locality to protect.
+    if (!a.decomp_mods && a.mod_count > 1 && batch % a.mod_count == 0 &&
+        (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
         g.group_span = batch / a.mod_count;
     fill_magics(g);
     switch (a.n_power - 8) {

@@ -111,6 +111,7 @@ struct KsMacArgs {
     int skip_identity;      // digit d at modulus d is not transformed: its NTT-domain limb is read from `ident`
     const u64* ident;       // [item][digit][N] NTT-domain limbs (the polynomial that was decomposed)
     u64 ident_item_stride;
+    int items;              // set by ks_row_mac_launch
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 

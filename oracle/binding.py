@@ -107,6 +107,10 @@ def lib():
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_keyswitch_mac.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.o_divide_round_lastq.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    L.o_cipher_broadcast_leveled.argtypes = [vp, vp, vp, ci, ci, ci, ci]
+    L.o_keyswitch_mac_leveled.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_divide_round_lastq_permute.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci]
+    L.o_base_conversion_DtoQtilde.argtypes = [vp, vp, vp, ci]
     i32p = ctypes.c_void_p
     L.o_tfhe_create.restype = ctypes.c_void_p
     L.o_tfhe_free.argtypes = [vp]

@@ -139,6 +139,7 @@ typedef struct o_m2 {
 } o_m2_t;
 void o_m2_build(octx_t* c);
 void o_m2_free(octx_t* c);
+void o_base_conversion_DtoQtilde(const octx_t* c, const u64* in, u64* out, int depth);
 
 /* primes given explicitly (Q then P); plain_modulus used for BFV only */
 octx_t* o_ctx_create(int scheme, int n_power, const u64* primes, int Q_size,

@@ -120,6 +120,13 @@ static void base_conversion_DtoQtilde(const octx_t* c, const o_m2_level_t* L, co
         }
 }
 
+/* exported form of the kernel above for the kernel-level parity test of
+ * hegpu_base_conversion_DtoQtilde: in [l][N] coefficient domain, out [d][rc][N] */
+void o_base_conversion_DtoQtilde(const octx_t* c, const u64* in, u64* out, int depth)
+{
+    base_conversion_DtoQtilde(c, &c->m2->lv[depth], in, out, c->Q_size - depth, depth);
+}
+
 /* switchkey.cu:287-398 keyswitch_multiply_accumulate_leveled_method_II_kernel
  * (also covers the non-leveled bfv call with level = 0) */
 static void keyswitch_mac_II(const u64* input, const u64* key, u64* output, const omod_t* mods, int first_rns,

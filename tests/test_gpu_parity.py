@@ -511,16 +511,20 @@ def test_reference_own_test_passes(torch, name):
     exe = os.path.join(root, "heongpu_amd", "lib", "ref_" + name)
     if not os.path.exists(exe):
         pytest.skip("reference test binary not built (no /root/reference at build time)")
-    # The programs draw fresh random messages (std::random_device) on every run, and one of them is
-    # flaky by construction on ANY correct backend: test_bfv_addition.cpp:256 expects
-    # `(m1 + m2 > t) ? m1 + m2 - t : m1 + m2`, i.e. the value t instead of 0 in a slot where m1 + m2 == t
-    # -- about n/t per parameter set, 16 % per run over its five sets (measured here: 14 of 60 runs,
-    # always in that comparison).  So a failed run is repeated; four failures in a row do not happen by
-    # that route (0.16^4 < 0.1 %).
+    # Every program must pass on its FIRST run.  The one exception is a flaw of the reference's own
+    # test: test_bfv_addition.cpp:56,155,256,356,458 expect `(m1 + m2 > t) ? m1 + m2 - t : m1 + m2`, i.e.
+    # the value t instead of 0 in a slot where m1 + m2 == t -- about n/t per parameter set, 16 % per run
+    # over its five sets (fresh std::random_device messages on every run; measured here: 14 of 60 runs,
+    # always in that comparison).  Only that program is repeated, and only when every failing assertion of
+    # the run is one of those `message_addition_result` comparisons.
+    import re
     for attempt in range(4):
         r = subprocess.run([exe], capture_output=True, text=True, timeout=1500, cwd="/tmp")
         print(r.stdout[-3000:], r.stderr[-1000:])
-        if r.returncode == 0:
+        if r.returncode == 0 or name != "test_bfv_addition":
+            break
+        failing = re.findall(r"Failure\nExpected equality of these values:\n\s+(.*)", r.stdout)
+        if not failing or any("message_addition_result" not in f for f in failing) or "unexpected exception" in r.stdout:
             break
     assert r.returncode == 0
     assert "[  FAILED  ]" not in r.stdout and r.stdout.count("[       OK ]") >= 1
