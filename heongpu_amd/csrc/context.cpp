@@ -485,6 +485,8 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
         hw[k] = make_ulonglong2(w1n, shoup_companion(w1n, q));
     }
     p.count = cnt;
+    p.has_fp = p.has_int = 0;
+    for (int k = 0; k < cnt; k++) (hm[k].fp ? p.has_fp : p.has_int) = 1;
     hipError_t e;
     if ((e = to_device(hm, &p.mods)) != hipSuccess) return e;
     if ((e = to_device(htw, &p.tw)) != hipSuccess) return e;
@@ -512,6 +514,7 @@ hipError_t Context::upload()
     if (uploaded) return hipSuccess;
     if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0');
     if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
+    if (const char* e = getenv("HEGPU_COL_MULTI")) col_multi = atoi(e); // 0 / 1 force a column-pass form
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)
         gauss_cdt.t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);
@@ -647,6 +650,9 @@ NttArgs Context::ntt_args(int table_set) const
     a.w1ninv = p.w1ninv;
     a.n_power = n_power;
     a.mod_count = p.count;
+    a.col_multi = col_multi;
+    a.plan_has_fp = p.has_fp;
+    a.plan_has_int = p.has_int;
     return a;
 }
 

@@ -29,6 +29,7 @@ struct NttPlan {
     ulonglong2* ninv = nullptr;
     ulonglong2* w1ninv = nullptr;
     int count = 0;
+    int has_fp = 0, has_int = 0; // moduli on the FP64 / on the integer butterflies
 };
 
 struct Context {
@@ -54,6 +55,7 @@ struct Context {
     // use the fused "row pass + key-switch MAC" kernel (HEGPU_FUSED_ROW_MAC=0 disables)
     bool fused_row_mac = true;
     bool fused_moddown = true; // HEGPU_FUSED_MODDOWN=0: separate stage-two kernel
+    int col_multi = -1;        // HEGPU_COL_MULTI: form of the decomposing column pass (NttArgs::col_multi)
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 
     // ---- device state (valid after upload())

@@ -356,8 +356,13 @@ __device__ __forceinline__ void wave_lds_fence()
 #define NTT_LAZY_BITS 57
 
 // Column pass: stages 0..S1-1 (row stride 256).  grid = (256/CT, batch).
-template <int S1, bool DECOMP, bool LAZY>
-__device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
+// SREG: the 16 source coefficients of the thread are already in registers (`sreg`, in load order:
+// group g, slot k at sreg[g * RA + k]) -- the multi-modulus column pass (ntt_fwd_col_multi) loads a
+// digit tile once and runs this body for every target modulus; it also needs the tile free again
+// before the next iteration writes it, hence the second barrier right after the exchange reads.
+template <int S1, bool DECOMP, bool LAZY, bool SREG = false>
+__device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds,
+                                             const u64* sreg = nullptr)
 {
     constexpr int R = 1 << S1;
     constexpr int CT = 4096 / R;
@@ -374,8 +379,8 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     // range does not cover v + q - half_mod for a 60-bit source modulus
     const u64 half_qP = a.half_on ? a.mods[a.half_src_mod].q : 0;
     const u64 half_hm = a.half_on ? a.half_mod[ps.mod] : 0;
-    auto ld = [&](const u64* p) -> u64 {
-        u64 v = gld(p);
+    auto ld = [&](const u64* p, int si) -> u64 {
+        u64 v = SREG ? sreg[si] : gld(p);
         if (DECOMP && a.half_on) v = sub_mod(reduce64(add_mod(v, a.half, half_qP), md), half_hm, md.q);
         return v;
     };
@@ -389,7 +394,7 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
             const int c = L % CT, rb = L / CT;
             u64 y[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = ld(&src[(u64) (rb + 16 * k) * 256 + c]);
+            for (int k = 0; k < RA; k++) y[k] = ld(&src[(u64) (rb + 16 * k) * 256 + c], g * RA + k);
             // DECOMP: the digit (< 2^60, a residue of another prime) is NOT reduced
             // first: the lazy butterflies only need x < 8q (q >= 2^57 here) or, on
             // the correction-free path, x + 64q < 2^64; congruence mod q is kept
@@ -401,9 +406,10 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = lds[col_phys((16 * r1 + k) * CT + col)];
+        if (SREG) __syncthreads();
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = ld(&src[(u64) k * 256 + col]);
+        for (int k = 0; k < 16; k++) x[k] = ld(&src[(u64) k * 256 + col], k);
     }
     ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
@@ -412,16 +418,19 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
 
 // FP64 column pass (Mod::fp).  Output: centred residues as raw doubles -- the
 // row pass of the same modulus consumes them as such.
-template <int S1, bool DECOMP, bool WIDE>
+template <int S1, bool DECOMP, bool WIDE, bool SREG = false>
 __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds,
-                                                ulonglong2* twl)
+                                                ulonglong2* twl, const u64* sreg = nullptr)
 {
     constexpr int R = 1 << S1;
     constexpr int CT = 4096 / R;
     constexpr int NSA = S1 - 4;
     constexpr int RA = 1 << NSA;
     constexpr int G = 16 / RA;
-    const int t = threadIdx.x;
+    int t = threadIdx.x;
+    // inside the modulus loop of ntt_fwd_col_multi: recompute the (cheap) LDS / store offsets in every
+    // iteration instead of keeping ~50 hoisted address registers alive across the loop
+    if constexpr (SREG) asm volatile("" : "+v"(t));
     const FC fc = make_fc(md.q);
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + blockIdx.x * CT;
@@ -438,13 +447,22 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     }
     const u64 half_qP = (DECOMP && a.half_on) ? a.mods[a.half_src_mod].q : 0;
     const double half_hm = (DECOMP && a.half_on) ? fp_from_u64(a.half_mod[ps.mod]) : 0.0;
-    auto load = [&](const u64* p) -> double {
-        u64 v = *p;
-        if (DECOMP && a.half_on) v = add_mod(v, a.half, half_qP);
+    // SREG: `sreg` holds the thread's 16 source coefficients, the mod-down half already added: for a
+    // source modulus of at most 52 bits as the bits of the converted double, for a wider one as u64
+    auto load = [&](const u64* p, int si) -> double {
         double r;
-        if constexpr (DECOMP && WIDE) r = fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
-        else if constexpr (DECOMP) r = fp_reduce(fp_from_u64(v), fc);
-        else r = fp_from_u64(v);
+        if constexpr (SREG && !WIDE) {
+            r = fp_reduce(as_f64(sreg[si]), fc);
+        } else {
+            u64 v = SREG ? sreg[si] : *p;
+            // keep the split conversion of a wide source inside the iteration (hoisted out of the modulus
+            // loop it would pin 64 more registers per lane for all of it)
+            if constexpr (SREG) asm volatile("" : "+v"(v));
+            if (!SREG && DECOMP && a.half_on) v = add_mod(v, a.half, half_qP);
+            if constexpr (DECOMP && WIDE) r = fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
+            else if constexpr (DECOMP) r = fp_reduce(fp_from_u64(v), fc);
+            else r = fp_from_u64(v);
+        }
         if (DECOMP && a.half_on) r = fp_reduce(r - half_hm, fc);
         return r;
     };
@@ -463,7 +481,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
             const int c = L % CT, rb = L / CT;
             double y[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = load(&src[(u64) (rb + 16 * k) * 256 + c]);
+            for (int k = 0; k < RA; k++) y[k] = load(&src[(u64) (rb + 16 * k) * 256 + c], g * RA + k);
             fp_ct_radix<NSA>(y, tw, 1u, fc);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
@@ -472,10 +490,11 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = as_f64(lds[col_phys((16 * r1 + k) * CT + col)]);
+        if (SREG) __syncthreads();
         fp_ct_radix<4>(x, twl, (u32) (RA + r1), fc);
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = load(&src[(u64) k * 256 + col]);
+        for (int k = 0; k < 16; k++) x[k] = load(&src[(u64) k * 256 + col], k);
         fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
     }
 #pragma unroll
@@ -490,12 +509,79 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     const PolySel ps = select_poly(a, blockIdx.y);
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
+    if (DECOMP && a.only_int && md.fp) return; // done by ntt_fwd_col_multi
     if (md.fp) {
         if (DECOMP && a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52)
             fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds, twl);
         else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds, twl);
     } else if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
+}
+
+// Decomposing column pass, one workgroup per SOURCE tile: the 16 coefficients a thread needs are
+// loaded once and stay in registers while the workgroup walks the rc target moduli of that digit
+// (reference: cipher_broadcast*_kernel + the first half of GPU_NTT for each of the rc copies,
+// switchkey.cu:11-59 / ckks/operator.cu:932-960).  No global load sits on the critical path of an
+// iteration, the source limb is read exactly once from HBM, and the stores of iteration j drain while
+// iteration j + 1 computes.  Two barriers per iteration (tile written -> read -> free again); the
+// second-round twiddles of the FP64 body are double-buffered by iteration parity, which the first
+// barrier of the following iteration makes safe.  grid = (256 / CT, items * digits).
+template <int S1>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col_multi(NttArgs a)
+{
+    constexpr int R = 1 << S1;
+    constexpr int CT = 4096 / R;
+    constexpr int NSA = S1 - 4;
+    constexpr int RA = 1 << NSA;
+    constexpr int G = 16 / RA;
+    __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
+    __shared__ ulonglong2 twl[(S1 > 4) ? 512 : 1];
+    const int t = threadIdx.x;
+    const int rc = a.decomp_mods;
+    const int digits = udiv16(a.polys_per_item, a.mg_decomp_mods);
+    const int item = udiv16(blockIdx.y, a.mg_per_item), digit = blockIdx.y - item * digits;
+    const u64 in_slot = (u64) digit * (a.decomp_in_mul ? a.decomp_in_mul : 1) + a.decomp_in_add;
+    const u64* __restrict__ src = a.in + (u64) item * a.in_item_stride + (in_slot << a.n_power) + blockIdx.x * CT;
+    u64 sreg[16];
+    if constexpr (NSA > 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int L = t + NTT_THREADS * g;
+            const int c = L % CT, rb = L / CT;
+#pragma unroll
+            for (int k = 0; k < RA; k++) sreg[g * RA + k] = src[(u64) (rb + 16 * k) * 256 + c];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = src[(u64) k * 256 + (t % CT)];
+    }
+    const Mod smd = a.mods[a.half_on ? a.half_src_mod : digit];
+    if (a.half_on) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = add_mod(sreg[k], a.half, smd.q);
+    }
+    const bool wide = smd.bit > 52; // uniform per workgroup
+    if (!wide) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = as_bits(fp_from_u64(sreg[k]));
+    }
+    int done = 0; // executed iterations (parity of the twiddle buffer)
+    for (int k = 0; k < rc; k++) {
+        PolySel ps;
+        ps.mod = a.mod_offset + (a.mod_order ? a.mod_order[k] : k);
+        ps.digit = digit;
+        ps.item = item;
+        ps.j = digit * rc + k;
+        ps.in_off = 0;
+        ps.out_off = (u64) item * a.out_item_stride + ((u64) ps.j << a.n_power);
+        if (a.skip_identity && ps.mod == digit) continue;
+        const Mod md = a.mods[ps.mod];
+        if (!md.fp) continue; // integer target moduli: ntt_fwd_col<S1, true> with only_int
+        ulonglong2* tl = twl + ((S1 > 4) ? 256 * (done & 1) : 0);
+        done++;
+        if (wide) fwd_col_body_fp<S1, true, true, true>(a, ps, md, lds, tl, sreg);
+        else fwd_col_body_fp<S1, true, false, true>(a, ps, md, lds, tl, sreg);
+    }
 }
 
 // Store of the forward row pass: plain, or through the mod-down epilogue (NttEpilogue).
@@ -1007,11 +1093,41 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
 }
 
 // ------------------------------------------------------------------ launch
+// The multi-modulus column pass needs enough source tiles to fill the chip on its own (one workgroup
+// per source tile instead of one per (source tile, target modulus)); below that the per-polynomial
+// kernel runs.  NttArgs::col_multi: 0 never, 1 always, otherwise automatic.
+template <int S1>
+static bool use_col_multi(const NttArgs& a, int batch)
+{
+    constexpr int CT = 4096 >> S1;
+    if (!a.decomp_mods || a.col_multi == 0 || batch % a.decomp_mods) return false;
+    if (a.col_multi == 1) return true;
+    return (long) (256 / CT) * (batch / a.decomp_mods) >= 2048;
+}
+
+// FP64 target moduli through the multi-modulus kernel, the integer ones (if the plan has any: the
+// 60-bit q0 and P of the C4 chain) through the per-polynomial kernel, which skips the rest
+template <int S1>
+static void launch_col_multi(const NttArgs& a, int batch, hipStream_t st)
+{
+    constexpr int CT = 4096 >> S1;
+    if (a.plan_has_fp)
+        hipLaunchKernelGGL((ntt_fwd_col_multi<S1>), dim3(256 / CT, batch / a.decomp_mods), dim3(NTT_THREADS), 0, st, a);
+    if (a.plan_has_int || !a.plan_has_fp) {
+        NttArgs c = a;
+        c.group_span = 0;
+        c.mg_group_span = 0;
+        c.only_int = a.plan_has_fp;
+        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, c);
+    }
+}
+
 template <int S1>
 static void launch_fwd_col_only(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
-    if (a.decomp_mods)
+    if (use_col_multi<S1>(a, batch)) launch_col_multi<S1>(a, batch, st);
+    else if (a.decomp_mods)
         hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((ntt_fwd_col<S1, false>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, a);
@@ -1021,7 +1137,9 @@ template <int S1>
 static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
-    if (a.decomp_mods) {
+    if (use_col_multi<S1>(a, batch)) {
+        launch_col_multi<S1>(a, batch, st);
+    } else if (a.decomp_mods) {
         NttArgs c = a; // natural order for the decomposing column pass (see ntt_launch_fwd_col)
         c.group_span = 0;
         c.mg_group_span = 0;

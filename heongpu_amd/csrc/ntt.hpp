@@ -83,6 +83,11 @@ struct NttArgs {
     int half_on, half_src_mod;
     u64 half;
     const u64* half_mod;
+    // decomposing launches: 0 = one workgroup per (source tile, target modulus), 1 = one workgroup per
+    // source tile walking all target moduli (ntt_fwd_col_multi), anything else = by launch size
+    int col_multi;
+    int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
+    int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

@@ -62,12 +62,15 @@ def _bfv(hg, oracle, n, t):
 
 
 # ------------------------------------------------------------------ config C4, exact chain
-def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch):
+@pytest.mark.parametrize("col_multi", [None, 1, 0], ids=["auto", "col_multi", "col_per_poly"])
+def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi):
     """BASELINE.json config C4 / bench.py's workload: CKKS N=2^16, Q = {60, 50 x 15}, P = {60}, depth 0,
     batch 3 (two distinct pairs + a twin): multiply -> relinearize_inplace -> rotate by one slot, every
-    limb compared with the oracle."""
+    limb compared with the oracle.  Both forms of the decomposing column pass (bench.py's batch of 64
+    takes the multi-modulus one, a batch of 3 would not on its own)."""
     n = 65536
-    c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])
+    with backend_switches(**({} if col_multi is None else dict(HEGPU_COL_MULTI=col_multi))):
+        c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])
     Q, Qp = 16, 17
     assert (c.Q_size, c.Q_prime_size) == (Q, Qp)
     batch, uniq = 3, 2
@@ -104,6 +107,8 @@ def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch):
 
 # ------------------------------------------------------------------ fusions switched off
 _SWITCHES = [
+    dict(HEGPU_COL_MULTI=1),
+    dict(HEGPU_COL_MULTI=1, HEGPU_FP_NTT=0),
     dict(HEGPU_FUSED_ROW_MAC=0),
     dict(HEGPU_FUSED_MODDOWN=0),
     dict(HEGPU_FP_NTT=0),
@@ -152,7 +157,7 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
         assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
 
 
-@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=0), dict(HEGPU_FP_NTT=0)],
+@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=0), dict(HEGPU_FP_NTT=0), dict(HEGPU_COL_MULTI=1)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_bfv_sequence_with_fusions_off(hg, oracle, torch, sw):
     """Config C1 shapes (BFV N=2^12 default chain): relinearize + rotate through the unfused key switch."""
@@ -179,6 +184,44 @@ def test_bfv_sequence_with_fusions_off(hg, oracle, torch, sw):
     got = hg.to_host(rot).reshape(batch, -1)
     for b in range(batch):
         assert np.array_equal(got[b], o.bfv_apply_galois(ct1[b], key, g)), "bfv rotate"
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_keyswitch_mixed_widths_multi_modulus_column_pass(hg, oracle, torch, depth):
+    """The multi-modulus column pass on a chain that mixes FP64 targets (50/36/45/49 bits) with integer
+    ones (60/55 bits) and narrow with wide source digits, inputs at their extremes (every residue q-1,
+    0/q-1 patterns, a key of all q-1), N = 2^12 and 2^14."""
+    for n in (4096, 16384):
+        bits = [60, 50, 36, 45, 55, 49]
+        with backend_switches(HEGPU_COL_MULTI=1):
+            c, o, primes = _ckks(hg, oracle, n, bits, [60], sec=hg.SEC_NONE)
+        Q, Qp = len(bits), len(bits) + 1
+        l = Q - depth
+        key = np.concatenate([np.full(n, primes[j] - 1, dtype=np.uint64) for _ in range(Q) for _c in range(2)
+                              for j in range(Qp)])
+        cts = []
+        full = np.concatenate([np.full(n, primes[j] - 1, dtype=np.uint64) for _p in range(3) for j in range(l)])
+        cts.append(full)
+        pat = full.copy().reshape(3 * l, n); pat[:, ::3] = 0
+        cts.append(pat.reshape(-1))
+        cts.append(synth_ct(primes, range(l), 3, n, 77))
+        batch = len(cts)
+        d = hg.to_device(np.concatenate(cts))
+        c.ckks_relinearize_inplace(d, 3 * l * n, hg.to_device(key), depth, batch, c.workspace(hg.OP_CKKS_RELIN, depth, batch))
+        torch.cuda.synchronize()
+        got = hg.to_host(d).reshape(batch, -1)
+        for b in range(batch):
+            want = o.ckks_relinearize(cts[b].copy(), key, depth)
+            assert np.array_equal(got[b][:2 * l * n], want[:2 * l * n]), (n, b)
+        if l >= 2:
+            cc = [x[:2 * l * n].copy() for x in cts]
+            d = hg.to_device(np.concatenate(cc))
+            c.ckks_rescale_inplace(d, 2 * l * n, depth, batch, c.workspace(hg.OP_CKKS_RESCALE, depth, batch))
+            torch.cuda.synchronize()
+            got = hg.to_host(d).reshape(batch, -1)
+            for b in range(batch):
+                w = o.ckks_rescale(cc[b].copy(), depth)
+                assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), ("rescale", n, b)
 
 
 # ------------------------------------------------------------------ kernel-level C-ABI entries
