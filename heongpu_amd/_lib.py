@@ -48,6 +48,8 @@ SIGNATURES = [
     ("hegpu_workspace_bytes", c_size_t, [voidp, c_int, c_int, c_int]),
     ("hegpu_ckks_multiply", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
     ("hegpu_ckks_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_probe_ckks_relinearize", c_int,
+     [voidp, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, ctypes.c_uint, voidp]),
     ("hegpu_ckks_rescale_inplace", c_int, [voidp, u64p, u64, c_int, c_int, voidp, c_size_t, voidp]),
     ("hegpu_ckks_apply_galois", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, c_int, voidp, c_size_t, voidp]),

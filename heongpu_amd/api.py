@@ -217,6 +217,12 @@ class Context:
                                                         ws.numel() * 8,
                                                         stream if stream is not None else _stream()))
 
+    def probe_ckks_relinearize(self, ct, cs, key, depth, batch, ws, phases, stream=None):
+        """measurement seam: only the launches selected by `phases` (include/hegpu.h)"""
+        _check(self._lib.hegpu_probe_ckks_relinearize(self._h, _ptr(ct), cs, _ptr(key), depth, batch, _ptr(ws),
+                                                      ws.numel() * 8, phases,
+                                                      stream if stream is not None else _stream()))
+
     def ckks_rescale_inplace(self, ct, cs, depth, batch, ws, stream=None):
         _check(self._lib.hegpu_ckks_rescale_inplace(self._h, _ptr(ct), cs, depth, batch, _ptr(ws), ws.numel() * 8,
                                                     stream if stream is not None else _stream()))

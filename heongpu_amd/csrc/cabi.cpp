@@ -411,6 +411,17 @@ int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs
                    "hegpu_ckks_relinearize_inplace");
 }
 
+int hegpu_probe_ckks_relinearize(hegpu_context* ctx, uint64_t* ct, uint64_t cs, const uint64_t* key, int depth,
+                                 int batch, void* ws, size_t ws_bytes, unsigned phases, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_RELIN, depth, batch, ws, ws_bytes);
+    if (ctx->c.P_size != 1) return fail(HEGPU_E_LOGIC, "the phase probe covers key-switching method I");
+    return hip_ret(op_ckks_relinearize(ctx->c, (u64*) ct, cs, (const u64*) key, depth, batch, (u64*) ws,
+                                       (hipStream_t) stream, phases),
+                   "hegpu_probe_ckks_relinearize");
+}
+
 int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, int depth, int batch, void* ws,
                                size_t ws_bytes, hegpu_stream stream)
 {

@@ -28,9 +28,11 @@ static int prime_loc_offset(const Context& c, int depth)
 // `ident` (with a.skip_identity): the NTT-domain limbs [digits][N] of the
 // polynomial being decomposed, `ident_stride` apart; digit d at modulus d is
 // taken from there instead of being transformed.
+// `which`: 1 = column pass only, 2 = row pass + inner product only, 3 = both (the measurement seam of
+// hegpu_probe_ckks_relinearize; the unfused path ignores it)
 static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
                                     int digits, int rc, int split, int level, const u64* ident, u64 ident_stride,
-                                    int batch, hipStream_t st)
+                                    int batch, hipStream_t st, int which = 3)
 {
     const int ppi = digits * rc;
     const int skip_identity = ident ? 1 : 0;
@@ -48,7 +50,8 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         NttArgs ca = a;
         ca.in = a.in + (u64) b0 * a.in_item_stride;
         ca.out = a.out + (u64) b0 * a.out_item_stride;
-        TRY(ntt_launch_fwd_col(ca, ppi * nb, st));
+        if (which & 1) TRY(ntt_launch_fwd_col(ca, ppi * nb, st));
+        if (!(which & 2)) continue;
         KsMacArgs k{};
         k.in = ca.out; k.in_item_stride = a.out_item_stride; k.key = key;
         k.out = acc + (u64) b0 * acc_stride; k.out_item_stride = acc_stride;
@@ -98,7 +101,7 @@ hipError_t op_ckks_multiply(const Context& c, const u64* ct1, u64 s1, const u64*
 
 // reference ckks/operator.cu:899-1023
 hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
-                               hipStream_t st)
+                               hipStream_t st, unsigned phases)
 {
     const int np = c.n_power;
     const u64 n = c.n;
@@ -116,7 +119,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     // re-reduced into its own modulus d and transformed back is that limb
     a.in = c2; a.out = temp2; a.mod_count = l; a.polys_per_item = l;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(ntt_launch(a, l * batch, true, st));
+    if (phases & RELIN_PHASE_INTT_C2) TRY(ntt_launch(a, l * batch, true, st));
     // digit decomposition c2 -> [l][rc][N] fused into the forward NTT's
     // first load; modulus order skips dropped primes                (:932-960)
     a = c.ntt_args(0);
@@ -124,13 +127,15 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.in_item_stride = per; a.out_item_stride = per;
     a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     // forward NTT of the digits + inner product with the key      (:956-988)
-    TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, c2, cs, batch, st));
+    const int which = ((phases & RELIN_PHASE_COLUMN) ? 1 : 0) | ((phases & RELIN_PHASE_ROW_MAC) ? 2 : 0);
+    if (which) TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, c2, cs, batch, st, which));
     // INTT of the two P-limb polynomials only                        (:996)
     a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
     a.in_item_stride = a.out_item_stride = per;
     a.poly_order = c.d32("new_input_locations") + 2 * depth;
-    TRY(ntt_launch(a, 2 * batch, true, st));
+    if (phases & RELIN_PHASE_INTT_P) TRY(ntt_launch(a, 2 * batch, true, st));
+    if (!(phases & RELIN_PHASE_MODDOWN)) return hipSuccess;
     // stage one: P limb (+half) reduced into every q_j               (:1003)
     if (!c.fused_moddown)
         TRY(rns_moddown_stage_one(temp2, per, temp1, per, mods, c.d64("half"), c.d64("half_mod"), np, Q, l, batch,

@@ -14,8 +14,11 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
 hipError_t op_ckks_multiply(const Context& c, const u64* ct1, u64 s1, const u64* ct2, u64 s2, u64* out, u64 so,
                             int depth, int batch, hipStream_t st);
+// `phases`: which launches of the sequence run (all by default; hegpu_probe_ckks_relinearize times them one by one)
+enum { RELIN_PHASE_INTT_C2 = 1, RELIN_PHASE_COLUMN = 2, RELIN_PHASE_ROW_MAC = 4, RELIN_PHASE_INTT_P = 8,
+       RELIN_PHASE_MODDOWN = 16, RELIN_PHASE_ALL = 31 };
 hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
-                               hipStream_t st);
+                               hipStream_t st, unsigned phases = RELIN_PHASE_ALL);
 hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int batch, u64* ws, hipStream_t st);
 hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                 int galois_elt, int depth, int batch, u64* ws, hipStream_t st);

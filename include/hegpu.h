@@ -163,6 +163,13 @@ int hegpu_ckks_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_st
 int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
                                    const uint64_t* relin_key, int depth, int batch, void* ws, size_t ws_bytes,
                                    hegpu_stream stream);
+/* Measurement seam (bench.py's per-kernel roofline, no reference counterpart): runs only the launches
+ * of hegpu_ckks_relinearize_inplace (method I) selected by `phases` -- 1 INTT of c2 (:919), 2 decomposing
+ * column pass and 4 row pass + inner product (:932-988), 8 INTT of the P limbs (:996), 16 mod-down NTT
+ * (:1003-1015) -- on whatever the buffers hold; results are meaningful only with all five (31). */
+int hegpu_probe_ckks_relinearize(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride, const uint64_t* relin_key,
+                                 int depth, int batch, void* ws, size_t ws_bytes, unsigned phases,
+                                 hegpu_stream stream);
 /* rescale_inplace_ckks_leveled (ckks/operator.cu:1156-1244):
  * ct [2][l][N] -> [2][l-1][N] in place (caller then uses depth+1) */
 int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride, int depth, int batch,

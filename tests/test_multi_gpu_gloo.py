@@ -3,11 +3,14 @@ evaluation-key broadcast -- with the oracle standing in for the GPU compute
 (the sharding code is identical; only the backend name differs on MI355X)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 
 from helpers import synth_ct, synth_key
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -100,3 +103,28 @@ def test_two_rank_sharded_mul_relin_matches_single_process(oracle):
             assert m[:2 * Q * n].tobytes() == blob, f"ciphertext {b} differs"
             covered.append(b)
     assert sorted(covered) == list(range(total))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (torch.distributed.run on
+    127.0.0.1); --launcher-selftest runs everything bench.py does around the kernels -- rendezvous,
+    contiguous sharding of the global batch, key broadcast from rank 0, MAX reduction of the elapsed
+    time -- on CPU with gloo and reports n_gpus = 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["key_broadcast_ok"]
+    assert line["slices"] == [[0, 64], [64, 64]] and line["global_batch"] == 128
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """under a launcher the world size must equal --gpus (the driver passes both)"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "world size" in (r.stdout + r.stderr)
