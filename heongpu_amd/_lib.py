@@ -58,6 +58,9 @@ SIGNATURES = [
     ("hegpu_bfv_apply_galois", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, voidp, c_size_t, voidp]),
     ("hegpu_rng_create", c_int, [u64, ctypes.POINTER(voidp)]),
+    ("hegpu_rng_create_seeded", c_int, [ctypes.c_char_p, ctypes.POINTER(voidp)]),
+    ("hegpu_rng_create_from_entropy", c_int, [ctypes.POINTER(voidp)]),
+    ("hegpu_drbg_block", c_int, [ctypes.c_char_p, u64, u64, ctypes.POINTER(ctypes.c_uint32)]),
     ("hegpu_rng_destroy", None, [voidp]),
     ("hegpu_generate_secret_key", c_int, [voidp, voidp, c_int, u64p, voidp, c_size_t, voidp]),
     ("hegpu_generate_public_key", c_int, [voidp, voidp, u64p, u64p, voidp, c_size_t, voidp]),

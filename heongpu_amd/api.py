@@ -444,12 +444,19 @@ GATE_NAND, GATE_AND, GATE_AND_FIRST_NOT, GATE_NOR, GATE_OR, GATE_XNOR, GATE_XOR,
 
 
 class Rng:
-    """The backend's DRBG handle (Philox4x32-10 streams, csrc/drbg.hpp)."""
+    """The backend's DRBG handle (ChaCha20 counter-mode streams, csrc/drbg.hpp).  Rng(int): the
+    reproducible 64-bit test seed; Rng(bytes of length 32): a full seed; Rng(None): OS entropy."""
 
-    def __init__(self, seed):
+    def __init__(self, seed=None):
         self._lib = _lib.load()
         h = ctypes.c_void_p()
-        _check(self._lib.hegpu_rng_create(int(seed) & (2**64 - 1), ctypes.byref(h)))
+        if seed is None:
+            _check(self._lib.hegpu_rng_create_from_entropy(ctypes.byref(h)))
+        elif isinstance(seed, (bytes, bytearray)):
+            assert len(seed) == 32
+            _check(self._lib.hegpu_rng_create_seeded(bytes(seed), ctypes.byref(h)))
+        else:
+            _check(self._lib.hegpu_rng_create(int(seed) & (2**64 - 1), ctypes.byref(h)))
         self._h = h
 
     def __del__(self):

@@ -4,7 +4,9 @@
 #include "host_params.hpp"
 #include "ops.hpp"
 #include "tfhe.hpp"
+#include <cerrno>
 #include <cstring>
+#include <sys/random.h>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -218,7 +220,14 @@ const void* hegpu_context_device_ptr(const hegpu_context* ctx, const char* name)
 
 int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order)
 {
-    return host::steps_to_galois_elt(steps, coeff_count, group_order);
+    // no exception may cross the C boundary; Galois elements are odd and positive (0: step count out
+    // of range, as the reference returns), so -1 is unambiguous
+    int elt = -1;
+    (void) guarded([&]() -> int {
+        elt = host::steps_to_galois_elt(steps, coeff_count, group_order);
+        return 0;
+    });
+    return elt;
 }
 
 #define NEED_CTX(ctx)                                                                      \
@@ -497,10 +506,55 @@ int hegpu_rng_create(uint64_t seed, hegpu_rng** out)
     return guarded([&]() -> int {
         if (!out) throw std::invalid_argument("null output");
         hegpu_rng* h = new hegpu_rng();
-        h->r.seed = seed;
+        h->r.seed = drbg_key_from_u64(seed);
         *out = h;
         return 0;
     });
+}
+
+int hegpu_rng_create_seeded(const uint8_t seed[32], hegpu_rng** out)
+{
+    return guarded([&]() -> int {
+        if (!out || !seed) throw std::invalid_argument("null argument");
+        hegpu_rng* h = new hegpu_rng();
+        for (int i = 0; i < 8; i++)
+            h->r.seed.k[i] = (u32) seed[4 * i] | ((u32) seed[4 * i + 1] << 8) | ((u32) seed[4 * i + 2] << 16) |
+                             ((u32) seed[4 * i + 3] << 24);
+        *out = h;
+        return 0;
+    });
+}
+
+int hegpu_rng_create_from_entropy(hegpu_rng** out)
+{
+    return guarded([&]() -> int {
+        if (!out) throw std::invalid_argument("null output");
+        uint8_t seed[32];
+        size_t got = 0;
+        while (got < sizeof(seed)) {
+            const ssize_t r = getrandom(seed + got, sizeof(seed) - got, 0);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                throw std::runtime_error("getrandom failed: no entropy source for the key generator");
+            }
+            got += (size_t) r;
+        }
+        const int rc = hegpu_rng_create_seeded(seed, out);
+        volatile uint8_t* z = seed;
+        for (size_t i = 0; i < sizeof(seed); i++) z[i] = 0;
+        return rc;
+    });
+}
+
+int hegpu_drbg_block(const uint8_t key[32], uint64_t stream, uint64_t index, uint32_t out[4])
+{
+    if (!key || !out) return fail(HEGPU_E_INVALID, "null argument");
+    DrbgKey k;
+    for (int i = 0; i < 8; i++)
+        k.k[i] = (u32) key[4 * i] | ((u32) key[4 * i + 1] << 8) | ((u32) key[4 * i + 2] << 16) | ((u32) key[4 * i + 3] << 24);
+    const DrbgOut o = drbg_block(k, stream, index);
+    for (int i = 0; i < 4; i++) out[i] = o.w[i];
+    return 0;
 }
 
 void hegpu_rng_destroy(hegpu_rng* rng) { delete rng; }

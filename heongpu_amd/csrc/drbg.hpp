@@ -1,46 +1,73 @@
 // drbg.hpp -- the backend's own deterministic random bit generator and the
 // three samplers of the key-generation / encryption path (host + device).
 //
-// The reference draws from rngongpu::RNG<AES> seeded with RAND_bytes
+// The reference draws from rngongpu::RNG<AES> (AES-CTR) seeded with RAND_bytes
 // (src/lib/util/random.cu:20-60): its streams can never be reproduced, only its
 // distributions (random.cuh:52-708): uniform mod q_i per limb, a rounded
 // Gaussian (sigma = 3.2, secstdparams.h:22) and a uniform ternary value shared
-// by all limbs of a coefficient.  Here the bits come from the counter-based
-// Philox4x32-10 generator (Salmon et al., "Parallel random numbers: as easy as
-// 1, 2, 3", SC'11), written from the published round function: every output
-// word is a pure function of (seed, stream, index), so the device kernels, the
-// host code and the CPU oracle produce identical samples without sharing state.
+// by all limbs of a coefficient.  Here the bits come from the ChaCha20 block
+// function (Bernstein's original layout: 256-bit key, 64-bit block counter,
+// 64-bit nonce; the same core as RFC 8439, whose section 2.3.2 vector pins this
+// implementation) used as a counter-mode PRF: key = the generator's 256-bit
+// seed, nonce = the stream id of the sampling call, counter = the sample index.
+// Every output word is a pure function of (seed, stream, index), so the device
+// kernels, the host code and the CPU oracle produce identical samples without
+// sharing state -- and, unlike the Philox generator of round 1, knowing outputs
+// (e.g. the public `a` polynomials) reveals nothing about the key or about the
+// other streams (secret key, noise).  Seeds: 256 bits from the OS
+// (hegpu_rng_create_from_entropy); the 64-bit-seed constructor exists for
+// reproducible tests only.
 #pragma once
 #include "modarith.cuh"
 
 namespace hegpu {
 
-struct PhiloxOut {
+struct DrbgKey {
+    u32 k[8];
+};
+struct DrbgOut {
     u32 w[4];
 };
 
-HG_HD PhiloxOut philox4x32_10(u32 k0, u32 k1, u32 c0, u32 c1, u32 c2, u32 c3)
+HG_HD u32 drbg_rotl(u32 v, int c) { return (v << c) | (v >> (32 - c)); }
+
+#define DRBG_QR(a, b, c, d)                \
+    a += b; d ^= a; d = drbg_rotl(d, 16);  \
+    c += d; b ^= c; b = drbg_rotl(b, 12);  \
+    a += b; d ^= a; d = drbg_rotl(d, 8);   \
+    c += d; b ^= c; b = drbg_rotl(b, 7);
+
+// first 128 bits of the ChaCha20 block (key, counter = index, nonce = stream)
+HG_HD DrbgOut drbg_block(const DrbgKey& key, u64 stream, u64 index)
 {
-    const u32 M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    const u32 c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;
+    u32 x0 = c0, x1 = c1, x2 = c2, x3 = c3;
+    u32 x4 = key.k[0], x5 = key.k[1], x6 = key.k[2], x7 = key.k[3];
+    u32 x8 = key.k[4], x9 = key.k[5], x10 = key.k[6], x11 = key.k[7];
+    u32 x12 = (u32) index, x13 = (u32) (index >> 32), x14 = (u32) stream, x15 = (u32) (stream >> 32);
     for (int r = 0; r < 10; r++) {
-        const u64 p0 = (u64) M0 * c0, p1 = (u64) M1 * c2;
-        const u32 n0 = (u32) (p1 >> 32) ^ c1 ^ k0;
-        const u32 n1 = (u32) p1;
-        const u32 n2 = (u32) (p0 >> 32) ^ c3 ^ k1;
-        const u32 n3 = (u32) p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += W0; k1 += W1;
+        DRBG_QR(x0, x4, x8, x12)
+        DRBG_QR(x1, x5, x9, x13)
+        DRBG_QR(x2, x6, x10, x14)
+        DRBG_QR(x3, x7, x11, x15)
+        DRBG_QR(x0, x5, x10, x15)
+        DRBG_QR(x1, x6, x11, x12)
+        DRBG_QR(x2, x7, x8, x13)
+        DRBG_QR(x3, x4, x9, x14)
     }
-    PhiloxOut o;
-    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    DrbgOut o;
+    o.w[0] = x0 + c0; o.w[1] = x1 + c1; o.w[2] = x2 + c2; o.w[3] = x3 + c3;
     return o;
 }
+#undef DRBG_QR
 
-// 128 bits for (seed, stream, index)
-HG_HD PhiloxOut drbg_block(u64 seed, u64 stream, u64 index)
+// test-only expansion of a 64-bit seed: key words 0 and 1, the rest zero
+HG_HD DrbgKey drbg_key_from_u64(u64 seed)
 {
-    return philox4x32_10((u32) seed, (u32) (seed >> 32), (u32) index, (u32) (index >> 32), (u32) stream,
-                         (u32) (stream >> 32));
+    DrbgKey k;
+    k.k[0] = (u32) seed; k.k[1] = (u32) (seed >> 32);
+    for (int i = 2; i < 8; i++) k.k[i] = 0;
+    return k;
 }
 
 // Rounded Gaussian by CDT inversion: cdt[k] = floor(2^63 * P(|X| <= k)) for
@@ -51,9 +78,9 @@ struct GaussCdt {
     u64 t[DRBG_GAUSS_MAX];
 };
 
-HG_HD int drbg_gaussian(u64 seed, u64 stream, u64 index, const GaussCdt& cdt)
+HG_HD int drbg_gaussian(const DrbgKey& seed, u64 stream, u64 index, const GaussCdt& cdt)
 {
-    const PhiloxOut o = drbg_block(seed, stream, index);
+    const DrbgOut o = drbg_block(seed, stream, index);
     const u64 r = (u64) o.w[0] | ((u64) o.w[1] << 32);
     const u64 u = r >> 1;
     int k = 0;
@@ -62,16 +89,16 @@ HG_HD int drbg_gaussian(u64 seed, u64 stream, u64 index, const GaussCdt& cdt)
 }
 
 // uniform in {-1, 0, 1}
-HG_HD int drbg_ternary(u64 seed, u64 stream, u64 index)
+HG_HD int drbg_ternary(const DrbgKey& seed, u64 stream, u64 index)
 {
-    const PhiloxOut o = drbg_block(seed, stream, index);
+    const DrbgOut o = drbg_block(seed, stream, index);
     return (int) (((u64) o.w[0] * 3) >> 32) - 1;
 }
 
 // uniform in [0, q): 128 random bits reduced mod q (bias < 2^-66)
-HG_HD u64 drbg_uniform(u64 seed, u64 stream, u64 index, const Mod& m)
+HG_HD u64 drbg_uniform(const DrbgKey& seed, u64 stream, u64 index, const Mod& m)
 {
-    const PhiloxOut o = drbg_block(seed, stream, index);
+    const DrbgOut o = drbg_block(seed, stream, index);
     const u64 lo = (u64) o.w[0] | ((u64) o.w[1] << 32), hi = (u64) o.w[2] | ((u64) o.w[3] << 32);
     return reduce128(hi, lo, m);
 }
@@ -82,11 +109,11 @@ HG_HD u64 drbg_uniform(u64 seed, u64 stream, u64 index, const Mod& m)
 // 2^32*sqrt(16/12), support +-6.9 sigma) scaled by one FP64 multiply and rounded: integer
 // arithmetic plus a single IEEE operation, hence identical on the device, the host and in the
 // CPU oracle.  c = alpha * 2^32 / (2^32 * sqrt(4/3)) = alpha / 1.1547005383792517.
-HG_HD int drbg_torus_gaussian(u64 seed, u64 stream, u64 index, double c)
+HG_HD int drbg_torus_gaussian(const DrbgKey& seed, u64 stream, u64 index, double c)
 {
     u64 sum = 0;
     for (int j = 0; j < 4; j++) {
-        const PhiloxOut o = drbg_block(seed, stream, 4 * index + j);
+        const DrbgOut o = drbg_block(seed, stream, 4 * index + j);
         sum += (u64) o.w[0] + (u64) o.w[1] + (u64) o.w[2] + (u64) o.w[3];
     }
     const double g = (double) ((long long) sum - (8ll << 32));
@@ -98,8 +125,8 @@ HG_HD int drbg_torus_gaussian(u64 seed, u64 stream, u64 index, double c)
     return (int) (u32) (long long) r; // wraps on the 32-bit torus
 }
 // uniform torus32 value / uniform bit
-HG_HD int drbg_torus_uniform(u64 seed, u64 stream, u64 index) { return (int) drbg_block(seed, stream, index).w[0]; }
-HG_HD int drbg_bit(u64 seed, u64 stream, u64 index) { return (int) (drbg_block(seed, stream, index).w[0] & 1u); }
+HG_HD int drbg_torus_uniform(const DrbgKey& seed, u64 stream, u64 index) { return (int) drbg_block(seed, stream, index).w[0]; }
+HG_HD int drbg_bit(const DrbgKey& seed, u64 stream, u64 index) { return (int) (drbg_block(seed, stream, index).w[0] & 1u); }
 
 // signed small integer -> residue
 HG_HD u64 lift_small(int v, u64 q) { return v < 0 ? q - (u64) (-v) : (u64) v; }

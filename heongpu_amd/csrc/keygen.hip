@@ -9,7 +9,7 @@ namespace hegpu {
 #define KG_THREADS 256
 
 __global__ __launch_bounds__(KG_THREADS) void k_kg_uniform(u64* __restrict__ out, const Mod* __restrict__ mods,
-                                                           int n_power, int limbs, u64 seed, u64 stream)
+                                                           int n_power, int limbs, DrbgKey seed, u64 stream)
 {
     const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
     const int limb = blockIdx.y, poly = blockIdx.z;
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_uniform(u64* __restrict__ out
 }
 
 __global__ __launch_bounds__(KG_THREADS) void k_kg_gaussian(u64* __restrict__ out, const Mod* __restrict__ mods,
-                                                            int n_power, int limbs, u64 seed, u64 stream,
+                                                            int n_power, int limbs, DrbgKey seed, u64 stream,
                                                             GaussCdt cdt)
 {
     const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_gaussian(u64* __restrict__ ou
 }
 
 __global__ __launch_bounds__(KG_THREADS) void k_kg_ternary(u64* __restrict__ out, const Mod* __restrict__ mods,
-                                                           int n_power, int limbs, u64 seed, u64 stream)
+                                                           int n_power, int limbs, DrbgKey seed, u64 stream)
 {
     const u64 n = (u64) blockIdx.x * KG_THREADS + threadIdx.x;
     const int poly = blockIdx.y;
@@ -36,21 +36,21 @@ __global__ __launch_bounds__(KG_THREADS) void k_kg_ternary(u64* __restrict__ out
     for (int j = 0; j < limbs; j++) out[(((u64) poly * limbs + j) << n_power) + n] = lift_small(v, mods[j].q);
 }
 
-hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                       hipStream_t st)
 {
     hipLaunchKernelGGL(k_kg_uniform, dim3((1u << n_power) / KG_THREADS, limbs, polys), dim3(KG_THREADS), 0, st, out,
                        mods, n_power, limbs, seed, stream);
     return hipGetLastError();
 }
-hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                        const GaussCdt& cdt, hipStream_t st)
 {
     hipLaunchKernelGGL(k_kg_gaussian, dim3((1u << n_power) / KG_THREADS, polys), dim3(KG_THREADS), 0, st, out, mods,
                        n_power, limbs, seed, stream, cdt);
     return hipGetLastError();
 }
-hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                       hipStream_t st)
 {
     hipLaunchKernelGGL(k_kg_ternary, dim3((1u << n_power) / KG_THREADS, polys), dim3(KG_THREADS), 0, st, out, mods,

@@ -6,13 +6,13 @@
 namespace hegpu {
 
 // out[poly][limb][N] uniform mod q_limb                    (random.cuh: modular_uniform_*)
-hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_uniform(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                       hipStream_t st);
 // out[poly][limb][N]: one rounded Gaussian per (poly, coefficient), lifted into every limb
-hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_gaussian(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                        const GaussCdt& cdt, hipStream_t st);
 // same with a uniform ternary value
-hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, u64 seed, u64 stream,
+hipError_t kg_ternary(u64* out, const Mod* mods, int n_power, int limbs, int polys, DrbgKey seed, u64 stream,
                       hipStream_t st);
 // secretkey_gen_kernel_v2 + secretkey_rns_kernel (keygeneration.cu:39-88): scatter `count`
 // (position, +-1) pairs into an all-zero polynomial and lift it into `limbs` limbs

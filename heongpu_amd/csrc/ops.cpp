@@ -463,7 +463,7 @@ hipError_t op_gen_secret_key(const Context& c, Rng& r, int hamming_weight, u64* 
     for (int i = 0; i < n; i++) index[i] = i;
     const u64 stream = r.stream++;
     for (int i = 0; i < hamming_weight; i++) {
-        const PhiloxOut o = drbg_block(r.seed, stream, (u64) i);
+        const DrbgOut o = drbg_block(r.seed, stream, (u64) i);
         const int j = i + (int) (((u64) o.w[0] * (u64) (n - i)) >> 32);
         std::swap(index[i], index[j]);
         host[i] = index[i];

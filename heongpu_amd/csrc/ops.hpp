@@ -42,7 +42,7 @@ hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* 
 // ---- key generation / encryption / decryption, key-switch method I
 // The generator state: every sampling call consumes one stream id of the DRBG (drbg.hpp).
 struct Rng {
-    u64 seed = 0;
+    DrbgKey seed{}; // 256-bit ChaCha20 key (drbg.hpp)
     u64 stream = 0;
 };
 // HEKeyGenerator::generate_secret_key_v2 (ckks/keygenerator.cu:85-160); sk [Q'][N], NTT domain

@@ -684,13 +684,13 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
 }
 
 // ------------------------------------------------------------------ front end: keys, encryption, decryption
-__global__ __launch_bounds__(256) void k_tfhe_gen_bits(int* __restrict__ out, int count, u64 seed, u64 stream)
+__global__ __launch_bounds__(256) void k_tfhe_gen_bits(int* __restrict__ out, int count, DrbgKey seed, u64 stream)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < count) out[i] = drbg_bit(seed, stream, (u64) i);
 }
 
-hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, u64 seed, u64 stream0, hipStream_t st)
+hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, DrbgKey seed, u64 stream0, hipStream_t st)
 {
     hipLaunchKernelGGL(k_tfhe_gen_bits, dim3((n + 255) / 256), dim3(256), 0, st, lwe_key, n, seed, stream0);
     hipLaunchKernelGGL(k_tfhe_gen_bits, dim3((kN + 255) / 256), dim3(256), 0, st, tlwe_key, kN, seed, stream0 + 1);
@@ -701,7 +701,7 @@ hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, u64 seed,
 __global__ __launch_bounds__(256) void k_tfhe_lwe_encrypt(int* __restrict__ out_a, int* __restrict__ out_b,
                                                           const int* __restrict__ key, const int* __restrict__ msg,
                                                           int ks_mode, const int* __restrict__ tlwe_key, int base_bit,
-                                                          int len, int n, double noise_c, u64 seed, u64 stream_a,
+                                                          int len, int n, double noise_c, DrbgKey seed, u64 stream_a,
                                                           u64 stream_e)
 {
     __shared__ u32 red[256];
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void k_tfhe_lwe_encrypt(int* __restrict__ out_
 }
 
 hipError_t tfhe_lwe_encrypt(int* out_a, int* out_b, const int* key, const int* msg, int ks_mode, const int* tlwe_key,
-                            int base_bit, int len, int n, u64 shape, double noise_c, u64 seed, u64 stream_a,
+                            int base_bit, int len, int n, u64 shape, double noise_c, DrbgKey seed, u64 stream_a,
                             u64 stream_e, hipStream_t st)
 {
     if (shape == 0) return hipSuccess;
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(64) void k_tfhe_key_ntt(const int* __restrict__ tlw
 // one wavefront per boot-key row (i, y, z), k = 1
 __global__ __launch_bounds__(64) void k_tfhe_gen_bootkey(u64* __restrict__ boot_key, const int* __restrict__ lwe_key,
                                                          const u64* __restrict__ tlwe_ntt, TfheDev p, double noise_c,
-                                                         u64 seed, u64 stream_a, u64 stream_e)
+                                                         DrbgKey seed, u64 stream_a, u64 stream_e)
 {
     __shared__ __attribute__((aligned(16))) u64 buf[TF_BUF];
     const int lane = threadIdx.x;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(64) void k_tfhe_gen_bootkey(u64* __restrict__ boot_
 }
 
 hipError_t tfhe_gen_bootkey(const TfheDev& p, u64* boot_key, const int* lwe_key, const int* tlwe_key, u64* tlwe_ntt,
-                            double noise_c, u64 seed, u64 stream_a, u64 stream_e, hipStream_t st)
+                            double noise_c, DrbgKey seed, u64 stream_a, u64 stream_e, hipStream_t st)
 {
     if (p.k != 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_tfhe_key_ntt, dim3(1), dim3(64), 0, st, tlwe_key, tlwe_ntt, p);

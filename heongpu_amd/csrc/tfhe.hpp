@@ -1,5 +1,6 @@
 // tfhe.hpp -- TFHE gate-bootstrapping launchers (internal C++).
 #pragma once
+#include "drbg.hpp"
 #include "modarith.cuh"
 
 namespace hegpu {
@@ -28,17 +29,17 @@ struct TfheDev {
 // ---- TFHE front end: keys, bit encryption, decryption (reference tfhe/keygenerator.cu,
 // encryptor.cu, decryptor.cu); samplers in drbg.hpp
 // binary LWE key [n] and TLWE key [k*N]
-hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, u64 seed, u64 stream0, hipStream_t st);
+hipError_t tfhe_gen_secret(int* lwe_key, int* tlwe_key, int n, int kN, DrbgKey seed, u64 stream0, hipStream_t st);
 // LWE encryptions under `key` [n]: a [shape][n], b [shape] = <a,key> + msg + noise.
 // msg: torus32 messages [shape], or (ks_mode) the key-switch key pattern
 // tlwe_key[i] * v * 2^(32 - (j+1)*base_bit) for shape index ((i*len + j)*(base-1) + v-1)
 hipError_t tfhe_lwe_encrypt(int* out_a, int* out_b, const int* key, const int* msg, int ks_mode, const int* tlwe_key,
-                            int base_bit, int len, int n, u64 shape, double noise_c, u64 seed, u64 stream_a,
+                            int base_bit, int len, int n, u64 shape, double noise_c, DrbgKey seed, u64 stream_a,
                             u64 stream_e, hipStream_t st);
 // boot key in the reference layout [n][k+1][l][k+1][N] (NTT domain mod the 60-bit prime): row
 // (i,y,z) = TLWE_S(0) + s_i * 2^(32 - (z+1)*bg_bit) on component y; tlwe_ntt: scratch [N]
 hipError_t tfhe_gen_bootkey(const TfheDev& p, u64* boot_key, const int* lwe_key, const int* tlwe_key, u64* tlwe_ntt,
-                            double noise_c, u64 seed, u64 stream_a, u64 stream_e, hipStream_t st);
+                            double noise_c, DrbgKey seed, u64 stream_a, u64 stream_e, hipStream_t st);
 // phase[s] = b[s] - <a[s], key>
 hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase, int n, int shape, hipStream_t st);
 

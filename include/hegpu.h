@@ -69,7 +69,8 @@ long hegpu_context_int(const hegpu_context* ctx, const char* name);
 long hegpu_context_get(const hegpu_context* ctx, const char* name, uint64_t* out, long cap);
 /* device address of a named device table ("new_prime_locations", ...) */
 const void* hegpu_context_device_ptr(const hegpu_context* ctx, const char* name);
-/* keygeneration.cu:684-728 steps_to_galois_elt */
+/* keygeneration.cu:684-728 steps_to_galois_elt; 0 for |steps| >= N/2 (the reference prints an error and
+ * returns 0 there); -1 only if the host code failed (no exception crosses this boundary) */
 int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order);
 
 /* ------------------------------------------------------------------ NTT seam
@@ -193,13 +194,21 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_s
                            size_t ws_bytes, hegpu_stream stream);
 
 /* ---- key generation, encryption, decryption (key-switching method I) ----
- * The random values are the backend's own (Philox4x32-10 counter DRBG seeded by the caller,
- * csrc/drbg.hpp): the reference's AES generator is seeded from RAND_bytes and cannot be
- * reproduced, only its distributions (uniform mod q_i, rounded Gaussian sigma = 3.2 clipped at
+ * The random values are the backend's own: a ChaCha20 counter-mode PRF keyed by a 256-bit seed
+ * (csrc/drbg.hpp; the reference's rngongpu::RNG<AES> is AES-CTR seeded from RAND_bytes and cannot be
+ * reproduced, only its distributions: uniform mod q_i, rounded Gaussian sigma = 3.2 clipped at
  * 6 sigma, uniform ternary; src/include/heongpu/util/random.cuh:52-708).  Workspaces:
  * hegpu_workspace_bytes(ctx, HEGPU_OP_KEYGEN_* / HEGPU_OP_CKKS_ENCRYPT, 0, 1).  All keys NTT domain. */
 typedef struct hegpu_rng hegpu_rng;
+/* 256 bits from the operating system (getrandom): the constructor to use for real keys */
+int hegpu_rng_create_from_entropy(hegpu_rng** out);
+/* caller-provided 256-bit seed (e.g. from an HSM or a KDF) */
+int hegpu_rng_create_seeded(const uint8_t seed[32], hegpu_rng** out);
+/* REPRODUCIBLE TESTS ONLY -- a 64-bit seed is brute-forceable: key words 0,1 = seed, rest zero */
 int hegpu_rng_create(uint64_t seed, hegpu_rng** out);
+/* the PRF itself (host side): first 128 bits of the ChaCha20 block with counter = index, nonce =
+ * stream; pinned by the RFC 8439 section 2.3.2 vector in tests/test_cabi.py */
+int hegpu_drbg_block(const uint8_t key[32], uint64_t stream, uint64_t index, uint32_t out[4]);
 void hegpu_rng_destroy(hegpu_rng* rng);
 /* HEKeyGenerator::generate_secret_key_v2 (src/lib/host/ckks/keygenerator.cu:85-160):
  * ternary with exactly hamming_weight non-zeros; sk [Q'][N].  Synchronises the stream once. */

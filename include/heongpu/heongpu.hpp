@@ -130,8 +130,8 @@ inline void hip(hipError_t e)
 // stream waits for that event).  hipMallocAsync is deliberately NOT used: on this ROCm the
 // default stream-ordered pool returns overlapping buffers (tools/hip_pool_repro.cpp,
 // profiles/r1h_hip_pool/repro.txt).  `max` caps what the cache keeps, `initial` is reserved
-// up front.  The host-side fields are accepted and ignored: nothing is parked in host memory
-// (see Ciphertext::store_in_host).
+// up front.  The host-side fields are accepted and ignored: pinned host memory (HostVector, the
+// storage manager's parking space) comes straight from hipHostMalloc.
 struct MemoryPoolConfig {
     std::optional<float> initial_device_fraction, max_device_fraction;
     std::optional<size_t> initial_device_bytes, max_device_bytes;
@@ -172,6 +172,7 @@ class MemoryPool {
             if (hipMalloc((void**) &b.p, b.bytes) == hipSuccess) {
                 reserved_ += b.bytes;
                 free_.insert({b.bytes, b});
+                arena_free_[b.p] = b.bytes;
             } else {
                 (void) hipGetLastError();
             }
@@ -268,6 +269,8 @@ class MemoryPool {
         if (it != free_.end()) {
             b = it->second;
             free_.erase(it);
+            if (b.arena) arena_free_.erase(b.p);
+            else cached_ -= b.bytes;
             if (b.arena && b.bytes - want >= (2u << 20)) { // split: the tail stays cached
                 Block tail = b;
                 tail.p = b.p + want;
@@ -278,6 +281,7 @@ class MemoryPool {
                     detail::hip(hipEventRecord(tail.freed, b.stream));
                 }
                 free_.insert({tail.bytes, tail});
+                arena_free_[tail.p] = tail.bytes;
                 b.bytes = want;
             }
             if (b.freed && b.stream != stream) detail::hip(hipStreamWaitEvent(stream, b.freed, 0));
@@ -307,8 +311,42 @@ class MemoryPool {
         b.stream = stream;
         if (!b.freed) (void) hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
         (void) hipEventRecord(b.freed, stream);
+        if (b.arena) { // pieces of the initial reservation coalesce with their free neighbours
+            auto next = arena_free_.find(b.p + b.bytes);
+            if (next != arena_free_.end()) absorb_locked(b, next->first, next->second, true);
+            auto prev = arena_free_.lower_bound(b.p);
+            if (prev != arena_free_.begin()) {
+                --prev;
+                if (prev->first + prev->second == b.p) absorb_locked(b, prev->first, prev->second, false);
+            }
+            arena_free_[b.p] = b.bytes;
+        } else {
+            cached_ += b.bytes;
+        }
         free_.insert({b.bytes, b});
-        if (reserved_ > max_cached_) release_cached_locked();
+        // the cap is on what the cache KEEPS (live memory is the caller's business): a working set above
+        // it must not turn every free into a device synchronisation
+        if (cached_ > max_cached_) release_cached_locked();
+    }
+    // merge the free arena piece (np, nbytes) into b; the merged block is reusable once both frees are done,
+    // so b's stream waits for the neighbour's event and b's event is recorded again
+    void absorb_locked(Block& b, char* np, size_t nbytes, bool after)
+    {
+        auto range = free_.equal_range(nbytes);
+        for (auto f = range.first; f != range.second; ++f) {
+            if (f->second.p != np) continue;
+            Block nb = f->second;
+            free_.erase(f);
+            arena_free_.erase(np);
+            if (nb.freed) {
+                (void) hipStreamWaitEvent(b.stream, nb.freed, 0);
+                (void) hipEventDestroy(nb.freed);
+            }
+            (void) hipEventRecord(b.freed, b.stream);
+            if (!after) b.p = np;
+            b.bytes += nbytes;
+            return;
+        }
     }
     void release_cached_locked()
     {
@@ -319,6 +357,7 @@ class MemoryPool {
             if (b.freed) (void) hipEventDestroy(b.freed);
             (void) hipFree(b.p);
             reserved_ -= b.bytes;
+            cached_ -= b.bytes;
             it = free_.erase(it);
         }
     }
@@ -348,7 +387,8 @@ class MemoryPool {
     std::multimap<size_t, Block> free_;        // cached blocks by size
     std::unordered_map<char*, Block> live_;    // blocks handed out
     std::map<char*, size_t> guarded_;          // only with HEGPU_POOL_GUARD
-    size_t reserved_ = 0, in_use_ = 0, max_cached_ = (size_t) -1;
+    std::map<char*, size_t> arena_free_;       // free pieces of the initial reservation by address (coalescing)
+    size_t reserved_ = 0, in_use_ = 0, cached_ = 0, max_cached_ = (size_t) -1; // cached_: free non-arena bytes
 };
 
 // util/devicevector.cuh:17-173: stream-ordered device buffer
@@ -368,9 +408,11 @@ template <typename T> class DeviceVector {
         return *this;
     }
     DeviceVector(DeviceVector&& o) noexcept : p_(o.p_), n_(o.n_), s_(o.s_) { o.p_ = nullptr; o.n_ = 0; }
+    // The buffer being replaced was last read by the work that produced `o` (an in-place operator on
+    // o's stream), possibly on another stream than the one it was allocated on: free it ordered after both.
     DeviceVector& operator=(DeviceVector&& o) noexcept
     {
-        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; s_ = o.s_; o.p_ = nullptr; o.n_ = 0; }
+        if (this != &o) { release(o.s_); p_ = o.p_; n_ = o.n_; s_ = o.s_; o.p_ = nullptr; o.n_ = 0; }
         return *this;
     }
     ~DeviceVector() { release(); }
@@ -387,9 +429,20 @@ template <typename T> class DeviceVector {
     void set_stream(hipStream_t s) { s_ = s; }
 
   private:
-    void release()
+    void release() { release(s_); }
+    void release(hipStream_t last_use)
     {
-        if (p_) MemoryPool::instance().deallocate(p_, n_ * sizeof(T), s_);
+        if (p_) {
+            if (last_use != s_) { // make the freeing stream wait for the allocation stream's work as well
+                hipEvent_t e = nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+                    (void) hipEventRecord(e, s_);
+                    (void) hipStreamWaitEvent(last_use, e, 0);
+                    (void) hipEventDestroy(e);
+                }
+            }
+            MemoryPool::instance().deallocate(p_, n_ * sizeof(T), last_use);
+        }
         p_ = nullptr;
         n_ = 0;
     }
@@ -403,7 +456,165 @@ template <typename T> class DeviceVector {
     hipStream_t s_ = nullptr;
 };
 
-template <typename T> using HostVector = std::vector<T>; // util/hostvector.cuh:17-31 (pinned there)
+// util/hostvector.cuh:17-31: host vector in pinned (page-locked) memory, so that the storage manager's
+// host <-> device copies are asynchronous DMA transfers (the reference: rmm_pinned_allocator)
+template <typename T> struct PinnedAllocator {
+    using value_type = T;
+    PinnedAllocator() = default;
+    template <typename U> PinnedAllocator(const PinnedAllocator<U>&) noexcept {}
+    T* allocate(size_t n)
+    {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); throw std::bad_alloc(); }
+        return (T*) p;
+    }
+    void deallocate(T* p, size_t) noexcept { (void) hipHostFree(p); }
+    template <typename U> bool operator==(const PinnedAllocator<U>&) const noexcept { return true; }
+    template <typename U> bool operator!=(const PinnedAllocator<U>&) const noexcept { return false; }
+};
+template <typename T> using HostVector = std::vector<T, PinnedAllocator<T>>;
+
+// ------------------------------------------------------------------ storage manager
+// util/storagemanager.cuh:113-275 (input_storage_manager / output_storage_manager) and the
+// store_in_host / store_in_device / copy_to_device / remove_from_* methods of every object
+// (e.g. ckks/ciphertext.cu:52-169).  An object's residues live either in HBM or in pinned host memory.
+// An operator that touches a HOST-stored object stages it on use (an asynchronous copy on the operator's
+// stream); when the operator returns, inputs go back to where they were (keep_initial_condition_, with a
+// copy-back because the operators take non-const references) or stay on the device, and every object the
+// operator wrote is placed where ExecutionOptions::storage_ says.
+namespace detail {
+class StoredBuffer;
+struct OpScope {
+    explicit OpScope(const ExecutionOptions& o) : o_(o), outer_(current() == nullptr)
+    {
+        if (outer_) current() = this;
+    }
+    ~OpScope() noexcept(false);
+    static OpScope*& current()
+    {
+        static thread_local OpScope* c = nullptr;
+        return c;
+    }
+    void staged(StoredBuffer* b) { if (std::find(staged_.begin(), staged_.end(), b) == staged_.end()) staged_.push_back(b); }
+    void written(StoredBuffer* b) { if (std::find(written_.begin(), written_.end(), b) == written_.end()) written_.push_back(b); }
+    hipStream_t stream() const { return o_.stream_; }
+
+  private:
+    ExecutionOptions o_;
+    bool outer_;
+    std::vector<StoredBuffer*> staged_, written_;
+};
+
+class StoredBuffer {
+  public:
+    StoredBuffer() = default;
+    StoredBuffer(DeviceVector<Data64>&& m) : dev_(std::move(m)) {}
+    StoredBuffer(const StoredBuffer& o) : dev_(o.dev_), host_(o.host_), st_(o.st_), staged_(o.staged_) {}
+    StoredBuffer& operator=(const StoredBuffer& o)
+    {
+        if (this != &o) { dev_ = o.dev_; host_ = o.host_; st_ = o.st_; staged_ = o.staged_; }
+        return *this;
+    }
+    StoredBuffer(StoredBuffer&&) = default;
+    StoredBuffer& operator=(StoredBuffer&&) = default;
+    // fresh residues from an operator: they are on the device, whatever the object held before is gone
+    StoredBuffer& operator=(DeviceVector<Data64>&& m)
+    {
+        dev_ = std::move(m);
+        drop_host();
+        st_ = storage_type::DEVICE;
+        staged_ = false;
+        if (OpScope* sc = OpScope::current()) sc->written(this);
+        return *this;
+    }
+    // device address; a HOST-stored object is staged first (on the running operator's stream)
+    Data64* data()
+    {
+        if (st_ == storage_type::HOST && !staged_ && !host_.empty()) {
+            OpScope* sc = OpScope::current();
+            copy_to_device(sc ? sc->stream() : dev_.stream());
+            if (sc) sc->staged(this);
+        }
+        return dev_.data();
+    }
+    const Data64* data() const { return const_cast<StoredBuffer*>(this)->data(); }
+    size_t size() const { return (st_ == storage_type::HOST && !staged_) ? host_.size() : dev_.size(); }
+    hipStream_t stream() const { return dev_.stream(); }
+    void set_stream(hipStream_t s) { dev_.set_stream(s); }
+    bool is_on_device() const noexcept { return st_ == storage_type::DEVICE; }
+    storage_type storage() const noexcept { return st_; }
+    void set_storage(storage_type t) { if (size() == 0) st_ = t; } // an empty object only records the wish
+    const HostVector<Data64>& host_data() const { return host_; }
+
+    void store_in_device(hipStream_t s = nullptr) // */ciphertext.cu store_in_device
+    {
+        if (st_ == storage_type::DEVICE) return;
+        if (!staged_ && !host_.empty()) upload(s);
+        drop_host();
+        st_ = storage_type::DEVICE;
+        staged_ = false;
+    }
+    void store_in_host(hipStream_t s = nullptr) // */ciphertext.cu store_in_host
+    {
+        if (st_ == storage_type::HOST && !staged_) return;
+        if (dev_.size()) {
+            host_.resize(dev_.size());
+            hip(hipMemcpyAsync(host_.data(), dev_.data(), dev_.size() * sizeof(Data64), hipMemcpyDeviceToHost, s));
+            hip(hipStreamSynchronize(s)); // the device buffer is released next; the host copy must be complete
+            dev_.set_stream(s);
+            dev_ = DeviceVector<Data64>();
+        }
+        st_ = storage_type::HOST;
+        staged_ = false;
+    }
+    void copy_to_device(hipStream_t s = nullptr) // host copy kept: the object still counts as HOST-stored
+    {
+        if (st_ == storage_type::DEVICE || staged_) return;
+        if (!host_.empty()) upload(s);
+        staged_ = true;
+    }
+    void remove_from_device(hipStream_t s = nullptr)
+    {
+        if (st_ != storage_type::HOST || !staged_) return;
+        dev_.set_stream(s);
+        dev_ = DeviceVector<Data64>();
+        staged_ = false;
+    }
+    void remove_from_host()
+    {
+        if (st_ == storage_type::HOST && staged_) { st_ = storage_type::DEVICE; staged_ = false; }
+        if (st_ == storage_type::DEVICE) drop_host();
+    }
+    bool staged() const noexcept { return staged_; }
+
+  private:
+    void upload(hipStream_t s)
+    {
+        DeviceVector<Data64> d(host_.size(), s);
+        hip(hipMemcpyAsync(d.data(), host_.data(), host_.size() * sizeof(Data64), hipMemcpyHostToDevice, s));
+        dev_ = std::move(d);
+    }
+    void drop_host() { HostVector<Data64>().swap(host_); }
+    DeviceVector<Data64> dev_;
+    HostVector<Data64> host_;
+    storage_type st_ = storage_type::DEVICE;
+    bool staged_ = false;
+};
+
+inline OpScope::~OpScope() noexcept(false)
+{
+    if (!outer_) return;
+    current() = nullptr;
+    for (StoredBuffer* b : written_)
+        if (o_.storage_ == storage_type::HOST) b->store_in_host(o_.stream_);
+    for (StoredBuffer* b : staged_) {
+        if (std::find(written_.begin(), written_.end(), b) != written_.end()) continue;
+        if (!b->staged()) continue;
+        if (o_.keep_initial_condition_) b->store_in_host(o_.stream_); // back to the host, with what the operator did to it
+        else b->remove_from_host();                                    // it lives on the device from now on
+    }
+}
+} // namespace detail
 
 // ------------------------------------------------------------------ context
 template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation is at the end of this file
@@ -632,7 +843,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         coeff_modulus_count_ = context->Q_size;
         cipher_size_ = 2;
         in_ntt_domain_ = (S == Scheme::CKKS); // CKKS ciphertexts live in the NTT domain (ckks/ciphertext.cu)
-        storage_type_ = options.storage_;
+        device_locations_.set_storage(options.storage_);
         device_locations_.set_stream(options.stream_);
     }
     Data64* data() { return device_locations_.data(); }
@@ -641,11 +852,13 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
     void switch_stream(hipStream_t s) { device_locations_.set_stream(s); }
     hipStream_t stream() const noexcept { return device_locations_.stream(); }
-    bool is_on_device() const noexcept { return storage_type_ == storage_type::DEVICE; }
-    // The reference can park objects in host memory (storage manager); here the residues always
-    // stay in HBM (288 GB) and these calls only keep the caller's bookkeeping consistent.
-    void store_in_device(hipStream_t = nullptr) { storage_type_ = storage_type::DEVICE; }
-    void store_in_host(hipStream_t = nullptr) { storage_type_ = storage_type::DEVICE; }
+    // storage manager (ckks/ciphertext.cu:52-169): park the residues in pinned host memory / bring them back
+    bool is_on_device() const noexcept { return device_locations_.is_on_device(); }
+    void store_in_device(hipStream_t s = nullptr) { device_locations_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_locations_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_locations_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_locations_.remove_from_device(s); }
+    void remove_from_host() { device_locations_.remove_from_host(); }
     inline int ring_size() const noexcept { return ring_size_; }
     inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
     inline int size() const noexcept { return cipher_size_; }
@@ -730,6 +943,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         if (ring != ring_size_ || count_mod != coeff_modulus_count_)
             throw std::runtime_error("Ciphertext binary does not match the context!");
         is.read((char*) &cipher_size_, sizeof(int));
+        if (!is || cipher_size_ < 2 || cipher_size_ > 3) throw std::runtime_error("Ciphertext size is not correct!");
         depth_ = 0;
         if (S == Scheme::CKKS) is.read((char*) &depth_, sizeof(int));
         is.read((char*) &in_ntt_domain_, sizeof(bool));
@@ -753,7 +967,6 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
         if (!is) throw std::runtime_error("Ciphertext binary is truncated!");
         device_locations_ = DeviceVector<Data64>(host, device_locations_.stream());
         detail::hip(hipStreamSynchronize(device_locations_.stream()));
-        storage_type_ = storage_type::DEVICE;
         ciphertext_generated_ = true;
     }
 
@@ -762,8 +975,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     double scale_ = 0;
     bool in_ntt_domain_ = false, rescale_required_ = false, relinearization_required_ = false;
     bool ciphertext_generated_ = false;
-    storage_type storage_type_ = storage_type::DEVICE;
-    DeviceVector<Data64> device_locations_;
+    detail::StoredBuffer device_locations_; // HBM or pinned host memory (storage manager)
 };
 
 namespace detail {
@@ -818,8 +1030,12 @@ template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N 
     }
     void memory_set(DeviceVector<Data64>&& m) { device_location_ = std::move(m); }
     void set_context(HEContext<S> context) { context_ = std::move(context); }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {} // keys stay in HBM (see Ciphertext::store_in_host)
+    bool is_on_device() const noexcept { return device_location_.is_on_device(); } // storage manager, see Ciphertext
+    void store_in_device(hipStream_t s = nullptr) { device_location_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_location_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_location_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_location_.remove_from_device(s); }
+    void remove_from_host() { device_location_.remove_from_host(); }
     // */evaluationkey.cu Relinkey::save/load (bfv :91-200): scheme, key type (u8), ring size, Q', Q,
     // d, d_tilda, r_prime (int), storage (u8), generated (bool), element count (u64), the key
     void save(std::ostream& os) const
@@ -857,7 +1073,7 @@ template <Scheme S> class Relinkey { // host/*/evaluationkey.cuh; size 2*d*Q'*N 
     HEContext<S> context_;
     int ring_size = 0, Q_prime_size_ = 0, Q_size_ = 0, d_ = 0, d_tilda_ = 0, r_prime_ = 0;
     Data64 relinkey_size_ = 0;
-    DeviceVector<Data64> device_location_;
+    detail::StoredBuffer device_location_; // HBM or pinned host memory (storage manager)
 };
 
 // A key that moves a ciphertext from one secret key to another (host/*/evaluationkey.cuh
@@ -880,8 +1096,12 @@ template <Scheme S> class Switchkey {
     size_t size() const { return (size_t) switchkey_size_; }
     void memory_set(DeviceVector<Data64>&& m) { device_location_ = std::move(m); }
     void set_context(HEContext<S> context) { context_ = std::move(context); }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {}
+    bool is_on_device() const noexcept { return device_location_.is_on_device(); } // storage manager, see Ciphertext
+    void store_in_device(hipStream_t s = nullptr) { device_location_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_location_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_location_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_location_.remove_from_device(s); }
+    void remove_from_host() { device_location_.remove_from_host(); }
     void save(std::ostream& os) const // */evaluationkey.cu Switchkey::save (bfv :835-882)
     {
         if (!switch_key_generated_) throw std::runtime_error("Switchkey is not generated so can not be serialized!");
@@ -915,7 +1135,7 @@ template <Scheme S> class Switchkey {
     HEContext<S> context_;
     int ring_size = 0, Q_prime_size_ = 0, Q_size_ = 0, d_ = 0;
     Data64 switchkey_size_ = 0;
-    DeviceVector<Data64> device_location_;
+    detail::StoredBuffer device_location_; // HBM or pinned host memory (storage manager)
 };
 
 template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration.cu:684-728
@@ -948,8 +1168,12 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
         device_location_[galois_element] = DeviceVector<Data64>(host, s);
     }
     void set_context(HEContext<S> context) { context_ = std::move(context); }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {}
+    bool is_on_device() const noexcept { for (const auto& k : device_location_) if (!k.second.is_on_device()) return false; return true; }
+    void store_in_device(hipStream_t s = nullptr) { for (auto& k : device_location_) k.second.store_in_device(s); } // storage manager, every element
+    void store_in_host(hipStream_t s = nullptr) { for (auto& k : device_location_) k.second.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { for (auto& k : device_location_) k.second.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { for (auto& k : device_location_) k.second.remove_from_device(s); }
+    void remove_from_host() { for (auto& k : device_location_) k.second.remove_from_host(); }
     // */evaluationkey.cu Galoiskey::save/load (bfv :540-760): header as Relinkey up to d, then
     // customized (bool), group order (int), storage (u8), generated (bool); the element table
     // (u32 list when customized, else (shift, element) int pairs); galois_elt_zero (int), key
@@ -1035,7 +1259,7 @@ template <Scheme S> class Galoiskey { // host/*/evaluationkey.cuh; keygeneration
     int galois_elt_zero = 0;
     std::map<int, int> galois_elt;                           // shift -> Galois element
     std::vector<std::uint32_t> custom_galois_elt;            // customized == true
-    std::map<int, DeviceVector<Data64>> device_location_;    // Galois element -> key
+    std::map<int, detail::StoredBuffer> device_location_;    // Galois element -> key (HBM or pinned host memory)
     int group_order_ = 5;
     keyswitching_type key_type = keyswitching_type::KEYSWITCHING_METHOD_I;
 
@@ -1080,8 +1304,12 @@ template <Scheme S> class Secretkey { // host/*/secretkey.cuh; [Q'][N], NTT doma
     const Data64* data() const { return device_locations_.data(); }
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
     void set_context(HEContext<S> context) { context_ = std::move(context); }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {}
+    bool is_on_device() const noexcept { return device_locations_.is_on_device(); } // storage manager, see Ciphertext
+    void store_in_device(hipStream_t s = nullptr) { device_locations_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_locations_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_locations_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_locations_.remove_from_device(s); }
+    void remove_from_host() { device_locations_.remove_from_host(); }
     inline int ring_size() const noexcept { return ring_size_; }
     inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
     // */secretkey.cu:235-345: scheme (u8), ring size, modulus count, n_power, hamming weight (int),
@@ -1125,7 +1353,7 @@ template <Scheme S> class Secretkey { // host/*/secretkey.cuh; [Q'][N], NTT doma
   private:
     HEContext<S> context_;
     int ring_size_ = 0, coeff_modulus_count_ = 0, n_power_ = 0;
-    DeviceVector<Data64> device_locations_;
+    detail::StoredBuffer device_locations_; // HBM or pinned host memory (storage manager)
 };
 
 template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT domain
@@ -1141,8 +1369,12 @@ template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT d
     const Data64* data() const { return device_locations_.data(); }
     void memory_set(DeviceVector<Data64>&& m) { device_locations_ = std::move(m); }
     void set_context(HEContext<S> context) { context_ = std::move(context); }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {}
+    bool is_on_device() const noexcept { return device_locations_.is_on_device(); } // storage manager, see Ciphertext
+    void store_in_device(hipStream_t s = nullptr) { device_locations_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_locations_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_locations_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_locations_.remove_from_device(s); }
+    void remove_from_host() { device_locations_.remove_from_host(); }
     inline int ring_size() const noexcept { return ring_size_; }
     inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
     // */publickey.cu:92-200: scheme (u8), ring size, modulus count (int), ntt flag, generated flag
@@ -1183,7 +1415,7 @@ template <Scheme S> class Publickey { // host/*/publickey.cuh; [2][Q'][N], NTT d
   private:
     HEContext<S> context_;
     int ring_size_ = 0, coeff_modulus_count_ = 0;
-    DeviceVector<Data64> device_locations_;
+    detail::StoredBuffer device_locations_; // HBM or pinned host memory (storage manager)
 };
 
 template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - depth][N] NTT domain (+ depth, scale); BFV: [N] mod t
@@ -1255,8 +1487,12 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
         device_locations_ = detail::read_payload(is, (size_t) plain_size, "Plaintext");
         plaintext_generated_ = true;
     }
-    void store_in_device(hipStream_t = nullptr) {}
-    void store_in_host(hipStream_t = nullptr) {}
+    bool is_on_device() const noexcept { return device_locations_.is_on_device(); } // storage manager, see Ciphertext
+    void store_in_device(hipStream_t s = nullptr) { device_locations_.store_in_device(s); }
+    void store_in_host(hipStream_t s = nullptr) { device_locations_.store_in_host(s); }
+    void copy_to_device(hipStream_t s = nullptr) { device_locations_.copy_to_device(s); }
+    void remove_from_device(hipStream_t s = nullptr) { device_locations_.remove_from_device(s); }
+    void remove_from_host() { device_locations_.remove_from_host(); }
     inline int depth() const noexcept { return depth_; }
     inline double scale() const noexcept { return scale_; }
     inline encoding encoding_type() const noexcept { return encoding_; }
@@ -1268,16 +1504,22 @@ template <Scheme S> class Plaintext { // host/*/plaintext.cuh -- CKKS: [Q - dept
 
   private:
     HEContext<S> context_;
-    DeviceVector<Data64> device_locations_;
+    detail::StoredBuffer device_locations_; // HBM or pinned host memory (storage manager)
 };
 
 // ------------------------------------------------------------------ key generator / encryptor / decryptor
 // Key-switching methods I and II (one or several special primes).  Random values come from the backend's DRBG
-// (csrc/drbg.hpp); like the reference's generator it is seeded from std::random_device unless
-// a seed is given.
+// (csrc/drbg.hpp: ChaCha20 in counter mode); like the reference's AES generator it is seeded from the
+// operating system (256 bits) unless a test seed is given.
 template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
   public:
-    explicit HEKeyGenerator(HEContext<S> context) : HEKeyGenerator(std::move(context), std::random_device{}()) {}
+    // 256 bits of operating-system entropy (getrandom) key the ChaCha20 DRBG
+    explicit HEKeyGenerator(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        detail::check(hegpu_rng_create_from_entropy(&rng_));
+    }
+    // REPRODUCIBLE TESTS ONLY: a 64-bit seed can be searched exhaustively
     HEKeyGenerator(HEContext<S> context, std::uint64_t seed) : context_(std::move(context))
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
@@ -1289,6 +1531,7 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
 
     void generate_secret_key(Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (sk.secret_key_generated_) throw std::logic_error("Secretkey is already generated!");
         DeviceVector<Data64> out((size_t) context_->Q_prime_size * context_->n, o.stream_);
         Workspace ws(context_, HEGPU_OP_KEYGEN_SECRET, o.stream_);
@@ -1299,6 +1542,7 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
     }
     void generate_public_key(Publickey<S>& pk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (pk.public_key_generated_) throw std::logic_error("Publickey is already generated!");
         DeviceVector<Data64> out((size_t) 2 * context_->Q_prime_size * context_->n, o.stream_);
@@ -1310,6 +1554,7 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
     }
     void generate_relin_key(Relinkey<S>& rk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (rk.relin_key_generated_) throw std::logic_error("Relinkey is already generated!");
         DeviceVector<Data64> out(rk.size(), o.stream_);
@@ -1323,6 +1568,7 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
     void generate_switch_key(Switchkey<S>& swk, Secretkey<S>& new_sk, Secretkey<S>& old_sk,
                              const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!old_sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (!new_sk.secret_key_generated_) throw std::logic_error("Ner Secretkey is not generated!");
         if (swk.switch_key_generated_) throw std::logic_error("Switchkey is already generated!");
@@ -1336,6 +1582,7 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
     }
     void generate_galois_key(Galoiskey<S>& gk, Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (gk.galois_key_generated_) throw std::logic_error("Galoiskey is already generated!");
         Workspace ws(context_, HEGPU_OP_KEYGEN_SWITCH, o.stream_);
@@ -1375,7 +1622,13 @@ template <Scheme S> class HEKeyGenerator { // host/*/keygenerator.cuh
 
 template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key encryption)
   public:
-    HEEncryptor(HEContext<S> context, Publickey<S>& pk) : HEEncryptor(std::move(context), pk, std::random_device{}()) {}
+    HEEncryptor(HEContext<S> context, Publickey<S>& pk) : context_(std::move(context)), pk_(&pk)
+    {
+        if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
+        if (!pk.public_key_generated_) throw std::logic_error("Publickey is not generated!");
+        detail::check(hegpu_rng_create_from_entropy(&rng_));
+    }
+    // REPRODUCIBLE TESTS ONLY (64-bit seed)
     HEEncryptor(HEContext<S> context, Publickey<S>& pk, std::uint64_t seed) : context_(std::move(context)), pk_(&pk)
     {
         if (!context_ || !context_->context_generated_) throw std::invalid_argument("HEContext is not generated!");
@@ -1388,6 +1641,7 @@ template <Scheme S> class HEEncryptor { // host/ckks/encryptor.cuh (public-key e
 
     void encrypt(Ciphertext<S>& ct, Plaintext<S>& pt, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!pt.plaintext_generated_ || pt.depth_ != 0) throw std::invalid_argument("Invalid plaintext size."); // encryptor.cuh:56
         DeviceVector<Data64> out((size_t) 2 * context_->Q_size * context_->n, o.stream_);
         const int opid = (S == Scheme::CKKS) ? HEGPU_OP_CKKS_ENCRYPT : HEGPU_OP_BFV_ENCRYPT;
@@ -1419,6 +1673,7 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
     }
     void decrypt(Plaintext<S>& pt, Ciphertext<S>& ct, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (ct.size() != 2) throw std::invalid_argument("Ciphertext should be relinearized first!");
         const int l = context_->Q_size - ct.depth();
         DeviceVector<Data64> out((S == Scheme::CKKS) ? (size_t) l * context_->n : (size_t) context_->n, o.stream_);
@@ -1445,6 +1700,7 @@ template <Scheme S> class HEDecryptor { // host/ckks/decryptor.cuh
     // norm are done here on the host with multi-word integers
     int remainder_noise_budget(Ciphertext<S>& ct, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::BFV, "the noise budget is defined for BFV");
         const int Q = context_->Q_size;
         const size_t n = context_->n;
@@ -1525,8 +1781,20 @@ template <> class HEEncoder<Scheme::BFV> { // host/bfv/encoder.cuh: batching ove
     }
     inline int slot_count() const noexcept { return context_->n; }
 
+    // messages in pinned host memory (HostVector, util/hostvector.cuh; benchmark_bfv.cpp:49,170)
+    template <typename T> void encode(Plaintext<S>& plain, const HostVector<T>& message, const ExecutionOptions& o = ExecutionOptions())
+    {
+        encode(plain, std::vector<T>(message.begin(), message.end()), o);
+    }
+    template <typename T> void decode(HostVector<T>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        std::vector<T> m;
+        decode(m, plain, o);
+        message.assign(m.begin(), m.end());
+    }
     void encode(Plaintext<S>& plain, const std::vector<int64_t>& message, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if ((int) message.size() > context_->n)
             throw std::invalid_argument("Message size can not be higher than the slot count."); // bfv/encoder.cuh:60
         DeviceVector<Data64> msg(message.size() ? message.size() : 1, o.stream_);
@@ -1543,11 +1811,13 @@ template <> class HEEncoder<Scheme::BFV> { // host/bfv/encoder.cuh: batching ove
     }
     void encode(Plaintext<S>& plain, const std::vector<uint64_t>& message, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         std::vector<int64_t> m(message.begin(), message.end());
         encode(plain, m, o);
     }
     void decode(std::vector<uint64_t>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         DeviceVector<Data64> out((size_t) context_->n, o.stream_), ws((size_t) context_->n, o.stream_);
         detail::check(hegpu_bfv_decode(context_->handle(), (const uint64_t*) plain.data(), (uint64_t*) out.data(),
                                        ws.data(), ws.size() * sizeof(Data64), o.stream_));
@@ -1558,6 +1828,7 @@ template <> class HEEncoder<Scheme::BFV> { // host/bfv/encoder.cuh: batching ove
     }
     void decode(std::vector<int64_t>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         std::vector<uint64_t> u;
         decode(u, plain, o);
         const uint64_t t = context_->get_plain_modulus();
@@ -1581,9 +1852,22 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     inline int slot_count() const noexcept { return context_->n >> 1; }
 
     // real vector into the slots, or (encoding::COEFFICIENT) as the polynomial itself (encoder.cuh:56-115)
+    // messages in pinned host memory (HostVector, util/hostvector.cuh; benchmark_ckks.cpp:64,186)
+    template <typename T> void encode(Plaintext<S>& plain, const HostVector<T>& message, double scale,
+                                      const ExecutionOptions& o = ExecutionOptions())
+    {
+        encode(plain, std::vector<T>(message.begin(), message.end()), scale, o);
+    }
+    template <typename T> void decode(HostVector<T>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
+    {
+        std::vector<T> m;
+        decode(m, plain, o);
+        message.assign(m.begin(), m.end());
+    }
     void encode(Plaintext<S>& plain, const std::vector<double>& message, double scale,
                 const ExecutionOptions& o = ExecutionOptions(), encoding type = encoding::SLOT)
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         check_scale(scale);
         if (type == encoding::SLOT && (int) message.size() > slot_count())
             throw std::invalid_argument("Vector size can not be higher than slot count!");        // :74
@@ -1608,6 +1892,7 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     void encode(Plaintext<S>& plain, const std::vector<Complex64>& message, double scale,
                 const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         check_scale(scale);
         if ((int) message.size() > slot_count())
             throw std::invalid_argument("Vector size can not be higher than slot count!");
@@ -1624,6 +1909,7 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     // one number in every slot (encoder.cuh:290-370)
     void encode(Plaintext<S>& plain, const double& message, double scale, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         check_scale(scale);
         DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
         detail::check(hegpu_ckks_encode_scalar(context_->handle(), message, scale, (uint64_t*) out.data(), o.stream_));
@@ -1632,11 +1918,13 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     void encode(Plaintext<S>& plain, const std::int64_t& message, double scale,
                 const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         encode(plain, static_cast<double>(message), scale, o); // encoder.cu:437
     }
 
     void decode(std::vector<double>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         const bool coeff = plain.encoding_ == encoding::COEFFICIENT; // encoder.cuh:383
         const size_t count = coeff ? (size_t) context_->n : (size_t) slot_count();
         DeviceVector<Data64> out(count, o.stream_);
@@ -1650,6 +1938,7 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     }
     void decode(std::vector<Complex64>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (plain.encoding_ == encoding::COEFFICIENT)
             throw std::invalid_argument("Coefficient encoded CKKS plaintext can not be decoded to complex slots."); // :438
         DeviceVector<Data64> out((size_t) 2 * slot_count(), o.stream_);
@@ -1694,14 +1983,17 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
 
     void add(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         binary(a, b, out, 0, o);
     }
     void sub(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         binary(a, b, out, 1, o);
     }
     void negate(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         const int l = limbs(a);
         DeviceVector<Data64> m((size_t) a.cipher_size_ * l * context_->n, o.stream_);
         detail::check(hegpu_addition(context_->handle(), (const uint64_t*) a.data(), nullptr, (uint64_t*) m.data(), l,
@@ -1713,6 +2005,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // host/ckks/operator.cuh:632-689, host/bfv/operator.cuh:348-391
     void multiply(Ciphertext<S>& a, Ciphertext<S>& b, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (a.relinearization_required_ || b.relinearization_required_)
             throw std::invalid_argument("Ciphertexts can not be multiplied because of the non-linear part! Please "
                                         "use relinearization operation!");
@@ -1746,12 +2039,14 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     }
     void multiply_inplace(Ciphertext<S>& a, Ciphertext<S>& b, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         multiply(a, b, a, o);
     }
 
     // host/ckks/operator.cuh:1053-1094: method I or II by the context's P_size
     void relinearize_inplace(Ciphertext<S>& a, Relinkey<S>& rk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!a.relinearization_required_)
             throw std::invalid_argument("Ciphertexts can not use relinearization, since no non-linear part!");
         const int l = limbs(a);
@@ -1773,6 +2068,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // host/ckks/operator.cuh:1423-1445 (CKKS only)
     void rescale_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::CKKS, "rescale is a CKKS operation");
         if (!a.rescale_required_ || a.relinearization_required_)
             throw std::invalid_argument("Ciphertexts can not be rescaled because ciphertext rescaling is not required "
@@ -1793,6 +2089,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void rotate_rows(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, int shift,
                      const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (shift == 0) { out = in; return; }
         const int g = hegpu_steps_to_galois_elt(shift, context_->n, gk.group_order_);
         if (gk.device_location_.count(g)) { apply_galois(in, out, gk, g, o); return; }
@@ -1817,6 +2114,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     }
     void rotate_rows_inplace(Ciphertext<S>& a, Galoiskey<S>& gk, int shift, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         Ciphertext<S> tmp(a);
         rotate_rows(tmp, a, gk, shift, o);
     }
@@ -1824,12 +2122,14 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // keyswitch; switchkey_*_method_I is the Galois path with the identity permutation).
     void keyswitch(Ciphertext<S>& in, Ciphertext<S>& out, Switchkey<S>& swk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!swk.switch_key_generated_) throw std::logic_error("Switchkey is not generated!");
         apply_key(in, out, swk.data(), 1, o);
     }
     void apply_galois(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, int galois_elt,
                       const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         auto it = gk.device_location_.find(galois_elt);
         if (it == gk.device_location_.end()) throw std::logic_error("Galois key not present!");
         apply_key(in, out, it->second.data(), galois_elt, o);
@@ -1865,6 +2165,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // CKKS: drop the last limb without dividing (ckks/operator.cuh mod_drop*)
     void mod_drop(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::CKKS, "mod_drop is a CKKS operation");
         const int l = limbs(a);
         if (l < 2) throw std::logic_error("Ciphertext modulus can not be reducible, since there is only one modulus");
@@ -1881,6 +2182,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void mod_drop_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { mod_drop(a, a, o); }
     void mod_drop_inplace(Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::CKKS, "mod_drop is a CKKS operation");
         const int l = context_->Q_size - p.depth_;
         if (l < 2) throw std::logic_error("Plaintext modulus can not be reducible, since there is only one modulus");
@@ -1893,23 +2195,28 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // ---- ciphertext (+,-,*) plaintext (host/*/operator.cuh add_plain / sub_plain / multiply_plain)
     void add_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         plain_addsub(a, p, out, 0, o);
     }
     void sub_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         plain_addsub(a, p, out, 1, o);
     }
     void add_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         plain_addsub(a, p, a, 0, o);
     }
     void sub_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         plain_addsub(a, p, a, 1, o);
     }
     void multiply_plain(Ciphertext<S>& a, Plaintext<S>& p, Ciphertext<S>& out,
                         const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (a.relinearization_required_) throw std::invalid_argument("Ciphertext should be relinearized first!");
         const int l = limbs(a);
         const size_t n = context_->n;
@@ -1943,12 +2250,14 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     }
     void multiply_plain_inplace(Ciphertext<S>& a, Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         multiply_plain(a, p, a, o);
     }
 
     // ---- BFV: domain changes and X^k (bfv/operator.cuh:884-1110)
     void transform_to_ntt(Plaintext<S>& p, Plaintext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::BFV, "BFV operation");
         if (p.in_ntt_domain_) { if (&p != &out) out = p; return; }
         if (p.size() < (size_t) context_->n) throw std::invalid_argument("Invalid Ciphertexts size!");
@@ -1961,6 +2270,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void transform_to_ntt_inplace(Plaintext<S>& p, const ExecutionOptions& o = ExecutionOptions()) { transform_to_ntt(p, p, o); }
     void transform_to_ntt(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::BFV, "BFV operation");
         if (a.relinearization_required_) throw std::invalid_argument("Ciphertexts can not be transformed to NTT!");
         change_domain(a, out, false, o);
@@ -1968,6 +2278,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void transform_to_ntt_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { transform_to_ntt(a, a, o); }
     void transform_from_ntt(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::BFV, "BFV operation");
         if (a.relinearization_required_) throw std::invalid_argument("Ciphertexts can not be transformed from NTT!");
         change_domain(a, out, true, o);
@@ -1975,6 +2286,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void transform_from_ntt_inplace(Ciphertext<S>& a, const ExecutionOptions& o = ExecutionOptions()) { transform_from_ntt(a, a, o); }
     void multiply_power_of_X(Ciphertext<S>& a, Ciphertext<S>& out, int index, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::BFV, "BFV operation");
         if (index == 0) return; // the reference leaves `out` untouched (bfv/operator.cuh:889)
         if (a.in_ntt_domain_) throw std::invalid_argument("Ciphertext should be in intt domain");
@@ -1989,6 +2301,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // ---- CKKS: one real constant in every slot (ckks/operator.cuh:312-390, :507-585, :812-925), +-i, conjugation
     void add_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (a.relinearization_required_)
             throw std::invalid_argument("Ciphertext and Plaintext can not be added because ciphertext has non-linear partl!");
         constant_op(HEGPU_CONST_ADD, a, c * a.scale_, out, o);
@@ -1996,6 +2309,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void add_plain_inplace(Ciphertext<S>& a, double c, const ExecutionOptions& o = ExecutionOptions()) { add_plain(a, c, a, o); }
     void sub_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (a.relinearization_required_)
             throw std::invalid_argument("Ciphertext and Plaintext can not be added because ciphertext has non-linear partl!");
         constant_op(HEGPU_CONST_SUB, a, c * a.scale_, out, o);
@@ -2004,6 +2318,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void multiply_plain(Ciphertext<S>& a, double c, Ciphertext<S>& out, double scale,
                         const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (a.relinearization_required_)
             throw std::invalid_argument("Ciphertext and Plaintext can not be multiplied because of the non-linear part! "
                                         "Please use relinearization operation!");
@@ -2014,6 +2329,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     }
     void multiply_plain_inplace(Ciphertext<S>& a, double c, double scale, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         multiply_plain(a, c, a, scale, o);
     }
     void mult_i(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions()) { times_i(a, out, 0, o); }
@@ -2021,16 +2337,19 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     // complex conjugate of every slot: the Galois element 2N - 1 (conjugate_ckks_method_I/II)
     void conjugate(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         static_assert(S == Scheme::CKKS, "conjugate is a CKKS operation");
         apply_galois(in, out, gk, gk.galois_elt_zero, o);
     }
     void apply_galois_inplace(Ciphertext<S>& a, Galoiskey<S>& gk, int galois_elt, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         Ciphertext<S> tmp(a);
         apply_galois(tmp, a, gk, galois_elt, o);
     }
     void mod_drop(Plaintext<S>& p, Plaintext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         out = p;
         mod_drop_inplace(out, o);
     }
@@ -2038,6 +2357,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
     void rotate_columns(Ciphertext<S>& in, Ciphertext<S>& out, Galoiskey<S>& gk,
                         const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         apply_galois(in, out, gk, gk.galois_elt_zero, o);
     }
 
@@ -2191,7 +2511,12 @@ template <> class HEKeyGenerator<Scheme::TFHE> { // host/tfhe/keygenerator.cuh
     static constexpr Scheme S = Scheme::TFHE;
 
   public:
-    explicit HEKeyGenerator(HEContext<S> context) : HEKeyGenerator(std::move(context), std::random_device{}()) {}
+    explicit HEKeyGenerator(HEContext<S> context) : context_(std::move(context))
+    {
+        if (!context_) throw std::invalid_argument("HEContext is not generated!");
+        detail::check(hegpu_rng_create_from_entropy(&rng_));
+    }
+    // REPRODUCIBLE TESTS ONLY (64-bit seed)
     HEKeyGenerator(HEContext<S> context, std::uint64_t seed) : context_(std::move(context))
     {
         if (!context_) throw std::invalid_argument("HEContext is not generated!");
@@ -2203,6 +2528,7 @@ template <> class HEKeyGenerator<Scheme::TFHE> { // host/tfhe/keygenerator.cuh
 
     void generate_secret_key(Secretkey<S>& sk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (sk.secret_key_generated_) throw std::logic_error("Secretkey is already generated!");
         sk.lwe_key_device_location_ = DeviceVector<int32_t>((size_t) context_->n_, o.stream_);
         sk.tlwe_key_device_location_ = DeviceVector<int32_t>((size_t) context_->k_ * context_->N_, o.stream_);
@@ -2213,6 +2539,7 @@ template <> class HEKeyGenerator<Scheme::TFHE> { // host/tfhe/keygenerator.cuh
     void generate_bootstrapping_key(Bootstrappingkey<S>& bk, Secretkey<S>& sk,
                                     const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
         if (bk.boot_key_generated_) throw std::logic_error("Bootstrappingkey is already generated!");
         bk.boot_key_device_location_ = DeviceVector<Data64>((size_t) context_->elems("bootkey_elems"), o.stream_);
@@ -2242,7 +2569,7 @@ template <> class HEEncryptor<Scheme::TFHE> { // host/tfhe/encryptor.cuh: symmet
     {
         if (!context_) throw std::invalid_argument("HEContext is not generated!");
         if (!sk.secret_key_generated_) throw std::logic_error("Secretkey is not generated!");
-        detail::check(hegpu_rng_create(std::random_device{}(), &rng_));
+        detail::check(hegpu_rng_create_from_entropy(&rng_));
     }
     ~HEEncryptor() { hegpu_rng_destroy(rng_); }
     HEEncryptor(const HEEncryptor&) = delete;
@@ -2250,6 +2577,7 @@ template <> class HEEncryptor<Scheme::TFHE> { // host/tfhe/encryptor.cuh: symmet
 
     void encrypt(Ciphertext<S>& ct, const std::vector<bool>& messages, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         const int shape = (int) messages.size();
         std::vector<int32_t> enc(messages.size());
         for (size_t i = 0; i < messages.size(); i++) enc[i] = messages[i] ? (1 << 29) : -(1 << 29); // +-1/8
@@ -2280,6 +2608,7 @@ template <> class HEDecryptor<Scheme::TFHE> { // host/tfhe/decryptor.cuh
     }
     void decrypt(Ciphertext<S>& ct, std::vector<bool>& messages, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         DeviceVector<int32_t> phase((size_t) ct.shape_, o.stream_);
         detail::check(hegpu_tfhe_decrypt_phase(context_->handle(), sk_->lwe_key_device_location_.data(),
                                                ct.a_device_location_.data(), ct.b_device_location_.data(), ct.shape_,
@@ -2320,6 +2649,7 @@ template <> class HELogicOperator<Scheme::TFHE> { // host/tfhe/operator.cuh: boo
 #undef HEONGPU_TFHE_GATE
     void NOT(Ciphertext<S>& in, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (!in.ciphertext_generated_) throw std::runtime_error("Input is not generated!");
         DeviceVector<int32_t> a((size_t) in.shape_ * context_->n_, o.stream_), b((size_t) in.shape_, o.stream_);
         detail::check(hegpu_tfhe_gate_precompute(context_->handle(), HEGPU_GATE_NOT, a.data(), b.data(),
@@ -2330,6 +2660,7 @@ template <> class HELogicOperator<Scheme::TFHE> { // host/tfhe/operator.cuh: boo
     void MUX(Ciphertext<S>& in1, Ciphertext<S>& in2, Ciphertext<S>& control, Ciphertext<S>& out,
              Bootstrappingkey<S>& bk, const ExecutionOptions& o = ExecutionOptions())
     {
+        detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (in1.shape_ != in2.shape_ || in1.shape_ != control.shape_)
             throw std::runtime_error("Ciphertexts size should be equal!");
         if (!(in1.ciphertext_generated_ && in2.ciphertext_generated_)) throw std::runtime_error("One or the inputs are generated!");

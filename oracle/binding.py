@@ -107,6 +107,7 @@ def lib():
     L.o_cipher_broadcast.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_keyswitch_mac.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.o_divide_round_lastq.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    L.o_drbg_block.argtypes = [ctypes.POINTER(ctypes.c_uint32), u64, u64, ctypes.POINTER(ctypes.c_uint32)]
     L.o_cipher_broadcast_leveled.argtypes = [vp, vp, vp, ci, ci, ci, ci]
     L.o_keyswitch_mac_leveled.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.o_divide_round_lastq_permute.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci]
@@ -148,11 +149,17 @@ def fill_poly(seed, limb, n, q):
 
 
 class ORng(ctypes.Structure):
-    """orng_t of o_keygen.c: (seed, next stream id)."""
-    _fields_ = [("seed", ctypes.c_uint64), ("stream", ctypes.c_uint64)]
+    """orng_t of o_keygen.c: (256-bit ChaCha20 key, next stream id).  ORng(int): the reproducible
+    64-bit test seed in key words 0,1 (as hegpu_rng_create); ORng(bytes of length 32): a full seed."""
+    _fields_ = [("seed", ctypes.c_uint32 * 8), ("stream", ctypes.c_uint64)]
 
     def __init__(self, seed):
-        super().__init__(int(seed) & (2**64 - 1), 0)
+        if isinstance(seed, (bytes, bytearray)):
+            words = [int.from_bytes(seed[4 * i:4 * i + 4], "little") for i in range(8)]
+        else:
+            v = int(seed) & (2**64 - 1)
+            words = [v & 0xFFFFFFFF, v >> 32, 0, 0, 0, 0, 0, 0]
+        super().__init__((ctypes.c_uint32 * 8)(*words), 0)
 
 
 class OracleContext:

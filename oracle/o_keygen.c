@@ -5,8 +5,8 @@
  *
  * The reference's random values cannot be reproduced (AES generator seeded
  * from RAND_bytes, src/lib/util/random.cu:20-60); what is restated here is
- * (a) the backend's published sampling rule -- Philox4x32-10 (Salmon et al.,
- * SC'11) keyed by the caller's seed, counter = (index, stream), the three
+ * (a) the backend's published sampling rule -- the ChaCha20 block function as a
+ * counter-mode PRF keyed by the 256-bit seed, counter = index, nonce = stream, the three
  * samplers of random.cuh:52-708 (uniform mod q_i from 128 bits, rounded
  * Gaussian sigma = 3.2 by CDT inversion clipped at 6 sigma, uniform ternary)
  * -- written independently of the product's csrc/drbg.hpp, and (b) the
@@ -21,29 +21,38 @@
 
 typedef unsigned __int128 u128;
 
-static void philox(uint32_t key0, uint32_t key1, const uint32_t ctr_in[4], uint32_t out[4])
+/* ChaCha20 block function, Bernstein's layout (256-bit key, 64-bit counter = index, 64-bit nonce =
+ * stream), written from the algorithm description in RFC 8439 section 2.1-2.3; the first four
+ * output words are the sample's 128 random bits. */
+typedef struct { uint32_t k[8]; } okey_t;
+#define ROTL32(v, c) (((v) << (c)) | ((v) >> (32 - (c))))
+static void quarter(uint32_t* s, int a, int b, int c, int d)
 {
-    uint32_t c[4] = { ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3] };
-    uint32_t k0 = key0, k1 = key1;
-    for (int round = 0; round < 10; round++) {
-        u64 prod0 = (u64) 0xD2511F53u * c[0];
-        u64 prod1 = (u64) 0xCD9E8D57u * c[2];
-        uint32_t n[4];
-        n[0] = (uint32_t) (prod1 >> 32) ^ c[1] ^ k0;
-        n[1] = (uint32_t) prod1;
-        n[2] = (uint32_t) (prod0 >> 32) ^ c[3] ^ k1;
-        n[3] = (uint32_t) prod0;
-        memcpy(c, n, sizeof(c));
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    memcpy(out, c, 4 * sizeof(uint32_t));
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = ROTL32(s[d], 16);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = ROTL32(s[b], 12);
+    s[a] += s[b]; s[d] ^= s[a]; s[d] = ROTL32(s[d], 8);
+    s[c] += s[d]; s[b] ^= s[c]; s[b] = ROTL32(s[b], 7);
 }
-
-static void block(u64 seed, u64 stream, u64 index, uint32_t out[4])
+static void block(okey_t seed, u64 stream, u64 index, uint32_t out[4])
 {
-    uint32_t ctr[4] = { (uint32_t) index, (uint32_t) (index >> 32), (uint32_t) stream, (uint32_t) (stream >> 32) };
-    philox((uint32_t) seed, (uint32_t) (seed >> 32), ctr, out);
+    uint32_t init[16] = { 0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u };
+    uint32_t s[16];
+    for (int i = 0; i < 8; i++) init[4 + i] = seed.k[i];
+    init[12] = (uint32_t) index; init[13] = (uint32_t) (index >> 32);
+    init[14] = (uint32_t) stream; init[15] = (uint32_t) (stream >> 32);
+    memcpy(s, init, sizeof(s));
+    for (int round = 0; round < 20; round += 2) {
+        quarter(s, 0, 4, 8, 12); quarter(s, 1, 5, 9, 13); quarter(s, 2, 6, 10, 14); quarter(s, 3, 7, 11, 15);
+        quarter(s, 0, 5, 10, 15); quarter(s, 1, 6, 11, 12); quarter(s, 2, 7, 8, 13); quarter(s, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 4; i++) out[i] = s[i] + init[i];
+}
+/* exported for the known-answer test (tests/test_oracle_keygen.py) */
+void o_drbg_block(const uint32_t key[8], u64 stream, u64 index, uint32_t out[4])
+{
+    okey_t k;
+    memcpy(k.k, key, sizeof(k.k));
+    block(k, stream, index, out);
 }
 
 #define GAUSS_MAX 19
@@ -53,7 +62,7 @@ static void gauss_cdt(u64 t[GAUSS_MAX])
     for (int k = 0; k < GAUSS_MAX; k++) t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);
 }
 
-static int sample_gaussian(u64 seed, u64 stream, u64 index, const u64* t)
+static int sample_gaussian(okey_t seed, u64 stream, u64 index, const u64* t)
 {
     uint32_t w[4];
     block(seed, stream, index, w);
@@ -64,14 +73,14 @@ static int sample_gaussian(u64 seed, u64 stream, u64 index, const u64* t)
     return (r & 1) ? -k : k;
 }
 
-static int sample_ternary(u64 seed, u64 stream, u64 index)
+static int sample_ternary(okey_t seed, u64 stream, u64 index)
 {
     uint32_t w[4];
     block(seed, stream, index, w);
     return (int) (((u64) w[0] * 3) >> 32) - 1;
 }
 
-static u64 sample_uniform(u64 seed, u64 stream, u64 index, u64 q)
+static u64 sample_uniform(okey_t seed, u64 stream, u64 index, u64 q)
 {
     uint32_t w[4];
     block(seed, stream, index, w);
@@ -81,7 +90,7 @@ static u64 sample_uniform(u64 seed, u64 stream, u64 index, u64 q)
 
 static u64 lift(int v, u64 q) { return v < 0 ? q - (u64) (-v) : (u64) v; }
 
-typedef struct { u64 seed, stream; } orng_t;
+typedef struct { okey_t seed; u64 stream; } orng_t;
 
 /* out[poly][limb][N] */
 static void fill_uniform(const octx_t* c, orng_t* r, u64* out, int limbs, int polys)
@@ -537,7 +546,7 @@ void o_bfv_decode(const octx_t* c, const u64* plain, u64* message)
  * (bootstrapping.cu:1385-1412), LWE bit encryption and the decryption phase
  * (tfhe/keygenerator.cu, encryptor.cu, decryptor.cu).  Noise: the backend's published rule, a
  * scaled Irwin-Hall(16) sum (one FP64 multiply + rint). */
-static int32_t torus_gaussian(u64 seed, u64 stream, u64 index, double c)
+static int32_t torus_gaussian(okey_t seed, u64 stream, u64 index, double c)
 {
     u64 sum = 0;
     for (int j = 0; j < 4; j++) {
@@ -548,7 +557,7 @@ static int32_t torus_gaussian(u64 seed, u64 stream, u64 index, double c)
     double g = (double) ((int64_t) sum - ((int64_t) 8 << 32));
     return (int32_t) (uint32_t) (int64_t) rint(g * c);
 }
-static int32_t torus_uniform(u64 seed, u64 stream, u64 index)
+static int32_t torus_uniform(okey_t seed, u64 stream, u64 index)
 {
     uint32_t w[4];
     block(seed, stream, index, w);
@@ -572,7 +581,7 @@ void o_tfhe_gen_secret(orng_t* r, int32_t* lwe_key, int32_t* tlwe_key)
     for (int i = 0; i < TF_N; i++) { uint32_t w[4]; block(r->seed, s0 + 1, (u64) i, w); tlwe_key[i] = (int32_t) (w[0] & 1u); }
 }
 
-static void lwe_encrypt(const int32_t* key, u64 s, uint32_t msg, int32_t* a, int32_t* b, double c, u64 seed,
+static void lwe_encrypt(const int32_t* key, u64 s, uint32_t msg, int32_t* a, int32_t* b, double c, okey_t seed,
                         u64 stream_a, u64 stream_e)
 {
     uint32_t acc = 0;

@@ -780,6 +780,86 @@ static void tfhe_gates()
     logic.MUX(cx, cy, cc, r, bk); check("tfhe MUX", [](bool a, bool b, bool s) { return s ? a : b; });
 }
 
+// util/storagemanager.cuh: objects parked in pinned host memory are staged on use, go back where they were
+// (keep_initial_condition_) or stay on the device, results land where ExecutionOptions::storage_ says; the
+// reference's example/basic/8_default_stream_usage.cpp pattern (store_in_host / store_in_device).
+static void storage_manager()
+{
+    constexpr auto S = Scheme::BFV;
+    const size_t n = 4096;
+    const Data64 t = 1032193;
+    HEContext<S> ctx = GenHEContext<S>();
+    ctx->set_poly_modulus_degree(n);
+    ctx->set_coeff_modulus_default_values(1);
+    ctx->set_plain_modulus(t);
+    ctx->generate();
+    HEKeyGenerator<S> keygen(ctx, 21);
+    Secretkey<S> sk(ctx);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk(ctx);
+    // a key generated straight into host memory (example/basic/4_switchkey_methods_bfv.cpp:70)
+    keygen.generate_relin_key(rk, sk, ExecutionOptions().set_storage_type(storage_type::HOST));
+    EXPECT(!rk.is_on_device(), "relin key generated with storage_type::HOST lives in host memory");
+    HEEncryptor<S> enc(ctx, pk, 22);
+    HEDecryptor<S> dec(ctx, sk);
+    HEArithmeticOperator<S> op(ctx);
+    HEEncoder<S> encoder(ctx);
+    HostVector<uint64_t> a(n), b(n); // pinned
+    for (size_t i = 0; i < n; i++) { a[i] = (i * 5 + 2) % t; b[i] = (i * i + 1) % t; }
+    unsigned flags = 0;
+    EXPECT(hipHostGetFlags(&flags, a.data()) == hipSuccess, "HostVector memory is page-locked (hipHostMalloc)");
+    Plaintext<S> pa(ctx), pb(ctx), pr(ctx);
+    encoder.encode(pa, a);
+    encoder.encode(pb, b);
+    Ciphertext<S> ca(ctx), cb(ctx), cs(ctx), cm(ctx);
+    enc.encrypt(ca, pa);
+    enc.encrypt(cb, pb);
+    const size_t words = ca.memory_size();
+    ca.store_in_host();
+    EXPECT(!ca.is_on_device() && ca.memory_size() == words, "store_in_host parks the ciphertext, its size is unchanged");
+    // input on the host, default options: staged for the operation, back on the host afterwards
+    op.add(ca, cb, cs);
+    EXPECT(!ca.is_on_device() && cs.is_on_device(), "HOST input is staged and returned; result on the device");
+    HostVector<uint64_t> slots;
+    dec.decrypt(pr, cs);
+    encoder.decode(slots, pr);
+    bool ok = slots.size() == n;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == (a[i] + b[i]) % t;
+    EXPECT(ok, "add with a HOST-stored operand gives a + b");
+    // result requested in host memory; relinearization key staged from the host
+    op.multiply(ca, cb, cm, ExecutionOptions().set_storage_type(storage_type::HOST));
+    EXPECT(!cm.is_on_device(), "ExecutionOptions::storage_ = HOST places the result in host memory");
+    op.relinearize_inplace(cm, rk); // in place on a HOST object: staged, modified, copied back
+    EXPECT(!cm.is_on_device() && !rk.is_on_device(), "in-place operator on HOST objects leaves them on the host");
+    dec.decrypt(pr, cm);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == (a[i] * b[i]) % t;
+    EXPECT(ok, "multiply + relinearize through host-parked ciphertext and key gives a .* b");
+    // keep_initial_condition_ = false: the staged input stays on the device
+    op.add(ca, cb, cs, ExecutionOptions().set_initial_location(false));
+    EXPECT(ca.is_on_device(), "set_initial_location(false): the HOST input now lives on the device");
+    ca.store_in_host();
+    ca.store_in_device();
+    dec.decrypt(pr, ca);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == a[i];
+    EXPECT(ok && ca.is_on_device(), "store_in_host / store_in_device round trip keeps the residues");
+    // copies of a parked object are parked objects with their own data
+    ca.store_in_host();
+    Ciphertext<S> copy = ca;
+    ca.store_in_device();
+    EXPECT(!copy.is_on_device(), "copy of a HOST-stored ciphertext is HOST-stored");
+    dec.decrypt(pr, copy);
+    encoder.decode(slots, pr);
+    ok = true;
+    for (size_t i = 0; ok && i < n; i++) ok = slots[i] == a[i];
+    EXPECT(ok, "the copy decrypts to the same message");
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -798,6 +878,7 @@ int main()
     bfv_pipeline();
     ckks_encoder_flow();
     memory_pool();
+    storage_manager();
     serializer_round_trip();
     serialize_all_objects();
     bfv_ntt_domain_and_shift();
