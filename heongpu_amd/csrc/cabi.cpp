@@ -106,8 +106,8 @@ int hegpu_context_create(int scheme, int n, const int* qb, int qn, const int* pb
         bits.insert(bits.end(), pb, pb + pn);
         int total = 0;
         for (int b : bits) total += b;
-        if (sec_level == HEGPU_SEC_128) {
-            if (host::max_logq_128(n) < total)
+        if (sec_level == HEGPU_SEC_128 || sec_level == HEGPU_SEC_192 || sec_level == HEGPU_SEC_256) {
+            if (host::max_logq((u64) n, sec_level) < total) // ckks/context.cu:94-119, secstdparams.h:25-79
                 throw std::runtime_error("Parameters do not align with the security recommendations "
                                          "provided by the lattice-estimator");
         } else if (sec_level != HEGPU_SEC_NONE) {
@@ -133,8 +133,9 @@ int hegpu_context_create_default(int scheme, int n, int p_count, uint64_t plain_
         int n_power;
         check_degree(n, n_power);
         if (p_count < 1) throw std::logic_error("P_modulus_size cannot be lower than 1!");
-        if (sec_level != HEGPU_SEC_128) throw std::runtime_error("Invalid security level");
-        std::vector<u64> chain = host::default_chain_128((u64) n);
+        if (sec_level != HEGPU_SEC_128 && sec_level != HEGPU_SEC_192 && sec_level != HEGPU_SEC_256)
+            throw std::runtime_error("Invalid security level"); // bfv/context.cu:285-360: no default chain without a level
+        std::vector<u64> chain = host::default_chain((u64) n, sec_level);
         if (chain.empty() || (int) chain.size() <= p_count) throw std::logic_error("no default chain");
         hegpu_context* h = new hegpu_context();
         try {
@@ -196,6 +197,8 @@ long hegpu_context_int(const hegpu_context* ctx, const char* name)
     if (!strcmp(name, "bsk_modulus")) return c.bsk_size;
     if (!strcmp(name, "scheme")) return c.scheme;
     if (!strcmp(name, "max_logq_128")) return host::max_logq_128((int) c.n); // util/secstdparams.h
+    if (!strcmp(name, "max_logq_192")) return host::max_logq(c.n, 192);
+    if (!strcmp(name, "max_logq_256")) return host::max_logq(c.n, 256);
     return -1;
 }
 

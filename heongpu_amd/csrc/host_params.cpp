@@ -131,58 +131,98 @@ std::vector<u64> power_table_bitrev(u64 base, u64 q, int n_power)
     return out;
 }
 
-std::vector<u64> default_chain_128(u64 n)
+// default prime chains per security level (reference src/lib/util/defaultmodulus.cpp:12-175; the
+// values are the reference's constants -- tests/golden/reference_constants.json holds them as extracted
+// from the reference tree and tests/test_oracle_golden.py compares)
+std::vector<u64> default_chain(u64 n, int sec_level)
 {
-    switch (n) {
-        case 4096:
-            return {0x800004001ULL, 0x800008001ULL, 0x1000002001ULL};
-        case 8192:
-            return {0x40000084001ULL, 0x400000b0001ULL, 0x8000002c001ULL,
-                    0x80000050001ULL, 0x80000064001ULL};
-        case 16384:
-            return {0x800000020001ULL,  0x8000001a8001ULL,  0x8000001e8001ULL,
-                    0x10000000d8001ULL, 0x1000000168001ULL, 0x10000001a0001ULL,
-                    0x10000001e0001ULL, 0x10000002b8001ULL, 0x10000002e8001ULL};
-        case 32768:
-            return {0x2000000002b0001ULL, 0x2000000003a0001ULL,
-                    0x2000000005b0001ULL, 0x200000000640001ULL,
-                    0x400000000270001ULL, 0x400000000350001ULL,
-                    0x400000000360001ULL, 0x4000000004d0001ULL,
-                    0x400000000570001ULL, 0x400000000660001ULL,
-                    0x4000000008a0001ULL, 0x400000000920001ULL,
-                    0x400000000980001ULL, 0x400000000990001ULL,
-                    0x400000000a40001ULL};
-        case 65536:
-            return {0x2000000003a0001ULL, 0x200000000640001ULL,
-                    0x200000000f80001ULL, 0x200000001460001ULL,
-                    0x2000000015a0001ULL, 0x2000000015e0001ULL,
-                    0x200000001b20001ULL, 0x200000001c00001ULL,
-                    0x200000001ee0001ULL, 0x400000000360001ULL,
-                    0x400000000660001ULL, 0x4000000008a0001ULL,
-                    0x400000000920001ULL, 0x400000000980001ULL,
-                    0x400000000a40001ULL, 0x400000000c00001ULL,
-                    0x400000000ea0001ULL, 0x400000001460001ULL,
-                    0x400000001700001ULL, 0x400000001740001ULL,
-                    0x4000000017a0001ULL, 0x400000001920001ULL,
-                    0x400000001b00001ULL, 0x400000001b60001ULL,
-                    0x400000001c40001ULL, 0x400000001ee0001ULL,
-                    0x400000001f20001ULL, 0x4000000020c0001ULL,
-                    0x400000002360001ULL, 0x400000002480001ULL};
+    if (sec_level == 128) {
+        switch (n) {
+            case 4096:
+                return {0x800004001ULL, 0x800008001ULL, 0x1000002001ULL};
+            case 8192:
+                return {0x40000084001ULL, 0x400000b0001ULL, 0x8000002c001ULL, 0x80000050001ULL, 0x80000064001ULL};
+            case 16384:
+                return {0x800000020001ULL, 0x8000001a8001ULL, 0x8000001e8001ULL, 0x10000000d8001ULL,
+                        0x1000000168001ULL, 0x10000001a0001ULL, 0x10000001e0001ULL, 0x10000002b8001ULL,
+                        0x10000002e8001ULL};
+            case 32768:
+                return {0x2000000002b0001ULL, 0x2000000003a0001ULL, 0x2000000005b0001ULL, 0x200000000640001ULL,
+                        0x400000000270001ULL, 0x400000000350001ULL, 0x400000000360001ULL, 0x4000000004d0001ULL,
+                        0x400000000570001ULL, 0x400000000660001ULL, 0x4000000008a0001ULL, 0x400000000920001ULL,
+                        0x400000000980001ULL, 0x400000000990001ULL, 0x400000000a40001ULL};
+            case 65536:
+                return {0x2000000003a0001ULL, 0x200000000640001ULL, 0x200000000f80001ULL, 0x200000001460001ULL,
+                        0x2000000015a0001ULL, 0x2000000015e0001ULL, 0x200000001b20001ULL, 0x200000001c00001ULL,
+                        0x200000001ee0001ULL, 0x400000000360001ULL, 0x400000000660001ULL, 0x4000000008a0001ULL,
+                        0x400000000920001ULL, 0x400000000980001ULL, 0x400000000a40001ULL, 0x400000000c00001ULL,
+                        0x400000000ea0001ULL, 0x400000001460001ULL, 0x400000001700001ULL, 0x400000001740001ULL,
+                        0x4000000017a0001ULL, 0x400000001920001ULL, 0x400000001b00001ULL, 0x400000001b60001ULL,
+                        0x400000001c40001ULL, 0x400000001ee0001ULL, 0x400000001f20001ULL, 0x4000000020c0001ULL,
+                        0x400000002360001ULL, 0x400000002480001ULL};
+        }
+    } else if (sec_level == 192) {
+        switch (n) {
+            case 4096:
+                return {0x1000002001ULL, 0x1000042001ULL};
+            case 8192:
+                return {0x100008c001ULL, 0x1000090001ULL, 0x10000c8001ULL, 0x2000088001ULL};
+            case 16384:
+                return {0x20000000b0001ULL, 0x2000000178001ULL, 0x20000001a0001ULL, 0x2000000208001ULL,
+                        0x20000003b0001ULL, 0x20000003c8001ULL};
+            case 32768:
+                return {0x40000000120001ULL, 0x400000001d0001ULL, 0x400000002c0001ULL, 0x40000000480001ULL,
+                        0x40000000540001ULL, 0x400000005c0001ULL, 0x400000006c0001ULL, 0x400000007b0001ULL,
+                        0x40000000890001ULL, 0x40000000b00001ULL, 0x40000000e40001ULL};
+            case 65536:
+                return {0x40000000120001ULL, 0x400000002c0001ULL, 0x40000000480001ULL, 0x40000000540001ULL,
+                        0x400000005c0001ULL, 0x400000006c0001ULL, 0x40000000b00001ULL, 0x40000000e40001ULL,
+                        0x40000000f60001ULL, 0x400000010a0001ULL, 0x400000011a0001ULL, 0x40000001200001ULL,
+                        0x40000001340001ULL, 0x400000017a0001ULL, 0x40000001c40001ULL, 0x40000001ca0001ULL,
+                        0x40000001d00001ULL, 0x40000002100001ULL, 0x400000022a0001ULL, 0x400000022e0001ULL,
+                        0x80000000080001ULL, 0x80000000440001ULL};
+        }
+    } else if (sec_level == 256) {
+        switch (n) {
+            case 4096:
+                return {0x8008001ULL, 0x10006001ULL};
+            case 8192:
+                return {0x2000088001ULL, 0x20000e0001ULL, 0x4000038001ULL};
+            case 16384:
+                return {0x200000008001ULL, 0x2000000a0001ULL, 0x2000000e0001ULL, 0x400000008001ULL,
+                        0x400000060001ULL};
+            case 32768:
+                return {0x4000000120001ULL, 0x40000001b0001ULL, 0x4000000270001ULL, 0x8000000110001ULL,
+                        0x8000000130001ULL, 0x80000001c0001ULL, 0x80000002c0001ULL, 0x80000004d0001ULL,
+                        0x80000004f0001ULL};
+            case 65536:
+                return {0x4000000120001ULL, 0x4000000420001ULL, 0x4000000660001ULL, 0x40000007e0001ULL,
+                        0x4000000800001ULL, 0x40000008a0001ULL, 0x7fffffffe0001ULL, 0x80000001c0001ULL,
+                        0x80000002c0001ULL, 0x8000000500001ULL, 0x8000000820001ULL, 0x8000000940001ULL,
+                        0x8000001120001ULL, 0x80000012a0001ULL, 0x8000001360001ULL, 0x80000014c0001ULL,
+                        0x8000001540001ULL, 0x8000001600001ULL};
+        }
     }
     return {};
 }
+std::vector<u64> default_chain_128(u64 n) { return default_chain(n, 128); }
 
-int max_logq_128(u64 n)
+// max total coefficient-modulus bits (reference util/secstdparams.h:25-79)
+int max_logq(u64 n, int sec_level)
 {
+    static const int table[3][5] = {{109, 218, 438, 881, 1761}, {74, 149, 300, 605, 1212}, {57, 115, 232, 465, 930}};
+    const int row = sec_level == 128 ? 0 : sec_level == 192 ? 1 : sec_level == 256 ? 2 : -1;
+    int col = -1;
     switch (n) {
-        case 4096: return 109;
-        case 8192: return 218;
-        case 16384: return 438;
-        case 32768: return 881;
-        case 65536: return 1761;
+        case 4096: col = 0; break;
+        case 8192: col = 1; break;
+        case 16384: col = 2; break;
+        case 32768: col = 3; break;
+        case 65536: col = 4; break;
     }
-    return 0;
+    return (row < 0 || col < 0) ? 0 : table[row][col];
 }
+int max_logq_128(u64 n) { return max_logq(n, 128); }
 
 int steps_to_galois_elt(int steps, int n, int group_order)
 {

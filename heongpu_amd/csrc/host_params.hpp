@@ -28,9 +28,11 @@ std::vector<u64> internal_primes(u64 n, int count); // 61-bit
 u64 minimal_primitive_root(u64 degree, u64 q);
 // out[j] = base^bitreverse(j, n_power) mod q
 std::vector<u64> power_table_bitrev(u64 base, u64 q, int n_power);
-// 128-bit-security default chain for n in {4096..65536}; empty if none
+// default chain for n in {4096..65536} at 128 / 192 / 256-bit security; empty if none
+std::vector<u64> default_chain(u64 n, int sec_level);
 std::vector<u64> default_chain_128(u64 n);
-// max total coefficient-modulus bits (reference secstdparams.h:25-79)
+// max total coefficient-modulus bits (reference secstdparams.h:25-79); 0 if none
+int max_logq(u64 n, int sec_level);
 int max_logq_128(u64 n);
 int steps_to_galois_elt(int steps, int n, int group_order);
 

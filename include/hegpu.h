@@ -32,7 +32,7 @@ typedef struct hegpu_context hegpu_context; /* opaque */
 typedef void* hegpu_stream;                 /* hipStream_t */
 
 enum { HEGPU_BFV = 1, HEGPU_CKKS = 2 };
-enum { HEGPU_SEC_NONE = 0, HEGPU_SEC_128 = 128 };
+enum { HEGPU_SEC_NONE = 0, HEGPU_SEC_128 = 128, HEGPU_SEC_192 = 192, HEGPU_SEC_256 = 256 };
 enum { HEGPU_TABLES_QP = 0, HEGPU_TABLES_Q_BSK = 1, HEGPU_TABLES_PLAIN = 2 /* BFV plain modulus t, batching */ };
 enum {
     HEGPU_E_INVALID = 10001, /* std::invalid_argument in the reference */

@@ -658,11 +658,13 @@ template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation
         if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
             throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
         if (p_count < 1) throw std::logic_error("P_modulus_size cannot be lower than 1!");
-        if (sec_level_ != sec_level_type::sec128)
-            throw std::runtime_error("Invalid security level"); // only the 128-bit table is carried so far
+        if (sec_level_ == sec_level_type::none)
+            throw std::runtime_error("Invalid security level"); // the default chains exist per level (128 / 192 / 256)
         hegpu_context* chain = nullptr;
         detail::check(hegpu_context_create_default(HEGPU_CKKS, n, p_count, 0, sec_abi(), &chain));
-        total_coeff_bit_count = (int) hegpu_context_int(chain, "max_logq_128");
+        total_coeff_bit_count = (int) hegpu_context_int(chain, sec_level_ == sec_level_type::sec128   ? "max_logq_128"
+                                                               : sec_level_ == sec_level_type::sec192 ? "max_logq_192"
+                                                                                                       : "max_logq_256");
         adopt_chain(chain);
         for (int i = 0; i < Q_size; i++) Q_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
         for (int i = Q_size; i < Q_prime_size; i++) P_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
@@ -786,7 +788,16 @@ template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation
     std::vector<Modulus64> prime_vector_;
 
   private:
-    int sec_abi() const { return sec_level_ == sec_level_type::none ? HEGPU_SEC_NONE : sec_level_ == sec_level_type::sec128 ? HEGPU_SEC_128 : -1; }
+    int sec_abi() const
+    {
+        switch (sec_level_) {
+            case sec_level_type::none: return HEGPU_SEC_NONE;
+            case sec_level_type::sec128: return HEGPU_SEC_128;
+            case sec_level_type::sec192: return HEGPU_SEC_192;
+            case sec_level_type::sec256: return HEGPU_SEC_256;
+        }
+        return -1;
+    }
     void adopt_chain(hegpu_context* c) // counts and primes of a host-only context, which is then dropped
     {
         Q_size = (int) hegpu_context_int(c, "Q_size");

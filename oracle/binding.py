@@ -50,6 +50,8 @@ def lib():
     L.o_generate_primes.argtypes = [u64, PI, ctypes.c_int, P64]
     L.o_generate_internal_primes.argtypes = [u64, ctypes.c_int, P64]
     L.o_default_modulus_128.argtypes = [u64, P64]
+    L.o_default_modulus.argtypes = [u64, ctypes.c_int, P64]
+    L.o_max_logq.argtypes = [u64, ctypes.c_int]
     L.o_steps_to_galois_elt.argtypes = [ctypes.c_int] * 3
     L.o_fill_poly.argtypes = [ctypes.c_void_p, u64, ctypes.c_int, u64, u64]
     L.o_ctx_create.restype = ctypes.c_void_p

@@ -58,6 +58,8 @@ void o_ntt_table(u64 psi, u64 q, int n_power, u64* out);
 void o_intt_table(u64 psi, u64 q, int n_power, u64* out);
 u64 o_n_inverse(u64 n, u64 q);
 int o_default_modulus_128(u64 n, u64* out); /* defaultmodulus.cpp:12-80 */
+int o_default_modulus(u64 n, int sec_level, u64* out); /* :12-175, levels 128 / 192 / 256 */
+int o_max_logq(u64 n, int sec_level);                /* util/secstdparams.h:25-79 */
 int o_steps_to_galois_elt(int steps, int n, int group_order);
 u64 o_splitmix64(u64 x);
 /* synthetic limb data: splitmix64(seed + limb*2^32 + idx) mod q */

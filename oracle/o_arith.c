@@ -220,25 +220,25 @@ u64 o_n_inverse(u64 n, u64 q)
     return o_modinv(n, &m);
 }
 
-/* defaultmodulus.cpp:12-80 (data): 128-bit-security default chains */
-int o_default_modulus_128(u64 n, u64* out)
+/* defaultmodulus.cpp:12-175 (data): default chains for 128 / 192 / 256-bit security */
+int o_default_modulus(u64 n, int sec_level, u64* out)
 {
-    static const u64 p4096[] = {0x800004001ULL, 0x800008001ULL,
-                                0x1000002001ULL};
-    static const u64 p8192[] = {0x40000084001ULL, 0x400000b0001ULL,
-                                0x8000002c001ULL, 0x80000050001ULL,
-                                0x80000064001ULL};
-    static const u64 p16384[] = {
-        0x800000020001ULL,  0x8000001a8001ULL,  0x8000001e8001ULL,
+    static const u64 p128_4096[] = {
+        0x800004001ULL, 0x800008001ULL, 0x1000002001ULL};
+    static const u64 p128_8192[] = {
+        0x40000084001ULL, 0x400000b0001ULL, 0x8000002c001ULL, 0x80000050001ULL,
+        0x80000064001ULL};
+    static const u64 p128_16384[] = {
+        0x800000020001ULL, 0x8000001a8001ULL, 0x8000001e8001ULL,
         0x10000000d8001ULL, 0x1000000168001ULL, 0x10000001a0001ULL,
         0x10000001e0001ULL, 0x10000002b8001ULL, 0x10000002e8001ULL};
-    static const u64 p32768[] = {
+    static const u64 p128_32768[] = {
         0x2000000002b0001ULL, 0x2000000003a0001ULL, 0x2000000005b0001ULL,
         0x200000000640001ULL, 0x400000000270001ULL, 0x400000000350001ULL,
         0x400000000360001ULL, 0x4000000004d0001ULL, 0x400000000570001ULL,
         0x400000000660001ULL, 0x4000000008a0001ULL, 0x400000000920001ULL,
         0x400000000980001ULL, 0x400000000990001ULL, 0x400000000a40001ULL};
-    static const u64 p65536[] = {
+    static const u64 p128_65536[] = {
         0x2000000003a0001ULL, 0x200000000640001ULL, 0x200000000f80001ULL,
         0x200000001460001ULL, 0x2000000015a0001ULL, 0x2000000015e0001ULL,
         0x200000001b20001ULL, 0x200000001c00001ULL, 0x200000001ee0001ULL,
@@ -249,18 +249,93 @@ int o_default_modulus_128(u64 n, u64* out)
         0x400000001920001ULL, 0x400000001b00001ULL, 0x400000001b60001ULL,
         0x400000001c40001ULL, 0x400000001ee0001ULL, 0x400000001f20001ULL,
         0x4000000020c0001ULL, 0x400000002360001ULL, 0x400000002480001ULL};
-    const u64* p;
-    int cnt;
-    switch (n) {
-        case 4096: p = p4096; cnt = 3; break;
-        case 8192: p = p8192; cnt = 5; break;
-        case 16384: p = p16384; cnt = 9; break;
-        case 32768: p = p32768; cnt = 15; break;
-        case 65536: p = p65536; cnt = 30; break;
+    static const u64 p192_4096[] = {
+        0x1000002001ULL, 0x1000042001ULL};
+    static const u64 p192_8192[] = {
+        0x100008c001ULL, 0x1000090001ULL, 0x10000c8001ULL, 0x2000088001ULL};
+    static const u64 p192_16384[] = {
+        0x20000000b0001ULL, 0x2000000178001ULL, 0x20000001a0001ULL,
+        0x2000000208001ULL, 0x20000003b0001ULL, 0x20000003c8001ULL};
+    static const u64 p192_32768[] = {
+        0x40000000120001ULL, 0x400000001d0001ULL, 0x400000002c0001ULL,
+        0x40000000480001ULL, 0x40000000540001ULL, 0x400000005c0001ULL,
+        0x400000006c0001ULL, 0x400000007b0001ULL, 0x40000000890001ULL,
+        0x40000000b00001ULL, 0x40000000e40001ULL};
+    static const u64 p192_65536[] = {
+        0x40000000120001ULL, 0x400000002c0001ULL, 0x40000000480001ULL,
+        0x40000000540001ULL, 0x400000005c0001ULL, 0x400000006c0001ULL,
+        0x40000000b00001ULL, 0x40000000e40001ULL, 0x40000000f60001ULL,
+        0x400000010a0001ULL, 0x400000011a0001ULL, 0x40000001200001ULL,
+        0x40000001340001ULL, 0x400000017a0001ULL, 0x40000001c40001ULL,
+        0x40000001ca0001ULL, 0x40000001d00001ULL, 0x40000002100001ULL,
+        0x400000022a0001ULL, 0x400000022e0001ULL, 0x80000000080001ULL,
+        0x80000000440001ULL};
+    static const u64 p256_4096[] = {
+        0x8008001ULL, 0x10006001ULL};
+    static const u64 p256_8192[] = {
+        0x2000088001ULL, 0x20000e0001ULL, 0x4000038001ULL};
+    static const u64 p256_16384[] = {
+        0x200000008001ULL, 0x2000000a0001ULL, 0x2000000e0001ULL,
+        0x400000008001ULL, 0x400000060001ULL};
+    static const u64 p256_32768[] = {
+        0x4000000120001ULL, 0x40000001b0001ULL, 0x4000000270001ULL,
+        0x8000000110001ULL, 0x8000000130001ULL, 0x80000001c0001ULL,
+        0x80000002c0001ULL, 0x80000004d0001ULL, 0x80000004f0001ULL};
+    static const u64 p256_65536[] = {
+        0x4000000120001ULL, 0x4000000420001ULL, 0x4000000660001ULL,
+        0x40000007e0001ULL, 0x4000000800001ULL, 0x40000008a0001ULL,
+        0x7fffffffe0001ULL, 0x80000001c0001ULL, 0x80000002c0001ULL,
+        0x8000000500001ULL, 0x8000000820001ULL, 0x8000000940001ULL,
+        0x8000001120001ULL, 0x80000012a0001ULL, 0x8000001360001ULL,
+        0x80000014c0001ULL, 0x8000001540001ULL, 0x8000001600001ULL};
+    const u64* p = NULL;
+    int cnt = 0;
+#define PICK(L, N) do { p = p##L##_##N; cnt = (int) (sizeof(p##L##_##N) / sizeof(u64)); } while (0)
+    switch (sec_level * 100000 + (int) n) {
+        case 128 * 100000 + 4096: PICK(128, 4096); break;
+        case 128 * 100000 + 8192: PICK(128, 8192); break;
+        case 128 * 100000 + 16384: PICK(128, 16384); break;
+        case 128 * 100000 + 32768: PICK(128, 32768); break;
+        case 128 * 100000 + 65536: PICK(128, 65536); break;
+        case 192 * 100000 + 4096: PICK(192, 4096); break;
+        case 192 * 100000 + 8192: PICK(192, 8192); break;
+        case 192 * 100000 + 16384: PICK(192, 16384); break;
+        case 192 * 100000 + 32768: PICK(192, 32768); break;
+        case 192 * 100000 + 65536: PICK(192, 65536); break;
+        case 256 * 100000 + 4096: PICK(256, 4096); break;
+        case 256 * 100000 + 8192: PICK(256, 8192); break;
+        case 256 * 100000 + 16384: PICK(256, 16384); break;
+        case 256 * 100000 + 32768: PICK(256, 32768); break;
+        case 256 * 100000 + 65536: PICK(256, 65536); break;
         default: return -1;
     }
+#undef PICK
     memcpy(out, p, sizeof(u64) * cnt);
     return cnt;
+}
+int o_default_modulus_128(u64 n, u64* out) { return o_default_modulus(n, 128, out); }
+
+/* util/secstdparams.h:25-79: max log2(Q*P) per degree and security level (0: none) */
+int o_max_logq(u64 n, int sec_level)
+{
+    switch (sec_level * 100000 + (int) n) {
+        case 128 * 100000 + 4096: return 109;
+        case 128 * 100000 + 8192: return 218;
+        case 128 * 100000 + 16384: return 438;
+        case 128 * 100000 + 32768: return 881;
+        case 128 * 100000 + 65536: return 1761;
+        case 192 * 100000 + 4096: return 74;
+        case 192 * 100000 + 8192: return 149;
+        case 192 * 100000 + 16384: return 300;
+        case 192 * 100000 + 32768: return 605;
+        case 192 * 100000 + 65536: return 1212;
+        case 256 * 100000 + 4096: return 57;
+        case 256 * 100000 + 8192: return 115;
+        case 256 * 100000 + 16384: return 232;
+        case 256 * 100000 + 32768: return 465;
+        case 256 * 100000 + 65536: return 930;
+    }
+    return 0;
 }
 
 /* keygeneration.cu:684-728 steps_to_galois_elt */

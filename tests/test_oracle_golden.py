@@ -159,3 +159,82 @@ def test_method_II_tables_product_vs_oracle(oracle, hg):
         o = oracle.OracleContext(oscheme, prod.n_power, primes, len(bits_q), len(bits_p), t)
         for name in ("m2_I_j", "m2_I_location", "m2_Mi_inv", "m2_matrix", "m2_prod"):
             assert np.array_equal(prod.table(name), o.table(name)), name
+
+
+# ------------------------------------------------------------------ every constant the reference tree holds
+# tests/golden/reference_constants.json is extracted from the reference by tools/extract_reference_constants.py
+# (defaultmodulus.cpp:12-175, secstdparams.h:22-79, tfhe/context.cu:23-57, benchmark/*.cpp).  With no limb-level
+# vectors in the reference and no way to build it here, this is the reference-held data there is: the oracle
+# AND the product's own host-side parameter code (csrc/host_params.cpp, a separate implementation) are held to it.
+REF = load("reference_constants.json")
+DEGREES = (4096, 8192, 16384, 32768, 65536)
+
+
+@pytest.mark.parametrize("level", [128, 192, 256])
+def test_default_chains_match_the_reference(oracle, hg, level):
+    import ctypes
+    sec = {128: hg.SEC_128, 192: hg.SEC_192, 256: hg.SEC_256}[level]
+    for n in DEGREES:
+        want = REF["default_modulus"][str(level)][str(n)]
+        out = (ctypes.c_uint64 * 64)()
+        cnt = oracle.lib().o_default_modulus(n, level, out)
+        assert [int(out[i]) for i in range(cnt)] == want, ("oracle", level, n)
+        c = hg.Context.from_default(hg.CKKS, n, 1, sec=sec)
+        assert [int(v) for v in c.table("modulus")] == want, ("product", level, n)
+        assert (c.Q_size, c.P_size) == (len(want) - 1, 1)
+        c.close()
+        # what the chains must satisfy for the transform: NTT-friendly primes within the security budget
+        bits = 0
+        for q in want:
+            assert oracle.lib().o_is_prime(q) and q % (2 * n) == 1, (level, n, hex(q))
+            bits += q.bit_length()
+        assert bits <= REF["max_logq"][str(level)][str(n)], (level, n, bits)
+        assert oracle.lib().o_max_logq(n, level) == REF["max_logq"][str(level)][str(n)]
+        assert c.__class__.from_default(hg.CKKS, n, 1, sec=sec).int("max_logq_%d" % level) == REF["max_logq"][str(level)][str(n)]
+
+
+@pytest.mark.parametrize("level", [128, 192, 256])
+def test_security_budget_is_enforced_like_the_reference(hg, level):
+    """ckks/context.cu:94-119: a chain whose total bit count exceeds the level's table entry is refused"""
+    sec = {128: hg.SEC_128, 192: hg.SEC_192, 256: hg.SEC_256}[level]
+    for n in (8192, 16384):
+        budget = REF["max_logq"][str(level)][str(n)]
+        b = 30
+        k = budget // b - 1
+        assert k >= 1
+        hg.Context.from_bit_sizes(hg.CKKS, n, [b] * k, [b], sec=sec).close()       # b (k + 1) <= budget
+        with pytest.raises(hg.HEError) as e:
+            hg.Context.from_bit_sizes(hg.CKKS, n, [b] * (k + 1), [b], sec=sec)     # one prime more
+        assert e.value.code == hg.E_RUNTIME and "security recommendations" in str(e.value)
+
+
+def test_minimal_roots_of_every_default_prime(oracle, hg):
+    """psi of every prime of every default chain: the oracle's and the product's root selection agree, the root
+    has order exactly 2N (psi^N = -1) -- what the reference's tables are built from (util.cu:312-380)."""
+    for level in ("128", "192", "256"):
+        for n in DEGREES:
+            chain = REF["default_modulus"][level][str(n)]
+            sec = {"128": hg.SEC_128, "192": hg.SEC_192, "256": hg.SEC_256}[level]
+            c = hg.Context.from_default(hg.CKKS, n, 1, sec=sec)
+            psi = [int(v) for v in c.table("psi")]
+            c.close()
+            for q, r in zip(chain, psi):
+                assert oracle.lib().o_min_primitive_root(2 * n, q) == r, (level, n, hex(q))
+                assert pow(r, n, q) == q - 1
+
+
+def test_tfhe_parameter_set_matches_the_reference(oracle, hg):
+    t = REF["tfhe"]
+    o = oracle.OracleTfhe()
+    assert o.prime == t["prime"] and oracle.lib().o_min_primitive_root(2 << t["ntt_log_size"], t["prime"]) == t["psi"]
+    assert (o.n, o.N, o.k, o.l, o.ks_length, o.ks_base) == (t["n"], t["N"], t["k"], t["bk_l"], t["ks_length"], 1 << t["ks_base_bit"])
+    p = hg.TfheContext()
+    assert p.prime == t["prime"]
+    for name in ("n", "N", "k", "bk_l", "bk_bg_bit", "ks_base_bit", "ks_length"):
+        assert p.int(name) == t[name], name
+
+
+def test_error_distribution_parameter():
+    """secstdparams.h:22 error_std_dev = 3.2 -- the value both Gaussian CDTs are built for (csrc/context.cpp,
+    oracle/o_keygen.c); the empirical sigma of generated keys is checked in tests/test_oracle_keygen.py"""
+    assert REF["error_std_dev"] == 3.2
