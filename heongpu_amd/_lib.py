@@ -33,6 +33,12 @@ SIGNATURES = [
     ("hegpu_context_device_ptr", voidp, [voidp, ctypes.c_char_p]),
     ("hegpu_steps_to_galois_elt", c_int, [c_int, c_int, c_int]),
     ("hegpu_ntt", c_int, [voidp, c_int, u64p, u64p, c_int, c_int, c_int, c_int, voidp, voidp, voidp]),
+    ("hegpu_GPU_NTT", c_int, [voidp, c_int, u64p, u64p, c_int, c_int, c_int, voidp]),
+    ("hegpu_GPU_NTT_Inplace", c_int, [voidp, c_int, u64p, c_int, c_int, c_int, voidp]),
+    ("hegpu_GPU_INTT", c_int, [voidp, c_int, u64p, u64p, c_int, c_int, c_int, voidp]),
+    ("hegpu_GPU_INTT_Inplace", c_int, [voidp, c_int, u64p, c_int, c_int, c_int, voidp]),
+    ("hegpu_GPU_NTT_Modulus_Ordered_Inplace", c_int, [voidp, c_int, u64p, c_int, c_int, c_int, c_int, voidp, voidp]),
+    ("hegpu_GPU_NTT_Poly_Ordered_Inplace", c_int, [voidp, c_int, u64p, c_int, c_int, c_int, c_int, voidp, voidp]),
     ("hegpu_addition", c_int, [voidp, u64p, u64p, u64p, c_int, c_int, c_int, c_int, voidp]),
     ("hegpu_cross_multiplication", c_int,
      [voidp, c_int, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),

@@ -269,6 +269,41 @@ int hegpu_ntt(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* o
     return hip_ret(ntt_launch(a, batch, inverse != 0, (hipStream_t) stream), "hegpu_ntt");
 }
 
+// the six gpuntt:: names (include/hegpu.h)
+int hegpu_GPU_NTT(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int mod_offset, int batch,
+                  int mod_count, hegpu_stream stream)
+{
+    return hegpu_ntt(ctx, table_set, in, out, 0, batch, mod_count, mod_offset, nullptr, nullptr, stream);
+}
+int hegpu_GPU_NTT_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int mod_offset, int batch, int mod_count,
+                          hegpu_stream stream)
+{
+    return hegpu_ntt(ctx, table_set, inout, inout, 0, batch, mod_count, mod_offset, nullptr, nullptr, stream);
+}
+int hegpu_GPU_INTT(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int mod_offset, int batch,
+                   int mod_count, hegpu_stream stream)
+{
+    return hegpu_ntt(ctx, table_set, in, out, 1, batch, mod_count, mod_offset, nullptr, nullptr, stream);
+}
+int hegpu_GPU_INTT_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int mod_offset, int batch,
+                           int mod_count, hegpu_stream stream)
+{
+    return hegpu_ntt(ctx, table_set, inout, inout, 1, batch, mod_count, mod_offset, nullptr, nullptr, stream);
+}
+int hegpu_GPU_NTT_Modulus_Ordered_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int inverse,
+                                          int mod_offset, int batch, int mod_count, const int* order,
+                                          hegpu_stream stream)
+{
+    if (!order) return fail(HEGPU_E_INVALID, "modulus order table is required");
+    return hegpu_ntt(ctx, table_set, inout, inout, inverse, batch, mod_count, mod_offset, order, nullptr, stream);
+}
+int hegpu_GPU_NTT_Poly_Ordered_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int inverse, int mod_offset,
+                                       int batch, int mod_count, const int* order, hegpu_stream stream)
+{
+    if (!order) return fail(HEGPU_E_INVALID, "polynomial order table is required");
+    return hegpu_ntt(ctx, table_set, inout, inout, inverse, batch, mod_count, mod_offset, nullptr, order, stream);
+}
+
 int hegpu_addition(hegpu_context* ctx, const uint64_t* in1, const uint64_t* in2, uint64_t* out, int limbs,
                    int parts, int batch, int op, hegpu_stream stream)
 {

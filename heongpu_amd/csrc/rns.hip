@@ -556,7 +556,9 @@ hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride,
 // residues) must stay in registers, so the kernels are instantiated for a
 // padded base size MAXB with every loop fully unrolled and guarded by the
 // (wave-uniform) real size.  Runtime-indexed arrays would live in scratch.
-#define BEHZ_MAX 40
+// 64 = the reference's MAX_BSK_SIZE (src/include/heongpu/kernel/defines.h:26); a 128-bit accumulator
+// takes 64 products of two 61-bit values (each < 2^122) without overflow.
+#define BEHZ_MAX 64
 
 template <int MAXB>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __restrict__ in1, u64 s1,
@@ -620,6 +622,7 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
     else if (m <= 8) LAUNCH(8);
     else if (m <= 16) LAUNCH(16);
     else if (m <= 24) LAUNCH(24);
+    else if (m <= 40) LAUNCH(40);
     else LAUNCH(BEHZ_MAX);
 #undef LAUNCH
     return hipGetLastError();
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
         u64 h2 = 0, l2 = 0;
 #pragma unroll
         for (int j = 0; j < MAXB; j++)
-            if (j < ob - 1) acc_mad(h2, l2, temp3[j], row[j]); // un-reduced: < 2^61 * 2^61 * 40 terms fits 128 bits
+            if (j < ob - 1) acc_mad(h2, l2, temp3[j], row[j]); // un-reduced: 64 terms below 2^122 fit 128 bits
         u64 t4 = reduce128(h2, l2, mi);
         u64 obase_ = b.msk_mod_q[i];
         u64 alpha_ = reduce64(alpha_sk, mi);
@@ -707,6 +710,7 @@ hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev
     else if (m <= 8) LAUNCH(8);
     else if (m <= 16) LAUNCH(16);
     else if (m <= 24) LAUNCH(24);
+    else if (m <= 40) LAUNCH(40);
     else LAUNCH(BEHZ_MAX);
 #undef LAUNCH
     return hipGetLastError();

@@ -85,6 +85,33 @@ int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order);
 int hegpu_ntt(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int inverse, int batch,
               int mod_count, int mod_offset, const int* mod_order, const int* poly_order, hegpu_stream stream);
 
+/* The six gpuntt:: entry points by name, for a maintainer who binds call site by call site.  The
+ * reference passes table / modulus / n^-1 pointers (offset by the caller for a sub-chain) and an
+ * ntt_rns_configuration; here the context owns the tables, so `table_set` + `mod_offset` select what those
+ * pointers selected, `inverse` is cfg.ntt_type == INVERSE (n^-1 of the same moduli is applied, as
+ * cfg.mod_inverse does), cfg.stream is the last argument.  All return 0 or an error code.
+ *   gpuntt::GPU_NTT(in, out, tables, moduli, cfg, batch, mod_count)              bfv/operator.cu:393
+ *   gpuntt::GPU_NTT_Inplace(inout, tables, moduli, cfg, batch, mod_count)        ckks/operator.cu:1011
+ *   gpuntt::GPU_INTT(in, out, itables, moduli, cfg, batch, mod_count)            ckks/operator.cu:1461
+ *   gpuntt::GPU_INTT_Inplace(inout, itables, moduli, cfg, batch, mod_count)      bfv/operator.cu:410, ckks :919
+ *   gpuntt::GPU_NTT_Modulus_Ordered_Inplace(inout, tables, moduli, cfg, batch, mod_count, order)   ckks :956,1524
+ *   gpuntt::GPU_NTT_Poly_Ordered_Inplace(inout, tables, moduli, cfg, batch, mod_count, order)      ckks :996,1197
+ * `order` is a DEVICE int array, as in the reference. */
+int hegpu_GPU_NTT(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int mod_offset, int batch,
+                  int mod_count, hegpu_stream stream);
+int hegpu_GPU_NTT_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int mod_offset, int batch,
+                          int mod_count, hegpu_stream stream);
+int hegpu_GPU_INTT(hegpu_context* ctx, int table_set, const uint64_t* in, uint64_t* out, int mod_offset, int batch,
+                   int mod_count, hegpu_stream stream);
+int hegpu_GPU_INTT_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int mod_offset, int batch,
+                           int mod_count, hegpu_stream stream);
+int hegpu_GPU_NTT_Modulus_Ordered_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int inverse,
+                                          int mod_offset, int batch, int mod_count, const int* order,
+                                          hegpu_stream stream);
+int hegpu_GPU_NTT_Poly_Ordered_Inplace(hegpu_context* ctx, int table_set, uint64_t* inout, int inverse,
+                                       int mod_offset, int batch, int mod_count, const int* order,
+                                       hegpu_stream stream);
+
 /* ------------------------------------------------------------------ kernels
  * 1:1 replacements of the reference __global__ kernels (grid dims become
  * arguments).  `table_set` selects the modulus array (Q' chain or q|Bsk). */

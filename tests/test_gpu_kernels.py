@@ -471,3 +471,85 @@ def test_c5_tfhe_4096_gates(hg, oracle, torch):
     assert np.array_equal(ga[:checked].reshape(-1), want_a) and np.array_equal(gb[:checked], want_b)
     assert np.array_equal(ga, np.tile(ga[:uniq], (rep, 1))), "a gate differs from its twin"
     assert np.array_equal(gb, np.tile(gb[:uniq], rep))
+
+
+def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch):
+    """BEHZ with Q + |Bsk| beyond 40 moduli (the reference allows MAX_BSK_SIZE = 64, defines.h:26):
+    BFV N=2^12, 42 primes of 30 bits + one special prime, multiply + relinearize against the oracle."""
+    n, t, Q = 4096, 65537, 42
+    c = hg.Context.from_bit_sizes(hg.BFV, n, [30] * Q, [31], plain_modulus=t, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, 12, primes, Q, 1, t)
+    c.upload()
+    L = len(c.table("q_Bsk_merge_modulus"))
+    assert L - Q > 40, (L, Q)
+    ct1 = synth_ct(primes, range(Q), 2, n, 1)
+    ct2 = synth_ct(primes, range(Q), 2, n, 2)
+    out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
+                   c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+    torch.cuda.synchronize()
+    want = o.bfv_multiply(ct1, ct2)
+    assert np.array_equal(hg.to_host(out), want)
+
+
+def test_six_gpuntt_entry_points_by_name(hg, oracle, torch):
+    """hegpu_GPU_NTT / _Inplace / GPU_INTT / _Inplace / GPU_NTT_Modulus_Ordered_Inplace /
+    GPU_NTT_Poly_Ordered_Inplace (include/hegpu.h: the names a maintainer binds call site by call site),
+    each against the oracle's restatement of the same gpuntt call, CKKS N=2^13 {40,35x3}|{40}, depth 1."""
+    from heongpu_amd import _lib
+    L = _lib.load()
+    n, Q, Qp, depth = 8192, 4, 5, 1
+    c, o, primes = _ckks(hg, oracle, n, [40, 35, 35, 35], [40])
+    h = c._h
+    st = torch.cuda.current_stream().cuda_stream
+    rc = Qp - depth
+    batch = 2 * Qp
+    x = np.concatenate([oracle.fill_poly(7 + i, i % Qp, n, primes[i % Qp]) for i in range(batch)])
+    want = o.ntt(x.copy(), batch, Qp)
+    d, out = hg.to_device(x), torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    assert L.hegpu_GPU_NTT(h, hg.TABLES_QP, d.data_ptr(), out.data_ptr(), 0, batch, Qp, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), want) and np.array_equal(hg.to_host(d), x)
+    assert L.hegpu_GPU_INTT(h, hg.TABLES_QP, out.data_ptr(), d.data_ptr(), 0, batch, Qp, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), x)
+    assert L.hegpu_GPU_NTT_Inplace(h, hg.TABLES_QP, d.data_ptr(), 0, batch, Qp, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), want)
+    assert L.hegpu_GPU_INTT_Inplace(h, hg.TABLES_QP, d.data_ptr(), 0, batch, Qp, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(d), x)
+    # caller-offset tables: the two P-limb polynomials only (ckks/operator.cu:996 passes tables + Q)
+    y = np.concatenate([oracle.fill_poly(50 + i, Q, n, primes[Q]) for i in range(2)])
+    dy = hg.to_device(y)
+    assert L.hegpu_GPU_NTT_Inplace(h, hg.TABLES_QP, dy.data_ptr(), Q, 2, 1, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(dy), o.ntt(y.copy(), 2, 1, mod_offset=Q))
+    # modulus ordered, forward and inverse (ckks/operator.cu:956,1524)
+    order = [int(v) for v in o.table("new_prime_locations")][Qp:Qp + rc]
+    z = np.concatenate([oracle.fill_poly(11 + i, 0, n, primes[order[i % rc]]) for i in range(3 * rc)])
+    wz = z.copy()
+    ord_arr = np.array(order, dtype=np.int32)
+    tab, itab, ninv = o.table("ntt_table"), o.table("intt_table"), o.table("n_inverse")
+    o.L.o_gpu_ntt_modulus_ordered(wz.ctypes.data, tab.ctypes.data, o.qp_mods, ninv.ctypes.data, 0, 13, 3 * rc, rc, ord_arr.ctypes.data)
+    dz = hg.to_device(z)
+    dev_order = c.device_ptr("new_prime_locations") + 4 * Qp
+    assert L.hegpu_GPU_NTT_Modulus_Ordered_Inplace(h, hg.TABLES_QP, dz.data_ptr(), 0, 0, 3 * rc, rc, dev_order, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(dz), wz)
+    assert L.hegpu_GPU_NTT_Modulus_Ordered_Inplace(h, hg.TABLES_QP, dz.data_ptr(), 1, 0, 3 * rc, rc, dev_order, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(dz), z)
+    # poly ordered: INTT of slots {rc-1, 2rc-1} with the P prime (relinearize, ckks/operator.cu:996)
+    slots = np.array([rc - 1, 2 * rc - 1], dtype=np.int32)
+    w = np.concatenate([oracle.fill_poly(90 + i, 0, n, primes[Qp - 1]) for i in range(2 * rc)])
+    ww = w.copy()
+    o.L.o_gpu_ntt_poly_ordered(ww.ctypes.data, itab.ctypes.data + Q * n * 8, o.mods_addr(Q), ninv.ctypes.data + Q * 8, 1, 13, 2, 1,
+                               slots.ctypes.data)
+    dw = hg.to_device(w)
+    dev_slots = c.device_ptr("new_input_locations") + 4 * 2 * depth
+    assert L.hegpu_GPU_NTT_Poly_Ordered_Inplace(h, hg.TABLES_QP, dw.data_ptr(), 1, Q, 2, 1, dev_slots, st) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(dw), ww)
+    assert L.hegpu_GPU_NTT_Poly_Ordered_Inplace(h, hg.TABLES_QP, dw.data_ptr(), 1, Q, 2, 1, None, st) != 0
