@@ -157,6 +157,31 @@ def ntt_sweep(torch, hg, timer):
     return out
 
 
+def hoisted_rotation_block(torch, hg, timer, ctx, B=16):
+    """k rotations of each of B ciphertexts at the C4 chain, the decomposition and the digit
+    NTT shared (hegpu_ckks_rotate_hoisted) against k separate hegpu_ckks_apply_galois calls."""
+    n, Q, Qp = ctx.n, ctx.Q_size, ctx.Q_prime_size
+    stream = torch.cuda.current_stream().cuda_stream
+    words = 2 * Q * n
+    ct = rnd(torch, B * words, 1 << 49)
+    ws = ctx.workspace(hg.OP_CKKS_GALOIS, 0, B)
+    kmax = 8
+    keys = [rnd(torch, Q * 2 * Qp * n, 1 << 49) for _ in range(kmax)]
+    elts = [hg.steps_to_galois_elt(i + 1, n, 5) for i in range(kmax)]
+    out = torch.empty(B * kmax * words, dtype=torch.int64, device="cuda")
+    res = {"workload": "CKKS N=2^16, Q=16 | P=1 (method I), depth 0, %d ciphertexts, k Galois elements each" % B, "by_k": {}}
+    for k in (1, 2, 4, 8):
+        h = timer.ms(lambda: ctx.ckks_rotate_hoisted(ct, words, out, k * words, keys[:k], elts[:k], 0, B, ws, stream=stream), 3)
+
+        def separate():
+            for i in range(k):
+                ctx.ckks_apply_galois(ct, words, out[i * B * words:], words, keys[i], elts[i], 0, B, ws, stream=stream)
+        s_ = timer.ms(separate, 3)
+        res["by_k"][str(k)] = {"hoisted_rotations_per_s": B * k / (h * 1e-3), "separate_rotations_per_s": B * k / (s_ * 1e-3),
+                               "hoisted_ms": h, "separate_ms": s_}
+    return res
+
+
 def secondary_block(torch, hg, timer):
     """The other BASELINE.json configurations, synthetic data, each with the algorithmic bytes of the
     reference's kernel sequence and the fraction of the 8 TB/s HBM peak that rate means."""
@@ -456,6 +481,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         line["ntt_by_degree"] = ntt_sweep(torch, hg, timer)
         line["secondary"] = secondary_block(torch, hg, timer)
+        del ct1, ct2, out, ws
+        line["secondary"]["hoisted_rotations"] = hoisted_rotation_block(torch, hg, timer, ctx)
 
     if rank != 0:
         if world > 1:

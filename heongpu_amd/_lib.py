@@ -59,6 +59,9 @@ SIGNATURES = [
     ("hegpu_ckks_rescale_inplace", c_int, [voidp, u64p, u64, c_int, c_int, voidp, c_size_t, voidp]),
     ("hegpu_ckks_apply_galois", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, c_int, c_int, c_int, voidp, c_size_t, voidp]),
+    ("hegpu_ckks_rotate_hoisted", c_int,
+     [voidp, u64p, u64, u64p, u64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_int), c_int, c_int, c_int, voidp,
+      c_size_t, voidp]),
     ("hegpu_bfv_multiply", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, voidp, c_size_t, voidp]),
     ("hegpu_bfv_relinearize_inplace", c_int, [voidp, u64p, u64, u64p, c_int, voidp, c_size_t, voidp]),
     ("hegpu_bfv_apply_galois", c_int,

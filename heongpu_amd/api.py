@@ -232,6 +232,15 @@ class Context:
                                                  batch, _ptr(ws), ws.numel() * 8,
                                                  stream if stream is not None else _stream()))
 
+    def ckks_rotate_hoisted(self, ct, cs, out, so, keys, galois_elts, depth, batch, ws, stream=None):
+        """fast_single_hoisting_rotation_ckks: keys = list of device tensors (None where galois_elts[i] == 0)"""
+        cnt = len(galois_elts)
+        kp = (ctypes.c_void_p * cnt)(*[(_ptr(k) if k is not None else None) for k in keys])
+        ge = (ctypes.c_int * cnt)(*[int(g) for g in galois_elts])
+        _check(self._lib.hegpu_ckks_rotate_hoisted(self._h, _ptr(ct), cs, _ptr(out), so, kp, ge, cnt, depth, batch,
+                                                   _ptr(ws), ws.numel() * 8,
+                                                   stream if stream is not None else _stream()))
+
     def bfv_multiply(self, ct1, s1, ct2, s2, out, so, batch, ws, stream=None):
         _check(self._lib.hegpu_bfv_multiply(self._h, _ptr(ct1), s1, _ptr(ct2), s2, _ptr(out), so, batch, _ptr(ws),
                                             ws.numel() * 8, stream if stream is not None else _stream()))

@@ -494,6 +494,27 @@ int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs,
                    "hegpu_ckks_apply_galois");
 }
 
+int hegpu_ckks_rotate_hoisted(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, uint64_t* out, uint64_t so,
+                              const uint64_t* const* keys, const int* galois_elts, int count, int depth, int batch,
+                              void* ws, size_t ws_bytes, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
+    if (count <= 0 || !keys || !galois_elts) return fail(HEGPU_E_INVALID, "rotate_hoisted: empty element list");
+    const uint64_t words = (uint64_t) 2 * (ctx->c.Q_size - depth) * ctx->c.n;
+    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "rotate_hoisted: out must not alias ct");
+    if (batch > 1 && so < (uint64_t) count * words) return fail(HEGPU_E_INVALID, "rotate_hoisted: out_stride too small");
+    for (int i = 0; i < count; i++) {
+        if (galois_elts[i] == 0) continue;
+        if (galois_elts[i] < 0 || !(galois_elts[i] & 1) || galois_elts[i] >= 2 * (int) ctx->c.n)
+            return fail(HEGPU_E_INVALID, "rotate_hoisted: Galois elements are odd and below 2N");
+        if (!keys[i]) return fail(HEGPU_E_INVALID, "rotate_hoisted: Galois key not present!");
+    }
+    return hip_ret(op_ckks_rotate_hoisted(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64* const*) keys,
+                                          galois_elts, count, depth, batch, (u64*) ws, (hipStream_t) stream),
+                   "hegpu_ckks_rotate_hoisted");
+}
+
 int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t s1, const uint64_t* ct2, uint64_t s2,
                        uint64_t* out, uint64_t so, int batch, void* ws, size_t ws_bytes, hegpu_stream stream)
 {

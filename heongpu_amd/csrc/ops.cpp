@@ -398,6 +398,87 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
     return ntt_launch(a, 2 * l * batch, false, st);
 }
 
+// Hoisted rotations: fast_single_hoisting_rotation_ckks_method_I / _II (reference ckks/operator.cu:4674-4953,
+// 5092-5446).  The reference computes, for every requested Galois element, the same INTT of the ciphertext, the
+// same digit decomposition (method I: ckks_duplicate_kernel, method II: base_conversion_DtoQtilde) and the same
+// forward NTT of the digits -- none of them depends on the element -- and then the key inner product, the INTT,
+// the mod-down + permutation and the final NTT that do.  Here the shared part runs once: the coefficient-domain
+// ciphertext and the NTT-domain digits stay in the workspace while the per-element part walks the keys, so every
+// output is bit-identical to the reference's (and to `count` separate hegpu_ckks_apply_galois calls).
+// out: [count][2][l][N] per ciphertext (`so` apart), entry i at i * 2 l N; galois_elts[i] == 0 copies the input
+// (global_memory_replace_kernel, :4708 / :5141).  Workspace: OP_CKKS_GALOIS.
+hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* const* keys,
+                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st)
+{
+    const int np = c.n_power;
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    const int l = Q - depth, rc = Qp - depth;
+    const bool m2 = c.P_size > 1;
+    const int digits = m2 ? c.m2_levels[depth].d : l;
+    const u64 per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n;
+    u64* temp0 = ws;                       // [2][l][N] coefficient-domain copy of ct
+    u64* temp2 = temp0 + (u64) 2 * l * n;  // [digits][rc][N] NTT-domain digits
+    u64* temp3 = temp2 + (u64) l * rc * n; // [2][rc][N]
+    const Mod* mods = c.plan_qp.mods;
+    const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    const u64 ct_words = (u64) 2 * l * n;
+    bool any = false;
+    for (int i = 0; i < count; i++) {
+        if (galois_elts[i] == 0)
+            TRY(rns_copy_limbs(ct, (u64) l * n, cs, out + (u64) i * ct_words, (u64) l * n, so, np, l, 2, batch, st));
+        else if (!keys[i]) return hipErrorInvalidValue;
+        else any = true;
+    }
+    if (!any) return hipSuccess;
+    {   // a single element has nothing to share: the fused key-switch path of the plain operator is faster
+        int nz = 0, which = -1;
+        for (int i = 0; i < count; i++)
+            if (galois_elts[i] != 0) { nz++; which = i; }
+        if (nz == 1) {
+            u64* oi = out + (u64) which * ct_words;
+            return m2 ? op_ckks_apply_galois_II(c, ct, cs, oi, so, keys[which], galois_elts[which], depth, batch, ws, st)
+                      : op_ckks_apply_galois(c, ct, cs, oi, so, keys[which], galois_elts[which], depth, batch, ws, st);
+        }
+    }
+
+    // ---- shared: INTT of both parts, digits, forward NTT of the digits
+    NttArgs a = c.ntt_args(0);
+    a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = cs; a.out_item_stride = per;
+    TRY(ntt_launch(a, 2 * l * batch, true, st));
+    a = c.ntt_args(0);
+    a.out = temp2; a.mod_count = rc; a.polys_per_item = digits * rc; a.mod_order = order;
+    a.in_item_stride = a.out_item_stride = per;
+    if (m2) {
+        TRY(dtoq(c, depth, temp0 + (u64) l * n, per, temp2, per, l, depth, batch, st));
+        a.in = temp2;
+    } else {
+        // digit d at modulus d is the NTT-domain limb of c1 itself
+        a.in = temp0 + (u64) l * n; a.decomp_mods = rc; a.skip_identity = 1;
+        TRY(rns_copy_diag(ct + (u64) l * n, cs, temp2, per, np, l, rc, batch, st));
+    }
+    TRY(ntt_launch(a, digits * rc * batch, false, st));
+
+    // ---- per Galois element
+    for (int i = 0; i < count; i++) {
+        if (galois_elts[i] == 0) continue;
+        u64* oi = out + (u64) i * ct_words;
+        TRY(rns_keyswitch_mac(temp2, per, keys[i], temp3, per, mods, np, digits, rc, Qp, l, depth, batch, st));
+        NttArgs b = c.ntt_args(0);
+        b.in = temp3; b.out = temp3; b.mod_count = rc; b.polys_per_item = 2 * rc; b.mod_order = order;
+        b.in_item_stride = b.out_item_stride = per;
+        TRY(ntt_launch(b, 2 * rc * batch, true, st));
+        TRY(rns_moddown_permute(temp3, per, temp0, per, oi, so, mods, c.d64("half"), c.d64("half_mod"),
+                                c.d64("last_q_modinv"), galois_elts[i], np, rc, l, Qp, Q, c.P_size, batch, st));
+        b = c.ntt_args(0);
+        b.in = oi; b.out = oi; b.mod_count = l; b.polys_per_item = 2 * l;
+        b.in_item_stride = b.out_item_stride = so;
+        TRY(ntt_launch(b, 2 * l * batch, false, st));
+    }
+    return hipSuccess;
+}
+
 // reference bfv/operator.cu:585-672
 hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
                                  hipStream_t st)

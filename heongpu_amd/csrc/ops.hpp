@@ -29,6 +29,11 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
 hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                int galois_elt, int batch, u64* ws, hipStream_t st);
 
+// fast_single_hoisting_rotation_ckks_method_I / _II (ckks/operator.cu:4674-5446): `count` rotations of one
+// ciphertext with the decomposition and the digit NTT shared; keys / galois_elts are HOST arrays
+hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* const* keys,
+                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st);
+
 // key-switching method II (P_size > 1)
 hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
                                   hipStream_t st);

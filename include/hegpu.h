@@ -206,6 +206,17 @@ int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_str
 int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
                             uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int depth,
                             int batch, void* ws, size_t ws_bytes, hegpu_stream stream);
+/* fast_single_hoisting_rotation_ckks (host/ckks/operator.cuh:2133-2196; method I ckks/operator.cu:4674-4953,
+ * method II :5092-5446): `count` Galois automorphisms of ONE ciphertext per batch item.  The INTT of the
+ * ciphertext, the digit decomposition and the forward NTT of the digits do not depend on the element and run
+ * once; per element: key inner product, INTT, mod-down + permutation, NTT.  Entry i is written to
+ * out + i * 2 l N (per item: out_stride apart), l = Q - depth; galois_elts[i] == 0 copies the input (the
+ * reference's result[0] / a zero shift).  galois_keys / galois_elts are HOST arrays of length count;
+ * galois_keys[i] is the DEVICE key of element i (ignored for 0).  Every entry is bit-identical to
+ * hegpu_ckks_apply_galois with the same element and key.  Workspace: HEGPU_OP_CKKS_GALOIS. */
+int hegpu_ckks_rotate_hoisted(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
+                              uint64_t out_stride, const uint64_t* const* galois_keys, const int* galois_elts,
+                              int count, int depth, int batch, void* ws, size_t ws_bytes, hegpu_stream stream);
 /* multiply_bfv (src/lib/host/bfv/operator.cu:336-430): coefficient domain,
  * ct [2][Q][N] x [2][Q][N] -> out [3][Q][N] */
 int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_stride, const uint64_t* ct2,

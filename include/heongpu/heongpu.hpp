@@ -2146,6 +2146,55 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         apply_key(in, out, it->second.data(), galois_elt, o);
     }
 
+    // host/ckks/operator.cuh:2133-2196 fast_single_hoisting_rotation_ckks (methods I and II by the key type):
+    // result = n1 ciphertexts back to back, entry i = input rotated by bsgs_shift[i] (a zero shift: the input);
+    // the INTT, the digit decomposition and the forward NTT of the digits are shared by all shifts whose
+    // Galois key exists (hegpu_ckks_rotate_hoisted); a shift without its own key goes through the
+    // power-of-two chain like rotate_rows (ckks/operator.cu:4833-4948), one rotation after the other.
+    DeviceVector<Data64> fast_single_hoisting_rotation_ckks(Ciphertext<S>& input1, std::vector<int>& bsgs_shift, int n1,
+                                                            Galoiskey<S>& galois_key, hipStream_t stream = nullptr)
+    {
+        static_assert(S == Scheme::CKKS, "hoisted rotations are a CKKS operation");
+        ExecutionOptions o;
+        o.set_stream(stream);
+        detail::OpScope storage_scope(o);
+        if (input1.rescale_required_ || input1.relinearization_required_)
+            throw std::invalid_argument("Ciphertext can not be rotated!");
+        const int l = limbs(input1);
+        const size_t n = context_->n, words = 2 * n * l;
+        if (input1.memory_size() < words) throw std::invalid_argument("Invalid Ciphertexts size!");
+        if (n1 < 1 || (size_t) n1 > bsgs_shift.size()) throw std::invalid_argument("Invalid rotation count!");
+        DeviceVector<Data64> result(words * n1, stream);
+        std::vector<const uint64_t*> keys(n1, nullptr);
+        std::vector<int> elts(n1, 0), chained;
+        for (int i = 0; i < n1; i++) {
+            // the reference copies the input into entry 0 whatever bsgs_shift[0] is (method I, :4708) and treats
+            // a zero shift as a copy (method II, :5138)
+            if (i == 0 || bsgs_shift[i] == 0) continue;
+            const int g = hegpu_steps_to_galois_elt(bsgs_shift[i], (int) n, galois_key.group_order_);
+            auto it = galois_key.device_location_.find(g);
+            if (it != galois_key.device_location_.end()) {
+                elts[i] = g;
+                keys[i] = (const uint64_t*) it->second.data();
+            } else {
+                chained.push_back(i);
+            }
+        }
+        const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_GALOIS, input1.depth_, 1);
+        DeviceVector<Data64> ws(wsb / 8, stream);
+        detail::check(hegpu_ckks_rotate_hoisted(context_->handle(), (const uint64_t*) input1.data(), 0,
+                                                (uint64_t*) result.data(), 0, keys.data(), elts.data(), n1,
+                                                input1.depth_, 1, ws.data(), wsb, stream));
+        for (int i : chained) { // no key of its own: rotate_rows' chain of power-of-two keys
+            Ciphertext<S> rot(input1);
+            rotate_rows(input1, rot, galois_key, bsgs_shift[i], o);
+            detail::hip(hipMemcpyAsync(result.data() + (size_t) i * words, rot.data(), words * sizeof(Data64),
+                                       hipMemcpyDeviceToDevice, stream));
+            detail::hip(hipStreamSynchronize(stream)); // `rot` is released on return
+        }
+        return result;
+    }
+
   private:
     void apply_key(Ciphertext<S>& in, Ciphertext<S>& out, const Data64* key, int galois_elt, const ExecutionOptions& o)
     {

@@ -73,6 +73,7 @@ def lib():
     L.o_ckks_relinearize.argtypes = [vp, vp, vp, ci]
     L.o_ckks_rescale.argtypes = [vp, vp, ci]
     L.o_ckks_apply_galois.argtypes = [vp, vp, vp, vp, ci, ci]
+    L.o_ckks_rotate_hoisted.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ci, ci]
     L.o_bfv_multiply.argtypes = [vp, vp, vp, vp]
     L.o_bfv_relinearize.argtypes = [vp, vp, vp]
     L.o_bfv_apply_galois.argtypes = [vp, vp, vp, vp, ci]
@@ -237,6 +238,16 @@ class OracleContext:
     def ckks_rescale(self, ct, depth=0):
         self.L.o_ckks_rescale(self.h, _p(ct), depth)
         return ct
+
+    def ckks_rotate_hoisted(self, ct, keys, galois_elts, depth=0):
+        """keys: list of numpy key arrays (None for a zero element); returns [count][2][l][N]"""
+        l = self.Q - depth
+        cnt = len(galois_elts)
+        out = np.zeros(cnt * 2 * l * self.n, dtype=np.uint64)
+        kp = (ctypes.c_void_p * cnt)(*[(k.ctypes.data if k is not None else None) for k in keys])
+        ge = (ctypes.c_int * cnt)(*[int(g) for g in galois_elts])
+        self.L.o_ckks_rotate_hoisted(self.h, _p(ct), _p(out), kp, ge, cnt, depth)
+        return out
 
     def ckks_apply_galois(self, ct, key, galois_elt, depth=0):
         l = self.Q - depth

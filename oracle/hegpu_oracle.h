@@ -174,6 +174,8 @@ void o_ckks_rescale(const octx_t* c, u64* ct, int depth);
 /* ckks/operator.cu:1422-1559 */
 void o_ckks_apply_galois(const octx_t* c, const u64* ct, u64* out,
                          const u64* galois_key, int galois_elt, int depth);
+void o_ckks_rotate_hoisted(const octx_t* c, const u64* ct, u64* out, const u64* const* keys,
+                           const int* galois_elts, int count, int depth); /* ckks/operator.cu:4674-5446 */
 /* bfv/operator.cu:336-430 */
 void o_bfv_multiply(const octx_t* c, const u64* ct1, const u64* ct2,
                     u64* out3);

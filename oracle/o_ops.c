@@ -109,6 +109,24 @@ void o_ckks_apply_galois(const octx_t* c, const u64* ct, u64* out,
     free(temp0);
 }
 
+/* ckks/operator.cu:4674-4953 fast_single_hoisting_rotation_ckks_method_I (the key of every shift
+ * present) and :5092-5446 (method II): result[i] = the input for a zero element, else the full
+ * apply_galois sequence on the ORIGINAL ciphertext -- the reference recomputes INTT, duplicate and NTT
+ * for every element ("TODO: make it efficient"), which is what is restated here.
+ * out [count][2][l][N]; keys[i] = the Galois key of galois_elts[i]. */
+void o_ckks_rotate_hoisted(const octx_t* c, const u64* ct, u64* out, const u64* const* keys,
+                           const int* galois_elts, int count, int depth)
+{
+    const int l = c->Q_size - depth;
+    const u64 words = (u64) 2 * l * c->n;
+    for (int i = 0; i < count; i++) {
+        u64* oi = out + (u64) i * words;
+        if (galois_elts[i] == 0) memcpy(oi, ct, words * sizeof(u64)); /* global_memory_replace_kernel */
+        else if (c->P_size == 1) o_ckks_apply_galois(c, ct, oi, keys[i], galois_elts[i], depth);
+        else o_ckks_apply_galois_II(c, ct, oi, keys[i], galois_elts[i], depth);
+    }
+}
+
 /* bfv/operator.cu:336-430 multiply_bfv */
 void o_bfv_multiply(const octx_t* c, const u64* ct1, const u64* ct2,
                     u64* out3)

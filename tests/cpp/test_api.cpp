@@ -256,6 +256,27 @@ static void ckks_pipeline()
         if (r >= n) want[r - n] = -m1[i]; else want[r] = m1[i];
     }
     EXPECT(maxerr(decode0(out), want, scale) < (1 << 14), "decrypt(rotate(c1)) = sigma_g(m1)");
+
+    // hoisted rotations (host/ckks/operator.cuh:2133-2196): entry i = the input rotated by bsgs_shift[i]; shifts
+    // with their own key share one decomposition, shift 3 has none and goes through the 2 + 1 chain
+    {
+        Galoiskey<S> gk3(ctx, std::vector<int>{1, 2, -1});
+        keygen.generate_galois_key(gk3, sk);
+        std::vector<int> shifts{0, 1, 2, -1, 3};
+        DeviceVector<Data64> many = op.fast_single_hoisting_rotation_ckks(c1, shifts, (int) shifts.size(), gk3);
+        const size_t words = 2 * (size_t) Q * n;
+        bool ok = many.size() == words * shifts.size();
+        for (size_t i = 0; ok && i < shifts.size(); i++) {
+            Ciphertext<S> single(ctx);
+            if (shifts[i] == 0) single = c1;
+            else op.rotate_rows(c1, single, gk3, shifts[i]);
+            Vec a(words), b;
+            (void) hipMemcpy(a.data(), many.data() + i * words, words * 8, hipMemcpyDeviceToHost);
+            single.get_data(b);
+            ok = ok && b.size() >= words && !memcmp(a.data(), b.data(), words * 8);
+        }
+        EXPECT(ok, "fast_single_hoisting_rotation_ckks: every entry equals the separate rotate_rows result, bit for bit");
+    }
     o_ctx_free(oc);
 }
 
