@@ -469,7 +469,15 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
             } else {
                 htw[k * n + j] = make_ulonglong2(w, shoup_companion(w, q));
             }
-            hitw[k * n + j] = make_ulonglong2(iw, shoup_companion(iw, q));
+            if (hm[k].fp) { // the inverse transform of an FP64 modulus reads (double(w), RN(w/q)) pairs as well
+                const double wd = (double) iw, wi = wd / (double) q;
+                u64 a, b;
+                memcpy(&a, &wd, 8);
+                memcpy(&b, &wi, 8);
+                hitw[k * n + j] = make_ulonglong2(a, b);
+            } else {
+                hitw[k * n + j] = make_ulonglong2(iw, shoup_companion(iw, q));
+            }
         }
         for (u64 c = 0; c < rows; c++)
             for (int st = 0; st < 4; st++)
@@ -480,9 +488,21 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
                         htwB[dst] = htw[k * n + src];
                         hitwB[dst] = hitw[k * n + src];
                     }
-        hn[k] = make_ulonglong2(ninv[k], shoup_companion(ninv[k], q));
         const u64 w1n = host::mul_mod(inv[k * n + 1], ninv[k], q);
-        hw[k] = make_ulonglong2(w1n, shoup_companion(w1n, q));
+        if (hm[k].fp) {
+            auto pair = [&](u64 v) {
+                const double vd = (double) v, vi = vd / (double) q;
+                u64 a, b;
+                memcpy(&a, &vd, 8);
+                memcpy(&b, &vi, 8);
+                return make_ulonglong2(a, b);
+            };
+            hn[k] = pair(ninv[k]);
+            hw[k] = pair(w1n);
+        } else {
+            hn[k] = make_ulonglong2(ninv[k], shoup_companion(ninv[k], q));
+            hw[k] = make_ulonglong2(w1n, shoup_companion(w1n, q));
+        }
     }
     p.count = cnt;
     p.has_fp = p.has_int = 0;
@@ -515,6 +535,7 @@ hipError_t Context::upload()
     if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0');
     if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
     if (const char* e = getenv("HEGPU_COL_MULTI")) col_multi = atoi(e); // 0 / 1 force a column-pass form
+    if (const char* e = getenv("HEGPU_SINGLE_PASS")) single_pass = atoi(e);
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)
         gauss_cdt.t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);
@@ -651,6 +672,7 @@ NttArgs Context::ntt_args(int table_set) const
     a.n_power = n_power;
     a.mod_count = p.count;
     a.col_multi = col_multi;
+    a.single_pass = single_pass;
     a.plan_has_fp = p.has_fp;
     a.plan_has_int = p.has_int;
     return a;

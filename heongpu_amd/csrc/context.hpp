@@ -56,6 +56,7 @@ struct Context {
     bool fused_row_mac = true;
     bool fused_moddown = true; // HEGPU_FUSED_MODDOWN=0: separate stage-two kernel
     int col_multi = -1;        // HEGPU_COL_MULTI: form of the decomposing column pass (NttArgs::col_multi)
+    int single_pass = 1;       // HEGPU_SINGLE_PASS=0: N <= 2^14 transforms through the two passes as well
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 
     // ---- device state (valid after upload())

@@ -705,6 +705,156 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
     else fwd_row_body<false>(a, ps, md, lds);
 }
 
+// ------------------------------------------------------------------ single pass, N <= 2^14
+// A limb of N <= 2^14 coefficients (128 KiB) fits the 160 KiB of LDS: one workgroup of N / 16 threads runs
+// all log2 N stages with the limb resident -- 2W of HBM traffic per limb instead of the 4W of the two passes.
+// The structure is the two passes back to back: thread group g (256 threads) does the column stages of column
+// tile g exactly as ntt_fwd_col does, but leaves its result in LDS, at the position the row stages of row tile
+// T = row / 16 read it from: limb[T][row_phys((row % 16) * 256 + col)] -- the row pass's own tile layout, so
+// the second half is fwd_row_body reading LDS instead of HBM.  The A -> B exchange of the column stages goes
+// through the column tile's own positions (private to the group; a thread reads and writes the same 16
+// positions in round B, so no barrier separates them).  Two __syncthreads per transform; every column-stage
+// twiddle is wave-uniform (r1 = thread / CT with CT >= 64) and comes through the scalar cache.
+template <int S1>
+__device__ __forceinline__ int single_pos(int row, int col)
+{
+    return (row >> 4) * 4096 + row_phys((row & 15) * 256 + col);
+}
+
+template <int S1, bool FP, bool LAZY>
+__device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* limb)
+{
+    constexpr int R = 1 << S1;
+    constexpr int CT = 4096 / R;
+    constexpr int NSA = S1 - 4;
+    constexpr int RA = 1 << NSA;
+    constexpr int G = 16 / RA;
+    const int t = threadIdx.x, g = t >> 8, tt = t & 255;
+    const QC qc = make_qc(md.q);
+    const FC fc = make_fc(md.q);
+    const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
+    const u64* __restrict__ src = a.in + ps.in_off + g * CT;
+    const int col = tt % CT, r1 = tt / CT;
+    // ---- column stages 0 .. S1-1
+    if constexpr (FP) {
+        double x[16];
+        if constexpr (NSA > 0) {
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                const int L = tt + 256 * gi;
+                const int c = L % CT, rb = L / CT;
+                double y[RA];
+#pragma unroll
+                for (int k = 0; k < RA; k++) y[k] = fp_from_u64(src[(u64) (rb + 16 * k) * 256 + c]);
+                fp_ct_radix<NSA>(y, tw, 1u, fc);
+#pragma unroll
+                for (int k = 0; k < RA; k++) limb[single_pos<S1>(rb + 16 * k, g * CT + c)] = as_bits(y[k]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = as_f64(limb[single_pos<S1>(16 * r1 + k, g * CT + col)]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp_from_u64(src[(u64) k * 256 + col]);
+        }
+        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) limb[single_pos<S1>(16 * r1 + k, g * CT + col)] = as_bits(x[k]);
+    } else {
+        u64 x[16];
+        if constexpr (NSA > 0) {
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                const int L = tt + 256 * gi;
+                const int c = L % CT, rb = L / CT;
+                u64 y[RA];
+#pragma unroll
+                for (int k = 0; k < RA; k++) y[k] = src[(u64) (rb + 16 * k) * 256 + c];
+                ct_radix<NSA, LAZY>(y, tw, 1u, qc);
+#pragma unroll
+                for (int k = 0; k < RA; k++) limb[single_pos<S1>(rb + 16 * k, g * CT + c)] = y[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = limb[single_pos<S1>(16 * r1 + k, g * CT + col)];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = src[(u64) k * 256 + col];
+        }
+        ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) limb[single_pos<S1>(16 * r1 + k, g * CT + col)] = x[k];
+    }
+    __syncthreads();
+    // ---- row stages S1 .. S1+7 on row tile g (16 rows of 256), wave-local exchanges as in fwd_row_body
+    u64* lds = limb + g * 4096;
+    const int row = tt >> 4, i0 = tt & 15;
+    const u32 crow = g * 16 + row;
+    const ulonglong2* __restrict__ tb = a.twB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0);
+    u64 r[16];
+    if constexpr (FP) {
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = as_f64(lds[row_phys(row * 256 + i0 + 16 * k)]);
+        fp_ct_radix<4>(x, tw, (1u << S1) + crow, fc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+            x[2 * k] = as_f64(v.x);
+            x[2 * k + 1] = as_f64(v.y);
+        }
+        fp_ct_radix16_tb(x, tb, fc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[k] = fp_to_u64(x[k]);
+    } else {
+        u64 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = lds[row_phys(row * 256 + i0 + 16 * k)];
+        ct_radix<4, LAZY>(x, tw, (1u << S1) + crow, qc);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = x[k];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+            x[2 * k] = v.x;
+            x[2 * k + 1] = v.y;
+        }
+        ct_radix16_tb<LAZY>(x, tb, qc);
+        if (LAZY) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) r[k] = reduce64(x[k], md);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) r[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) = make_ulonglong2(r[2 * k], r[2 * k + 1]);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        row_store(a, ps, md, a.out + ps.out_off, (u64) g * 4096 + row * 256 + i0 + 16 * k,
+                  lds[row_phys(row * 256 + i0 + 16 * k)]);
+}
+
+// grid = batch polynomials, N / 16 threads, N * 8 bytes of dynamic LDS
+template <int S1>
+__global__ __launch_bounds__(16 << S1, 4) void ntt_fwd_single(NttArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 limb[];
+    const PolySel ps = select_poly(a, blockIdx.x);
+    const Mod md = a.mods[ps.mod];
+    if (md.fp) fwd_single_body<S1, true, false>(a, ps, md, limb);
+    else if (md.bit <= NTT_LAZY_BITS) fwd_single_body<S1, false, true>(a, ps, md, limb);
+    else fwd_single_body<S1, false, false>(a, ps, md, limb);
+}
+
 // ------------------------------------------------------------------ fused row pass + key-switch MAC
 __device__ __forceinline__ void acc128(u64& hi, u64& lo, u64 a, u64 b)
 {
@@ -1002,94 +1152,250 @@ hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
 }
 
 // ------------------------------------------------------------------ inverse
-// Row pass first (GS stages with t = 1..128), reads a.in, writes a.out.
-__global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
+// Gentleman-Sande stages from t = 1 upward: row stages first (t = 1..128 on contiguous rows), then the
+// column stages, n^-1 folded into the very last one.  Two arithmetic policies share the bodies:
+//   ArInt  lazy Shoup butterflies, values in [0, 4q) between stages (any modulus below 2^61);
+//   ArFp   exact FP64 (fpmod.cuh) for moduli below 2^50 (Mod::fp): x' = x + y, y' = fp_mul(x - y, w).  The
+//          sums double per stage, so every second stage ends with a centred reduction: from |x| <= q to
+//          <= 4q < 2^53 and back to q/2; a product of d = x - y (|d| <= 4q) stays exact because
+//          |h - kq| <= 1.5 q + ulp(h)/2 < 2^52 is an integer.  11 FP64 instructions per butterfly against ~25
+//          integer ones.  The inverse tables of such a modulus hold (double(w), RN(w/q)) pairs.
+__device__ __forceinline__ void fp_gs_bfly(double& x, double& y, ulonglong2 w, const FC& c)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
-    const int t = threadIdx.x;
-    const PolySel ps = select_poly(a, blockIdx.y);
-    const Mod md = a.mods[ps.mod];
-    const QC qc = make_qc(md.q);
-    const int s1 = a.n_power - 8;
-    const ulonglong2* __restrict__ tw = a.itw + ((u64) ps.mod << a.n_power);
-    const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
-    u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
+    const double s = x + y, d = x - y;
+    x = s;
+    y = fp_mul(d, as_f64(w.x), as_f64(w.y), c);
+}
 
-    const int row = t >> 4, i0 = t & 15;
-    const u32 crow = blockIdx.x * 16 + row;
+struct ArInt {
+    typedef u64 T;
+    QC qc;
+    __device__ __forceinline__ explicit ArInt(const Mod& md) : qc(make_qc(md.q)) {}
+    __device__ __forceinline__ T from_canon(u64 v) const { return v; }
+    __device__ __forceinline__ T from_bits(u64 v) const { return v; }
+    __device__ __forceinline__ u64 to_bits(T v) const { return v; }
+    template <int LOGR>
+    __device__ __forceinline__ void radix(T (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, u32 root0) const
+    {
+        gs_radix<LOGR>(x, tw, root0, qc);
+    }
+    __device__ __forceinline__ void radix16_tb(T (&x)[16], const ulonglong2* __restrict__ tb) const { gs_radix16_tb(x, tb, qc); }
+    template <int LOGR>
+    __device__ __forceinline__ void radix_last(T (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, ulonglong2 ninv,
+                                               ulonglong2 w1ninv, u64 (&out)[1 << LOGR]) const
+    {
+        gs_radix_last<LOGR>(x, tw, 1u, ninv, w1ninv, qc);
+#pragma unroll
+        for (int k = 0; k < (1 << LOGR); k++) out[k] = x[k];
+    }
+};
+
+struct ArFp {
+    typedef double T;
+    FC fc;
+    __device__ __forceinline__ explicit ArFp(const Mod& md) : fc(make_fc(md.q)) {}
+    __device__ __forceinline__ T from_canon(u64 v) const { return fp_from_u64(v); }
+    __device__ __forceinline__ T from_bits(u64 v) const { return as_f64(v); }
+    __device__ __forceinline__ u64 to_bits(T v) const { return as_bits(v); }
+    template <int N>
+    __device__ __forceinline__ void reduce_all(T (&x)[N]) const
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) x[k] = fp_reduce(x[k], fc);
+    }
+    // LOGR GS stages (local stage s = LOGR-1 .. 0, block b uses root (root0 << s) + b); inputs |x| <= q
+    template <int LOGR>
+    __device__ __forceinline__ void radix(T (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, u32 root0) const
+    {
+        int done = 0;
+#pragma unroll
+        for (int s = LOGR - 1; s >= 0; s--) {
+            const int half = (1 << LOGR) >> (s + 1);
+#pragma unroll
+            for (int b = 0; b < (1 << s); b++) {
+                const ulonglong2 w = tw[(root0 << s) + b];
+#pragma unroll
+                for (int j = 0; j < half; j++) fp_gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+            }
+            if ((++done & 1) == 0 || s == 0) reduce_all(x);
+        }
+    }
+    __device__ __forceinline__ void radix16_tb(T (&x)[16], const ulonglong2* __restrict__ tb) const
+    {
+#pragma unroll
+        for (int s = 3; s >= 0; s--) {
+            const int half = 8 >> s;
+#pragma unroll
+            for (int b = 0; b < (1 << s); b++) {
+                const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+#pragma unroll
+                for (int j = 0; j < half; j++) fp_gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+            }
+            if (s == 2 || s == 0) reduce_all(x);
+        }
+    }
+    // the last LOGR stages of the transform: n^-1 folded into the final one, canonical residues out
+    template <int LOGR>
+    __device__ __forceinline__ void radix_last(T (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, ulonglong2 ninv,
+                                               ulonglong2 w1ninv, u64 (&out)[1 << LOGR]) const
+    {
+        int done = 0;
+#pragma unroll
+        for (int s = LOGR - 1; s >= 1; s--) {
+            const int half = (1 << LOGR) >> (s + 1);
+#pragma unroll
+            for (int b = 0; b < (1 << s); b++) {
+                const ulonglong2 w = tw[(1u << s) + b];
+#pragma unroll
+                for (int j = 0; j < half; j++) fp_gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+            }
+            if ((++done & 1) == 0) reduce_all(x);
+        }
+        constexpr int half = (1 << LOGR) >> 1;
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+            const double sum = x[j] + x[j + half], d = x[j] - x[j + half];
+            out[j] = fp_to_u64(fp_canon(fp_mul(sum, as_f64(ninv.x), as_f64(ninv.y), fc), fc));
+            out[j + half] = fp_to_u64(fp_canon(fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), fc), fc));
+        }
+    }
+};
+
+// Row stages of one 16-row tile.  src: 16 x 256 coefficients in global memory (canonical residues); `lds`: the
+// tile's 4096-element exchange buffer.  TO_LDS: leave the result in `lds` (row_phys layout, the single pass)
+// instead of storing it to dst.  crow0 = global index of the tile's first row.
+template <typename AR, bool TO_LDS>
+__device__ __forceinline__ void inv_row_part(const AR& ar, const NttArgs& a, int mod, int tt, u32 crow0,
+                                             const u64* __restrict__ src, u64* __restrict__ dst, u64* lds)
+{
+    typedef typename AR::T T;
+    const int s1 = a.n_power - 8;
+    const ulonglong2* __restrict__ tw = a.itw + ((u64) mod << a.n_power);
+    const int row = tt >> 4, i0 = tt & 15;
+    const u32 crow = crow0 + row;
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = gld(&src[row * 256 + i0 + 16 * k]);
     wave_lds_fence();
-    u64 x[16];
-    {
+    T x[16];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
-            x[2 * k] = v.x;
-            x[2 * k + 1] = v.y;
-        }
+    for (int k = 0; k < 8; k++) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+        x[2 * k] = ar.from_canon(v.x);
+        x[2 * k + 1] = ar.from_canon(v.y);
     }
-    gs_radix16_tb(x, a.itwB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), qc);
-    wave_lds_fence();
-    {
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
-                make_ulonglong2(x[2 * k], x[2 * k + 1]);
-    }
+    ar.radix16_tb(x, a.itwB + ((u64) mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0));
     wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = lds[row_phys(row * 256 + i0 + 16 * k)];
-    gs_radix<4>(x, tw, (1u << s1) + crow, qc);
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
+            make_ulonglong2(ar.to_bits(x[2 * k]), ar.to_bits(x[2 * k + 1]));
+    wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 16; k++) gst(&dst[row * 256 + i0 + 16 * k], x[k]);
+    for (int k = 0; k < 16; k++) x[k] = ar.from_bits(lds[row_phys(row * 256 + i0 + 16 * k)]);
+    ar.template radix<4>(x, tw, (1u << s1) + crow);
+    if constexpr (TO_LDS) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = ar.to_bits(x[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) gst(&dst[row * 256 + i0 + 16 * k], ar.to_bits(x[k]));
+    }
 }
 
-// Column pass last: GS stages S1-1..0, N^-1 folded into the final stage.
-// In place on a.out.  grid = (256/CT, batch).
-template <int S1>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
+// Column stages of one column tile (R rows x CT columns), results to global memory.  FROM_LDS: the row
+// stages left their output in the LDS-resident limb (`buf` = the limb, positions single_pos); otherwise the
+// tile is read from `p` (global, in place) and `buf` is the tile's 4096-element exchange buffer.
+template <int S1, typename AR, bool FROM_LDS>
+__device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int mod, int tt, int g, u64* __restrict__ p,
+                                             u64* buf)
 {
+    typedef typename AR::T T;
     constexpr int R = 1 << S1;
     constexpr int CT = 4096 / R;
     constexpr int NSA = S1 - 4;
     constexpr int RA = 1 << NSA;
     constexpr int G = 16 / RA;
-    __shared__ u64 lds[(NSA > 0) ? COL_LDS_ELEMS : 1];
-
-    const int t = threadIdx.x;
-    const PolySel ps = select_poly(a, blockIdx.y);
-    const Mod md = a.mods[ps.mod];
-    const QC qc = make_qc(md.q);
-    const ulonglong2* __restrict__ tw = a.itw + ((u64) ps.mod << a.n_power);
-    const ulonglong2 ninv = a.ninv[ps.mod], w1ninv = a.w1ninv[ps.mod];
-    u64* __restrict__ p = a.out + ps.out_off + blockIdx.x * CT;
-
-    const int col = t % CT, r1 = t / CT;
-    u64 x[16];
+    const ulonglong2* __restrict__ tw = a.itw + ((u64) mod << a.n_power);
+    const ulonglong2 ninv = a.ninv[mod], w1ninv = a.w1ninv[mod];
+    const int col = tt % CT, r1 = tt / CT;
+    auto pos = [&](int row, int c) -> int {
+        if constexpr (FROM_LDS) return single_pos<S1>(row, g * CT + c);
+        else return col_phys(row * CT + c);
+    };
+    T x[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = gld(&p[(u64) (16 * r1 + k) * 256 + col]);
+    for (int k = 0; k < 16; k++)
+        x[k] = ar.from_bits(FROM_LDS ? buf[pos(16 * r1 + k, col)] : gld(&p[(u64) (16 * r1 + k) * 256 + col]));
     if constexpr (NSA > 0) {
-        gs_radix<4>(x, tw, (u32) (RA + r1), qc);
+        ar.template radix<4>(x, tw, (u32) (RA + r1));
 #pragma unroll
-        for (int k = 0; k < 16; k++) lds[col_phys((16 * r1 + k) * CT + col)] = x[k];
+        for (int k = 0; k < 16; k++) buf[pos(16 * r1 + k, col)] = ar.to_bits(x[k]);
         __syncthreads();
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int L = t + NTT_THREADS * g;
+        for (int gi = 0; gi < G; gi++) {
+            const int L = tt + NTT_THREADS * gi;
             const int c = L % CT, rb = L / CT;
-            u64 y[RA];
+            T y[RA];
+            u64 o[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = lds[col_phys((rb + 16 * k) * CT + c)];
-            gs_radix_last<NSA>(y, tw, 1u, ninv, w1ninv, qc);
+            for (int k = 0; k < RA; k++) y[k] = ar.from_bits(buf[pos(rb + 16 * k, c)]);
+            ar.template radix_last<NSA>(y, tw, ninv, w1ninv, o);
 #pragma unroll
-            for (int k = 0; k < RA; k++) gst(&p[(u64) (rb + 16 * k) * 256 + c], y[k]);
+            for (int k = 0; k < RA; k++) gst(&p[(u64) (rb + 16 * k) * 256 + c], o[k]);
         }
     } else {
-        gs_radix_last<4>(x, tw, 1u, ninv, w1ninv, qc);
+        u64 o[16];
+        ar.template radix_last<4>(x, tw, ninv, w1ninv, o);
 #pragma unroll
-        for (int k = 0; k < 16; k++) gst(&p[(u64) k * 256 + col], x[k]);
+        for (int k = 0; k < 16; k++) gst(&p[(u64) k * 256 + col], o[k]);
     }
+}
+
+// Row pass: reads a.in, writes a.out (FP64 moduli: centred residues as raw doubles, consumed by ntt_inv_col).
+__global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    const PolySel ps = select_poly(a, blockIdx.y);
+    const Mod md = a.mods[ps.mod];
+    const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
+    u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
+    if (md.fp) inv_row_part<ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
+    else inv_row_part<ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
+}
+
+// Column pass last, in place on a.out.  grid = (256 / CT, batch).
+template <int S1>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
+{
+    constexpr int CT = 4096 >> S1;
+    __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
+    const PolySel ps = select_poly(a, blockIdx.y);
+    const Mod md = a.mods[ps.mod];
+    u64* __restrict__ p = a.out + ps.out_off + blockIdx.x * CT;
+    if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds);
+    else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds);
+}
+
+// Single pass for N <= 2^14 (see ntt_fwd_single): thread group g runs the row stages of row tile g into the
+// LDS-resident limb, then the column stages of column tile g out of it.  grid = batch, N / 16 threads.
+template <int S1, typename AR>
+__device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, const PolySel& ps, u64* limb)
+{
+    constexpr int CT = 4096 >> S1;
+    const int t = threadIdx.x, g = t >> 8, tt = t & 255;
+    inv_row_part<AR, true>(ar, a, ps.mod, tt, g * 16, a.in + ps.in_off + (u64) g * 4096, nullptr, limb + g * 4096);
+    __syncthreads();
+    inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb);
+}
+
+template <int S1>
+__global__ __launch_bounds__(16 << S1, 4) void ntt_inv_single(NttArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 limb[];
+    const PolySel ps = select_poly(a, blockIdx.x);
+    const Mod md = a.mods[ps.mod];
+    if (md.fp) inv_single_body<S1>(ArFp(md), a, ps, limb);
+    else inv_single_body<S1>(ArInt(md), a, ps, limb);
 }
 
 // ------------------------------------------------------------------ launch
@@ -1137,6 +1443,15 @@ template <int S1>
 static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
+    if constexpr (S1 <= 6) {
+        if (!a.decomp_mods && a.single_pass) { // LDS-resident single pass (N <= 2^14)
+            static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_fwd_single<S1>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
+            (void) attr;
+            hipLaunchKernelGGL((ntt_fwd_single<S1>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            return;
+        }
+    }
     if (use_col_multi<S1>(a, batch)) {
         launch_col_multi<S1>(a, batch, st);
     } else if (a.decomp_mods) {
@@ -1157,6 +1472,15 @@ template <int S1>
 static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
+    if constexpr (S1 <= 6) {
+        if (a.single_pass && !a.poly_order) { // LDS-resident single pass (N <= 2^14)
+            static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_inv_single<S1>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
+            (void) attr;
+            hipLaunchKernelGGL((ntt_inv_single<S1>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL(ntt_inv_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, a);
     NttArgs b = a;
     b.in = a.out;

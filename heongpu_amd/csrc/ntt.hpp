@@ -86,6 +86,7 @@ struct NttArgs {
     // decomposing launches: 0 = one workgroup per (source tile, target modulus), 1 = one workgroup per
     // source tile walking all target moduli (ntt_fwd_col_multi), anything else = by launch size
     int col_multi;
+    int single_pass; // N <= 2^14: one LDS-resident pass per transform (HEGPU_SINGLE_PASS=0: the two passes)
     int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
     int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
 };

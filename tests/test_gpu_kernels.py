@@ -107,6 +107,7 @@ def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi):
 
 # ------------------------------------------------------------------ fusions switched off
 _SWITCHES = [
+    dict(HEGPU_SINGLE_PASS=0),
     dict(HEGPU_COL_MULTI=1),
     dict(HEGPU_COL_MULTI=1, HEGPU_FP_NTT=0),
     dict(HEGPU_FUSED_ROW_MAC=0),
@@ -157,7 +158,8 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
         assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
 
 
-@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=0), dict(HEGPU_FP_NTT=0), dict(HEGPU_COL_MULTI=1)],
+@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=0), dict(HEGPU_FP_NTT=0), dict(HEGPU_COL_MULTI=1),
+                                dict(HEGPU_SINGLE_PASS=0)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_bfv_sequence_with_fusions_off(hg, oracle, torch, sw):
     """Config C1 shapes (BFV N=2^12 default chain): relinearize + rotate through the unfused key switch."""
@@ -590,3 +592,35 @@ def test_hoisted_rotations(hg, oracle, torch, depth, method):
         c.ckks_apply_galois(d, words, one, words, dkeys[i], elts[i], depth, batch, ws)
         torch.cuda.synchronize()
         assert np.array_equal(hg.to_host(one).reshape(batch, words), got[:, i]), ("vs apply_galois", i)
+
+
+@pytest.mark.parametrize("single", [1, 0], ids=["single_pass", "two_pass"])
+@pytest.mark.parametrize("n_power", [12, 13, 14])
+def test_ntt_small_degrees_both_forms(hg, oracle, torch, n_power, single):
+    """N <= 2^14: the LDS-resident single pass (ntt_fwd_single) and the two passes give the oracle's transform,
+    FP64 moduli (30 / 45 / 50 bits), lazy integer (55) and full-range integer (60 / 61-bit Bsk) ones, batches
+    that wrap around the modulus list, plain and modulus-ordered."""
+    n = 1 << n_power
+    with backend_switches(HEGPU_SINGLE_PASS=single):
+        c, o, primes = _ckks(hg, oracle, n, [60, 30, 45, 50, 55], [60], sec=hg.SEC_NONE)
+    Qp = 6
+    batch = 3 * Qp + 2
+    x = np.concatenate([oracle.fill_poly(7 + i, i % Qp, n, primes[i % Qp]) for i in range(batch)])
+    x[:4] = [0, primes[0] - 1, 1, primes[0] // 2]
+    want = o.ntt(x.copy(), batch, Qp)
+    d = hg.to_device(x)
+    out = torch.empty_like(d)
+    c.ntt(d, out, False, batch, Qp)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), want)
+    c.ntt(out, out, True, batch, Qp)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), x)
+    # extremes on an FP64 modulus: all q-1 and alternating 0 / q-1
+    q = primes[3]
+    y = np.concatenate([np.full(n, q - 1, dtype=np.uint64), np.tile(np.array([0, q - 1], dtype=np.uint64), n // 2)])
+    wy = o.ntt(y.copy(), 2, 1, mod_offset=3)
+    dy = hg.to_device(y)
+    c.ntt(dy, dy, False, 2, 1, mod_offset=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(dy), wy)
