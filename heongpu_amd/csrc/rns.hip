@@ -560,6 +560,11 @@ hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride,
 // takes 64 products of two 61-bit values (each < 2^122) without overflow.
 #define BEHZ_MAX 64
 
+// Branch-free bodies: entries beyond the real base size are computed on a clamped (valid) index and
+// zeroed with a wave-uniform select, the inner products run over all MAXB slots (a zero operand adds
+// nothing).  Guarding every slot with `if (i < ib)` instead made the compiler carry the whole register
+// array through a chain of conditional blocks -- 236 registers and one wave per SIMD at MAXB = 16 -- so
+// MAXB is kept close to the real size (behz_slots) and the few wasted products are accepted.
 template <int MAXB>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __restrict__ in1, u64 s1,
                                                                  const u64* __restrict__ in2, u64 s2,
@@ -575,30 +580,28 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * (ob + ib)) << n_power);
 #pragma unroll
     for (int i = 0; i < MAXB; i++) {
-        temp[i] = 0;
-        if (i < ib) {
-            const Mod mi = b.ibase[i];
-            u64 v = input[location + ((u64) i << n_power)];
-            po[(u64) i << n_power] = v;
-            temp[i] = mul_barrett(v, b.mtilde_inv_punct[i], mi); // x * m_tilde * (q/q_i)^-1, one product
-        }
+        const int ii = i < ib ? i : ib - 1;
+        const Mod mi = b.ibase[ii];
+        const u64 v = input[location + ((u64) ii << n_power)];
+        po[(u64) ii << n_power] = v; // slots beyond ib rewrite limb ib-1 with its own value
+        const u64 t = mul_barrett(v, b.mtilde_inv_punct[ii], mi); // x * m_tilde * (q/q_i)^-1, one product
+        temp[i] = i < ib ? t : 0;
     }
     // m_tilde channel: m_tilde = 2^32, so reduction, product and sum modulo it are plain 32-bit
     // arithmetic (the same canonical values as the Barrett routines of the reference, multiplication.cu:44-60)
     u32 acc_mt32 = 0;
 #pragma unroll
-    for (int j = 0; j < MAXB; j++)
-        if (j < ib) acc_mt32 += (u32) temp[j] * (u32) b.base_change_matrix_m_tilde[j];
+    for (int j = 0; j < MAXB; j++) acc_mt32 += (u32) temp[j] * (u32) b.base_change_matrix_m_tilde[j < ib ? j : 0];
     const u64 mt = b.m_tilde.q;
     u64 r_mt = (u64) (u32) (acc_mt32 * (u32) b.inv_prod_q_mod_m_tilde);
     r_mt = mt - r_mt;
+#pragma unroll 1
     for (int i = 0; i < ob; i++) {
         const Mod mo = b.obase[i];
         const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
         u64 hi = 0, lo = 0;
 #pragma unroll
-        for (int j = 0; j < MAXB; j++)
-            if (j < ib) acc_mad(hi, lo, temp[j], row[j]);
+        for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, temp[j], row[j < ib ? j : 0]);
         u64 t2 = reduce128(hi, lo, mo);
         u64 t3 = r_mt;
         if (t3 >= (mt >> 1)) {
@@ -611,19 +614,30 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     }
 }
 
+// padded size for a base of m moduli: steps of 2 up to 16, of 4 up to 32, of 8 up to 64
+static int behz_slots(int m)
+{
+    if (m <= 16) return (m + 1) & ~1;
+    if (m <= 32) return (m + 3) & ~3;
+    return (m + 7) & ~7;
+}
+#define BEHZ_DISPATCH(m)                                                                     \
+    switch (behz_slots(m)) {                                                                 \
+        case 2: LAUNCH(2); break;   case 4: LAUNCH(4); break;   case 6: LAUNCH(6); break;    \
+        case 8: LAUNCH(8); break;   case 10: LAUNCH(10); break; case 12: LAUNCH(12); break;  \
+        case 14: LAUNCH(14); break; case 16: LAUNCH(16); break; case 20: LAUNCH(20); break;  \
+        case 24: LAUNCH(24); break; case 28: LAUNCH(28); break; case 32: LAUNCH(32); break;  \
+        case 40: LAUNCH(40); break; case 48: LAUNCH(48); break; case 56: LAUNCH(56); break;  \
+        default: LAUNCH(64); break;                                                          \
+    }
+
 hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
                                const BehzDev& b, int n_power, int batch, hipStream_t st)
 {
-    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
+    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 4, batch);
-    const int m = b.ibase_size;
 #define LAUNCH(M) hipLaunchKernelGGL(k_fast_convertion<M>, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
-    if (m <= 4) LAUNCH(4);
-    else if (m <= 8) LAUNCH(8);
-    else if (m <= 16) LAUNCH(16);
-    else if (m <= 24) LAUNCH(24);
-    else if (m <= 40) LAUNCH(40);
-    else LAUNCH(BEHZ_MAX);
+    BEHZ_DISPATCH(b.ibase_size)
 #undef LAUNCH
     return hipGetLastError();
 }
@@ -641,49 +655,73 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     u64 reg_q[MAXB], temp3[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; i++) {
-        reg_q[i] = 0;
-        if (i < ib) {
-            const Mod mi = b.ibase[i];
-            reg_q[i] = mul_barrett(pq[(u64) i << n_power], b.t_inv_punct[i], mi); // x * t * (q/q_i)^-1
-        }
+        const int ii = i < ib ? i : ib - 1;
+        const u64 v = mul_barrett(pq[(u64) ii << n_power], b.t_inv_punct[ii], b.ibase[ii]); // x * t * (q/q_i)^-1
+        reg_q[i] = i < ib ? v : 0;
     }
+    // rows 0 .. ob-2: the moduli of B (-> temp3), row ob-1: m_sk.  (The two forms are written out: sharing
+    // the row computation through a lambda cost 30 registers.)
     u64 reg_Bsk_last = 0;
+    if constexpr (MAXB <= 16) {
+        // MAXB + 1 unrolled iterations on a clamped row index cover ob <= MAXB + 1 (the surplus ones
+        // recompute the m_sk row): static register indices, no selects
 #pragma unroll
-    for (int i = 0; i < MAXB; i++) {
-        temp3[i] = 0;
-        if (i < ob) {
-            const Mod mo = b.obase[i];
-            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
-            u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
+        for (int i = 0; i <= MAXB; i++) {
+            const int ii = i < ob - 1 ? i : ob - 1;
+            const bool last = i >= ob - 1;
+            const Mod mo = b.obase[ii];
+            const u64* __restrict__ row = b.base_change_matrix_Bsk + ii * ib;
+            const u64 rb = mul_barrett(pB[(u64) ii << n_power], t, mo);
             u64 hi = 0, lo = 0;
 #pragma unroll
-            for (int j = 0; j < MAXB; j++)
-                if (j < ib) acc_mad(hi, lo, reg_q[j], row[j]);
-            u64 tmp = reduce128(hi, lo, mo);
+            for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, reg_q[j], row[j < ib ? j : 0]);
+            const u64 tmp = reduce128(hi, lo, mo);
             u64 t2 = sub_mod(mo.q, tmp, mo.q);
             t2 = add_mod(t2, rb, mo.q);
-            if (i < ob - 1) temp3[i] = mul_barrett(t2, b.invq_inv_punct_B[i], mo); // * q^-1 * (B/b_i)^-1
-            else reg_Bsk_last = mul_barrett(t2, b.inv_prod_q_mod_Bsk[i], mo);
+            const u64 v = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[ii] : b.invq_inv_punct_B[ii], mo); // * q^-1 [* (B/b_i)^-1]
+            if (i < MAXB) temp3[i] = last ? 0 : v;
+            reg_Bsk_last = last ? v : reg_Bsk_last;
+        }
+    } else {
+        // large bases: a run-time loop keeps code size and register pressure down; the row's slot of
+        // temp3 is picked with wave-uniform selects
+#pragma unroll
+        for (int i = 0; i < MAXB; i++) temp3[i] = 0;
+#pragma unroll 1
+        for (int i = 0; i < ob; i++) {
+            const Mod mo = b.obase[i];
+            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
+            const u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
+            u64 hi = 0, lo = 0;
+#pragma unroll
+            for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, reg_q[j], row[j < ib ? j : 0]);
+            const u64 tmp = reduce128(hi, lo, mo);
+            u64 t2 = sub_mod(mo.q, tmp, mo.q);
+            t2 = add_mod(t2, rb, mo.q);
+            const bool last = i == ob - 1;
+            const u64 v = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[i] : b.invq_inv_punct_B[i], mo);
+            if (last) reg_Bsk_last = v;
+#pragma unroll
+            for (int k = 0; k < MAXB; k++) temp3[k] = (!last && k == i) ? v : temp3[k];
         }
     }
     const Mod msk = b.obase[ob - 1];
     u64 hi = 0, lo = 0;
 #pragma unroll
-    for (int j = 0; j < MAXB; j++)
-        if (j < ob - 1) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j]);
+    for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j < ob - 1 ? j : 0]);
     u64 t4sk = reduce128(hi, lo, msk);
     u64 alpha_sk = sub_mod(msk.q, reg_Bsk_last, msk.q);
     alpha_sk = add_mod(alpha_sk, t4sk, msk.q);
     alpha_sk = mul_barrett(alpha_sk, b.inv_prod_B_mod_m_sk, msk);
     const bool neg = alpha_sk > (msk.q >> 1);
     u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * ib) << n_power);
+#pragma unroll 1
     for (int i = 0; i < ib; i++) {
         const Mod mi = b.ibase[i];
         const u64* __restrict__ row = b.base_change_matrix_q + i * (ob - 1);
         u64 h2 = 0, l2 = 0;
 #pragma unroll
-        for (int j = 0; j < MAXB; j++)
-            if (j < ob - 1) acc_mad(h2, l2, temp3[j], row[j]); // un-reduced: 64 terms below 2^122 fit 128 bits
+        for (int j = 0; j < MAXB; j++) acc_mad(h2, l2, temp3[j], row[j < ob - 1 ? j : 0]); // un-reduced: 64 terms below 2^122 fit 128 bits
         u64 t4 = reduce128(h2, l2, mi);
         u64 obase_ = b.msk_mod_q[i];
         u64 alpha_ = reduce64(alpha_sk, mi);
@@ -702,16 +740,12 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
 hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev& b, int n_power, int batch,
                           hipStream_t st)
 {
-    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX) return hipErrorInvalidValue;
+    if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1 || b.obase_size < 2)
+        return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
-    const int m = b.ibase_size > b.obase_size ? b.ibase_size : b.obase_size;
+    const int m = b.ibase_size > b.obase_size - 1 ? b.ibase_size : b.obase_size - 1;
 #define LAUNCH(M) hipLaunchKernelGGL(k_fast_floor<M>, g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
-    if (m <= 4) LAUNCH(4);
-    else if (m <= 8) LAUNCH(8);
-    else if (m <= 16) LAUNCH(16);
-    else if (m <= 24) LAUNCH(24);
-    else if (m <= 40) LAUNCH(40);
-    else LAUNCH(BEHZ_MAX);
+    BEHZ_DISPATCH(m)
 #undef LAUNCH
     return hipGetLastError();
 }
