@@ -512,7 +512,7 @@ def test_reference_own_test_passes(torch, name):
     if not os.path.exists(exe):
         pytest.skip("reference test binary not built (no /root/reference at build time)")
     # Every program must pass on its FIRST run.  The one exception is a flaw of the reference's own
-    # test: test_bfv_addition.cpp:56,155,256,356,458 expect `(m1 + m2 > t) ? m1 + m2 - t : m1 + m2`, i.e.
+    # test: test_bfv_addition.cpp:55,154,254,354,456 expect `(m1 + m2 > t) ? m1 + m2 - t : m1 + m2`, i.e.
     # the value t instead of 0 in a slot where m1 + m2 == t -- about n/t per parameter set, 16 % per run
     # over its five sets (fresh std::random_device messages on every run; measured here: 14 of 60 runs,
     # always in that comparison).  Only that program is repeated, and only when every failing assertion of
