@@ -84,6 +84,8 @@ SIGNATURES = [
     ("hegpu_bfv_plain_to_ntt", c_int, [voidp, u64p, u64p, voidp]),
     ("hegpu_negacyclic_shift", c_int, [voidp, u64p, u64p, c_int, c_int, c_int, voidp]),
     ("hegpu_ckks_constant_op", c_int, [voidp, c_int, u64p, ctypes.c_double, u64p, c_int, c_int, voidp]),
+    ("hegpu_ckks_gaussian_integer_op", c_int,
+     [voidp, c_int, u64p, ctypes.c_double, ctypes.c_double, u64p, c_int, c_int, voidp]),
     ("hegpu_ckks_mult_i", c_int, [voidp, u64p, u64p, c_int, c_int, c_int, voidp]),
     ("hegpu_cipherplain_multiplication", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),
     ("hegpu_bfv_plain_addsub", c_int, [voidp, u64p, u64p, u64p, c_int, voidp]),

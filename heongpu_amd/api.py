@@ -400,6 +400,15 @@ class Context:
                                                 stream if stream is not None else _stream()))
         return out
 
+    def ckks_gaussian_integer_op(self, op, ct, re, im, limbs, parts=2, out=None, stream=None):
+        """op 0 / 1 = add / multiply by the constant round(re) + round(im) i in every slot"""
+        import torch
+        if out is None:
+            out = torch.empty(parts * limbs * self.n, dtype=torch.int64, device="cuda")
+        _check(self._lib.hegpu_ckks_gaussian_integer_op(self._h, op, _ptr(ct), float(re), float(im), _ptr(out), limbs,
+                                                        parts, stream if stream is not None else _stream()))
+        return out
+
     def ckks_mult_i(self, ct, limbs, parts=2, divide=False, out=None, stream=None):
         import torch
         if out is None:

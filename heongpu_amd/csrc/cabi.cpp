@@ -853,6 +853,22 @@ int hegpu_ckks_constant_op(hegpu_context* ctx, int op, const uint64_t* ct, doubl
                    "hegpu_ckks_constant_op");
 }
 
+int hegpu_ckks_gaussian_integer_op(hegpu_context* ctx, int op, const uint64_t* ct, double re, double im, uint64_t* out,
+                                   int limbs, int parts, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
+    if (op < 0 || op > 1) return fail(HEGPU_E_INVALID, "unknown constant operation");
+    if (limbs <= 0 || limbs > ctx->c.Q_size || parts < 2 || parts > 3) return fail(HEGPU_E_INVALID, "bad ciphertext shape");
+    for (double v : {re, im})
+        if (!(v == v) || v >= 3.4e38 || v <= -3.4e38) return fail(HEGPU_E_INVALID, "constant out of range");
+    return guarded([&]() -> int {
+        return hip_ret(kg_ckks_gaussian((const u64*) ct, re, im, (u64*) out, ctx->c.d64("psi_half"), ctx->c.plan_qp.mods,
+                                        ctx->c.n_power, limbs, parts, op, (hipStream_t) stream),
+                       "hegpu_ckks_gaussian_integer_op");
+    });
+}
+
 int hegpu_ckks_mult_i(hegpu_context* ctx, const uint64_t* ct, uint64_t* out, int limbs, int parts, int divide,
                       hegpu_stream stream)
 {

@@ -431,6 +431,45 @@ hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mo
     return hipGetLastError();
 }
 
+// cipher_add_by_gaussian_integer_kernel / cipher_mult_by_gaussian_integer_kernel (multiplication.cu:497-570):
+// the constant round(re) + round(im) * i in every slot.  In the NTT domain i is +psi^(N/2) on the first half
+// of the positions and -psi^(N/2) on the second, so the slot constant is re +- im * psi^(N/2) mod q_j; op 0
+// adds it to part 0 (the other parts are copied), op 1 multiplies every part by it.  The reference turns the
+// rounded doubles into residues with NTL big integers (ckks/operator.cu:583-617); a double is m * 2^e, so the
+// residue comes from its two 64-bit halves exactly (|value| < 2^128).
+__device__ __forceinline__ u64 residue_of_rounded(double value, const Mod& m)
+{
+    double c = round(value);
+    const bool neg = signbit(c);
+    c = fabs(c);
+    const double two64 = 18446744073709551616.0;
+    const u64 lo = (u64) fmod(c, two64), hi = (u64) (c / two64);
+    const u64 r = reduce128(hi, lo, m);
+    return (neg && r) ? m.q - r : r; // NTL: (x % q) made non-negative
+}
+__global__ __launch_bounds__(KG_THREADS) void k_kg_ckks_gaussian(const u64* __restrict__ ct, double re, double im,
+                                                                 u64* __restrict__ out, const u64* __restrict__ psi_half,
+                                                                 const Mod* __restrict__ mods, int n_power, int op)
+{
+    const u32 idx = blockIdx.x * KG_THREADS + threadIdx.x;
+    const u64 loc = idx + ((u64) blockIdx.y << n_power) + (((u64) gridDim.y * blockIdx.z) << n_power);
+    const u64 x = ct[loc];
+    if (op == 0 && blockIdx.z != 0) { out[loc] = x; return; }
+    const Mod m = mods[blockIdx.y];
+    const u64 c_real = residue_of_rounded(re, m), c_imag = residue_of_rounded(im, m);
+    const u64 const_imag = mul_barrett(c_imag, psi_half[blockIdx.y], m);
+    const u64 k = (idx < (1u << (n_power - 1))) ? add_mod(c_real, const_imag, m.q) : sub_mod(c_real, const_imag, m.q);
+    out[loc] = op == 0 ? add_mod(x, k, m.q) : mul_barrett(x, k, m);
+}
+
+hipError_t kg_ckks_gaussian(const u64* ct, double re, double im, u64* out, const u64* psi_half, const Mod* mods,
+                            int n_power, int limbs, int parts, int op, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kg_ckks_gaussian, dim3((1u << n_power) / KG_THREADS, limbs, parts), dim3(KG_THREADS), 0, st, ct,
+                       re, im, out, psi_half, mods, n_power, op);
+    return hipGetLastError();
+}
+
 // cipher_mult_by_i_kernel / cipher_div_by_i_kernel (multiplication.cu:441-495): in the NTT domain the
 // monomial X^(N/2) (= i in every slot) is +psi^(N/2) on the first half of the positions and -psi^(N/2) on
 // the second; psi_half[j] = forward table entry 1 of modulus j

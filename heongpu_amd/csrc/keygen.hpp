@@ -87,6 +87,9 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
 // CKKS ciphertext with one constant: op 0 add, 1 subtract (part 0 only), 2 multiply (all parts)
 hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mods, int n_power, int limbs, int parts,
                             int op, hipStream_t st);
+// cipher_add_by_gaussian_integer_kernel / cipher_mult_by_gaussian_integer_kernel (multiplication.cu:497-570)
+hipError_t kg_ckks_gaussian(const u64* ct, double re, double im, u64* out, const u64* psi_half, const Mod* mods,
+                            int n_power, int limbs, int parts, int op, hipStream_t st);
 hipError_t kg_ckks_mult_i(const u64* ct, u64* out, const u64* psi_half, const Mod* mods, int n_power, int limbs,
                           int parts, int divide, hipStream_t st);
 

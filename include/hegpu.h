@@ -340,6 +340,12 @@ int hegpu_cipherplain_multiplication(hegpu_context* ctx, const uint64_t* ct, con
 enum { HEGPU_CONST_ADD = 0, HEGPU_CONST_SUB = 1, HEGPU_CONST_MUL = 2 };
 int hegpu_ckks_constant_op(hegpu_context* ctx, int op, const uint64_t* ct, double value, uint64_t* out, int limbs,
                            int parts, hegpu_stream stream);
+/* add_constant_plain_ckks_v2 / multiply_const_plain_ckks_v2 (ckks/operator.cu:567-724, kernels
+ * multiplication.cu:497-570): the Gaussian integer round(re) + round(im) i in every slot of an NTT-domain
+ * ciphertext; op 0: added to part 0, op 1: every part multiplied by it.  re / im are the already scaled
+ * values (the caller applies input.scale resp. the modulus factor exactly as the reference's host code does). */
+int hegpu_ckks_gaussian_integer_op(hegpu_context* ctx, int op, const uint64_t* ct, double re, double im, uint64_t* out,
+                                   int limbs, int parts, hegpu_stream stream);
 /* HEArithmeticOperator::mult_i / div_i (cipher_mult_by_i_kernel / cipher_div_by_i_kernel,
  * multiplication.cu:441-495): every slot times +-i, no level consumed */
 int hegpu_ckks_mult_i(hegpu_context* ctx, const uint64_t* ct, uint64_t* out, int limbs, int parts, int divide,

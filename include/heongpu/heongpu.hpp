@@ -874,6 +874,7 @@ template <Scheme S> class Ciphertext { // host/{ckks,bfv}/ciphertext.cuh
     inline int coeff_modulus_count() const noexcept { return coeff_modulus_count_; }
     inline int size() const noexcept { return cipher_size_; }
     inline int depth() const noexcept { return depth_; }
+    inline int level() const noexcept { return coeff_modulus_count_ - (depth_ + 1); } // ckks/ciphertext.cuh:162
     inline double scale() const noexcept { return scale_; }
     inline bool in_ntt_domain() const noexcept { return in_ntt_domain_; }
     inline bool rescale_required() const noexcept { return rescale_required_; }
@@ -2392,6 +2393,31 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         multiply_plain(a, c, a, scale, o);
     }
+    // host/ckks/operator.cuh:586-926: a complex constant in every slot (add_constant_plain_ckks_v2 /
+    // multiply_const_plain_ckks_v2, ckks/operator.cu:567-724) and scale_up (:726-740)
+    void add_plain_v2(Ciphertext<S>& a, Complex64 c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        detail::OpScope storage_scope(o);
+        gaussian(a, out, 0, c.real() * a.scale_, c.imag() * a.scale_, o);
+    }
+    void multiply_plain_v2(Ciphertext<S>& a, Complex64 c, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        detail::OpScope storage_scope(o);
+        // a constant with a fractional part is scaled by the current last modulus (ckks/operator.cu:648-677)
+        auto fractional = [](double v) { return v != 0 && (v - (double) (std::int64_t) v) != 0; };
+        double factor = 1.0;
+        if (fractional(c.real()) || fractional(c.imag())) factor = (double) context_->prime_vector_[limbs(a) - 1].value;
+        const double sc = a.scale_ * factor;
+        gaussian(a, out, 1, c.real() * factor, c.imag() * factor, o);
+        out.scale_ = sc;
+    }
+    void scale_up(Ciphertext<S>& a, double scale, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions())
+    {
+        detail::OpScope storage_scope(o);
+        const double sc = a.scale_ * scale; // the original scale, not its integer part (:737-739)
+        gaussian(a, out, 1, (double) (std::uint64_t) scale, 0.0, o);
+        out.scale_ = sc;
+    }
     void mult_i(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions()) { times_i(a, out, 0, o); }
     void div_i(Ciphertext<S>& a, Ciphertext<S>& out, const ExecutionOptions& o = ExecutionOptions()) { times_i(a, out, 1, o); }
     // complex conjugate of every slot: the Galois element 2N - 1 (conjugate_ckks_method_I/II)
@@ -2466,6 +2492,17 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
         DeviceVector<Data64> m((size_t) parts * l * context_->n, o.stream_);
         detail::check(hegpu_ckks_constant_op(context_->handle(), op, (const uint64_t*) a.data(), value,
                                              (uint64_t*) m.data(), l, parts, o.stream_));
+        if (&a != &out) copy_meta(a, out);
+        out.memory_set(std::move(m));
+    }
+    void gaussian(Ciphertext<S>& a, Ciphertext<S>& out, int op, double re, double im, const ExecutionOptions& o)
+    {
+        static_assert(S == Scheme::CKKS, "complex constants are a CKKS operation");
+        const int l = limbs(a), parts = a.relinearization_required_ ? 3 : 2;
+        if (a.memory_size() < (size_t) parts * l * context_->n) throw std::invalid_argument("Invalid Ciphertexts size!");
+        DeviceVector<Data64> m((size_t) parts * l * context_->n, o.stream_);
+        detail::check(hegpu_ckks_gaussian_integer_op(context_->handle(), op, (const uint64_t*) a.data(), re, im,
+                                                     (uint64_t*) m.data(), l, parts, o.stream_));
         if (&a != &out) copy_meta(a, out);
         out.memory_set(std::move(m));
     }

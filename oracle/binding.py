@@ -103,6 +103,7 @@ def lib():
     L.o_negacyclic_shift.argtypes = [vp, vp, vp, ci, ci, ci]
     L.o_ckks_constant_op.argtypes = [vp, ci, vp, ctypes.c_double, vp, ci, ci]
     L.o_ckks_mult_i.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.o_ckks_gaussian_integer_op.argtypes = [vp, ci, vp, ctypes.c_double, ctypes.c_double, vp, ci, ci]
     L.o_ckks_decode_ex.argtypes = [vp, ci, vp, ci, ctypes.c_double, vp]
     L.o_bfv_decode.argtypes = [vp, vp, vp]
     L.o_fast_convertion.argtypes = [vp, vp, vp, vp]
@@ -345,6 +346,12 @@ class OracleContext:
         out = np.zeros(parts * limbs * self.n, dtype=np.uint64)
         self.L.o_ckks_constant_op(self.h, op, _p(np.ascontiguousarray(ct, dtype=np.uint64)), float(value), _p(out),
                                   limbs, parts)
+        return out
+
+    def ckks_gaussian_integer_op(self, op, ct, re, im, limbs, parts=2):
+        out = np.zeros(parts * limbs * self.n, dtype=np.uint64)
+        self.L.o_ckks_gaussian_integer_op(self.h, op, _p(np.ascontiguousarray(ct, dtype=np.uint64)), float(re), float(im),
+                                          _p(out), limbs, parts)
         return out
 
     def ckks_mult_i(self, ct, limbs, parts=2, divide=False):

@@ -278,6 +278,39 @@ void o_ckks_constant_op(const octx_t* c, int op, const u64* ct, double value, u6
         }
 }
 
+/* add_constant_plain_ckks_v2 / multiply_const_plain_ckks_v2 (ckks/operator.cu:567-724) with
+ * cipher_add_by_gaussian_integer_kernel / cipher_mult_by_gaussian_integer_kernel (multiplication.cu:497-570).
+ * re / im: the already scaled doubles; the reference rounds them, converts to NTL::ZZ and takes the
+ * non-negative residue modulo every q_j (operator.cu:586-617) -- restated with 128-bit integers. */
+static u64 zz_residue(double value, u64 q)
+{
+    double v = round(value);
+    const int neg = signbit(v) != 0;
+    v = fabs(v);
+    const double two64 = 18446744073709551616.0;
+    const u128 wide = ((u128) (u64) (v / two64) << 64) | (u64) fmod(v, two64);
+    u64 r = (u64) (wide % q);
+    if (neg && r) r = q - r; /* real_mod < 0 -> += q */
+    return r;
+}
+void o_ckks_gaussian_integer_op(const octx_t* c, int op, const u64* ct, double re, double im, u64* out, int limbs,
+                                int parts)
+{
+    for (int z = 0; z < parts; z++)
+        for (int y = 0; y < limbs; y++) {
+            const omod_t* m = &c->mod[y];
+            const u64 psi = c->ntt_table[1 + ((u64) y << c->n_power)];
+            const u64 c_real = zz_residue(re, m->value), c_imag = zz_residue(im, m->value);
+            const u64 const_imag = o_mult(c_imag, psi, m);
+            for (u64 i = 0; i < c->n; i++) {
+                const u64 loc = i + ((u64) y << c->n_power) + (((u64) limbs * z) << c->n_power);
+                const u64 k = (i < (c->n >> 1)) ? o_add(c_real, const_imag, m) : o_sub(c_real, const_imag, m);
+                if (op == 0) out[loc] = (z == 0) ? o_add(ct[loc], k, m) : ct[loc];
+                else out[loc] = o_mult(ct[loc], k, m);
+            }
+        }
+}
+
 /* cipher_mult_by_i_kernel / cipher_div_by_i_kernel (multiplication.cu:441-495) */
 void o_ckks_mult_i(const octx_t* c, const u64* ct, u64* out, int limbs, int parts, int divide)
 {

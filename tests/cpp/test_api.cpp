@@ -433,6 +433,40 @@ static void ckks_encoder_flow()
     e = 0;
     for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - x[i] * y[i]));
     EXPECT(e < 1e-5, "ckks: sub_plain_inplace, multiply_plain (aliased output), rescale");
+    // complex constants in every slot (add_plain_v2 / multiply_plain_v2 / scale_up, operator.cuh:586-926)
+    {
+        std::vector<Complex64> gc;
+        Ciphertext<S> cw(ctx), cv(ctx);
+        enc.encrypt(cw, px);
+        op.add_plain_v2(cw, Complex64(1.5, -0.25), cv);
+        dec.decrypt(pr, cv);
+        encoder.decode(gc, pr);
+        e = 0;
+        for (int i = 0; i < slots; i++) e = std::max(e, std::abs(gc[i] - Complex64(x[i] + 1.5, -0.25)));
+        EXPECT(e < 1e-6, "ckks: add_plain_v2 adds the complex constant to every slot");
+        op.multiply_plain_v2(cw, Complex64(0.5, 2.0), cv); // fractional: the constant is scaled by the last modulus
+        EXPECT(cv.scale() > scale * 1e11, "ckks: multiply_plain_v2 with a fractional constant multiplies the scale by q_l");
+        EXPECT(!cv.rescale_required(), "ckks: ... and, like the reference, does not flag the result for rescaling");
+        dec.decrypt(pr, cv);
+        encoder.decode(gc, pr);
+        e = 0;
+        for (int i = 0; i < slots; i++) e = std::max(e, std::abs(gc[i] - Complex64(x[i], 0) * Complex64(0.5, 2.0)));
+        EXPECT(e < 1e-5, "ckks: multiply_plain_v2 multiplies every slot by the complex constant");
+        op.multiply_plain_v2(cw, Complex64(-3.0, 0.0), cv); // integer constant: no extra scale
+        EXPECT(cv.scale() == cw.scale(), "ckks: an integer constant leaves the scale unchanged");
+        dec.decrypt(pr, cv);
+        encoder.decode(got, pr);
+        e = 0;
+        for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] + 3.0 * x[i]));
+        EXPECT(e < 1e-6, "ckks: multiply_plain_v2 by -3");
+        op.scale_up(cw, 1024.0, cv);
+        EXPECT(cv.scale() == cw.scale() * 1024.0 && cv.level() == cw.level(), "ckks: scale_up multiplies the scale");
+        dec.decrypt(pr, cv);
+        encoder.decode(got, pr);
+        e = 0;
+        for (int i = 0; i < slots; i++) e = std::max(e, std::fabs(got[i] - x[i]));
+        EXPECT(e < 1e-6, "ckks: scale_up keeps the message");
+    }
 }
 
 // save / load in the reference's wire format + zlib file framing (util/serializer.h)

@@ -6,6 +6,8 @@ decode) runs on the GPU alone and returns the slot-wise results."""
 import numpy as np
 import pytest
 
+from helpers import synth_ct
+
 pytestmark = pytest.mark.gpu
 
 
@@ -131,3 +133,26 @@ def test_constant_operations_and_mult_i_match_oracle(hg, oracle, torch):
         e = d.clone()
         c.ckks_constant_op(2, e, 3.0 * 2.0 ** 30, l, parts, out=e)
         assert np.array_equal(hg.to_host(e), o.ckks_constant_op(2, ct, 3.0 * 2.0 ** 30, l, parts))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_gaussian_integer_constant_ops(hg, oracle, parts):
+    """hegpu_ckks_gaussian_integer_op (add_constant_plain_ckks_v2 / multiply_const_plain_ckks_v2,
+    ckks/operator.cu:567-724; kernels multiplication.cu:497-570): a complex constant in every slot, residues of
+    the rounded doubles taken exactly (positive, negative, beyond 2^64, zero imaginary part)."""
+    import torch
+    n = 4096
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, [50, 40, 40], [50], sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, 12, primes, 3, 1)
+    c.upload()
+    for depth in (0, 1):
+        l = 3 - depth
+        ct = synth_ct(primes, range(l), parts, n, 21 + depth)
+        d = hg.to_device(ct)
+        for re, im in ((3.0, 0.0), (-7.49, 2.5), (1.5 * 2**40, -3.25 * 2**40), (2.0**70 + 12345.0, -(2.0**66)), (0.0, -1.0)):
+            for op in (0, 1):
+                got = hg.to_host(c.ckks_gaussian_integer_op(op, d, re, im, l, parts))
+                torch.cuda.synchronize()
+                want = o.ckks_gaussian_integer_op(op, ct, re, im, l, parts)
+                assert np.array_equal(got, want), (depth, re, im, op)
