@@ -297,11 +297,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    rank, world, local_rank = sharding.init_distributed(args.backend or "nccl")
+    # one process per GPU; on a box with fewer devices than ranks (a functional check of the multi-rank path
+    # with --backend gloo on one GPU) ranks share devices
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    rank, world, local_rank = sharding.init_distributed(args.backend or "nccl", device_index=dev_index)
     if world != args.gpus:
         raise SystemExit("bench.py: world size %d (WORLD_SIZE) does not match --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
 
     ctx = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
     ctx.upload()

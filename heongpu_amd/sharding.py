@@ -6,9 +6,10 @@ There is no per-operation collective: ciphertexts never cross ranks
 import os
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, device_index=None):
     """Initialise torch.distributed from the torchrun environment.  Returns
-    (rank, world, local_rank); world == 1 means single process, no group."""
+    (rank, world, local_rank); world == 1 means single process, no group.
+    device_index: the GPU this rank uses (default: LOCAL_RANK)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -20,8 +21,9 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            idx = local_rank if device_index is None else device_index
+            torch.cuda.set_device(idx)
+            kwargs["device_id"] = torch.device("cuda", idx)
         dist.init_process_group(backend, **kwargs)
     return rank, world, local_rank
 
