@@ -354,6 +354,13 @@ __device__ __forceinline__ void wave_lds_fence()
 // ------------------------------------------------------------------ forward
 // Moduli below 2^57 take the correction-free butterflies (see ct_bfly).
 #define NTT_LAZY_BITS 57
+// The ROW stages alone can run correction-free for somewhat larger moduli: the column pass of such a
+// modulus (conditional subtraction per butterfly) hands over values below 8q, eight correction-free
+// stages add at most 4q each, and 40q < 2^64 holds up to q = floor(2^64 / 40) (2^58.67: the 58- and
+// "59"-bit primes of the default chains, which sit just above 2^58).  The one exact reduction at the end
+// (or the 128-bit inner product of ks_row_mac: 64 digits * 40q * q < 2^128) takes any such value.
+#define NTT_ROW_LAZY_MAX_Q 0x0666666666666666ull
+__device__ __forceinline__ bool row_stages_lazy(const Mod& md) { return md.bit <= NTT_LAZY_BITS || md.q <= NTT_ROW_LAZY_MAX_Q; }
 
 // Column pass: stages 0..S1-1 (row stride 256).  grid = (256/CT, batch).
 // SREG: the 16 source coefficients of the thread are already in registers (`sreg`, in load order:
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
     if (a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.fp) fwd_row_body_fp(a, ps, md, lds);
-    else if (md.bit <= NTT_LAZY_BITS) fwd_row_body<true>(a, ps, md, lds);
+    else if (row_stages_lazy(md)) fwd_row_body<true>(a, ps, md, lds);
     else fwd_row_body<false>(a, ps, md, lds);
 }
 
@@ -951,7 +958,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
     const u64* __restrict__ pk = a.key + ((u64) midx << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
     const u64 dig_off = (u64) a.rc << a.n_power;
     const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
-    const bool lazy = md.bit <= NTT_LAZY_BITS;
+    // beyond 2^57 the un-reduced output (< 40q) times a key residue is below 2^122.7: 32 digits fit 128 bits
+    const bool lazy = md.bit <= NTT_LAZY_BITS || (row_stages_lazy(md) && a.digits <= 32);
     // digit-invariant twiddles of the first four stages, shared by the 16 lanes of a row (see
     // ks_row_mac_fp; the per-lane ones of the last four stages would need 61 KiB as pairs)
     __shared__ ulonglong2 twa[15 * 16];
