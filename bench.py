@@ -433,7 +433,8 @@ def main():
         ("ckks_multiply: k_cross_multiplication", timer.ms(
             lambda: ctx.ckks_multiply(ct1, ct_elems, ct2, ct_elems, out, out_elems, 0, B, stream=stream)),
          7 * l * W * B, "read 4l, write 3l limbs"),
-        ("INTT of c2: ntt_inv_row + ntt_inv_col", probe(1), 2 * l * W * B, "l limb INTTs, 2W each"),
+        ("INTT of c2: ntt_inv_row + ntt_inv_col", probe(1), 2 * l * W * B,
+         "l limb INTTs, 2W each (the column stages of the FP64 limbs run inside the next group's kernel)"),
         ("decomposing column pass: ntt_fwd_col_multi + ntt_fwd_col<8,true>", probe(2),
          (l + l * rc - l) * W * B, "read l source limbs once, write l*Q' - l half-transformed digits"),
         ("row pass + key inner product: ks_row_mac_fp + ks_row_mac", probe(4),

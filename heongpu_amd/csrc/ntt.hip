@@ -525,72 +525,6 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
 
-// Decomposing column pass, one workgroup per SOURCE tile: the 16 coefficients a thread needs are
-// loaded once and stay in registers while the workgroup walks the rc target moduli of that digit
-// (reference: cipher_broadcast*_kernel + the first half of GPU_NTT for each of the rc copies,
-// switchkey.cu:11-59 / ckks/operator.cu:932-960).  No global load sits on the critical path of an
-// iteration, the source limb is read exactly once from HBM, and the stores of iteration j drain while
-// iteration j + 1 computes.  Two barriers per iteration (tile written -> read -> free again); the
-// second-round twiddles of the FP64 body are double-buffered by iteration parity, which the first
-// barrier of the following iteration makes safe.  grid = (256 / CT, items * digits).
-template <int S1>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col_multi(NttArgs a)
-{
-    constexpr int R = 1 << S1;
-    constexpr int CT = 4096 / R;
-    constexpr int NSA = S1 - 4;
-    constexpr int RA = 1 << NSA;
-    constexpr int G = 16 / RA;
-    __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
-    __shared__ ulonglong2 twl[(S1 > 4) ? 512 : 1];
-    const int t = threadIdx.x;
-    const int rc = a.decomp_mods;
-    const int digits = udiv16(a.polys_per_item, a.mg_decomp_mods);
-    const int item = udiv16(blockIdx.y, a.mg_per_item), digit = blockIdx.y - item * digits;
-    const u64 in_slot = (u64) digit * (a.decomp_in_mul ? a.decomp_in_mul : 1) + a.decomp_in_add;
-    const u64* __restrict__ src = a.in + (u64) item * a.in_item_stride + (in_slot << a.n_power) + blockIdx.x * CT;
-    u64 sreg[16];
-    if constexpr (NSA > 0) {
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int L = t + NTT_THREADS * g;
-            const int c = L % CT, rb = L / CT;
-#pragma unroll
-            for (int k = 0; k < RA; k++) sreg[g * RA + k] = src[(u64) (rb + 16 * k) * 256 + c];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) sreg[k] = src[(u64) k * 256 + (t % CT)];
-    }
-    const Mod smd = a.mods[a.half_on ? a.half_src_mod : digit];
-    if (a.half_on) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) sreg[k] = add_mod(sreg[k], a.half, smd.q);
-    }
-    const bool wide = smd.bit > 52; // uniform per workgroup
-    if (!wide) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) sreg[k] = as_bits(fp_from_u64(sreg[k]));
-    }
-    int done = 0; // executed iterations (parity of the twiddle buffer)
-    for (int k = 0; k < rc; k++) {
-        PolySel ps;
-        ps.mod = a.mod_offset + (a.mod_order ? a.mod_order[k] : k);
-        ps.digit = digit;
-        ps.item = item;
-        ps.j = digit * rc + k;
-        ps.in_off = 0;
-        ps.out_off = (u64) item * a.out_item_stride + ((u64) ps.j << a.n_power);
-        if (a.skip_identity && ps.mod == digit) continue;
-        const Mod md = a.mods[ps.mod];
-        if (!md.fp) continue; // integer target moduli: ntt_fwd_col<S1, true> with only_int
-        ulonglong2* tl = twl + ((S1 > 4) ? 256 * (done & 1) : 0);
-        done++;
-        if (wide) fwd_col_body_fp<S1, true, true, true>(a, ps, md, lds, tl, sreg);
-        else fwd_col_body_fp<S1, true, false, true>(a, ps, md, lds, tl, sreg);
-    }
-}
-
 // Store of the forward row pass: plain, or through the mod-down epilogue (NttEpilogue).
 // `e` = element offset inside the limb; x canonical.
 __device__ __forceinline__ void row_store(const NttArgs& a, const PolySel& ps, const Mod& md, u64* __restrict__ p, u64 e,
@@ -1313,9 +1247,10 @@ __device__ __forceinline__ void inv_row_part(const AR& ar, const NttArgs& a, int
 // Column stages of one column tile (R rows x CT columns), results to global memory.  FROM_LDS: the row
 // stages left their output in the LDS-resident limb (`buf` = the limb, positions single_pos); otherwise the
 // tile is read from `p` (global, in place) and `buf` is the tile's 4096-element exchange buffer.
-template <int S1, typename AR, bool FROM_LDS>
+// KEEP: the results also stay in `keep` (slot gi * RA + k, the load order of the forward column stages)
+template <int S1, typename AR, bool FROM_LDS, bool KEEP = false>
 __device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int mod, int tt, int g, u64* __restrict__ p,
-                                             u64* buf)
+                                             u64* buf, u64 (&keep)[16])
 {
     typedef typename AR::T T;
     constexpr int R = 1 << S1;
@@ -1350,12 +1285,20 @@ __device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int
             ar.template radix_last<NSA>(y, tw, ninv, w1ninv, o);
 #pragma unroll
             for (int k = 0; k < RA; k++) gst(&p[(u64) (rb + 16 * k) * 256 + c], o[k]);
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int k = 0; k < RA; k++) keep[gi * RA + k] = o[k];
+            }
         }
     } else {
         u64 o[16];
         ar.template radix_last<4>(x, tw, ninv, w1ninv, o);
 #pragma unroll
         for (int k = 0; k < 16; k++) gst(&p[(u64) k * 256 + col], o[k]);
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) keep[k] = o[k];
+        }
     }
 }
 
@@ -1379,9 +1322,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
     __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
     const PolySel ps = select_poly(a, blockIdx.y);
     const Mod md = a.mods[ps.mod];
+    if (a.only_int && md.fp) return; // a src_inv decomposing launch finishes these limbs itself
     u64* __restrict__ p = a.out + ps.out_off + blockIdx.x * CT;
-    if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds);
-    else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds);
+    u64 unused[16];
+    if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
+    else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
 }
 
 // Single pass for N <= 2^14 (see ntt_fwd_single): thread group g runs the row stages of row tile g into the
@@ -1393,7 +1338,8 @@ __device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, 
     const int t = threadIdx.x, g = t >> 8, tt = t & 255;
     inv_row_part<AR, true>(ar, a, ps.mod, tt, g * 16, a.in + ps.in_off + (u64) g * 4096, nullptr, limb + g * 4096);
     __syncthreads();
-    inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb);
+    u64 unused[16];
+    inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused);
 }
 
 template <int S1>
@@ -1404,6 +1350,85 @@ __global__ __launch_bounds__(16 << S1, 4) void ntt_inv_single(NttArgs a)
     const Mod md = a.mods[ps.mod];
     if (md.fp) inv_single_body<S1>(ArFp(md), a, ps, limb);
     else inv_single_body<S1>(ArInt(md), a, ps, limb);
+}
+
+// Decomposing column pass, one workgroup per SOURCE tile: the 16 coefficients a thread needs are
+// loaded once and stay in registers while the workgroup walks the rc target moduli of that digit
+// (reference: cipher_broadcast*_kernel + the first half of GPU_NTT for each of the rc copies,
+// switchkey.cu:11-59 / ckks/operator.cu:932-960).  No global load sits on the critical path of an
+// iteration, the source limb is read exactly once from HBM, and the stores of iteration j drain while
+// iteration j + 1 computes.  With NttArgs::src_inv the workgroup first finishes the inverse transform
+// of its source tile (see below).  Two barriers per iteration (tile written -> read -> free again); the
+// second-round twiddles of the FP64 body are double-buffered by iteration parity, which the first
+// barrier of the following iteration makes safe.  grid = (256 / CT, items * digits).
+template <int S1>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col_multi(NttArgs a)
+{
+    constexpr int R = 1 << S1;
+    constexpr int CT = 4096 / R;
+    constexpr int NSA = S1 - 4;
+    constexpr int RA = 1 << NSA;
+    constexpr int G = 16 / RA;
+    __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
+    __shared__ ulonglong2 twl[(S1 > 4) ? 512 : 1];
+    const int t = threadIdx.x;
+    const int rc = a.decomp_mods;
+    const int digits = udiv16(a.polys_per_item, a.mg_decomp_mods);
+    const int item = udiv16(blockIdx.y, a.mg_per_item), digit = blockIdx.y - item * digits;
+    const u64 in_slot = (u64) digit * (a.decomp_in_mul ? a.decomp_in_mul : 1) + a.decomp_in_add;
+    const u64* __restrict__ src = a.in + (u64) item * a.in_item_stride + (in_slot << a.n_power) + blockIdx.x * CT;
+    u64 sreg[16];
+    const int smod = a.half_on ? a.half_src_mod : digit;
+    if (a.src_inv && a.mods[smod].fp) {
+        // The source limb is still half-way through its INVERSE transform (row stages done by ntt_inv_row):
+        // the column tile its last stages produce is exactly the tile this workgroup decomposes, in the very
+        // register layout (rows rb + 16 k of column c), so they run here -- ntt_inv_col's write of the
+        // coefficient-domain limb and the re-read disappear.  The tile is still stored (in place): the
+        // integer target moduli are transformed by the per-polynomial kernel, which reads it.  FP64 source
+        // moduli only: with the integer inverse inlined as well the modulus loop below lost a wave per SIMD;
+        // limbs of integer moduli get their column stages from ntt_inv_col (ntt_launch_inv_rows).
+        const Mod im = a.mods[smod];
+        inv_col_part<S1, ArFp, false, true>(ArFp(im), a, smod, t, 0, const_cast<u64*>(src), lds, sreg);
+        __syncthreads(); // the exchange tile is free again
+    } else if constexpr (NSA > 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int L = t + NTT_THREADS * g;
+            const int c = L % CT, rb = L / CT;
+#pragma unroll
+            for (int k = 0; k < RA; k++) sreg[g * RA + k] = src[(u64) (rb + 16 * k) * 256 + c];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = src[(u64) k * 256 + (t % CT)];
+    }
+    const Mod smd = a.mods[a.half_on ? a.half_src_mod : digit];
+    if (a.half_on) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = add_mod(sreg[k], a.half, smd.q);
+    }
+    const bool wide = smd.bit > 52; // uniform per workgroup
+    if (!wide) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sreg[k] = as_bits(fp_from_u64(sreg[k]));
+    }
+    int done = 0; // executed iterations (parity of the twiddle buffer)
+    for (int k = 0; k < rc; k++) {
+        PolySel ps;
+        ps.mod = a.mod_offset + (a.mod_order ? a.mod_order[k] : k);
+        ps.digit = digit;
+        ps.item = item;
+        ps.j = digit * rc + k;
+        ps.in_off = 0;
+        ps.out_off = (u64) item * a.out_item_stride + ((u64) ps.j << a.n_power);
+        if (a.skip_identity && ps.mod == digit) continue;
+        const Mod md = a.mods[ps.mod];
+        if (!md.fp) continue; // integer target moduli: ntt_fwd_col<S1, true> with only_int
+        ulonglong2* tl = twl + ((S1 > 4) ? 256 * (done & 1) : 0);
+        done++;
+        if (wide) fwd_col_body_fp<S1, true, true, true>(a, ps, md, lds, tl, sreg);
+        else fwd_col_body_fp<S1, true, false, true>(a, ps, md, lds, tl, sreg);
+    }
 }
 
 // ------------------------------------------------------------------ launch
@@ -1508,10 +1533,49 @@ static void fill_magics(NttArgs& g)
     g.epi.mg_limbs = magic16(g.epi.limbs);
 }
 
+bool ntt_decomp_uses_multi(const NttArgs& a, int batch)
+{
+    if (!a.plan_has_fp) return false;
+    switch (a.n_power - 8) {
+        case 4: return use_col_multi<4>(a, batch);
+        case 5: return use_col_multi<5>(a, batch);
+        case 6: return use_col_multi<6>(a, batch);
+        case 7: return use_col_multi<7>(a, batch);
+        case 8: return use_col_multi<8>(a, batch);
+    }
+    return false;
+}
+
+hipError_t ntt_launch_inv_rows(const NttArgs& a, int batch, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (a.n_power < 12 || a.n_power > 16 || batch > 65535) return hipErrorInvalidValue;
+    NttArgs g = a;
+    g.group_span = 0;
+    if (!a.poly_order && a.mod_count > 1 && batch % a.mod_count == 0 &&
+        (!a.polys_per_item || a.polys_per_item % a.mod_count == 0))
+        g.group_span = batch / a.mod_count;
+    fill_magics(g);
+    hipLaunchKernelGGL(ntt_inv_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, g);
+    if (a.plan_has_int) { // limbs of integer moduli: column stages here, the FP64 ones in the src_inv launch
+        NttArgs b = g;
+        b.in = g.out;
+        b.in_item_stride = g.out_item_stride;
+        b.only_int = 1;
+        switch (a.n_power - 8) {
+#define CASE(S) case S: hipLaunchKernelGGL(ntt_inv_col<S>, dim3(256 / (4096 >> S), batch), dim3(NTT_THREADS), 0, st, b); break;
+            CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        }
+    }
+    return hipGetLastError();
+}
+
 hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
     if (a.n_power < 12 || a.n_power > 16 || batch > 65535 || a.poly_order) return hipErrorInvalidValue;
+    if (a.src_inv && !ntt_decomp_uses_multi(a, batch)) return hipErrorInvalidValue;
     NttArgs g = a;
     g.group_span = 0;
     // A decomposing launch walks the polynomials in their natural order (item, digit, modulus slot):
@@ -1539,6 +1603,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (batch <= 0) return hipSuccess;
     if (a.n_power < 12 || a.n_power > 16) return hipErrorInvalidValue;
     if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
+    if (a.src_inv && (!a.decomp_mods || batch > 65535 || !ntt_decomp_uses_multi(a, batch))) return hipErrorInvalidValue;
     if (batch > 65535) {
         // gridDim.y limit: split (poly_order / mod_order semantics need the
         // absolute polynomial index, so only plain batches are split)

@@ -89,9 +89,19 @@ struct NttArgs {
     int single_pass; // N <= 2^14: one LDS-resident pass per transform (HEGPU_SINGLE_PASS=0: the two passes)
     int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
     int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
+    // Decomposing launch through the multi-modulus kernel only (ntt_decomp_uses_multi): the source limbs are
+    // the output of ntt_launch_inv_rows -- for FP64 source moduli: inverse row stages done, column stages
+    // still to do -- and the kernel finishes their inverse transform itself (in place, the coefficient-domain
+    // limbs are stored too).
+    int src_inv;
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);
+// whether a decomposing launch of this shape takes the multi-modulus column kernel (so that src_inv may be used)
+bool ntt_decomp_uses_multi(const NttArgs& a, int batch);
+// first half of an inverse transform: row stages of every limb, column stages only for the limbs of integer
+// moduli; the FP64 limbs are finished by the src_inv decomposing launch that follows
+hipError_t ntt_launch_inv_rows(const NttArgs& a, int batch, hipStream_t st);
 // forward column pass only (the row pass is done by ks_row_mac_launch)
 hipError_t ntt_launch_fwd_col(const NttArgs& a, int batch, hipStream_t st);
 

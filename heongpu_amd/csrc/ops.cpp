@@ -119,13 +119,22 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     // re-reduced into its own modulus d and transformed back is that limb
     a.in = c2; a.out = temp2; a.mod_count = l; a.polys_per_item = l;
     a.in_item_stride = cs; a.out_item_stride = per;
-    if (phases & RELIN_PHASE_INTT_C2) TRY(ntt_launch(a, l * batch, true, st));
     // digit decomposition c2 -> [l][rc][N] fused into the forward NTT's
     // first load; modulus order skips dropped primes                (:932-960)
-    a = c.ntt_args(0);
-    a.in = temp2; a.out = temp1; a.mod_count = rc; a.polys_per_item = l * rc; a.decomp_mods = rc;
-    a.in_item_stride = per; a.out_item_stride = per;
-    a.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    NttArgs dgt = c.ntt_args(0);
+    dgt.in = temp2; dgt.out = temp1; dgt.mod_count = rc; dgt.polys_per_item = l * rc; dgt.decomp_mods = rc;
+    dgt.in_item_stride = per; dgt.out_item_stride = per;
+    dgt.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    // When the decomposing column pass is the multi-modulus kernel (one launch for the whole batch), it also
+    // finishes the inverse transform of its source tiles: only the row stages of the INTT run on their own.
+    const bool fuse_inv = c.fused_row_mac && c.fuse_inverse && (long) l * rc * batch <= 65535 &&
+                          ntt_decomp_uses_multi(dgt, l * rc * batch);
+    if (phases & RELIN_PHASE_INTT_C2) {
+        if (fuse_inv) TRY(ntt_launch_inv_rows(a, l * batch, st));
+        else TRY(ntt_launch(a, l * batch, true, st));
+    }
+    dgt.src_inv = fuse_inv ? 1 : 0;
+    a = dgt;
     // forward NTT of the digits + inner product with the key      (:956-988)
     const int which = ((phases & RELIN_PHASE_COLUMN) ? 1 : 0) | ((phases & RELIN_PHASE_ROW_MAC) ? 2 : 0);
     if (which) TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, c2, cs, batch, st, which));
@@ -134,7 +143,18 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
     a.in_item_stride = a.out_item_stride = per;
     a.poly_order = c.d32("new_input_locations") + 2 * depth;
-    if (phases & RELIN_PHASE_INTT_P) TRY(ntt_launch(a, 2 * batch, true, st));
+    // the same fusion for the mod-down transform, whose source is the inverse transform of the P limbs
+    NttArgs md = c.ntt_args(0);
+    md.in = temp2; md.out = temp1; md.mod_count = l; md.polys_per_item = 2 * l;
+    md.in_item_stride = md.out_item_stride = per;
+    md.decomp_mods = l; md.decomp_in_mul = l + 1; md.decomp_in_add = l;
+    md.half_on = 1; md.half_src_mod = Q;
+    const bool fuse_inv_p = c.fused_moddown && c.fuse_inverse && (long) 2 * l * batch <= 65535 &&
+                            ntt_decomp_uses_multi(md, 2 * l * batch);
+    if (phases & RELIN_PHASE_INTT_P) {
+        if (fuse_inv_p) TRY(ntt_launch_inv_rows(a, 2 * batch, st));
+        else TRY(ntt_launch(a, 2 * batch, true, st));
+    }
     if (!(phases & RELIN_PHASE_MODDOWN)) return hipSuccess;
     // stage one: P limb (+half) reduced into every q_j               (:1003)
     if (!c.fused_moddown)
@@ -155,6 +175,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
         a.epi.out = ct; a.epi.out_item_stride = cs;
         a.epi.inv = c.d64("last_q_modinv");
         a.epi.limbs = l;
+        a.src_inv = fuse_inv_p ? 1 : 0;
         return ntt_launch(a, 2 * l * batch, false, st);
     }
     TRY(ntt_launch(a, 2 * l * batch, false, st));

@@ -110,6 +110,7 @@ _SWITCHES = [
     dict(HEGPU_SINGLE_PASS=0),
     dict(HEGPU_COL_MULTI=1),
     dict(HEGPU_COL_MULTI=1, HEGPU_FP_NTT=0),
+    dict(HEGPU_COL_MULTI=1, HEGPU_FUSE_INVERSE=0),
     dict(HEGPU_FUSED_ROW_MAC=0),
     dict(HEGPU_FUSED_MODDOWN=0),
     dict(HEGPU_FP_NTT=0),
