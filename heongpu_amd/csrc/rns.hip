@@ -160,6 +160,40 @@ __device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
     hi += h + (lo < l);
 }
 
+// sum_j v[j] * row[j < valid ? j : 0] as a 128-bit integer, every operand below 2^61 (residues and table
+// entries of moduli of at most 61 bits; v[j] == 0 beyond `valid`).  A 128-bit multiply-accumulate per term
+// costs ~19 instructions, most of them carries and the shifted addends of the 4-multiply chain.  Here the four
+// partial products of eight terms at a time are summed by weight instead -- a0*b1, a1*b0 < 2^61 and
+// a1*b1 < 2^58 cannot overflow 64 bits in eight terms, so each is one v_mad_u64_u32 with a 64-bit addend; only
+// a0*b0 needs a carry count -- and the columns are put together once per eight terms: 6 instructions per term.
+template <int M>
+__device__ __forceinline__ void dot128(const u64 (&v)[M], const u64* __restrict__ row, int valid, u64& hi, u64& lo)
+{
+    hi = lo = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < M; j0 += 8) {
+        u64 s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+        u32 c00 = 0;
+#pragma unroll
+        for (int j = j0; j < j0 + 8 && j < M; j++) {
+            const u64 b = row[j < valid ? j : 0];
+            const u32 a0 = (u32) v[j], a1 = (u32) (v[j] >> 32), b0 = (u32) b, b1 = (u32) (b >> 32);
+            const u64 p = (u64) a0 * b0;
+            s00 += p;
+            c00 += s00 < p;
+            s01 += (u64) a0 * b1;
+            s10 += (u64) a1 * b0;
+            s11 += (u64) a1 * b1;
+        }
+        const u64 mid = s01 + s10;
+        const u64 cm = mid < s01;
+        const u64 l = s00 + (mid << 32);
+        const u64 h = s11 + (mid >> 32) + (cm << 32) + c00 + (l < s00);
+        lo += l;
+        hi += h + (lo < l);
+    }
+}
+
 // Workgroups are ordered batch-fastest (blockIdx.x = ciphertext): the `batch`
 // workgroups that read the same key tile (same limb, same 512 coefficients)
 // are dispatched back to back, so the evaluation key streams from HBM once
@@ -599,9 +633,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     for (int i = 0; i < ob; i++) {
         const Mod mo = b.obase[i];
         const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
-        u64 hi = 0, lo = 0;
-#pragma unroll
-        for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, temp[j], row[j < ib ? j : 0]);
+        u64 hi, lo;
+        dot128(temp, row, ib, hi, lo);
         u64 t2 = reduce128(hi, lo, mo);
         u64 t3 = r_mt;
         if (t3 >= (mt >> 1)) {
@@ -642,6 +675,9 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
     return hipGetLastError();
 }
 
+#ifndef FF_UNROLL_MAX
+#define FF_UNROLL_MAX 0
+#endif
 template <int MAXB>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restrict__ in, u64 si,
                                                             u64* __restrict__ out1, u64 so, BehzDev b, int n_power)
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     // rows 0 .. ob-2: the moduli of B (-> temp3), row ob-1: m_sk.  (The two forms are written out: sharing
     // the row computation through a lambda cost 30 registers.)
     u64 reg_Bsk_last = 0;
-    if constexpr (MAXB <= 16) {
+    if constexpr (MAXB <= FF_UNROLL_MAX) {
         // MAXB + 1 unrolled iterations on a clamped row index cover ob <= MAXB + 1 (the surplus ones
         // recompute the m_sk row): static register indices, no selects
 #pragma unroll
@@ -672,9 +708,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
             const Mod mo = b.obase[ii];
             const u64* __restrict__ row = b.base_change_matrix_Bsk + ii * ib;
             const u64 rb = mul_barrett(pB[(u64) ii << n_power], t, mo);
-            u64 hi = 0, lo = 0;
-#pragma unroll
-            for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, reg_q[j], row[j < ib ? j : 0]);
+            u64 hi, lo;
+            dot128(reg_q, row, ib, hi, lo);
             const u64 tmp = reduce128(hi, lo, mo);
             u64 t2 = sub_mod(mo.q, tmp, mo.q);
             t2 = add_mod(t2, rb, mo.q);
@@ -692,9 +727,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
             const Mod mo = b.obase[i];
             const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
             const u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
-            u64 hi = 0, lo = 0;
-#pragma unroll
-            for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, reg_q[j], row[j < ib ? j : 0]);
+            u64 hi, lo;
+            dot128(reg_q, row, ib, hi, lo);
             const u64 tmp = reduce128(hi, lo, mo);
             u64 t2 = sub_mod(mo.q, tmp, mo.q);
             t2 = add_mod(t2, rb, mo.q);
@@ -706,9 +740,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
         }
     }
     const Mod msk = b.obase[ob - 1];
-    u64 hi = 0, lo = 0;
-#pragma unroll
-    for (int j = 0; j < MAXB; j++) acc_mad(hi, lo, temp3[j], b.base_change_matrix_msk[j < ob - 1 ? j : 0]);
+    u64 hi, lo;
+    dot128(temp3, b.base_change_matrix_msk, ob - 1, hi, lo);
     u64 t4sk = reduce128(hi, lo, msk);
     u64 alpha_sk = sub_mod(msk.q, reg_Bsk_last, msk.q);
     alpha_sk = add_mod(alpha_sk, t4sk, msk.q);
@@ -719,9 +752,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     for (int i = 0; i < ib; i++) {
         const Mod mi = b.ibase[i];
         const u64* __restrict__ row = b.base_change_matrix_q + i * (ob - 1);
-        u64 h2 = 0, l2 = 0;
-#pragma unroll
-        for (int j = 0; j < MAXB; j++) acc_mad(h2, l2, temp3[j], row[j < ob - 1 ? j : 0]); // un-reduced: 64 terms below 2^122 fit 128 bits
+        u64 h2, l2;
+        dot128(temp3, row, ob - 1, h2, l2); // un-reduced: 64 terms below 2^122 fit 128 bits
         u64 t4 = reduce128(h2, l2, mi);
         u64 obase_ = b.msk_mod_q[i];
         u64 alpha_ = reduce64(alpha_sk, mi);
