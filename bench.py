@@ -247,10 +247,21 @@ def secondary_block(torch, hg, timer):
             ctx.ckks_relinearize_inplace(ob, 3 * Q * n, key, 0, B, wsb, stream=stream)
             ctx.ckks_rescale_inplace(ob, 3 * Q * n, 0, B, wsb2, stream=stream)
         c2[B] = timer.ms(seq, 5)
+        if B == 1:
+            # the same sequence captured once and replayed as one hipGraph launch (the operator entries
+            # allocate nothing and never synchronise): the launch-bound batch-1 case
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gs = torch.cuda.current_stream().cuda_stream
+                ctx.ckks_multiply(c1b, 2 * Q * n, c2b, 2 * Q * n, ob, 3 * Q * n, 0, B, stream=gs)
+                ctx.ckks_relinearize_inplace(ob, 3 * Q * n, key, 0, B, wsb, stream=gs)
+                ctx.ckks_rescale_inplace(ob, 3 * Q * n, 0, B, wsb2, stream=gs)
+            c2["graph"] = timer.ms(graph.replay, 5)
     op_bytes = (6 * Q * Q + 32 * Q + 8 + 6 + 16 * (Q - 1)) * W
     sec["c2_ckks_n14"] = {
         "workload": "CKKS N=2^14, Q=8 {50,40x7} | P=1 {50}, multiply + relinearize + rescale",
-        "latency_us_batch1": c2[1] * 1e3, "ops_per_s_batch64": 64 / (c2[64] * 1e-3),
+        "latency_us_batch1": c2[1] * 1e3, "latency_us_batch1_hipgraph_replay": c2["graph"] * 1e3,
+        "ops_per_s_batch64": 64 / (c2[64] * 1e-3),
         "reference_sequence_bytes_per_op": op_bytes,
         "frac_of_hbm_peak_batch64": op_bytes * 64 / (c2[64] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     ctx.close()

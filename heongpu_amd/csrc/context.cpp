@@ -536,6 +536,8 @@ hipError_t Context::upload()
     if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
     if (const char* e = getenv("HEGPU_COL_MULTI")) col_multi = atoi(e); // 0 / 1 force a column-pass form
     if (const char* e = getenv("HEGPU_SINGLE_PASS")) single_pass = atoi(e);
+    if (const char* e = getenv("HEGPU_NTT_GALOIS")) ntt_galois = (e[0] != '0');
+    if (const char* e = getenv("HEGPU_GALOIS_SCATTER")) galois_scatter = (e[0] != '0');
     if (const char* e = getenv("HEGPU_FUSE_INVERSE")) fuse_inverse = (e[0] != '0');
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)

@@ -57,6 +57,8 @@ struct Context {
     bool fused_moddown = true; // HEGPU_FUSED_MODDOWN=0: separate stage-two kernel
     int col_multi = -1;        // HEGPU_COL_MULTI: form of the decomposing column pass (NttArgs::col_multi)
     int single_pass = 1;       // HEGPU_SINGLE_PASS=0: N <= 2^14 transforms through the two passes as well
+    bool ntt_galois = true;    // HEGPU_NTT_GALOIS=0: CKKS rotations in the reference's order (permutation in the coefficient domain)
+    bool galois_scatter = true; // HEGPU_GALOIS_SCATTER=0: the NTT-domain permutation as a kernel of its own (gather) instead of the mod-down epilogue's store
     bool fuse_inverse = true;  // HEGPU_FUSE_INVERSE=0: the INTT feeding a decomposing launch runs on its own
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 

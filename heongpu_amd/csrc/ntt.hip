@@ -539,8 +539,13 @@ __device__ __forceinline__ void row_store(const NttArgs& a, const PolySel& ps, c
     const u64 ks = ep.ks[ep.ks_item_stride * ps.item + ((u64) (part * ep.ks_part_limbs + limb) << a.n_power) + e];
     const u64 off = ((u64) (part * ep.limbs + limb) << a.n_power) + e;
     u64 r = mul_barrett(sub_mod(ks, x, md.q), ep.inv[ps.mod], md);
-    if (ep.ct) r = add_mod(ep.ct[ep.ct_item_stride * ps.item + off], r, md.q);
-    ep.out[ep.out_item_stride * ps.item + off] = r;
+    if (ep.ct && (!ep.ct_parts || part < ep.ct_parts)) r = add_mod(ep.ct[ep.ct_item_stride * ps.item + off], r, md.q);
+    u64 dst = off;
+    if (ep.galois_inv) {
+        const u32 ex = ((2u * (__brev((u32) e) >> (32 - a.n_power)) + 1u) * ep.galois_inv) & ((2u << a.n_power) - 1u);
+        dst = off - e + (__brev((ex - 1u) >> 1) >> (32 - a.n_power));
+    }
+    ep.out[ep.out_item_stride * ps.item + dst] = r;
 }
 
 // Row pass: stages S1..S1+7 on contiguous rows of 256, 16 rows per block.

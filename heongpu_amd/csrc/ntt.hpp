@@ -19,6 +19,11 @@ struct NttEpilogue {
     int ks_part_limbs;
     const u64* ct;      // added term (NULL: none), limb at ((part * limbs + limb) << n_power); may alias out
     u64 ct_item_stride;
+    int ct_parts;       // only parts below this get the added term (0: every part)
+    // Galois automorphism b(X) = a(X^g) applied to the result, as a slot scatter: the value of slot j goes to
+    // slot j' with 2 br(j') + 1 = (2 br(j) + 1) * galois_inv mod 2N, galois_inv = g^-1 mod 2N (0: none).  The
+    // added term is read unpermuted (it is permuted with the sum).  out must not alias ct then.
+    unsigned galois_inv;
     u64* out;           // same layout as ct
     u64 out_item_stride;
     const u64* inv;     // per-modulus P^-1

@@ -99,27 +99,29 @@ hipError_t op_ckks_multiply(const Context& c, const u64* ct1, u64 s1, const u64*
                                     st);
 }
 
-// reference ckks/operator.cu:899-1023
-hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
-                               hipStream_t st, unsigned phases)
+// Key switch (method I) of one NTT-domain polynomial per item, the shared core of relinearize and rotate
+// (reference ckks/operator.cu:919-1020 and :1461-1545):
+//   out[part p] = moddown(sum_i digit_i(src) * key[i][p]) + (p < add_parts ? add[part p] : 0),   p = 0, 1
+// src: [l][N] per item, src_stride apart; add / out: [2][l][N] per item.  temp1: [l][rc][N], temp2: [2][rc][N]
+// per item, both `per` apart.  out may alias add.
+static u64 inv_mod_2n(u64 g, u64 two_n);
+static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_stride, const u64* add, u64 add_stride,
+                                      int add_parts, u64* outp, u64 out_stride, const u64* key, int depth, int batch,
+                                      u64* temp1, u64* temp2, u64 per, hipStream_t st, unsigned phases,
+                                      int galois_elt = 0)
 {
     const int np = c.n_power;
-    const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
     const int l = Q - depth, rc = Qp - depth;
-    const u64 per = ((u64) l * rc + 2 * rc) * n;
-    u64* temp1 = ws;                      // [l][rc][N] per item, later [2][l][N]
-    u64* temp2 = ws + (u64) l * rc * n;   // [2][rc][N] per item
-    u64* c2 = ct + ((u64) l << (np + 1));
     const Mod* mods = c.plan_qp.mods;
 
     NttArgs a = c.ntt_args(0);
-    // INTT(c2), batch l per item (:919) -- out of place into the (not yet used)
-    // accumulator region: c2 itself stays in the NTT domain because digit d
+    // INTT(src), batch l per item (:919) -- out of place into the (not yet used)
+    // accumulator region: src itself stays in the NTT domain because digit d
     // re-reduced into its own modulus d and transformed back is that limb
-    a.in = c2; a.out = temp2; a.mod_count = l; a.polys_per_item = l;
-    a.in_item_stride = cs; a.out_item_stride = per;
-    // digit decomposition c2 -> [l][rc][N] fused into the forward NTT's
+    a.in = src; a.out = temp2; a.mod_count = l; a.polys_per_item = l;
+    a.in_item_stride = src_stride; a.out_item_stride = per;
+    // digit decomposition src -> [l][rc][N] fused into the forward NTT's
     // first load; modulus order skips dropped primes                (:932-960)
     NttArgs dgt = c.ntt_args(0);
     dgt.in = temp2; dgt.out = temp1; dgt.mod_count = rc; dgt.polys_per_item = l * rc; dgt.decomp_mods = rc;
@@ -137,7 +139,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     a = dgt;
     // forward NTT of the digits + inner product with the key      (:956-988)
     const int which = ((phases & RELIN_PHASE_COLUMN) ? 1 : 0) | ((phases & RELIN_PHASE_ROW_MAC) ? 2 : 0);
-    if (which) TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, c2, cs, batch, st, which));
+    if (which) TRY(keyswitch_ntt_mac(c, a, key, temp2, per, l, rc, l, depth, src, src_stride, batch, st, which));
     // INTT of the two P-limb polynomials only                        (:996)
     a = c.ntt_args(0);
     a.in = temp2; a.out = temp2; a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 2;
@@ -160,8 +162,8 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
     if (!c.fused_moddown)
         TRY(rns_moddown_stage_one(temp2, per, temp1, per, mods, c.d64("half"), c.d64("half_mod"), np, Q, l, batch,
                                   st));
-    // forward NTT of that (:1011) with stage one as its load transform and stage two -- (x - last) * P^-1 + ct, written over ct
-    // parts 0,1 (:1015) -- as the epilogue of its row pass
+    // forward NTT of that (:1011) with stage one as its load transform and stage two -- (x - last) * P^-1 + add, written to
+    // out parts 0,1 (:1015) -- as the epilogue of its row pass
     a = c.ntt_args(0);
     a.in = temp1; a.out = temp1; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = a.out_item_stride = per;
@@ -171,16 +173,31 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
         a.half_on = 1; a.half_src_mod = Q; a.half = c.h64("half")[0]; a.half_mod = c.d64("half_mod");
         a.epi.on = 1;
         a.epi.ks = temp2; a.epi.ks_item_stride = per; a.epi.ks_part_limbs = l + 1;
-        a.epi.ct = ct; a.epi.ct_item_stride = cs;
-        a.epi.out = ct; a.epi.out_item_stride = cs;
+        a.epi.ct = add; a.epi.ct_item_stride = add_stride; a.epi.ct_parts = add_parts;
+        a.epi.out = outp; a.epi.out_item_stride = out_stride;
         a.epi.inv = c.d64("last_q_modinv");
         a.epi.limbs = l;
+        a.epi.galois_inv = galois_elt ? (unsigned) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0u;
         a.src_inv = fuse_inv_p ? 1 : 0;
         return ntt_launch(a, 2 * l * batch, false, st);
     }
+    if (add_parts != 2 || galois_elt) return hipErrorInvalidValue; // the stand-alone stage two adds both parts (relinearize only)
     TRY(ntt_launch(a, 2 * l * batch, false, st));
-    return rns_moddown_stage_two(temp1, per, temp2, per, l + 1, ct, cs, ct, cs, mods, c.d64("last_q_modinv"), np, l,
-                                 1, batch, st);
+    return rns_moddown_stage_two(temp1, per, temp2, per, l + 1, add, add_stride, outp, out_stride, mods,
+                                 c.d64("last_q_modinv"), np, l, 1, batch, st);
+}
+
+// reference ckks/operator.cu:899-1023
+hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
+                               hipStream_t st, unsigned phases)
+{
+    const u64 n = c.n;
+    const int l = c.Q_size - depth, rc = c.Qp_size - depth;
+    const u64 per = ((u64) l * rc + 2 * rc) * n;
+    u64* temp1 = ws;                      // [l][rc][N] per item, later [2][l][N]
+    u64* temp2 = ws + (u64) l * rc * n;   // [2][rc][N] per item
+    return ckks_keyswitch_core(c, ct + ((u64) l << (c.n_power + 1)), cs, ct, cs, 2, ct, cs, key, depth, batch, temp1,
+                               temp2, per, st, phases);
 }
 
 // reference ckks/operator.cu:1156-1244
@@ -247,6 +264,20 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     const Mod* mods = c.plan_qp.mods;
     const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
 
+    if (c.fused_row_mac && c.fused_moddown && c.ntt_galois) {
+        // The key switch of c1 exactly as relinearize does it (c0 added to part 0 by the mod-down epilogue), all
+        // in the NTT domain, and the automorphism last, as a slot gather of both parts.  Against the reference's
+        // order (INTT of both parts, ..., INTT of 2 rc limbs, mod-down + permute in the coefficient domain, NTT
+        // of 2 l limbs) this never transforms c0, inverse-transforms 2 instead of 2 rc accumulator limbs and has
+        // no scattered stores; the residues are the same (the permutation commutes with the transform, the
+        // mod-down is the same exact integer function either way).
+        if (c.galois_scatter)
+            return ckks_keyswitch_core(c, ct + (u64) l * n, cs, ct, cs, 1, out, so, key, depth, batch, temp2, temp3, per, st,
+                                       RELIN_PHASE_ALL, galois_elt);
+        TRY(ckks_keyswitch_core(c, ct + (u64) l * n, cs, ct, cs, 1, temp0, per, key, depth, batch, temp2, temp3, per, st,
+                                RELIN_PHASE_ALL));
+        return rns_permute_ntt(temp0, per, out, so, galois_elt, np, 2 * l, batch, st);
+    }
     NttArgs a = c.ntt_args(0);
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
@@ -463,11 +494,20 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
         }
     }
 
-    // ---- shared: INTT of both parts, digits, forward NTT of the digits
+    // Method I with the mod-down fused into its transform: every element stays in the NTT domain -- inner product,
+    // INTT of the two P limbs, mod-down transform whose epilogue adds c0 and scatters through the automorphism
+    // (see op_ckks_apply_galois).  c0 is never transformed, so only c1 goes through the shared INTT.
+    const bool ntt_domain = !m2 && c.fused_moddown && c.ntt_galois;
+    // ---- shared: INTT of both parts (of c1 only: ntt_domain), digits, forward NTT of the digits
     NttArgs a = c.ntt_args(0);
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(ntt_launch(a, 2 * l * batch, true, st));
+    if (ntt_domain) {
+        a.in = ct + (u64) l * n; a.out = temp0 + (u64) l * n; a.polys_per_item = l;
+        TRY(ntt_launch(a, l * batch, true, st));
+    } else {
+        TRY(ntt_launch(a, 2 * l * batch, true, st));
+    }
     a = c.ntt_args(0);
     a.out = temp2; a.mod_count = rc; a.polys_per_item = digits * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
@@ -486,6 +526,12 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
         if (galois_elts[i] == 0) continue;
         u64* oi = out + (u64) i * ct_words;
         TRY(rns_keyswitch_mac(temp2, per, keys[i], temp3, per, mods, np, digits, rc, Qp, l, depth, batch, st));
+        if (ntt_domain) {
+            // temp0 is free once the digits exist: scratch of the mod-down transform
+            TRY(ckks_keyswitch_core(c, nullptr, 0, ct, cs, 1, oi, so, nullptr, depth, batch, temp0, temp3, per, st,
+                                    RELIN_PHASE_INTT_P | RELIN_PHASE_MODDOWN, galois_elts[i]));
+            continue;
+        }
         NttArgs b = c.ntt_args(0);
         b.in = temp3; b.out = temp3; b.mod_count = rc; b.polys_per_item = 2 * rc; b.mod_order = order;
         b.in_item_stride = b.out_item_stride = per;

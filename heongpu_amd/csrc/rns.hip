@@ -568,6 +568,37 @@ hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- Galois automorphism in the NTT domain
+// b(X) = a(X^g): slot j of the transform holds the value at psi^(2 br(j) + 1) (reference switchkey.cu:1461-1476),
+// and b(psi^e) = a(psi^(e g mod 2N)), so the automorphism is the slot gather out[j] = in[j'] with
+// 2 br(j') + 1 = (2 br(j) + 1) g mod 2N -- no sign, no arithmetic, the same map for every limb.  (The reference
+// permutes in the coefficient domain, fused into the mod-down, switchkey.cu:1621-1813, and transforms after
+// that; the canonical residues are the same.)  Coalesced 16-byte writes, 8-byte gathers that stay inside
+// one limb (512 KiB at N = 2^16: L2-resident while the workgroups of that limb run).
+__global__ __launch_bounds__(RNS_THREADS) void k_permute_ntt(const u64* __restrict__ in, u64 in_stride,
+                                                             u64* __restrict__ out, u64 out_stride, int n_power,
+                                                             u32 galois_elt)
+{
+    const u32 j = (u32) coeff0();
+    const u32 mask = (2u << n_power) - 1u;
+    const u32 e0 = (2u * (__brev(j) >> (32 - n_power)) + 1u) * galois_elt & mask;
+    const u32 e1 = (2u * (__brev(j + 1) >> (32 - n_power)) + 1u) * galois_elt & mask;
+    const u32 s0 = __brev((e0 - 1u) >> 1) >> (32 - n_power), s1 = __brev((e1 - 1u) >> 1) >> (32 - n_power);
+    const u64* pi = in + in_stride * blockIdx.z + ((u64) blockIdx.y << n_power);
+    ulonglong2 v;
+    v.x = pi[s0];
+    v.y = pi[s1];
+    st2(out + out_stride * blockIdx.z + ((u64) blockIdx.y << n_power) + j, v);
+}
+
+hipError_t rns_permute_ntt(const u64* in, u64 in_stride, u64* out, u64 out_stride, int galois_elt, int n_power,
+                           int limbs, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_permute_ntt, grid3(n_power, limbs, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
+                       out_stride, n_power, (u32) galois_elt);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(RNS_THREADS) void k_copy_diag(const u64* __restrict__ in, u64 in_stride,
                                                            u64* __restrict__ out, u64 out_stride, int n_power, int rc)
 {

@@ -78,6 +78,9 @@ hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64
 
 // plain strided copy of `limbs` limbs x `parts` parts (switchkey.cu:776-790,
 // bfv_duplicate's c0 copy)
+// Galois automorphism b(X) = a(X^g) of `limbs` NTT-domain limbs per item (slot gather); out must not alias in
+hipError_t rns_permute_ntt(const u64* in, u64 in_stride, u64* out, u64 out_stride, int galois_elt, int n_power,
+                           int limbs, int batch, hipStream_t st);
 hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64* out,
                           u64 out_part_stride, u64 out_stride, int n_power, int limbs, int parts,
                           int batch, hipStream_t st);
