@@ -532,7 +532,7 @@ static void free_plan(NttPlan& p)
 hipError_t Context::upload()
 {
     if (uploaded) return hipSuccess;
-    if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0');
+    if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
     if (const char* e = getenv("HEGPU_COL_MULTI")) col_multi = atoi(e); // 0 / 1 force a column-pass form
     if (const char* e = getenv("HEGPU_SINGLE_PASS")) single_pass = atoi(e);

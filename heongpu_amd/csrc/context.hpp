@@ -53,10 +53,10 @@ struct Context {
     std::vector<M2Level> m2_levels;
     int m2_width = 0; // digit width m: 2 for BFV, P_size for CKKS
     // use the fused "row pass + key-switch MAC" kernel (HEGPU_FUSED_ROW_MAC=0 disables)
-    bool fused_row_mac = true;
+    int fused_row_mac = -1;    // HEGPU_FUSED_ROW_MAC: 1 / 0 force the fused / the reference's key-switch sequence, otherwise by launch size (ops.cpp: use_fused_row_mac)
     bool fused_moddown = true; // HEGPU_FUSED_MODDOWN=0: separate stage-two kernel
     int col_multi = -1;        // HEGPU_COL_MULTI: form of the decomposing column pass (NttArgs::col_multi)
-    int single_pass = 1;       // HEGPU_SINGLE_PASS=0: N <= 2^14 transforms through the two passes as well
+    int single_pass = -1;      // HEGPU_SINGLE_PASS: 1 / 0 force the single pass / the two passes for N <= 2^14, otherwise by launch size (NttArgs::single_pass)
     bool ntt_galois = true;    // HEGPU_NTT_GALOIS=0: CKKS rotations in the reference's order (permutation in the coefficient domain)
     bool galois_scatter = true; // HEGPU_GALOIS_SCATTER=0: the NTT-domain permutation as a kernel of its own (gather) instead of the mod-down epilogue's store
     bool fuse_inverse = true;  // HEGPU_FUSE_INVERSE=0: the INTT feeding a decomposing launch runs on its own

@@ -1466,6 +1466,12 @@ static void launch_col_multi(const NttArgs& a, int batch, hipStream_t st)
     }
 }
 
+#define NTT_SINGLE_PASS_MIN_LIMBS 256
+static bool use_single_pass(const NttArgs& a, int batch)
+{
+    return a.single_pass == 1 || (a.single_pass != 0 && batch >= NTT_SINGLE_PASS_MIN_LIMBS);
+}
+
 template <int S1>
 static void launch_fwd_col_only(const NttArgs& a, int batch, hipStream_t st)
 {
@@ -1482,7 +1488,7 @@ static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
     if constexpr (S1 <= 6) {
-        if (!a.decomp_mods && a.single_pass) { // LDS-resident single pass (N <= 2^14)
+        if (!a.decomp_mods && use_single_pass(a, batch)) { // LDS-resident single pass (N <= 2^14)
             static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_fwd_single<S1>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             (void) attr;
@@ -1511,7 +1517,7 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
 {
     constexpr int CT = 4096 >> S1;
     if constexpr (S1 <= 6) {
-        if (a.single_pass && !a.poly_order) { // LDS-resident single pass (N <= 2^14)
+        if (use_single_pass(a, batch) && !a.poly_order) { // LDS-resident single pass (N <= 2^14)
             static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_inv_single<S1>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             (void) attr;

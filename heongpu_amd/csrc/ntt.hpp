@@ -91,7 +91,10 @@ struct NttArgs {
     // decomposing launches: 0 = one workgroup per (source tile, target modulus), 1 = one workgroup per
     // source tile walking all target moduli (ntt_fwd_col_multi), anything else = by launch size
     int col_multi;
-    int single_pass; // N <= 2^14: one LDS-resident pass per transform (HEGPU_SINGLE_PASS=0: the two passes)
+    // N <= 2^14: one LDS-resident pass per transform.  1 always, 0 never (the two passes), otherwise by launch
+    // size: one workgroup per limb needs a launch that fills the chip; a small one finishes sooner as two passes
+    // of four times as many workgroups (C2, one ciphertext: inverse of 8 limbs 19.6 us against 6.0 + 5.5 us).
+    int single_pass;
     int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
     int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
     // Decomposing launch through the multi-modulus kernel only (ntt_decomp_uses_multi): the source limbs are

@@ -30,6 +30,15 @@ static int prime_loc_offset(const Context& c, int depth)
 // taken from there instead of being transformed.
 // `which`: 1 = column pass only, 2 = row pass + inner product only, 3 = both (the measurement seam of
 // hegpu_probe_ckks_relinearize; the unfused path ignores it)
+// The fused row pass + inner product runs one workgroup per (ciphertext, target modulus, 16-row tile) that walks
+// all digits; a launch too small to fill the chip finishes sooner as the reference's sequence -- the transform of
+// all digits x moduli as independent limbs, then the element-wise inner product (C2, one ciphertext: 39 -> 27 us).
+static bool use_fused_row_mac(const Context& c, int rc, int batch)
+{
+    if (c.fused_row_mac >= 0) return c.fused_row_mac != 0;
+    return (long) batch * rc * (long) (c.n >> 12) >= 128;
+}
+
 static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
                                     int digits, int rc, int split, int level, const u64* ident, u64 ident_stride,
                                     int batch, hipStream_t st, int which = 3)
@@ -37,7 +46,7 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
     const int ppi = digits * rc;
     const int skip_identity = ident ? 1 : 0;
     a.skip_identity = skip_identity;
-    if (!c.fused_row_mac) {
+    if (!use_fused_row_mac(c, rc, batch)) {
         if (ident) TRY(rns_copy_diag(ident, ident_stride, a.out, a.out_item_stride, c.n_power, digits, rc, batch, st));
         TRY(ntt_launch(a, ppi * batch, false, st));
         return rns_keyswitch_mac(a.out, a.out_item_stride, key, acc, acc_stride, c.plan_qp.mods, c.n_power, digits, rc,
@@ -129,7 +138,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
     dgt.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     // When the decomposing column pass is the multi-modulus kernel (one launch for the whole batch), it also
     // finishes the inverse transform of its source tiles: only the row stages of the INTT run on their own.
-    const bool fuse_inv = c.fused_row_mac && c.fuse_inverse && (long) l * rc * batch <= 65535 &&
+    const bool fuse_inv = use_fused_row_mac(c, rc, batch) && c.fuse_inverse && (long) l * rc * batch <= 65535 &&
                           ntt_decomp_uses_multi(dgt, l * rc * batch);
     if (phases & RELIN_PHASE_INTT_C2) {
         if (fuse_inv) TRY(ntt_launch_inv_rows(a, l * batch, st));
@@ -264,7 +273,7 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
     const Mod* mods = c.plan_qp.mods;
     const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
 
-    if (c.fused_row_mac && c.fused_moddown && c.ntt_galois) {
+    if (c.fused_moddown && c.ntt_galois) {
         // The key switch of c1 exactly as relinearize does it (c0 added to part 0 by the mod-down epilogue), all
         // in the NTT domain, and the automorphism last, as a slot gather of both parts.  Against the reference's
         // order (INTT of both parts, ..., INTT of 2 rc limbs, mod-down + permute in the coefficient domain, NTT

@@ -107,10 +107,12 @@ def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi):
 
 # ------------------------------------------------------------------ fusions switched off
 _SWITCHES = [
+    dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1),  # forced: a small launch would pick the other forms
+    dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=0),
     dict(HEGPU_SINGLE_PASS=0),
-    dict(HEGPU_COL_MULTI=1),
-    dict(HEGPU_COL_MULTI=1, HEGPU_FP_NTT=0),
-    dict(HEGPU_COL_MULTI=1, HEGPU_FUSE_INVERSE=0),
+    dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
+    dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1, HEGPU_FP_NTT=0),
+    dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1, HEGPU_FUSE_INVERSE=0),
     dict(HEGPU_NTT_GALOIS=0),
     dict(HEGPU_GALOIS_SCATTER=0),
     dict(HEGPU_FUSED_ROW_MAC=0),
@@ -161,7 +163,8 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
         assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
 
 
-@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=0), dict(HEGPU_FP_NTT=0), dict(HEGPU_COL_MULTI=1),
+@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_FUSED_ROW_MAC=0),
+                                dict(HEGPU_FP_NTT=0), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
                                 dict(HEGPU_SINGLE_PASS=0)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_bfv_sequence_with_fusions_off(hg, oracle, torch, sw):
@@ -198,7 +201,7 @@ def test_keyswitch_mixed_widths_multi_modulus_column_pass(hg, oracle, torch, dep
     0/q-1 patterns, a key of all q-1), N = 2^12 and 2^14."""
     for n in (4096, 16384):
         bits = [60, 50, 36, 45, 55, 49]
-        with backend_switches(HEGPU_COL_MULTI=1):
+        with backend_switches(HEGPU_COL_MULTI=1, HEGPU_FUSED_ROW_MAC=1):
             c, o, primes = _ckks(hg, oracle, n, bits, [60], sec=hg.SEC_NONE)
         Q, Qp = len(bits), len(bits) + 1
         l = Q - depth
@@ -628,40 +631,3 @@ def test_ntt_small_degrees_both_forms(hg, oracle, torch, n_power, single):
     torch.cuda.synchronize()
     assert np.array_equal(hg.to_host(dy), wy)
 
-
-# ------------------------------------------------------------------ hipGraph capture of an operator sequence
-def test_operator_sequence_replays_from_a_hip_graph(hg, oracle, torch):
-    """The operator entries allocate nothing and never synchronise (all temporaries live in the caller's
-    workspace), so a whole multiply -> relinearize -> rescale sequence (config C2's chain, batch 1 -- the
-    launch-bound case) can be captured once on a stream and replayed as one hipGraph launch.  The replay must
-    produce what the directly launched sequence and the oracle produce."""
-    n = 16384
-    c, o, primes = _ckks(hg, oracle, n, [50] + [40] * 7, [50])
-    Q, Qp = 8, 9
-    key = synth_key(primes, Q, Qp, n, 3)
-    ct1, ct2 = synth_ct(primes, range(Q), 2, n, 1), synth_ct(primes, range(Q), 2, n, 2)
-    d1, d2, dk = hg.to_device(ct1), hg.to_device(ct2), hg.to_device(key)
-    ws1, ws2 = c.workspace(hg.OP_CKKS_RELIN, 0, 1), c.workspace(hg.OP_CKKS_RESCALE, 0, 1)
-
-    def seq(out, stream):
-        c.ckks_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, 0, 1, stream=stream)
-        c.ckks_relinearize_inplace(out, 3 * Q * n, dk, 0, 1, ws1, stream=stream)
-        c.ckks_rescale_inplace(out, 3 * Q * n, 0, 1, ws2, stream=stream)
-
-    direct = torch.zeros(3 * Q * n, dtype=torch.int64, device="cuda")
-    seq(direct, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    replayed = torch.zeros(3 * Q * n, dtype=torch.int64, device="cuda")
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        seq(replayed, torch.cuda.current_stream().cuda_stream)
-    replayed.zero_()
-    for _ in range(3):  # a replay recomputes from d1, d2: idempotent
-        graph.replay()
-    torch.cuda.synchronize()
-    want = o.ckks_multiply(ct1, ct2, 0)
-    o.ckks_relinearize(want, key, 0)
-    want = o.ckks_rescale(want[:2 * Q * n].copy(), 0)
-    keep = 2 * (Q - 1) * n
-    assert np.array_equal(hg.to_host(direct)[:keep], want[:keep])
-    assert np.array_equal(hg.to_host(replayed)[:keep], want[:keep])
