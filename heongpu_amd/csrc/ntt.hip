@@ -34,9 +34,6 @@ namespace hegpu {
 // Ablation hooks for tools/exp/ntt_exp.hip (0 in the product build):
 // 1 = memory traffic only (butterflies skipped), 2 = arithmetic only,
 // 3 = data traffic only (no butterflies, no twiddle loads).
-#ifndef KS_EXP
-#define KS_EXP 0
-#endif
 #ifndef NTT_EXP_MODE
 #define NTT_EXP_MODE 0
 #endif
@@ -1003,25 +1000,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
         const u64* px = ident ? a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096 : p;
         u64 xr[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-#if KS_EXP & 1
-            xr[k] = as_bits((double) (t + k + i));
-#else
-            xr[k] = px[row * 256 + i0 + 16 * k];
-#endif
-        }
+        for (int k = 0; k < 16; k++) xr[k] = px[row * 256 + i0 + 16 * k];
         const u64* k0 = pk + key_off2 * i;
         const u64* k1 = k0 + key_off1;
         u64 kv0[16], kv1[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-#if KS_EXP & 2
-            kv0[k] = (u64) (t * 3 + k + i);
-            kv1[k] = (u64) (t * 5 + k + i);
-#else
             kv0[k] = k0[16 * k];
             kv1[k] = k1[16 * k];
-#endif
         }
         if (ident) {
 #pragma unroll
