@@ -429,7 +429,8 @@ size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int ba
 #define CHECK_OP(ctx, want_scheme, op, depth, batch, ws, ws_bytes)                                            \
     do {                                                                                                      \
         if ((ctx)->c.scheme != (want_scheme)) return fail(HEGPU_E_INVALID, "context scheme mismatch");        \
-        if ((batch) <= 0) return fail(HEGPU_E_INVALID, "batch must be positive");                             \
+        if ((batch) < 0) return fail(HEGPU_E_INVALID, "batch must not be negative");                          \
+        if ((batch) == 0) return 0; /* an empty batch is a no-op */                                           \
         if ((depth) < 0 || (depth) >= (ctx)->c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");         \
         if ((op) && (!(ws) || (ws_bytes) < hegpu_workspace_bytes(ctx, op, depth, batch)))                     \
             return fail(HEGPU_E_INVALID, "workspace too small");                                              \
@@ -520,7 +521,8 @@ int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t s1, con
 {
     NEED_CTX(ctx);
     if (ctx->c.scheme != SCHEME_BFV) return fail(HEGPU_E_INVALID, "context scheme mismatch");
-    if (batch <= 0) return fail(HEGPU_E_INVALID, "batch must be positive");
+    if (batch < 0) return fail(HEGPU_E_INVALID, "batch must not be negative");
+    if (batch == 0) return 0;
     if (!ws || ws_bytes < hegpu_workspace_bytes(ctx, OP_BFV_MULTIPLY, 0, batch))
         return fail(HEGPU_E_INVALID, "workspace too small");
     return hip_ret(op_bfv_multiply(ctx->c, (const u64*) ct1, s1, (const u64*) ct2, s2, (u64*) out, so, batch,

@@ -104,6 +104,7 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
 hipError_t op_ckks_multiply(const Context& c, const u64* ct1, u64 s1, const u64* ct2, u64 s2, u64* out, u64 so,
                             int depth, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     return rns_cross_multiplication(ct1, s1, ct2, s2, out, so, c.plan_qp.mods, c.n_power, c.Q_size - depth, batch,
                                     st);
 }
@@ -200,6 +201,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
 hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
                                hipStream_t st, unsigned phases)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const u64 n = c.n;
     const int l = c.Q_size - depth, rc = c.Qp_size - depth;
     const u64 per = ((u64) l * rc + 2 * rc) * n;
@@ -212,6 +214,7 @@ hipError_t op_ckks_relinearize(const Context& c, u64* ct, u64 cs, const u64* key
 // reference ckks/operator.cu:1156-1244
 hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, P = c.P_size;
@@ -262,6 +265,7 @@ hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int bat
 hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                 int galois_elt, int depth, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -312,6 +316,7 @@ hipError_t op_ckks_apply_galois(const Context& c, const u64* ct, u64 cs, u64* ou
 hipError_t op_bfv_multiply(const Context& c, const u64* ct1, u64 s1, const u64* ct2, u64 s2, u64* out, u64 so,
                            int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int L = c.Q_size + c.bsk_size;
@@ -334,6 +339,7 @@ hipError_t op_bfv_multiply(const Context& c, const u64* ct1, u64 s1, const u64* 
 hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
                               hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -358,6 +364,7 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
 hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                int galois_elt, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -393,6 +400,7 @@ static hipError_t dtoq(const Context& c, int lvl, const u64* in, u64 in_stride, 
 hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
                                   hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -429,6 +437,7 @@ hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* 
 hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                    int galois_elt, int depth, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -471,6 +480,7 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
 hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* const* keys,
                                   const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -559,6 +569,7 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
 hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
                                  hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;
@@ -582,6 +593,7 @@ hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* k
 hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* key,
                                   int galois_elt, int batch, u64* ws, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
     const u64 n = c.n;
     const int Q = c.Q_size, Qp = c.Qp_size;

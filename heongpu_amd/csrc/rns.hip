@@ -50,6 +50,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_addition(const u64* __restrict_
 hipError_t rns_addition(const u64* a, const u64* b, u64* out, const Mod* mods, int n_power, int limbs,
                         int parts, int batch, int op, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     dim3 g = grid3(n_power, limbs, parts * batch);
     if (op == 0) hipLaunchKernelGGL(k_addition<0>, g, dim3(RNS_THREADS), 0, st, a, b, out, mods, n_power, limbs);
     else if (op == 1) hipLaunchKernelGGL(k_addition<1>, g, dim3(RNS_THREADS), 0, st, a, b, out, mods, n_power, limbs);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_addition_strided(const u64* a, 
 hipError_t rns_addition_strided(const u64* a, u64 sa, const u64* b, u64 sb, u64* out, u64 so, const Mod* mods,
                                 int n_power, int limbs, int parts, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_addition_strided, grid3(n_power, limbs, parts * batch), dim3(RNS_THREADS), 0, st, a, sa, b,
                        sb, out, so, mods, n_power, limbs, parts);
     return hipGetLastError();
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_cross_multiplication(const u64*
 hipError_t rns_cross_multiplication(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
                                     const Mod* mods, int n_power, int decomp_size, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_cross_multiplication, grid3(n_power, decomp_size, batch), dim3(RNS_THREADS), 0, st, in1,
                        s1, in2, s2, out, so, mods, n_power, decomp_size);
     return hipGetLastError();
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_decompose(const u64* __restrict
 hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods, int n_power,
                          int digits, int nmods, int split, int level, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_decompose, grid3(n_power, digits, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
                        out_stride, mods, n_power, nmods, split, level);
     return hipGetLastError();
@@ -251,6 +255,7 @@ hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* 
                              const Mod* mods, int n_power, int digits, int nmods, int key_limbs, int split,
                              int level, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (digits > 64) return hipErrorInvalidValue; // 128-bit accumulator bound
     // up to four ciphertexts per workgroup share every key load when the batch allows it
     if (batch % 4 == 0) {
@@ -312,6 +317,7 @@ hipError_t rns_divide_round_lastq(const u64* in, u64 in_stride, const u64* ct, u
                                   const u64* last_q_modinv, int n_power, int decomp, int switchkey, int batch,
                                   hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_divide_round_lastq, grid3(n_power, decomp, 2 * batch), dim3(RNS_THREADS), 0, st, in,
                        in_stride, ct, ct_stride, out, out_stride, mods, half, half_mod, last_q_modinv, n_power,
                        decomp, switchkey);
@@ -347,6 +353,7 @@ hipError_t rns_moddown_stage_one(const u64* in, u64 in_stride, u64* out, u64 out
                                  const u64* half, const u64* half_mod, int n_power, int first_decomp,
                                  int cur_decomp, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_moddown_stage_one, grid3(n_power, 2, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
                        out_stride, mods, half, half_mod, n_power, first_decomp, cur_decomp);
     return hipGetLastError();
@@ -385,6 +392,7 @@ hipError_t rns_moddown_stage_two(const u64* in_last, u64 last_stride, const u64*
                                  const u64* last_q_modinv, int n_power, int cur_decomp, int with_ct, int batch,
                                  hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_moddown_stage_two, grid3(n_power, cur_decomp, 2 * batch), dim3(RNS_THREADS), 0, st,
                        in_last, last_stride, in, in_stride, in_limbs, ct, ct_stride, out, out_stride, mods,
                        last_q_modinv, n_power, cur_decomp, with_ct);
@@ -432,6 +440,7 @@ hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out,
                                          const int* I_location, int n_power, int d, int rc, int l, int level,
                                          int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     dim3 g((1u << n_power) / RNS_THREADS, d, batch);
     hipLaunchKernelGGL(k_base_conversion_DtoQtilde, g, dim3(RNS_THREADS), 0, st, in, in_stride, out, out_stride,
                        mods, matrix, mi_inv, prod, I_j, I_location, n_power, rc, l, level);
@@ -490,6 +499,7 @@ hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64
                                 const u64* last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp,
                                 int first_Q, int P_size, int with_ct, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (P_size > 15) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
     hipLaunchKernelGGL(k_moddown_extended, g, dim3(RNS_THREADS), 0, st, in, in_stride, ct, ct_stride, out,
@@ -536,6 +546,7 @@ hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64
                                const u64* last_q_modinv, int galois_elt, int n_power, int Qp_cur, int Q_cur,
                                int first_Qp, int first_Q, int P_size, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
     if (P_size > 15) return hipErrorInvalidValue;
     if (P_size == 1)
@@ -563,6 +574,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_copy_limbs(const u64* __restric
 hipError_t rns_copy_limbs(const u64* in, u64 in_part_stride, u64 in_stride, u64* out, u64 out_part_stride,
                           u64 out_stride, int n_power, int limbs, int parts, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_copy_limbs, grid3(n_power, limbs, parts * batch), dim3(RNS_THREADS), 0, st, in,
                        in_part_stride, in_stride, out, out_part_stride, out_stride, n_power, parts);
     return hipGetLastError();
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_permute_ntt(const u64* __restri
 hipError_t rns_permute_ntt(const u64* in, u64 in_stride, u64* out, u64 out_stride, int galois_elt, int n_power,
                            int limbs, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_permute_ntt, grid3(n_power, limbs, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
                        out_stride, n_power, (u32) galois_elt);
     return hipGetLastError();
@@ -611,6 +624,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_copy_diag(const u64* __restrict
 hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride, int n_power, int limbs, int rc,
                          int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     hipLaunchKernelGGL(k_copy_diag, grid3(n_power, limbs, batch), dim3(RNS_THREADS), 0, st, in, in_stride, out,
                        out_stride, n_power, rc);
     return hipGetLastError();
@@ -698,6 +712,7 @@ static int behz_slots(int m)
 hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
                                const BehzDev& b, int n_power, int batch, hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 4, batch);
 #define LAUNCH(M) hipLaunchKernelGGL(k_fast_convertion<M>, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
@@ -803,6 +818,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
 hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev& b, int n_power, int batch,
                           hipStream_t st)
 {
+    if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1 || b.obase_size < 2)
         return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, 3, batch);

@@ -12,7 +12,8 @@
  *  - all data is uint64 residues in the reference's limb-major planar layout:
  *    element [part][limb][coeff] of a ciphertext at
  *    coeff + (limb << n_power) + part * (limbs << n_power);
- *  - batched calls take `batch` ciphertexts `*_stride` ELEMENTS apart;
+ *  - batched calls take `batch` ciphertexts `*_stride` ELEMENTS apart (batch == 0: nothing is launched, the call
+ *    succeeds; batch < 0: an error);
  *  - every call is asynchronous on `stream`; return value 0 = success,
  *    otherwise a hipError_t code (or HEGPU_E_* below); hegpu_last_error()
  *    returns a message for the calling thread;

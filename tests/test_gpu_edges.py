@@ -1,0 +1,140 @@
+"""Edge cases of the operator entries on the GPU: empty batches, the deepest level (one limb left), a one-prime
+chain, the smallest and the largest ring, the smallest prime size the reference accepts (30 bits) next to the
+largest (60), a batch beyond one launch's grid -- each compared limb for limb with the oracle."""
+import numpy as np
+import pytest
+
+from helpers import synth_ct, synth_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _ckks(hg, oracle, n, log_q, log_p):
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, log_p, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, c.n_power, primes, len(log_q), len(log_p))
+    c.upload()
+    return c, o, primes
+
+
+def test_empty_batch_is_a_no_op(hg, oracle, torch):
+    """batch == 0: every operator entry returns success and touches nothing."""
+    n = 4096
+    c, o, primes = _ckks(hg, oracle, n, [40, 30, 30], [40])
+    Q, Qp = 3, 4
+    sentinel = 0x5A5A5A5A5A5A5A5A
+    out = torch.full((3 * Q * n,), sentinel, dtype=torch.int64, device="cuda")
+    src = hg.to_device(synth_ct(primes, range(Q), 3, n, 1))
+    key = hg.to_device(synth_key(primes, Q, Qp, n, 2))
+    ws = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(src, 2 * Q * n, src, 2 * Q * n, out, 3 * Q * n, 0, 0)
+    c.ckks_relinearize_inplace(out, 3 * Q * n, key, 0, 0, ws)
+    c.ckks_rescale_inplace(out, 3 * Q * n, 0, 0, ws)
+    c.ckks_apply_galois(src, 2 * Q * n, out, 2 * Q * n, key, 3, 0, 0, ws)
+    c.ntt(out, out, False, 0, Q)
+    torch.cuda.synchronize()
+    assert bool((out == sentinel).all())
+
+
+@pytest.mark.parametrize("n", [4096, 65536])
+def test_deepest_level_and_one_prime_chain(hg, oracle, torch, n):
+    """l = 1 (depth Q - 1): relinearize and rotate on the last remaining limb; rescale from two limbs to one;
+    and a chain that only ever has one prime (Q = 1, P = 1).  Smallest and largest ring."""
+    c, o, primes = _ckks(hg, oracle, n, [45, 30, 36], [45])
+    Q, Qp = 3, 4
+    key = synth_key(primes, Q, Qp, n, 3)
+    gkey = synth_key(primes, Q, Qp, n, 4)
+    g = hg.steps_to_galois_elt(1, n, 5)
+    for depth in (2, 1):
+        l = Q - depth
+        a, b = synth_ct(primes, range(l), 2, n, 10 + depth), synth_ct(primes, range(l), 2, n, 20 + depth)
+        out = torch.empty(3 * l * n, dtype=torch.int64, device="cuda")
+        c.ckks_multiply(hg.to_device(a), 2 * l * n, hg.to_device(b), 2 * l * n, out, 3 * l * n, depth, 1)
+        c.ckks_relinearize_inplace(out, 3 * l * n, hg.to_device(key), depth, 1, c.workspace(hg.OP_CKKS_RELIN, depth, 1))
+        torch.cuda.synchronize()
+        want = o.ckks_relinearize(o.ckks_multiply(a, b, depth), key, depth)
+        got = hg.to_host(out)
+        assert np.array_equal(got[:2 * l * n], want[:2 * l * n]), ("relinearize", depth)
+        rot = torch.empty(2 * l * n, dtype=torch.int64, device="cuda")
+        c.ckks_apply_galois(hg.to_device(a), 2 * l * n, rot, 2 * l * n, hg.to_device(gkey), g, depth, 1,
+                            c.workspace(hg.OP_CKKS_GALOIS, depth, 1))
+        torch.cuda.synchronize()
+        assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois(a, gkey, g, depth)), ("rotate", depth)
+        if l == 2:
+            c.ckks_rescale_inplace(out, 3 * l * n, depth, 1, c.workspace(hg.OP_CKKS_RESCALE, depth, 1))
+            torch.cuda.synchronize()
+            w = o.ckks_rescale(want[:2 * l * n].copy(), depth)
+            assert np.array_equal(hg.to_host(out)[:2 * n], w[:2 * n]), "rescale to one limb"
+    c.close()
+    c, o, primes = _ckks(hg, oracle, n, [50], [51])
+    key = synth_key(primes, 1, 2, n, 5)
+    a, b = synth_ct(primes, range(1), 2, n, 6), synth_ct(primes, range(1), 2, n, 7)
+    out = torch.empty(3 * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(hg.to_device(a), 2 * n, hg.to_device(b), 2 * n, out, 3 * n, 0, 1)
+    c.ckks_relinearize_inplace(out, 3 * n, hg.to_device(key), 0, 1, c.workspace(hg.OP_CKKS_RELIN, 0, 1))
+    torch.cuda.synchronize()
+    want = o.ckks_relinearize(o.ckks_multiply(a, b, 0), key, 0)
+    assert np.array_equal(hg.to_host(out)[:2 * n], want[:2 * n]), "Q = 1"
+
+
+def test_smallest_and_largest_prime_sizes_together(hg, oracle, torch):
+    """30-bit primes (the reference's minimum, ckks/context.cu:100-110) next to 60-bit ones: narrow FP64 targets
+    fed by wide digits and the other way round, through multiply -> relinearize -> rescale -> rotate."""
+    n = 8192
+    bits = [60, 30, 30, 31, 60, 30]
+    c, o, primes = _ckks(hg, oracle, n, bits, [60])
+    Q, Qp = len(bits), len(bits) + 1
+    key, gkey = synth_key(primes, Q, Qp, n, 3), synth_key(primes, Q, Qp, n, 4)
+    batch = 2
+    a = [synth_ct(primes, range(Q), 2, n, 30 + i) for i in range(batch)]
+    b = [synth_ct(primes, range(Q), 2, n, 40 + i) for i in range(batch)]
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(hg.to_device(np.concatenate(a)), 2 * Q * n, hg.to_device(np.concatenate(b)), 2 * Q * n, out, 3 * Q * n, 0, batch)
+    c.ckks_relinearize_inplace(out, 3 * Q * n, hg.to_device(key), 0, batch, c.workspace(hg.OP_CKKS_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    want = [o.ckks_relinearize(o.ckks_multiply(a[i], b[i], 0), key, 0) for i in range(batch)]
+    for i in range(batch):
+        assert np.array_equal(got[i][:2 * Q * n], want[i][:2 * Q * n]), ("relinearize", i)
+    c.ckks_rescale_inplace(out, 3 * Q * n, 0, batch, c.workspace(hg.OP_CKKS_RESCALE, 0, batch))
+    g = hg.steps_to_galois_elt(-3, n, 5)
+    rot = torch.empty(batch * 2 * Q * n, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(hg.to_device(np.concatenate(a)), 2 * Q * n, rot, 2 * Q * n, hg.to_device(gkey), g, 0, batch,
+                        c.workspace(hg.OP_CKKS_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    got, gr = hg.to_host(out).reshape(batch, -1), hg.to_host(rot).reshape(batch, -1)
+    for i in range(batch):
+        w = o.ckks_rescale(want[i][:2 * Q * n].copy(), 0)
+        assert np.array_equal(got[i][:2 * (Q - 1) * n], w[:2 * (Q - 1) * n]), ("rescale", i)
+        assert np.array_equal(gr[i], o.ckks_apply_galois(a[i], gkey, g, 0)), ("rotate", i)
+
+
+def test_batch_beyond_one_grid(hg, oracle, torch):
+    """More polynomials than one launch's grid holds (65535): a plain NTT of 70 000 limbs at N = 2^12 is cut into
+    pieces on modulus-cycle boundaries; sampled limbs against the oracle, the round trip for all of them."""
+    n, limbs = 4096, 70000
+    c, o, primes = _ckks(hg, oracle, n, [40, 30, 30, 30], [40])
+    mc = 5
+    assert limbs % mc == 0
+    rng = np.random.default_rng(11)
+    x = np.empty(limbs * n, dtype=np.uint64)
+    v = x.reshape(limbs, n)
+    for j in range(mc):
+        v[j::mc] = rng.integers(0, primes[j], (limbs // mc, n), dtype=np.uint64)
+    d = hg.to_device(x)
+    y = torch.empty_like(d)
+    c.ntt(d, y, False, limbs, mc)
+    torch.cuda.synchronize()
+    got = hg.to_host(y).reshape(limbs, n)
+    for i in (0, 1, 4, 32767, 65534, 65535, 65536, 69999):
+        assert np.array_equal(got[i], o.ntt(v[i].copy(), 1, 1, mod_offset=i % mc)), i
+    c.ntt(y, y, True, limbs, mc)
+    torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(y), x)
