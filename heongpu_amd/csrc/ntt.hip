@@ -525,32 +525,52 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
 
-// Store of the forward row pass: plain, or through the mod-down epilogue (NttEpilogue).
-// `e` = element offset inside the limb; x canonical.
-__device__ __forceinline__ void row_store(const NttArgs& a, const PolySel& ps, const Mod& md, u64* __restrict__ p, u64 e,
-                                          u64 x)
+// Store of the forward row pass: plain, or through the mod-down epilogue (NttEpilogue).  The thread's 16
+// canonical results sit in the row tile `lds` at row_phys(row * 256 + i0 + 16 k); e0 = element offset of k = 0
+// inside the limb.  The epilogue's operands (16 accumulator values, 16 of the added ciphertext) are requested
+// eight at a time before anything is computed: one memory latency per half instead of one per element.
+__device__ __forceinline__ void row_store_all(const NttArgs& a, const PolySel& ps, const Mod& md, u64* __restrict__ p,
+                                              u64 e0, const u64* lds, int row, int i0)
 {
     if (!a.epi.on) {
-        gst(&p[e], x);
+#pragma unroll
+        for (int k = 0; k < 16; k++) gst(&p[e0 + 16 * k], lds[row_phys(row * 256 + i0 + 16 * k)]);
         return;
     }
     const NttEpilogue& ep = a.epi;
     const int part = udiv16(ps.j, ep.mg_limbs), limb = ps.j - part * ep.limbs;
-    const u64 ks = ep.ks[ep.ks_item_stride * ps.item + ((u64) (part * ep.ks_part_limbs + limb) << a.n_power) + e];
-    const u64 off = ((u64) (part * ep.limbs + limb) << a.n_power) + e;
-    u64 r = mul_barrett(sub_mod(ks, x, md.q), ep.inv[ps.mod], md);
-    if (ep.ct && (!ep.ct_parts || part < ep.ct_parts)) r = add_mod(ep.ct[ep.ct_item_stride * ps.item + off], r, md.q);
-    u64 dst = off;
-    if (ep.galois_inv) {
-        const u32 ex = ((2u * (__brev((u32) e) >> (32 - a.n_power)) + 1u) * ep.galois_inv) & ((2u << a.n_power) - 1u);
-        dst = off - e + (__brev((ex - 1u) >> 1) >> (32 - a.n_power));
+    const u64* __restrict__ ks = ep.ks + ep.ks_item_stride * ps.item + ((u64) (part * ep.ks_part_limbs + limb) << a.n_power) + e0;
+    const u64 off = ((u64) (part * ep.limbs + limb) << a.n_power);
+    const bool with_ct = ep.ct && (!ep.ct_parts || part < ep.ct_parts);
+    const u64* ct = with_ct ? ep.ct + ep.ct_item_stride * ps.item + off + e0 : nullptr; // may alias out: no __restrict__
+    u64* out = ep.out + ep.out_item_stride * ps.item + off;
+    const u64 inv = ep.inv[ps.mod];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u64 kv[8], cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) kv[k] = ks[16 * (8 * h + k)];
+        if (with_ct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[k] = ct[16 * (8 * h + k)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int kk = 8 * h + k;
+            const u64 x = lds[row_phys(row * 256 + i0 + 16 * kk)];
+            u64 r = mul_barrett(sub_mod(kv[k], x, md.q), inv, md);
+            if (with_ct) r = add_mod(cv[k], r, md.q);
+            const u64 e = e0 + 16 * kk;
+            u64 dst = e;
+            if (ep.galois_inv) {
+                const u32 ex = ((2u * (__brev((u32) e) >> (32 - a.n_power)) + 1u) * ep.galois_inv) & ((2u << a.n_power) - 1u);
+                dst = __brev((ex - 1u) >> 1) >> (32 - a.n_power);
+            }
+            out[dst] = r;
+        }
     }
-    ep.out[ep.out_item_stride * ps.item + dst] = r;
 }
 
-// Row pass: stages S1..S1+7 on contiguous rows of 256, 16 rows per block.
-// Values arrive lazily reduced from the column pass; the result is canonical.
-// grid = (N/4096, batch); in place on a.out.
 template <bool LAZY>
 __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
 {
@@ -596,10 +616,7 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
         *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
             make_ulonglong2(x[2 * k], x[2 * k + 1]);
     wave_lds_fence();
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        row_store(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0 + 16 * k,
-                  lds[row_phys(row * 256 + i0 + 16 * k)]);
+    row_store_all(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0, lds, row, i0);
 #endif
 }
 
@@ -634,10 +651,7 @@ __device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel&
         *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) =
             make_ulonglong2(fp_to_u64(x[2 * k]), fp_to_u64(x[2 * k + 1]));
     wave_lds_fence();
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        row_store(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0 + 16 * k,
-                  lds[row_phys(row * 256 + i0 + 16 * k)]);
+    row_store_all(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0, lds, row, i0);
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
@@ -783,10 +797,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
     for (int k = 0; k < 8; k++)
         *reinterpret_cast<ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]) = make_ulonglong2(r[2 * k], r[2 * k + 1]);
     wave_lds_fence();
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        row_store(a, ps, md, a.out + ps.out_off, (u64) g * 4096 + row * 256 + i0 + 16 * k,
-                  lds[row_phys(row * 256 + i0 + 16 * k)]);
+    row_store_all(a, ps, md, a.out + ps.out_off, (u64) g * 4096 + row * 256 + i0, lds, row, i0);
 }
 
 // grid = batch polynomials, N / 16 threads, N * 8 bytes of dynamic LDS
