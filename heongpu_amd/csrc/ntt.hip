@@ -386,13 +386,27 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     // range does not cover v + q - half_mod for a 60-bit source modulus
     const u64 half_qP = a.half_on ? a.mods[a.half_src_mod].q : 0;
     const u64 half_hm = a.half_on ? a.half_mod[ps.mod] : 0;
-    auto ld = [&](const u64* p, int si) -> u64 {
-        u64 v = SREG ? sreg[si] : gld(p);
-        if (DECOMP && a.half_on) v = sub_mod(reduce64(add_mod(v, a.half, half_qP), md), half_hm, md.q);
-        return v;
-    };
+    // all 16 loads in one block, then (uniform condition, one branch) the mod-down load transform: a branch per
+    // element would serialise the loads -- one memory latency each
     u64 x[16];
     const int col = t % CT, r1 = t / CT;
+    u64 v[16];
+    if constexpr (NSA > 0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int L = t + NTT_THREADS * g;
+            const int c = L % CT, rb = L / CT;
+#pragma unroll
+            for (int k = 0; k < RA; k++) v[g * RA + k] = SREG ? sreg[g * RA + k] : gld(&src[(u64) (rb + 16 * k) * 256 + c]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = SREG ? sreg[k] : gld(&src[(u64) k * 256 + col]);
+    }
+    if (DECOMP && a.half_on) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = sub_mod(reduce64(add_mod(v[k], a.half, half_qP), md), half_hm, md.q);
+    }
     if constexpr (NSA > 0) {
         // round A: G groups of radix RA, rows rbase + 16k
 #pragma unroll
@@ -401,7 +415,7 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
             const int c = L % CT, rb = L / CT;
             u64 y[RA];
 #pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = ld(&src[(u64) (rb + 16 * k) * 256 + c], g * RA + k);
+            for (int k = 0; k < RA; k++) y[k] = v[g * RA + k];
             // DECOMP: the digit (< 2^60, a residue of another prime) is NOT reduced
             // first: the lazy butterflies only need x < 8q (q >= 2^57 here) or, on
             // the correction-free path, x + 64q < 2^64; congruence mod q is kept
@@ -416,7 +430,7 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
         if (SREG) __syncthreads();
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = ld(&src[(u64) k * 256 + col], k);
+        for (int k = 0; k < 16; k++) x[k] = v[k];
     }
     ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
@@ -456,22 +470,38 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     const double half_hm = (DECOMP && a.half_on) ? fp_from_u64(a.half_mod[ps.mod]) : 0.0;
     // SREG: `sreg` holds the thread's 16 source coefficients, the mod-down half already added: for a
     // source modulus of at most 52 bits as the bits of the converted double, for a wider one as u64
-    auto load = [&](const u64* p, int si) -> double {
-        double r;
+    // CNT source values -> reduced doubles.  The loads first, then (uniform conditions, one branch each around a
+    // whole loop) the mod-down "+ half" / "- half mod q_j": a branch per element would split the loads into one
+    // basic block -- one memory latency -- each.
+    auto load_all = [&](auto& y, auto addr, int si0) {
+        constexpr int CNT = sizeof(y) / sizeof(y[0]);
         if constexpr (SREG && !WIDE) {
-            r = fp_reduce(as_f64(sreg[si]), fc);
+#pragma unroll
+            for (int k = 0; k < CNT; k++) y[k] = fp_reduce(as_f64(sreg[si0 + k]), fc);
         } else {
-            u64 v = SREG ? sreg[si] : *p;
-            // keep the split conversion of a wide source inside the iteration (hoisted out of the modulus
-            // loop it would pin 64 more registers per lane for all of it)
-            if constexpr (SREG) asm volatile("" : "+v"(v));
-            if (!SREG && DECOMP && a.half_on) v = add_mod(v, a.half, half_qP);
-            if constexpr (DECOMP && WIDE) r = fp_mul(fp_from_u32((u32) (v >> 32)), c32, c32i, fc) + fp_from_u32((u32) v);
-            else if constexpr (DECOMP) r = fp_reduce(fp_from_u64(v), fc);
-            else r = fp_from_u64(v);
+            u64 v[CNT];
+#pragma unroll
+            for (int k = 0; k < CNT; k++) {
+                v[k] = SREG ? sreg[si0 + k] : *addr(k);
+                // keep the split conversion of a wide source inside the iteration (hoisted out of the modulus
+                // loop it would pin 64 more registers per lane for all of it)
+                if constexpr (SREG) asm volatile("" : "+v"(v[k]));
+            }
+            if (!SREG && DECOMP && a.half_on) {
+#pragma unroll
+                for (int k = 0; k < CNT; k++) v[k] = add_mod(v[k], a.half, half_qP);
+            }
+#pragma unroll
+            for (int k = 0; k < CNT; k++) {
+                if constexpr (DECOMP && WIDE) y[k] = fp_mul(fp_from_u32((u32) (v[k] >> 32)), c32, c32i, fc) + fp_from_u32((u32) v[k]);
+                else if constexpr (DECOMP) y[k] = fp_reduce(fp_from_u64(v[k]), fc);
+                else y[k] = fp_from_u64(v[k]);
+            }
         }
-        if (DECOMP && a.half_on) r = fp_reduce(r - half_hm, fc);
-        return r;
+        if (DECOMP && a.half_on) {
+#pragma unroll
+            for (int k = 0; k < CNT; k++) y[k] = fp_reduce(y[k] - half_hm, fc);
+        }
     };
 
     double x[16];
@@ -487,8 +517,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
             const int L = t + NTT_THREADS * g;
             const int c = L % CT, rb = L / CT;
             double y[RA];
-#pragma unroll
-            for (int k = 0; k < RA; k++) y[k] = load(&src[(u64) (rb + 16 * k) * 256 + c], g * RA + k);
+            load_all(y, [&](int k) { return &src[(u64) (rb + 16 * k) * 256 + c]; }, g * RA);
             fp_ct_radix<NSA>(y, tw, 1u, fc);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
@@ -500,8 +529,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
         if (SREG) __syncthreads();
         fp_ct_radix<4>(x, twl, (u32) (RA + r1), fc);
     } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = load(&src[(u64) k * 256 + col], k);
+        load_all(x, [&](int k) { return &src[(u64) k * 256 + col]; }, 0);
         fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
     }
 #pragma unroll
@@ -554,19 +582,26 @@ __device__ __forceinline__ void row_store_all(const NttArgs& a, const PolySel& p
 #pragma unroll
             for (int k = 0; k < 8; k++) cv[k] = ct[16 * (8 * h + k)];
         }
+        // (uniform conditions around whole loops: a branch per element would split the loads and stores into
+        // sixteen basic blocks again)
+        u64 r[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int kk = 8 * h + k;
-            const u64 x = lds[row_phys(row * 256 + i0 + 16 * kk)];
-            u64 r = mul_barrett(sub_mod(kv[k], x, md.q), inv, md);
-            if (with_ct) r = add_mod(cv[k], r, md.q);
-            const u64 e = e0 + 16 * kk;
-            u64 dst = e;
-            if (ep.galois_inv) {
-                const u32 ex = ((2u * (__brev((u32) e) >> (32 - a.n_power)) + 1u) * ep.galois_inv) & ((2u << a.n_power) - 1u);
-                dst = __brev((ex - 1u) >> 1) >> (32 - a.n_power);
+        for (int k = 0; k < 8; k++)
+            r[k] = mul_barrett(sub_mod(kv[k], lds[row_phys(row * 256 + i0 + 16 * (8 * h + k))], md.q), inv, md);
+        if (with_ct) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = add_mod(cv[k], r[k], md.q);
+        }
+        if (ep.galois_inv) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 e = (u32) e0 + 16 * (8 * h + k);
+                const u32 ex = ((2u * (__brev(e) >> (32 - a.n_power)) + 1u) * ep.galois_inv) & ((2u << a.n_power) - 1u);
+                out[__brev((ex - 1u) >> 1) >> (32 - a.n_power)] = r[k];
             }
-            out[dst] = r;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) out[e0 + 16 * (8 * h + k)] = r[k];
         }
     }
 }
