@@ -532,7 +532,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                      const int* __restrict__ in_b,
                                                                      const u64* __restrict__ prepared,
                                                                      int* __restrict__ out_a, int* __restrict__ out_b,
-                                                                     TfheDev p, int encoded, int shape, int exp_mode)
+                                                                     TfheDev p, int encoded, int shape)
 {
     if (prepared[0] != 1) return; // integer-layout key: k_tfhe_blind_rotate runs instead
     const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
@@ -567,14 +567,15 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // key polynomials of this wavefront: [(i,y,z)][o = 2c+half][k][lane].  The per-CU load
         // pipeline (~20 GB/s of L2 hits) cannot stream 128 KiB per gate and iteration, so the
         // 64 values a lane needs stay in registers for the TF_G gates of the workgroup.
-        // kv[r] = key polynomial of output (wv + r) & 3: r = 0 is this wavefront's own output
-        const u64* bkp = bk + ((((u64) i * 2 + y) * 2 + z) * 4) * TF_N + lane;
+        // kv[r] = key polynomial (digit wavefront (wv + r) & 3, output wv): every wavefront sums ITS output over
+        // the four transformed digits (read from the other wavefronts' staging areas) in registers
+        const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
         double kv[4][16];
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                kv[r][k] = (exp_mode & 1) ? 3.0 : as_f64(bkp[(u64) ((wv + r) & 3) * TF_N + k * 64]);
+                kv[r][k] = as_f64(bkp[(u64) (((wv + r) & 3) * 4) * TF_N + k * 64]);
         for (int gi = 0; gi < ng; gi++) {
             const int aN = modswitch(in_a[(u64) (g0 + gi) * n + i], 10);
             double x[16];
@@ -592,22 +593,25 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 x[k] = (double) d;
             }
             fwave_ntt1024(x, buf[wv], p.ftw, TW_LDS ? twf : p.ftw, fc, lane);
-            // x is the "twiddle" of the products: companion RN(x/p') ~ x * RN(1/p'), recomputed
-            // per product (one multiply) rather than held in 32 more registers
-            // own output first (plain store into the own staging area, free after the transform)
+            // The transformed digit goes to the own staging area (free after the transform); after the barrier
+            // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
+            // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
+            // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
 #pragma unroll
-            for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc));
+            for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
             __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc);
 #pragma unroll
             for (int r = 1; r < 4; r++) {
-                double* ob = reinterpret_cast<double*>(&buf[(wv + r) & 3][lane]);
+                const u64* ob = &buf[(wv + r) & 3][lane];
 #pragma unroll
-                for (int k = 0; k < 16; k++) atomicAdd(&ob[k * 64], fp_mul(kv[r][k], x[k], x[k] * fc.qi, fc));
+                for (int k = 0; k < 16; k++) {
+                    const double xo = as_f64(ob[k * 64]);
+                    x[k] += fp_mul(kv[r][k], xo, xo * fc.qi, fc);
+                }
             }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = as_f64(buf[wv][k * 64 + lane]);
-            wave_fence();
+            __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
             fwave_intt1024(x, buf[wv], p.fitw, TW_LDS ? twi : p.fitw, p.fninv, p.fw1ninv, fc, lane);
             // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
 #pragma unroll
@@ -876,17 +880,16 @@ hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b,
                              int* out_b, int encoded, int shape, hipStream_t st)
 {
     // both kernels cover all gates; the one whose key layout is absent exits at once
-    static const int exp_mode = getenv("HEGPU_TFHE_EXP") ? atoi(getenv("HEGPU_TFHE_EXP")) : 0; // timing ablations only
     // one gate per workgroup: measured faster than four gates sharing the key registers at every
     // batch size (64 k vs 53 k gates/s at 4096 gates; 7.4 ms for a batch of 8); the shared
     // variant stays selectable for experiments
     static const int g4_min = getenv("HEGPU_TFHE_G4_MIN") ? atoi(getenv("HEGPU_TFHE_G4_MIN")) : 0x7fffffff;
     if (shape >= g4_min)
         hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<4>, dim3((shape + 3) / 4), dim3(TF_THREADS), 0, st, in_a, in_b,
-                           bk_prepared, out_a, out_b, p, encoded, shape, exp_mode);
+                           bk_prepared, out_a, out_b, p, encoded, shape);
     else
         hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<1>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
-                           out_a, out_b, p, encoded, shape, exp_mode);
+                           out_a, out_b, p, encoded, shape);
     hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
                        out_b, p, encoded);
     return hipGetLastError();
