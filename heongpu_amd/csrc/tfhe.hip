@@ -255,12 +255,11 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = lane + 64 * k;
-            int r;
-            if (aN < TF_N) r = (j < aN) ? -acc[y][TF_N - aN + j] : acc[y][j - aN];
-            else {
-                const int m = aN - TF_N;
-                r = (j < m) ? acc[y][TF_N - m + j] : -acc[y][j - m];
-            }
+            // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
+            // arithmetic and a select (branches per element would put every LDS read in its own basic block)
+            const int idx = (j - aN) & (2 * TF_N - 1);
+            const int v = acc[y][idx & (TF_N - 1)];
+            const int r = (idx & TF_N) ? -v : v;
             const u32 diff = (u32) r - (u32) acc[y][j];
             const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
             x[k] = (d < 0) ? (u64) (c.q + (long long) d) : (u64) d;
@@ -582,12 +581,11 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int j = lane + 64 * k;
-                int r;
-                if (aN < TF_N) r = (j < aN) ? -acc[gi][y][TF_N - aN + j] : acc[gi][y][j - aN];
-                else {
-                    const int m = aN - TF_N;
-                    r = (j < m) ? acc[gi][y][TF_N - m + j] : -acc[gi][y][j - m];
-                }
+                // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
+                // arithmetic and a select (branches per element would put every LDS read in its own basic block)
+                const int idx = (j - aN) & (2 * TF_N - 1);
+                const int v = acc[gi][y][idx & (TF_N - 1)];
+                const int r = (idx & TF_N) ? -v : v;
                 const u32 diff = (u32) r - (u32) acc[gi][y][j];
                 const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
                 x[k] = (double) d;
