@@ -507,6 +507,8 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     p.count = cnt;
     p.has_fp = p.has_int = 0;
     for (int k = 0; k < cnt; k++) (hm[k].fp ? p.has_fp : p.has_int) = 1;
+    p.fp.assign(cnt, 0);
+    for (int k = 0; k < cnt; k++) p.fp[k] = hm[k].fp ? 1 : 0;
     hipError_t e;
     if ((e = to_device(hm, &p.mods)) != hipSuccess) return e;
     if ((e = to_device(htw, &p.tw)) != hipSuccess) return e;

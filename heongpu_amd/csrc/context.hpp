@@ -30,6 +30,7 @@ struct NttPlan {
     ulonglong2* w1ninv = nullptr;
     int count = 0;
     int has_fp = 0, has_int = 0; // moduli on the FP64 / on the integer butterflies
+    std::vector<unsigned char> fp; // host copy of Mod::fp per modulus
 };
 
 struct Context {

@@ -541,7 +541,16 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
 {
     __shared__ u64 lds[(S1 > 4) ? COL_LDS_ELEMS : 1];
     __shared__ ulonglong2 twl[(S1 > 4) ? 256 : 1]; // second-round twiddles of the FP64 path
-    const PolySel ps = select_poly(a, blockIdx.y);
+    int poly = blockIdx.y;
+    if (DECOMP && a.only_int && a.int_slot_count > 0) {
+        // compact grid over (item, digit, integer slot)
+        const int cnt = a.int_slot_count, digits = a.polys_per_item / a.decomp_mods;
+        const int per_item = digits * cnt;
+        const int item = poly / per_item, r = poly - item * per_item;
+        const int digit = r / cnt, w = r - digit * cnt;
+        poly = item * a.polys_per_item + digit * a.decomp_mods + a.int_slots[w];
+    }
+    const PolySel ps = select_poly(a, poly);
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (DECOMP && a.only_int && md.fp) return; // done by ntt_fwd_col_multi
@@ -1503,12 +1512,15 @@ static void launch_col_multi(const NttArgs& a, int batch, hipStream_t st)
     constexpr int CT = 4096 >> S1;
     if (a.plan_has_fp)
         hipLaunchKernelGGL((ntt_fwd_col_multi<S1>), dim3(256 / CT, batch / a.decomp_mods), dim3(NTT_THREADS), 0, st, a);
-    if (a.plan_has_int || !a.plan_has_fp) {
+    if ((a.plan_has_int || !a.plan_has_fp) && !(a.plan_has_fp && a.int_slot_count < 0)) {
         NttArgs c = a;
         c.group_span = 0;
         c.mg_group_span = 0;
         c.only_int = a.plan_has_fp;
-        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, c);
+        int polys = batch;
+        if (c.only_int && a.int_slot_count > 0) polys = batch / a.decomp_mods * a.int_slot_count;
+        else c.int_slot_count = 0;
+        hipLaunchKernelGGL((ntt_fwd_col<S1, true>), dim3(256 / CT, polys), dim3(NTT_THREADS), 0, st, c);
     }
 }
 

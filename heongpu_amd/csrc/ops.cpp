@@ -39,6 +39,21 @@ static bool use_fused_row_mac(const Context& c, int rc, int batch)
     return (long) batch * rc * (long) (c.n >> 12) >= 128;
 }
 
+// The target slots of a decomposing launch over the Q' chain whose moduli run on the integer butterflies
+// (NttArgs::int_slots).  `order`: host copy of the launch's mod_order (nullptr: slot k is modulus k).
+static void fill_int_slots(const Context& c, NttArgs& a, const u64* order)
+{
+    int cnt = 0;
+    for (int k = 0; k < a.decomp_mods; k++) {
+        const int m = a.mod_offset + (order ? (int) order[k] : k);
+        if (m < 0 || m >= (int) c.plan_qp.fp.size()) { a.int_slot_count = 0; return; }
+        if (c.plan_qp.fp[m]) continue;
+        if (cnt == 8) { a.int_slot_count = 0; return; } // more than the list holds: full grid
+        a.int_slots[cnt++] = k;
+    }
+    a.int_slot_count = cnt ? cnt : -1;
+}
+
 static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
                                     int digits, int rc, int split, int level, const u64* ident, u64 ident_stride,
                                     int batch, hipStream_t st, int which = 3)
@@ -137,6 +152,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
     dgt.in = temp2; dgt.out = temp1; dgt.mod_count = rc; dgt.polys_per_item = l * rc; dgt.decomp_mods = rc;
     dgt.in_item_stride = per; dgt.out_item_stride = per;
     dgt.mod_order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    fill_int_slots(c, dgt, c.h64("new_prime_locations").data() + prime_loc_offset(c, depth));
     // When the decomposing column pass is the multi-modulus kernel (one launch for the whole batch), it also
     // finishes the inverse transform of its source tiles: only the row stages of the INTT run on their own.
     const bool fuse_inv = use_fused_row_mac(c, rc, batch) && c.fuse_inverse && (long) l * rc * batch <= 65535 &&
@@ -161,6 +177,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
     md.in_item_stride = md.out_item_stride = per;
     md.decomp_mods = l; md.decomp_in_mul = l + 1; md.decomp_in_add = l;
     md.half_on = 1; md.half_src_mod = Q;
+    fill_int_slots(c, md, nullptr);
     const bool fuse_inv_p = c.fused_moddown && c.fuse_inverse && (long) 2 * l * batch <= 65535 &&
                             ntt_decomp_uses_multi(md, 2 * l * batch);
     if (phases & RELIN_PHASE_INTT_P) {
@@ -189,6 +206,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
         a.epi.limbs = l;
         a.epi.galois_inv = galois_elt ? (unsigned) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0u;
         a.src_inv = fuse_inv_p ? 1 : 0;
+        fill_int_slots(c, a, nullptr);
         return ntt_launch(a, 2 * l * batch, false, st);
     }
     if (add_parts != 2 || galois_elt) return hipErrorInvalidValue; // the stand-alone stage two adds both parts (relinearize only)
