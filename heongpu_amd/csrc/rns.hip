@@ -510,6 +510,7 @@ hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64
 
 // ---------------------------------------------------------------- mod-down + Galois permutation
 // One coefficient per thread: the destination index i*g mod N scatters.
+#define MDP_PER 4
 template <bool SINGLE_P>
 __global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
     const u64* __restrict__ in, u64 in_stride, const u64* __restrict__ in2, u64 in2_stride, u64* __restrict__ out,
@@ -517,28 +518,41 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
     const u64* __restrict__ last_q_modinv, int galois_elt, int n_power, int Qp_cur, int Q_cur, int first_Qp,
     int first_Q, int P_size)
 {
-    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    // MDP_PER coefficients per thread, RNS_THREADS apart (a workgroup per 256 coefficients is bound by the rate
+    // workgroups can be started at: 229 k of them at C3)
     const int y = blockIdx.y;
     const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
     const Mod m = mods[y];
-    const u64* pin = in + in_stride * b + (((u64) Qp_cur << n_power) * z) + idx;
-    u64 x = pin[(u64) y << n_power];
-    if (SINGLE_P) {
-        u64 l = pin[(u64) Q_cur << n_power];
-        l = add_mod(l, half[0], mods[first_Qp - 1].q);
-        l = reduce64(l, m);
-        l = sub_mod(l, half_mod[y], m.q);
-        l = sub_mod(x, l, m.q);
-        x = mul_barrett(l, last_q_modinv[y], m);
-    } else {
-        x = moddown_multi(x, pin, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur, first_Qp, first_Q,
-                          P_size);
+    const u32 idx0 = blockIdx.x * (RNS_THREADS * MDP_PER) + threadIdx.x;
+    const u64* pin0 = in + in_stride * b + (((u64) Qp_cur << n_power) * z);
+    u64 xs[MDP_PER], ls[MDP_PER], cs[MDP_PER];
+#pragma unroll
+    for (int r = 0; r < MDP_PER; r++) {
+        const u32 idx = idx0 + RNS_THREADS * r;
+        xs[r] = pin0[((u64) y << n_power) + idx];
+        if (SINGLE_P) ls[r] = pin0[((u64) Q_cur << n_power) + idx];
+        cs[r] = (z == 0) ? in2[in2_stride * b + ((u64) y << n_power) + idx] : 0;
     }
-    if (z == 0) x = add_mod(in2[in2_stride * b + ((u64) y << n_power) + idx], x, m.q);
-    const u32 raw = idx * (u32) galois_elt;
-    const u32 dst = raw & ((1u << n_power) - 1);
-    if ((raw >> n_power) & 1) x = m.q - x; // no zero test: reference switchkey.cu:1694,1711
-    out[out_stride * b + (((u64) Q_cur << n_power) * z) + ((u64) y << n_power) + dst] = x;
+#pragma unroll
+    for (int r = 0; r < MDP_PER; r++) {
+        const u32 idx = idx0 + RNS_THREADS * r;
+        u64 x = xs[r];
+        if (SINGLE_P) {
+            u64 l = add_mod(ls[r], half[0], mods[first_Qp - 1].q);
+            l = reduce64(l, m);
+            l = sub_mod(l, half_mod[y], m.q);
+            l = sub_mod(x, l, m.q);
+            x = mul_barrett(l, last_q_modinv[y], m);
+        } else {
+            x = moddown_multi(x, pin0 + idx, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur, first_Qp, first_Q,
+                              P_size);
+        }
+        if (z == 0) x = add_mod(cs[r], x, m.q);
+        const u32 raw = idx * (u32) galois_elt;
+        const u32 dst = raw & ((1u << n_power) - 1);
+        if ((raw >> n_power) & 1) x = m.q - x; // no zero test: reference switchkey.cu:1694,1711
+        out[out_stride * b + (((u64) Q_cur << n_power) * z) + ((u64) y << n_power) + dst] = x;
+    }
 }
 
 hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64 in2_stride, u64* out,
@@ -547,7 +561,7 @@ hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64
                                int first_Qp, int first_Q, int P_size, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
-    dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
+    dim3 g((1u << n_power) / (RNS_THREADS * MDP_PER), Q_cur, 2 * batch);
     if (P_size > 15) return hipErrorInvalidValue;
     if (P_size == 1)
         hipLaunchKernelGGL(k_moddown_permute<true>, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride, out,
