@@ -487,6 +487,8 @@ int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs,
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
     if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
+    if (galois_elt <= 0 || !(galois_elt & 1) || galois_elt >= 2 * (int) ctx->c.n)
+        return fail(HEGPU_E_INVALID, "apply_galois: Galois elements are odd and below 2N");
     return hip_ret(ctx->c.P_size == 1
                        ? op_ckks_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
                                               galois_elt, depth, batch, (u64*) ws, (hipStream_t) stream)
