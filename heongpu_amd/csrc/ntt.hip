@@ -1304,13 +1304,87 @@ __device__ __forceinline__ void inv_row_part(const AR& ar, const NttArgs& a, int
     }
 }
 
+// Where the inverse transform's results go when NttArgs::iepi is on (see NttInvEpilogue): everything the
+// epilogue needs for one polynomial, set up once per workgroup.
+struct InvEpi {
+    const u64* last; // P limb of the part (coefficient domain)
+    const u64* ct;   // added limb or nullptr
+    u64* out;
+    Mod md;
+    u64 half, qP, hm, inv;
+    int galois, n_power;
+};
+__device__ __forceinline__ bool inv_epi_setup(const NttArgs& a, const PolySel& ps, InvEpi& e, bool& skip)
+{
+    skip = false;
+    if (!a.iepi.on) return false;
+    const NttInvEpilogue& ep = a.iepi;
+    const int part = udiv16(ps.j, ep.mg_slots), limb = ps.j - part * (ep.limbs + 1);
+    if (limb == ep.limbs) { skip = true; return true; } // the P limb: transformed by its own launch
+    const u64 item_in = a.out_item_stride * ps.item;
+    e.last = a.out + item_in + ((u64) (part * (ep.limbs + 1) + ep.limbs) << a.n_power);
+    const u64 off = (u64) (part * ep.limbs + limb) << a.n_power;
+    e.ct = (ep.ct && part < ep.add_parts) ? ep.ct + ep.ct_item_stride * ps.item + off : nullptr;
+    e.out = ep.out + ep.out_item_stride * ps.item + off;
+    e.md = a.mods[ps.mod];
+    e.half = ep.half;
+    e.qP = a.mods[ep.p_mod].q;
+    e.hm = ep.half_mod[limb];
+    e.inv = ep.inv[limb];
+    e.galois = ep.galois_elt;
+    e.n_power = a.n_power;
+    return true;
+}
+// CNT canonical results o[k] of elements e0 + pos(k) of the limb: plain store to p + pos(k), or the epilogue.  The
+// epilogue's operands are requested for all CNT elements before anything is computed (uniform conditions around
+// whole loops -- see row_store_all).
+template <int CNT, bool EPI, typename POS>
+__device__ __forceinline__ void inv_store(const InvEpi& epr, u64* __restrict__ p, u32 e0, POS pos, const u64 (&o)[CNT])
+{
+    if constexpr (!EPI) {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) gst(&p[pos(k)], o[k]);
+        return;
+    }
+    const InvEpi* ep = &epr;
+    u64 lv[CNT], cv[CNT], r[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; k++) lv[k] = ep->last[e0 + pos(k)];
+    if (ep->ct) {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) cv[k] = ep->ct[e0 + pos(k)];
+    }
+#pragma unroll
+    for (int k = 0; k < CNT; k++) {
+        u64 l = add_mod(lv[k], ep->half, ep->qP);
+        l = reduce64(l, ep->md);
+        l = sub_mod(l, ep->hm, ep->md.q);
+        r[k] = mul_barrett(sub_mod(o[k], l, ep->md.q), ep->inv, ep->md);
+    }
+    if (ep->ct) {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) r[k] = add_mod(cv[k], r[k], ep->md.q);
+    }
+    if (ep->galois) {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) {
+            const u32 raw = (e0 + (u32) pos(k)) * (u32) ep->galois;
+            // no zero test on the negation: reference switchkey.cu:1694,1711
+            ep->out[raw & ((1u << ep->n_power) - 1u)] = ((raw >> ep->n_power) & 1u) ? ep->md.q - r[k] : r[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CNT; k++) ep->out[e0 + pos(k)] = r[k];
+    }
+}
+
 // Column stages of one column tile (R rows x CT columns), results to global memory.  FROM_LDS: the row
 // stages left their output in the LDS-resident limb (`buf` = the limb, positions single_pos); otherwise the
 // tile is read from `p` (global, in place) and `buf` is the tile's 4096-element exchange buffer.
 // KEEP: the results also stay in `keep` (slot gi * RA + k, the load order of the forward column stages)
-template <int S1, typename AR, bool FROM_LDS, bool KEEP = false>
+template <int S1, typename AR, bool FROM_LDS, bool KEEP = false, bool EPI = false>
 __device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int mod, int tt, int g, u64* __restrict__ p,
-                                             u64* buf, u64 (&keep)[16])
+                                             u64* buf, u64 (&keep)[16], const InvEpi& ep = InvEpi(), u32 e0 = 0)
 {
     typedef typename AR::T T;
     constexpr int R = 1 << S1;
@@ -1343,8 +1417,16 @@ __device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int
 #pragma unroll
             for (int k = 0; k < RA; k++) y[k] = ar.from_bits(buf[pos(rb + 16 * k, c)]);
             ar.template radix_last<NSA>(y, tw, ninv, w1ninv, o);
+            if constexpr (RA == 16) {
+                // two halves: sixteen elements' worth of epilogue operands would not fit the register budget
+                u64 oa[8], ob[8];
 #pragma unroll
-            for (int k = 0; k < RA; k++) gst(&p[(u64) (rb + 16 * k) * 256 + c], o[k]);
+                for (int k = 0; k < 8; k++) { oa[k] = o[k]; ob[k] = o[8 + k]; }
+                inv_store<8, EPI>(ep, p, e0, [&](int k) { return (u32) ((rb + 16 * k) * 256 + c); }, oa);
+                inv_store<8, EPI>(ep, p, e0, [&](int k) { return (u32) ((rb + 16 * (8 + k)) * 256 + c); }, ob);
+            } else {
+                inv_store<RA, EPI>(ep, p, e0, [&](int k) { return (u32) ((rb + 16 * k) * 256 + c); }, o);
+            }
             if constexpr (KEEP) {
 #pragma unroll
                 for (int k = 0; k < RA; k++) keep[gi * RA + k] = o[k];
@@ -1353,8 +1435,13 @@ __device__ __forceinline__ void inv_col_part(const AR& ar, const NttArgs& a, int
     } else {
         u64 o[16];
         ar.template radix_last<4>(x, tw, ninv, w1ninv, o);
+        {
+            u64 oa[8], ob[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) gst(&p[(u64) k * 256 + col], o[k]);
+            for (int k = 0; k < 8; k++) { oa[k] = o[k]; ob[k] = o[8 + k]; }
+            inv_store<8, EPI>(ep, p, e0, [&](int k) { return (u32) (k * 256 + col); }, oa);
+            inv_store<8, EPI>(ep, p, e0, [&](int k) { return (u32) ((8 + k) * 256 + col); }, ob);
+        }
         if constexpr (KEEP) {
 #pragma unroll
             for (int k = 0; k < 16; k++) keep[k] = o[k];
@@ -1367,6 +1454,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const PolySel ps = select_poly(a, blockIdx.y);
+    if (a.iepi.on && ps.j - udiv16(ps.j, a.iepi.mg_slots) * (a.iepi.limbs + 1) == a.iepi.limbs) return; // P limb: own launch
     const Mod md = a.mods[ps.mod];
     const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
     u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
@@ -1374,8 +1462,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
     else inv_row_part<ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
 }
 
-// Column pass last, in place on a.out.  grid = (256 / CT, batch).
-template <int S1>
+// Column pass last, in place on a.out.  grid = (256 / CT, batch).  EPI: with NttArgs::iepi (a kernel of its own:
+// the epilogue's state would cost the plain transform a wave per SIMD).
+template <int S1, bool EPI = false>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
 {
     constexpr int CT = 4096 >> S1;
@@ -1385,31 +1474,47 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
     if (a.only_int && md.fp) return; // a src_inv decomposing launch finishes these limbs itself
     u64* __restrict__ p = a.out + ps.out_off + blockIdx.x * CT;
     u64 unused[16];
-    if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
-    else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
+    if constexpr (EPI) {
+        InvEpi epi;
+        bool skip;
+        inv_epi_setup(a, ps, epi, skip);
+        if (skip) return;
+        if (md.fp) inv_col_part<S1, ArFp, false, false, true>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused, epi, blockIdx.x * CT);
+        else inv_col_part<S1, ArInt, false, false, true>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused, epi, blockIdx.x * CT);
+    } else {
+        if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
+        else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
+    }
 }
 
 // Single pass for N <= 2^14 (see ntt_fwd_single): thread group g runs the row stages of row tile g into the
 // LDS-resident limb, then the column stages of column tile g out of it.  grid = batch, N / 16 threads.
-template <int S1, typename AR>
+template <int S1, bool EPI, typename AR>
 __device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, const PolySel& ps, u64* limb)
 {
     constexpr int CT = 4096 >> S1;
     const int t = threadIdx.x, g = t >> 8, tt = t & 255;
+    InvEpi epi;
+    if constexpr (EPI) {
+        bool skip;
+        inv_epi_setup(a, ps, epi, skip);
+        if (skip) return; // (uniform per workgroup: before any barrier)
+    }
     inv_row_part<AR, true>(ar, a, ps.mod, tt, g * 16, a.in + ps.in_off + (u64) g * 4096, nullptr, limb + g * 4096);
     __syncthreads();
     u64 unused[16];
-    inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused);
+    if constexpr (EPI) inv_col_part<S1, AR, true, false, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused, epi, g * CT);
+    else inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused);
 }
 
-template <int S1>
+template <int S1, bool EPI = false>
 __global__ __launch_bounds__(16 << S1, 4) void ntt_inv_single(NttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u64 limb[];
     const PolySel ps = select_poly(a, blockIdx.x);
     const Mod md = a.mods[ps.mod];
-    if (md.fp) inv_single_body<S1>(ArFp(md), a, ps, limb);
-    else inv_single_body<S1>(ArInt(md), a, ps, limb);
+    if (md.fp) inv_single_body<S1, EPI>(ArFp(md), a, ps, limb);
+    else inv_single_body<S1, EPI>(ArInt(md), a, ps, limb);
 }
 
 // Decomposing column pass, one workgroup per SOURCE tile: the 16 coefficients a thread needs are
@@ -1576,10 +1681,16 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
     constexpr int CT = 4096 >> S1;
     if constexpr (S1 <= 6) {
         if (use_single_pass(a, batch) && !a.poly_order) { // LDS-resident single pass (N <= 2^14)
-            static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_inv_single<S1>,
+            static const hipError_t attr = hipFuncSetAttribute((const void*) ntt_inv_single<S1, false>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
+            static const hipError_t attr_e = hipFuncSetAttribute((const void*) ntt_inv_single<S1, true>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             (void) attr;
-            hipLaunchKernelGGL((ntt_inv_single<S1>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            (void) attr_e;
+            if (a.iepi.on)
+                hipLaunchKernelGGL((ntt_inv_single<S1, true>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            else
+                hipLaunchKernelGGL((ntt_inv_single<S1, false>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
             return;
         }
     }
@@ -1587,7 +1698,8 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
     NttArgs b = a;
     b.in = a.out;
     b.in_item_stride = a.out_item_stride;
-    hipLaunchKernelGGL(ntt_inv_col<S1>, dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, b);
+    if (a.iepi.on) hipLaunchKernelGGL((ntt_inv_col<S1, true>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, b);
+    else hipLaunchKernelGGL((ntt_inv_col<S1, false>), dim3(256 / CT, batch), dim3(NTT_THREADS), 0, st, b);
 }
 
 static unsigned magic16(int d) { return d <= 1 ? 0u : (unsigned) ((0x100000000ull + (unsigned) d - 1) / (unsigned) d); }
@@ -1600,6 +1712,7 @@ static void fill_magics(NttArgs& g)
     g.mg_polys_per_item = magic16(g.polys_per_item);
     g.mg_decomp_mods = magic16(g.decomp_mods);
     g.epi.mg_limbs = magic16(g.epi.limbs);
+    g.iepi.mg_slots = magic16(g.iepi.limbs + 1);
 }
 
 bool ntt_decomp_uses_multi(const NttArgs& a, int batch)
@@ -1632,7 +1745,7 @@ hipError_t ntt_launch_inv_rows(const NttArgs& a, int batch, hipStream_t st)
         b.in_item_stride = g.out_item_stride;
         b.only_int = 1;
         switch (a.n_power - 8) {
-#define CASE(S) case S: hipLaunchKernelGGL(ntt_inv_col<S>, dim3(256 / (4096 >> S), batch), dim3(NTT_THREADS), 0, st, b); break;
+#define CASE(S) case S: hipLaunchKernelGGL((ntt_inv_col<S, false>), dim3(256 / (4096 >> S), batch), dim3(NTT_THREADS), 0, st, b); break;
             CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         }
@@ -1673,6 +1786,8 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (a.n_power < 12 || a.n_power > 16) return hipErrorInvalidValue;
     if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
     if (a.src_inv && (!a.decomp_mods || batch > 65535 || !ntt_decomp_uses_multi(a, batch))) return hipErrorInvalidValue;
+    if (a.iepi.on && (!inverse || a.poly_order || a.polys_per_item != 2 * (a.iepi.limbs + 1) || batch % a.polys_per_item))
+        return hipErrorInvalidValue;
     if (batch > 65535) {
         // gridDim.y limit: split (poly_order / mod_order semantics need the
         // absolute polynomial index, so only plain batches are split)

@@ -32,6 +32,30 @@ struct NttEpilogue {
     unsigned mg_limbs; // set by ntt_launch: ceil(2^32 / limbs), see NttArgs::mg_*
 };
 
+// Optional epilogue of the INVERSE transform (BFV key switching, one special prime): the coefficient-domain limb x
+// of modulus q_j the transform produces is not stored; instead
+//     v = (x - ((p + half) mod P mod q_j - half_mod[j])) * inv[j]  (+ ct if part < add_parts)
+// goes to out -- divide_round_lastq_kernel / divide_round_lastq_permute_bfv_kernel (reference
+// switchkey.cu:400-478, 1621-1813) fused into the transform that produces their operand; with galois_elt != 0
+// through the coefficient permutation out[(i g) mod N] = +-v.  An item is [2][limbs + 1][N] (polynomial
+// j = part * (limbs + 1) + limb); slot `limbs` of a part is the P limb, which must ALREADY be in the coefficient
+// domain (its own launch, before this one): the launch skips those two polynomials and reads p from them.
+struct NttInvEpilogue {
+    int on;
+    int limbs;         // Q
+    int add_parts;     // parts below this get ct added
+    int p_mod;         // modulus index of P
+    int galois_elt;    // 0: no permutation
+    unsigned mg_slots; // set by ntt_launch: ceil(2^32 / (limbs + 1))
+    u64 half;          // floor(P / 2)
+    const u64* half_mod; // [limbs]
+    const u64* inv;      // [limbs]  P^-1 mod q_j
+    const u64* ct;     // [2][limbs][N] per item (may alias out when galois_elt == 0)
+    u64 ct_item_stride;
+    u64* out;          // [2][limbs][N] per item
+    u64 out_item_stride;
+};
+
 struct NttArgs {
     const u64* in;            // batch polynomials (or base for poly_order)
     u64* out;                 // may equal in
@@ -79,6 +103,7 @@ struct NttArgs {
     // operands: ~20 instructions each, 12 % of the FP64 column pass.
     unsigned mg_group_span, mg_per_item, mg_polys_per_item, mg_mod_count, mg_decomp_mods;
     NttEpilogue epi; // forward only, needs polys_per_item
+    NttInvEpilogue iepi; // inverse only, needs polys_per_item == 2 * (limbs + 1)
     // Decomposing launches read digit d from input slot d * decomp_in_mul + decomp_in_add
     // (0 means 1 / 0).  half_on: the loaded residue v of modulus `half_src_mod` becomes
     // ((v + half) mod that modulus) mod q_j - half_mod[j] -- the first stage of the leveled

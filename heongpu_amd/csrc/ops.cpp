@@ -353,6 +353,33 @@ hipError_t op_bfv_multiply(const Context& c, const u64* ct1, u64 s1, const u64* 
     return rns_fast_floor(temp2, per, out, so, c.behz, np, batch, st);                     // :416
 }
 
+// BFV key switching, tail: acc [2][Q'][N] (NTT domain, `per` apart) -> INTT -> divide by the special prime with
+// rounding -> + ct (parts below add_parts) [-> Galois permutation] -> out [2][Q][N].  The reference runs the INTT
+// of all 2 Q' limbs and then divide_round_lastq(_permute_bfv)_kernel (bfv/operator.cu:571-576, 846-853); here the
+// two P limbs are inverse-transformed first and the division is the epilogue of the Q limbs' inverse transform
+// (NttInvEpilogue): the coefficient-domain accumulator is never written or read back.
+static hipError_t bfv_intt_moddown(const Context& c, u64* acc, u64 per, const u64* ct, u64 cs, int add_parts, u64* out,
+                                   u64 so, int galois_elt, int batch, hipStream_t st)
+{
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size;
+    for (int part = 0; part < 2; part++) {
+        NttArgs a = c.ntt_args(0);
+        a.in = a.out = acc + (u64) (part * Qp + Q) * n;
+        a.mod_count = 1; a.mod_offset = Q; a.polys_per_item = 1;
+        a.in_item_stride = a.out_item_stride = per;
+        TRY(ntt_launch(a, batch, true, st));
+    }
+    NttArgs a = c.ntt_args(0);
+    a.in = a.out = acc; a.mod_count = Qp; a.polys_per_item = 2 * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    a.iepi.on = 1; a.iepi.limbs = Q; a.iepi.add_parts = add_parts; a.iepi.p_mod = Q; a.iepi.galois_elt = galois_elt;
+    a.iepi.half = c.h64("half")[0]; a.iepi.half_mod = c.d64("half_mod"); a.iepi.inv = c.d64("last_q_modinv");
+    a.iepi.ct = ct; a.iepi.ct_item_stride = cs;
+    a.iepi.out = out; a.iepi.out_item_stride = so;
+    return ntt_launch(a, 2 * Qp * batch, true, st);
+}
+
 // reference bfv/operator.cu:505-583
 hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
                               hipStream_t st)
@@ -370,6 +397,8 @@ hipError_t op_bfv_relinearize(const Context& c, u64* ct, u64 cs, const u64* key,
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, nullptr, 0, batch, st));             // :531-566
+    if (c.P_size == 1 && c.fused_moddown)
+        return bfv_intt_moddown(c, temp2, per, ct, cs, 2, ct, cs, 0, batch, st);            // :571-576 in one transform
     a.decomp_mods = 0; a.in_item_stride = per;
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :571
@@ -395,6 +424,8 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
     a.decomp_mods = Qp;
     a.in_item_stride = cs; a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp2, per, Q, Qp, Qp, 0, nullptr, 0, batch, st));             // :805-840
+    if (c.P_size == 1 && c.fused_moddown)
+        return bfv_intt_moddown(c, temp2, per, ct, cs, 1, out, so, galois_elt, batch, st);  // :846-853 in one transform
     a.decomp_mods = 0; a.in_item_stride = per;
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :846

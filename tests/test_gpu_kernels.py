@@ -165,7 +165,8 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
 
 @pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_FUSED_ROW_MAC=0),
                                 dict(HEGPU_FP_NTT=0), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
-                                dict(HEGPU_SINGLE_PASS=0)],
+                                dict(HEGPU_SINGLE_PASS=0), dict(HEGPU_FUSED_MODDOWN=0),
+                                dict(HEGPU_FUSED_MODDOWN=0, HEGPU_SINGLE_PASS=1)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_bfv_sequence_with_fusions_off(hg, oracle, torch, sw):
     """Config C1 shapes (BFV N=2^12 default chain): relinearize + rotate through the unfused key switch."""
