@@ -20,16 +20,6 @@ static int prime_loc_offset(const Context& c, int depth)
     return location;
 }
 
-// Forward NTT of the key-switch digits followed by the inner product with the
-// key.  `a` is the fully configured forward transform (plain or decomposing)
-// whose output is [digits][rc][N] per ciphertext at a.out; the result
-// [2][rc][N] goes to `acc`.  Fused path: column pass + ks_row_mac; otherwise
-// two-pass NTT + rns_keyswitch_mac.
-// `ident` (with a.skip_identity): the NTT-domain limbs [digits][N] of the
-// polynomial being decomposed, `ident_stride` apart; digit d at modulus d is
-// taken from there instead of being transformed.
-// `which`: 1 = column pass only, 2 = row pass + inner product only, 3 = both (the measurement seam of
-// hegpu_probe_ckks_relinearize; the unfused path ignores it)
 // The fused row pass + inner product runs one workgroup per (ciphertext, target modulus, 16-row tile) that walks
 // all digits; a launch too small to fill the chip finishes sooner as the reference's sequence -- the transform of
 // all digits x moduli as independent limbs, then the element-wise inner product (C2, one ciphertext: 39 -> 27 us).
@@ -54,6 +44,16 @@ static void fill_int_slots(const Context& c, NttArgs& a, const u64* order)
     a.int_slot_count = cnt ? cnt : -1;
 }
 
+// Forward NTT of the key-switch digits followed by the inner product with the
+// key.  `a` is the fully configured forward transform (plain or decomposing)
+// whose output is [digits][rc][N] per ciphertext at a.out; the result
+// [2][rc][N] goes to `acc`.  Fused path: column pass + ks_row_mac; otherwise
+// two-pass NTT + rns_keyswitch_mac.
+// `ident` (with a.skip_identity): the NTT-domain limbs [digits][N] of the
+// polynomial being decomposed, `ident_stride` apart; digit d at modulus d is
+// taken from there instead of being transformed.
+// `which`: 1 = column pass only, 2 = row pass + inner product only, 3 = both (the measurement seam of
+// hegpu_probe_ckks_relinearize; the unfused path ignores it)
 static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key, u64* acc, u64 acc_stride,
                                     int digits, int rc, int split, int level, const u64* ident, u64 ident_stride,
                                     int batch, hipStream_t st, int which = 3)
