@@ -238,3 +238,34 @@ def test_error_distribution_parameter():
     """secstdparams.h:22 error_std_dev = 3.2 -- the value both Gaussian CDTs are built for (csrc/context.cpp,
     oracle/o_keygen.c); the empirical sigma of generated keys is checked in tests/test_oracle_keygen.py"""
     assert REF["error_std_dev"] == 3.2
+
+
+def test_galois_automorphism_is_a_slot_gather_in_the_ntt_domain(oracle, hg):
+    """The index map behind the NTT-domain rotations (csrc/rns.hip k_permute_ntt, NttEpilogue::galois_inv), pinned
+    on the CPU with the oracle's transform: for b(X) = a(X^g) -- the reference's coefficient permutation
+    out[(i g) mod N] = +-a[i] (switchkey.cu:1689-1711) -- NTT(b)[j] = NTT(a)[j'] with
+    2 br(j') + 1 = (2 br(j) + 1) g mod 2N; and the scatter form with g^-1 mod 2N is the same permutation."""
+    n, np_ = 4096, 12
+    prod = hg.Context.from_bit_sizes(hg.CKKS, n, [40, 30, 30], [40], sec=hg.SEC_NONE)
+    primes = [int(v) for v in prod.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, np_, primes, 3, 1)
+    rng = np.random.default_rng(5)
+    br = np.array([int(format(j, "012b")[::-1], 2) for j in range(n)], dtype=np.int64)
+    j = np.arange(n, dtype=np.int64)
+    for g in (5, 25, 3, 2 * n - 1, oracle.lib().o_steps_to_galois_elt(-7, n, 5)):
+        src = br[(((2 * br[j] + 1) * g) % (2 * n) - 1) // 2]                   # gather: out[j] = in[src[j]]
+        ginv = pow(int(g), -1, 2 * n)
+        dst = br[(((2 * br[j] + 1) * ginv) % (2 * n) - 1) // 2]                # scatter: out[dst[j]] = in[j]
+        assert np.array_equal(dst[src], j) and np.array_equal(src[dst], j)
+        for m in range(3):
+            q = primes[m]
+            a = rng.integers(0, q, n, dtype=np.uint64)
+            b = np.zeros(n, dtype=np.uint64)
+            e = (j * g) % (2 * n)
+            b[e % n] = np.where(e >= n, (q - a) % q, a)
+            A = o.ntt(a.copy(), 1, 1, mod_offset=m)
+            B = o.ntt(b.copy(), 1, 1, mod_offset=m)
+            assert np.array_equal(B, A[src]), (g, m)
+            scattered = np.empty_like(A)
+            scattered[dst] = A
+            assert np.array_equal(scattered, B), (g, m)
