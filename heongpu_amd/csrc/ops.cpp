@@ -62,7 +62,12 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
     const int skip_identity = ident ? 1 : 0;
     a.skip_identity = skip_identity;
     if (!use_fused_row_mac(c, rc, batch)) {
-        if (ident) TRY(rns_copy_diag(ident, ident_stride, a.out, a.out_item_stride, c.n_power, digits, rc, batch, st));
+        // identity digits (digit d at modulus d: the transform gives back the NTT-domain limb): copied instead of
+        // transformed -- unless this path was chosen for a small launch, where one kernel less is worth more than
+        // one transform in ten (same residues either way)
+        if (ident && c.fused_row_mac == 0)
+            TRY(rns_copy_diag(ident, ident_stride, a.out, a.out_item_stride, c.n_power, digits, rc, batch, st));
+        else a.skip_identity = 0;
         TRY(ntt_launch(a, ppi * batch, false, st));
         return rns_keyswitch_mac(a.out, a.out_item_stride, key, acc, acc_stride, c.plan_qp.mods, c.n_power, digits, rc,
                                  c.Qp_size, split, level, batch, st);
