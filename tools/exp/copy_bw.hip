@@ -77,6 +77,36 @@ __global__ __launch_bounds__(256) void row16(const ulonglong2* __restrict__ in, 
 #pragma unroll
     for (int k = 0; k < 8; k++) { x[k].x += 1; out[base + 16 * k] = x[k]; }
 }
+// the same contiguous stream with non-temporal hints (`nt`): loads, stores, both; and a read-only stream
+template <int MODE>
+__global__ __launch_bounds__(256) void lin16nt(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out)
+{
+    const size_t base = (size_t) blockIdx.x * 2048 + threadIdx.x;
+    ulonglong2 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (MODE & 1) {
+            x[k].x = __builtin_nontemporal_load(&in[base + 256 * k].x);
+            x[k].y = __builtin_nontemporal_load(&in[base + 256 * k].y);
+        } else x[k] = in[base + 256 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        x[k].x += 1;
+        if (MODE & 2) {
+            __builtin_nontemporal_store(x[k].x, &out[base + 256 * k].x);
+            __builtin_nontemporal_store(x[k].y, &out[base + 256 * k].y);
+        } else out[base + 256 * k] = x[k];
+    }
+}
+__global__ __launch_bounds__(256) void rd16(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out)
+{
+    const size_t base = (size_t) blockIdx.x * 2048 + threadIdx.x;
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const ulonglong2 v = in[base + 256 * k]; s += v.x ^ v.y; }
+    if (s == 0x1234567887654321ull) out[base] = make_ulonglong2(s, s);
+}
 // write-only / read-only streams of the column-pass shape (the decomposing pass reads from L2)
 __global__ __launch_bounds__(256) void wr8(u64* __restrict__ out)
 {
@@ -111,7 +141,7 @@ int main(int argc, char** argv)
         for (int r = 0; r < reps; r++) launch();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("%-6s %6zu limbs (%7.1f MiB each way): %8.3f ms  %7.1f GB/s\n", name, limbs, bytes / 1048576.0, ms,
+        printf("%-14s %6zu limbs (%7.1f MiB each way): %8.3f ms  %7.1f GB/s\n", name, limbs, bytes / 1048576.0, ms,
                factor * bytes / (ms * 1e-3) / 1e9);
     };
     const unsigned g8 = (unsigned) (limbs * 16), g16c = (unsigned) (limbs * 8);
@@ -121,6 +151,10 @@ int main(int argc, char** argv)
     run("col16", [&] { hipLaunchKernelGGL(col16, dim3(g16c), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 2);
     run("row8", [&] { hipLaunchKernelGGL(row8, dim3(g8), dim3(256), 0, 0, in, out); }, 2);
     run("row16", [&] { hipLaunchKernelGGL(row16, dim3(g8), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 2);
+    run("lin16 nt-load", [&] { hipLaunchKernelGGL((lin16nt<1>), dim3(g8), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 2);
+    run("lin16 nt-store", [&] { hipLaunchKernelGGL((lin16nt<2>), dim3(g8), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 2);
+    run("lin16 nt-both", [&] { hipLaunchKernelGGL((lin16nt<3>), dim3(g8), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 2);
+    run("rd16", [&] { hipLaunchKernelGGL(rd16, dim3(g8), dim3(256), 0, 0, (const ulonglong2*) in, (ulonglong2*) out); }, 1);
     run("wr8", [&] { hipLaunchKernelGGL(wr8, dim3(g8), dim3(256), 0, 0, out); }, 1);
     run("wr16", [&] { hipLaunchKernelGGL(wr16, dim3(g16c), dim3(256), 0, 0, (ulonglong2*) out); }, 1);
     return 0;

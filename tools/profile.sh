@@ -81,7 +81,7 @@ for (c, k, g), s in step.items():
     e = res["step_kernels"].setdefault(re.sub(r"\(.*", "", k) + f" grid {g}", {"bytes_per_step": 0.0})
     e["bytes_per_step"] += (2 if c == "FETCH_SIZE" else 1) * s * 1024 / steps
 try:
-    rows = [l.split() for l in open(f"{out}/copy_bw.txt") if l.startswith("lin16")]
+    rows = [l.split() for l in open(f"{out}/copy_bw.txt") if l.split()[:1] == ["lin16"] and "nt-" not in l]
     res["copy_ceiling_GBps"] = float(rows[-1][-2])
     res["copy_ceiling_note"] = "tools/exp/copy_bw lin16: contiguous 16 B/lane read+write stream, 8 GiB each way"
 except Exception as e:
