@@ -521,9 +521,9 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
 __global__ void k_tfhe_set_header(u64* hdr, u64 fmt) { hdr[0] = fmt; }
 
 // TF_G gates per workgroup, wavefront w = (y,z): digit polynomial z of accumulator
-// y -> forward NTT -> products with the four key polynomials BK_i[y][z][c][half]
-// summed over the wavefronts in LDS -> wavefront w inverse-transforms output
-// o = w (c = w >> 1, half = w & 1) and adds it into the accumulator.  The 64
+// y -> forward NTT -> staged in LDS; wavefront w then sums ITS output o = w (c = w >> 1, half = w & 1) over the
+// four transformed digits times the key polynomials BK_i[y'][z'][c][half] in registers, inverse-transforms it
+// and adds it into the accumulator (two 16-bit halves per coefficient: integer atomics on the LDS words).  The 64
 // key values a lane needs in iteration i are loaded once and reused for the
 // TF_G gates (the 64 MiB key stream is the other resource next to the ALU).
 template <int TF_G>
