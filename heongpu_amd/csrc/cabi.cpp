@@ -364,7 +364,7 @@ int hegpu_base_conversion_DtoQtilde(hegpu_context* ctx, const uint64_t* in, uint
                                                  c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
                                                  c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
                                                  c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc,
-                                                 c.Q_size - depth, depth, batch, (hipStream_t) stream),
+                                                 c.Q_size - depth, depth, c.m2_width, batch, (hipStream_t) stream),
                    "hegpu_base_conversion_DtoQtilde");
 }
 

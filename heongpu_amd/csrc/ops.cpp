@@ -447,7 +447,7 @@ static hipError_t dtoq(const Context& c, int lvl, const u64* in, u64 in_stride, 
                                          c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
                                          c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
                                          c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc, l, level,
-                                         batch, st);
+                                         c.m2_width, batch, st);
 }
 
 // reference ckks/operator.cu:1025-1154

@@ -402,6 +402,12 @@ hipError_t rns_moddown_stage_two(const u64* in_last, u64 last_stride, const u64*
 // ---------------------------------------------------------------- method II: digit -> Q~ base conversion
 // IEEE single-precision overflow estimate exactly as the reference computes it:
 // r = sum_i (float)y_i / (float)q_i in digit order, roundf.
+// Digit g = the `cnt` primes from s0 on, raised to every modulus of Q~ by the fast base conversion with the
+// fp32 overflow estimate (switchkey.cu:816-870).  MAXC: cnt padded (the digit's residues stay in registers; the
+// padded ones are zero).  The products with the conversion matrix are summed as 128-bit integers and reduced
+// once per target modulus -- the digit residue is NOT reduced into the target modulus first (the reference does:
+// reduce_forced, then mult): below 2^61 it is a valid factor of the lazy sum, and the canonical result is the same.
+template <int MAXC>
 __global__ __launch_bounds__(RNS_THREADS) void k_base_conversion_DtoQtilde(
     const u64* __restrict__ in, u64 in_stride, u64* __restrict__ out, u64 out_stride, const Mod* __restrict__ mods,
     const u64* __restrict__ matrix, const u64* __restrict__ mi_inv, const u64* __restrict__ prod,
@@ -412,23 +418,25 @@ __global__ __launch_bounds__(RNS_THREADS) void k_base_conversion_DtoQtilde(
     const int cnt = I_j_[g], s0 = I_location_[g];
     const u64* pin = in + in_stride * blockIdx.z + idx + ((u64) s0 << n_power);
     u64* po = out + out_stride * blockIdx.z + idx + (((u64) g * rc) << n_power);
-    u64 partial[20];
+    u64 partial[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) partial[i] = pin[(u64) (i < cnt ? i : 0) << n_power]; // all loads first
     float r = 0.0f;
-    for (int i = 0; i < cnt; i++) {
-        const Mod m = mods[s0 + i];
-        partial[i] = mul_barrett(pin[(u64) i << n_power], mi_inv[s0 + i], m);
-        r = __fadd_rn(r, __fdiv_rn((float) partial[i], (float) m.q));
+#pragma unroll
+    for (int i = 0; i < MAXC; i++) {
+        const int ii = i < cnt ? i : 0;
+        const Mod m = mods[s0 + ii];
+        const u64 v = mul_barrett(partial[i], mi_inv[s0 + ii], m);
+        partial[i] = i < cnt ? v : 0;
+        const float q = __fdiv_rn((float) v, (float) m.q);
+        r = i < cnt ? __fadd_rn(r, q) : r; // same order and operations as the reference's loop
     }
     const u64 r_ = (u64) roundf(r);
+#pragma unroll 1
     for (int i = 0; i < rc; i++) {
         const Mod m = mods[(i < l) ? i : i + level];
-        u64 hi = 0, lo = 0;
-        for (int j = 0; j < cnt; j++) {
-            u64 h2, l2;
-            mul64wide(reduce64(partial[j], m), matrix[j + i * cnt + s0 * rc], h2, l2);
-            lo += l2;
-            hi += h2 + (lo < l2);
-        }
+        u64 hi, lo;
+        dot128(partial, matrix + (u64) i * cnt + (u64) s0 * rc, cnt, hi, lo);
         const u64 temp = reduce128(hi, lo, m);
         const u64 r_mul = mul_barrett(r_, prod[i + g * rc], m);
         po[(u64) i << n_power] = sub_mod(temp, r_mul, m.q);
@@ -438,12 +446,20 @@ __global__ __launch_bounds__(RNS_THREADS) void k_base_conversion_DtoQtilde(
 hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
                                          const u64* matrix, const u64* mi_inv, const u64* prod, const int* I_j,
                                          const int* I_location, int n_power, int d, int rc, int l, int level,
-                                         int batch, hipStream_t st)
+                                         int max_cnt, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
+    if (max_cnt < 1 || max_cnt > 32) return hipErrorInvalidValue;
     dim3 g((1u << n_power) / RNS_THREADS, d, batch);
-    hipLaunchKernelGGL(k_base_conversion_DtoQtilde, g, dim3(RNS_THREADS), 0, st, in, in_stride, out, out_stride,
-                       mods, matrix, mi_inv, prod, I_j, I_location, n_power, rc, l, level);
+#define LAUNCH(M)                                                                                                  \
+    hipLaunchKernelGGL(k_base_conversion_DtoQtilde<M>, g, dim3(RNS_THREADS), 0, st, in, in_stride, out, out_stride, \
+                       mods, matrix, mi_inv, prod, I_j, I_location, n_power, rc, l, level)
+    if (max_cnt <= 2) LAUNCH(2);
+    else if (max_cnt <= 4) LAUNCH(4);
+    else if (max_cnt <= 8) LAUNCH(8);
+    else if (max_cnt <= 16) LAUNCH(16);
+    else LAUNCH(32);
+#undef LAUNCH
     return hipGetLastError();
 }
 
@@ -476,6 +492,11 @@ __device__ __forceinline__ u64 moddown_multi(u64 x, const u64* pin, int y, const
     return x;
 }
 
+// All Q_cur limbs of one coefficient (and part) per thread.  The reference's kernel (one thread per limb) redoes
+// the mod-down chain AMONG the special primes -- P (P - 1) / 2 reductions that do not depend on the limb -- for
+// every one of the Q_cur limbs; here it runs once (r[k] = special prime P_size - 1 - k, static register indices)
+// and leaves the P_size values lh_i the limbs need.  Same arithmetic per value as moddown_multi.
+template <int PMAX>
 __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
     const u64* __restrict__ in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out, u64 out_stride,
     const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
@@ -483,15 +504,69 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
     int P_size, int with_ct)
 {
     const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
-    const int y = blockIdx.y;
     const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
-    const Mod m = mods[y];
     const u64* pin = in + in_stride * b + (((u64) Qp_cur << n_power) * z) + idx;
-    u64 x = moddown_multi(pin[(u64) y << n_power], pin, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur,
-                          first_Qp, first_Q, P_size);
-    const u64 loc = ((u64) y << n_power) + (((u64) Q_cur << n_power) * z) + idx;
-    if (with_ct == 1 || (with_ct == 2 && z == 0)) x = add_mod(ct[ct_stride * b + loc], x, m.q);
-    out[out_stride * b + loc] = x;
+    u64 r[PMAX];
+#pragma unroll
+    for (int k = 0; k < PMAX; k++) r[k] = pin[(u64) (Q_cur + (k < P_size ? P_size - 1 - k : 0)) << n_power];
+    int loc[PMAX];
+    {
+        int location_ = 0;
+#pragma unroll
+        for (int i = 0; i < PMAX; i++) {
+            loc[i] = location_;
+            location_ += first_Qp - 1 - i;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PMAX; i++) {
+        if (i < P_size) {
+            r[i] = add_mod(r[i], half[i], mods[first_Qp - 1 - i].q); // lh_i
+#pragma unroll
+            for (int k = i + 1; k < PMAX; k++) {
+                if (k < P_size) {
+                    const int j = P_size - 1 - k;
+                    const Mod mj = mods[first_Q + j];
+                    u64 t1 = reduce64(r[i], mj);
+                    t1 = sub_mod(t1, half_mod[loc[i] + first_Q + j], mj.q);
+                    t1 = sub_mod(r[k], t1, mj.q);
+                    r[k] = mul_barrett(t1, last_q_modinv[loc[i] + first_Q + j], mj);
+                }
+            }
+        }
+    }
+    const u64 part = ((u64) Q_cur << n_power) * z;
+    const bool add = with_ct == 1 || (with_ct == 2 && z == 0);
+    const u64* pc = ct + (add ? ct_stride * b + part + idx : 0);
+    u64* po = out + out_stride * b + part + idx;
+    for (int y0 = 0; y0 < Q_cur; y0 += 4) {
+        u64 x[4], c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // loads first
+            const int y = (y0 + u < Q_cur) ? y0 + u : Q_cur - 1;
+            x[u] = pin[(u64) y << n_power];
+            c4[u] = add ? pc[(u64) y << n_power] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int y = (y0 + u < Q_cur) ? y0 + u : Q_cur - 1;
+            const Mod m = mods[y];
+            u64 v = x[u];
+#pragma unroll
+            for (int i = 0; i < PMAX; i++) {
+                if (i < P_size) {
+                    u64 t1 = reduce64(r[i], m);
+                    t1 = sub_mod(t1, half_mod[loc[i] + y], m.q);
+                    t1 = sub_mod(v, t1, m.q);
+                    v = mul_barrett(t1, last_q_modinv[loc[i] + y], m);
+                }
+            }
+            x[u] = add ? add_mod(c4[u], v, m.q) : v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (y0 + u < Q_cur) po[(u64) (y0 + u) << n_power] = x[u];
+    }
 }
 
 hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
@@ -500,11 +575,16 @@ hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64
                                 int first_Q, int P_size, int with_ct, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
-    if (P_size > 15) return hipErrorInvalidValue;
-    dim3 g((1u << n_power) / RNS_THREADS, Q_cur, 2 * batch);
-    hipLaunchKernelGGL(k_moddown_extended, g, dim3(RNS_THREADS), 0, st, in, in_stride, ct, ct_stride, out,
-                       out_stride, mods, half, half_mod, last_q_modinv, n_power, Qp_cur, Q_cur, first_Qp, first_Q,
-                       P_size, with_ct);
+    if (P_size > 15 || P_size < 1) return hipErrorInvalidValue;
+    dim3 g((1u << n_power) / RNS_THREADS, 1, 2 * batch);
+#define LAUNCH(M)                                                                                                    \
+    hipLaunchKernelGGL(k_moddown_extended<M>, g, dim3(RNS_THREADS), 0, st, in, in_stride, ct, ct_stride, out, out_stride, \
+                       mods, half, half_mod, last_q_modinv, n_power, Qp_cur, Q_cur, first_Qp, first_Q, P_size, with_ct)
+    if (P_size <= 2) LAUNCH(2);
+    else if (P_size <= 4) LAUNCH(4);
+    else if (P_size <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
     return hipGetLastError();
 }
 

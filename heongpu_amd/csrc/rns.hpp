@@ -41,7 +41,7 @@ hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* 
 hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
                                          const u64* matrix, const u64* mi_inv, const u64* prod, const int* I_j,
                                          const int* I_location, int n_power, int d, int rc, int l, int level,
-                                         int batch, hipStream_t st);
+                                         int max_cnt /* widest digit */, int batch, hipStream_t st);
 
 // reference switchkey.cu:480-611 / 1222-1282 (mod-down by P_size primes);
 // with_ct: 0 none, 1 both parts, 2 part 0 only
