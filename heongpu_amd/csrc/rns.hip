@@ -463,45 +463,21 @@ hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out,
     return hipGetLastError();
 }
 
-// mod-down of limb y by the P_size special primes, one at a time, last first
-// (the loop of switchkey.cu:497-534 / 1239-1276 / 1650-1683)
-__device__ __forceinline__ u64 moddown_multi(u64 x, const u64* pin, int y, const Mod& m, const Mod* __restrict__ mods,
-                                             const u64* __restrict__ half, const u64* __restrict__ half_mod,
-                                             const u64* __restrict__ last_q_modinv, int n_power, int Q_cur,
-                                             int first_Qp, int first_Q, int P_size)
-{
-    u64 last_ct[15];
-    for (int i = 0; i < P_size; i++) last_ct[i] = pin[(u64) (Q_cur + i) << n_power];
-    int location_ = 0;
-    for (int i = 0; i < P_size; i++) {
-        u64 lh = last_ct[P_size - 1 - i];
-        lh = add_mod(lh, half[i], mods[first_Qp - 1 - i].q);
-        for (int j = 0; j < (P_size - 1 - i); j++) {
-            const Mod mj = mods[first_Q + j];
-            u64 t1 = reduce64(lh, mj);
-            t1 = sub_mod(t1, half_mod[location_ + first_Q + j], mj.q);
-            t1 = sub_mod(last_ct[j], t1, mj.q);
-            last_ct[j] = mul_barrett(t1, last_q_modinv[location_ + first_Q + j], mj);
-        }
-        u64 t1 = reduce64(lh, m);
-        t1 = sub_mod(t1, half_mod[location_ + y], m.q);
-        t1 = sub_mod(x, t1, m.q);
-        x = mul_barrett(t1, last_q_modinv[location_ + y], m);
-        location_ += (first_Qp - 1 - i);
-    }
-    return x;
-}
-
+// Mod-down by the P_size special primes, one at a time, last first (the loop of switchkey.cu:497-534 / 1239-1276 /
+// 1650-1683): step i takes lh_i = (special prime P_size-1-i's limb + half_i), and every remaining limb (special
+// or not) becomes (x - (lh_i mod q - half_mod_i)) * P_i^-1.
 // All Q_cur limbs of one coefficient (and part) per thread.  The reference's kernel (one thread per limb) redoes
 // the mod-down chain AMONG the special primes -- P (P - 1) / 2 reductions that do not depend on the limb -- for
 // every one of the Q_cur limbs; here it runs once (r[k] = special prime P_size - 1 - k, static register indices)
-// and leaves the P_size values lh_i the limbs need.  Same arithmetic per value as moddown_multi.
+// and leaves the P_size values lh_i the limbs need.
+// galois_elt != 0: the result goes through the coefficient permutation out[(i g) mod N] = +-v
+// (divide_round_lastq_permute_*_kernel with P_size > 1, switchkey.cu:1621-1813).
 template <int PMAX>
 __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
     const u64* __restrict__ in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out, u64 out_stride,
     const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
     const u64* __restrict__ last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp, int first_Q,
-    int P_size, int with_ct)
+    int P_size, int with_ct, int galois_elt)
 {
     const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
     const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
@@ -538,7 +514,9 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
     const u64 part = ((u64) Q_cur << n_power) * z;
     const bool add = with_ct == 1 || (with_ct == 2 && z == 0);
     const u64* pc = ct + (add ? ct_stride * b + part + idx : 0);
-    u64* po = out + out_stride * b + part + idx;
+    const u32 raw = idx * (u32) galois_elt;
+    const bool neg = galois_elt && ((raw >> n_power) & 1);
+    u64* po = out + out_stride * b + part + (galois_elt ? (raw & ((1u << n_power) - 1)) : idx);
     for (int y0 = 0; y0 < Q_cur; y0 += 4) {
         u64 x[4], c4[4];
 #pragma unroll
@@ -561,7 +539,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
                     v = mul_barrett(t1, last_q_modinv[loc[i] + y], m);
                 }
             }
-            x[u] = add ? add_mod(c4[u], v, m.q) : v;
+            v = add ? add_mod(c4[u], v, m.q) : v;
+            x[u] = neg ? m.q - v : v; // no zero test on the negation: reference switchkey.cu:1694,1711
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -579,19 +558,21 @@ hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64
     dim3 g((1u << n_power) / RNS_THREADS, 1, 2 * batch);
 #define LAUNCH(M)                                                                                                    \
     hipLaunchKernelGGL(k_moddown_extended<M>, g, dim3(RNS_THREADS), 0, st, in, in_stride, ct, ct_stride, out, out_stride, \
-                       mods, half, half_mod, last_q_modinv, n_power, Qp_cur, Q_cur, first_Qp, first_Q, P_size, with_ct)
-    if (P_size <= 2) LAUNCH(2);
-    else if (P_size <= 4) LAUNCH(4);
-    else if (P_size <= 8) LAUNCH(8);
-    else LAUNCH(16);
-#undef LAUNCH
+                       mods, half, half_mod, last_q_modinv, n_power, Qp_cur, Q_cur, first_Qp, first_Q, P_size, with_ct,    \
+                       galois_elt)
+#define MODDOWN_EXT_DISPATCH \
+    if (P_size <= 2) LAUNCH(2); \
+    else if (P_size <= 4) LAUNCH(4); \
+    else if (P_size <= 8) LAUNCH(8); \
+    else LAUNCH(16)
+    const int galois_elt = 0;
+    MODDOWN_EXT_DISPATCH;
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- mod-down + Galois permutation
 // One coefficient per thread: the destination index i*g mod N scatters.
 #define MDP_PER 4
-template <bool SINGLE_P>
 __global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
     const u64* __restrict__ in, u64 in_stride, const u64* __restrict__ in2, u64 in2_stride, u64* __restrict__ out,
     u64 out_stride, const Mod* __restrict__ mods, const u64* __restrict__ half, const u64* __restrict__ half_mod,
@@ -610,22 +591,19 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_permute(
     for (int r = 0; r < MDP_PER; r++) {
         const u32 idx = idx0 + RNS_THREADS * r;
         xs[r] = pin0[((u64) y << n_power) + idx];
-        if (SINGLE_P) ls[r] = pin0[((u64) Q_cur << n_power) + idx];
+        ls[r] = pin0[((u64) Q_cur << n_power) + idx];
         cs[r] = (z == 0) ? in2[in2_stride * b + ((u64) y << n_power) + idx] : 0;
     }
 #pragma unroll
     for (int r = 0; r < MDP_PER; r++) {
         const u32 idx = idx0 + RNS_THREADS * r;
         u64 x = xs[r];
-        if (SINGLE_P) {
+        {
             u64 l = add_mod(ls[r], half[0], mods[first_Qp - 1].q);
             l = reduce64(l, m);
             l = sub_mod(l, half_mod[y], m.q);
             l = sub_mod(x, l, m.q);
             x = mul_barrett(l, last_q_modinv[y], m);
-        } else {
-            x = moddown_multi(x, pin0 + idx, y, m, mods, half, half_mod, last_q_modinv, n_power, Q_cur, first_Qp, first_Q,
-                              P_size);
         }
         if (z == 0) x = add_mod(cs[r], x, m.q);
         const u32 raw = idx * (u32) galois_elt;
@@ -644,15 +622,22 @@ hipError_t rns_moddown_permute(const u64* in, u64 in_stride, const u64* in2, u64
     dim3 g((1u << n_power) / (RNS_THREADS * MDP_PER), Q_cur, 2 * batch);
     if (P_size > 15) return hipErrorInvalidValue;
     if (P_size == 1)
-        hipLaunchKernelGGL(k_moddown_permute<true>, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride, out,
+        hipLaunchKernelGGL(k_moddown_permute, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride, out,
                            out_stride, mods, half, half_mod, last_q_modinv, galois_elt, n_power, Qp_cur, Q_cur,
                            first_Qp, first_Q, P_size);
-    else
-        hipLaunchKernelGGL(k_moddown_permute<false>, g, dim3(RNS_THREADS), 0, st, in, in_stride, in2, in2_stride,
-                           out, out_stride, mods, half, half_mod, last_q_modinv, galois_elt, n_power, Qp_cur, Q_cur,
-                           first_Qp, first_Q, P_size);
+    else {
+        // several special primes: all limbs of a coefficient per thread (k_moddown_extended), the sum with the
+        // other ciphertext part (part 0 only) and the permutation on the way out
+        const u64* ct = in2;
+        const u64 ct_stride = in2_stride;
+        const int with_ct = 2;
+        dim3 g((1u << n_power) / RNS_THREADS, 1, 2 * batch);
+        MODDOWN_EXT_DISPATCH;
+    }
     return hipGetLastError();
 }
+#undef LAUNCH
+#undef MODDOWN_EXT_DISPATCH
 
 // ---------------------------------------------------------------- strided limb copy
 __global__ __launch_bounds__(RNS_THREADS) void k_copy_limbs(const u64* __restrict__ in, u64 in_part_stride,
