@@ -266,6 +266,29 @@ def secondary_block(torch, hg, timer):
         "frac_of_hbm_peak_batch64": op_bytes * 64 / (c2[64] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     ctx.close()
 
+    # ---- key-switching method II (selected by the reference whenever P_size > 1): the C4 shape with four special
+    # primes, Q = 16 x 50 bits | P = 4 x 50 bits (d = 4 digits of 4 primes), multiply + relinearize, 64 pairs
+    n, B = 1 << 16, 64
+    ctx = hg.Context.from_bit_sizes(hg.CKKS, n, [50] * 16, [50] * 4, sec=hg.SEC_NONE)
+    ctx.upload()
+    Q, Qp = ctx.Q_size, ctx.Q_prime_size
+    d = -(-Q // 4)
+    c1b, c2b = rnd(torch, 2 * Q * n * B), rnd(torch, 2 * Q * n * B)
+    ob = torch.empty(3 * Q * n * B, dtype=torch.int64, device="cuda")
+    key = rnd(torch, d * 2 * Qp * n)
+    wsb = ctx.workspace(hg.OP_CKKS_RELIN, 0, B)
+
+    def seq2():
+        ctx.ckks_multiply(c1b, 2 * Q * n, c2b, 2 * Q * n, ob, 3 * Q * n, 0, B, stream=stream)
+        ctx.ckks_relinearize_inplace(ob, 3 * Q * n, key, 0, B, wsb, stream=stream)
+    m2 = timer.ms(seq2, 3)
+    sec["ckks_n16_method_II"] = {
+        "workload": "CKKS N=2^16, Q=16 x 50 bits | P=4 x 50 bits (hybrid key switching, 4 digits), multiply + relinearize, "
+                    "%d pairs" % B,
+        "multiply_relinearize_per_s": B / (m2 * 1e-3), "ms_per_batch": m2}
+    ctx.close()
+    del c1b, c2b, ob, key, wsb
+
     # ---- C5: TFHE STD128 NAND gate bootstrap, 8192 concurrent gates (the whole config on one GPU;
     # its 8-GPU share is 1024)
     t = hg.TfheContext()

@@ -215,6 +215,32 @@ void Context::build_host()
             }
             m2_levels.push_back(L);
         }
+        // The mod-down by the P special primes, one at a time (x <- (x - t_i) / P_(i), t_i = lh_i mod q - half_mod_i,
+        // P_(i) = primes[Qp-1-i]), flattened for a limb q_y of Q:
+        //     x_final = W0 * (x - u),   W0 = prod_i P_(i)^-1,   u = sum_i lh_i * G_i - C,
+        //     G_i = prod_{k<i} P_(k),   C = sum_i half_mod_i * G_i                              (all mod q_y)
+        // so that u can be transformed on its own and the division become the epilogue of that transform
+        // (ops.cpp: ckks_moddown_multi).  Tables indexed by the absolute modulus index y < Q.
+        {
+            vec W0(Q), G((size_t) Q * P), C(Q);
+            for (int y = 0; y < Q; y++) {
+                const u64 q = primes[y];
+                u64 w = 1, g = 1, c = 0;
+                int loc = 0;
+                for (int i = 0; i < P; i++) {
+                    G[(size_t) y * P + i] = g;
+                    c = (c + mul_mod(host["half_mod"][loc + y], g, q)) % q;
+                    w = mul_mod(w, host["last_q_modinv"][loc + y], q);
+                    g = mul_mod(g, primes[Qp - 1 - i] % q, q);
+                    loc += (Qp - 1) - i;
+                }
+                W0[y] = w;
+                C[y] = c;
+            }
+            host["m2_md_W0"] = W0;
+            host["m2_md_G"] = G;
+            host["m2_md_C"] = C;
+        }
         host["m2_I_j"] = Ij;
         host["m2_I_location"] = Iloc;
         host["m2_Mi_inv"] = mi;
@@ -554,6 +580,9 @@ hipError_t Context::upload()
                                        "half",
                                        "half_mod",
                                        "factor",
+                                       "m2_md_W0",
+                                       "m2_md_G",
+                                       "m2_md_C",
                                        "rescaled_last_q_modinv",
                                        "rescaled_half_mod",
                                        "rescaled_half",

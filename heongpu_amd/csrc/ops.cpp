@@ -451,6 +451,43 @@ static hipError_t dtoq(const Context& c, int lvl, const u64* in, u64 in_stride, 
 }
 
 // reference ckks/operator.cu:1025-1154
+// CKKS key switching with several special primes, tail: acc [2][rc][N] (NTT domain) -> out [2][l][N] =
+// moddown(acc) + ct (parts below add_parts; 0 = both) [-> Galois automorphism].  The reference runs the INTT of all
+// 2 rc limbs, divide_round_lastq_extended_leveled_kernel, the NTT of 2 l limbs and an addition
+// (ckks/operator.cu:1131-1149).  Here only the 2 P special limbs are inverse-transformed; from them one kernel
+// forms, per limb of Q, the value u whose transform the forward pass's epilogue subtracts from the accumulated limb
+// before multiplying by W0 = prod P_i^-1 (context.cpp m2_md_*): the same exact integer function, so the same
+// residues.  scratch: [2][l][N] per item (`per` apart).
+static hipError_t ckks_moddown_multi(const Context& c, u64* acc, u64* scratch, u64 per, const u64* ct, u64 cs,
+                                     int add_parts, u64* out, u64 so, int depth, int galois_elt, int batch,
+                                     hipStream_t st)
+{
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size, P = c.P_size;
+    const int l = Q - depth, rc = Qp - depth;
+    for (int part = 0; part < 2; part++) {
+        NttArgs a = c.ntt_args(0);
+        a.in = a.out = acc + (u64) (part * rc + l) * n;
+        a.mod_count = P; a.mod_offset = Q; a.polys_per_item = P;
+        a.in_item_stride = a.out_item_stride = per;
+        TRY(ntt_launch(a, P * batch, true, st));
+    }
+    TRY(rns_moddown_multi_stage_one(acc, per, scratch, per, c.plan_qp.mods, c.d64("half"), c.d64("half_mod"),
+                                    c.d64("last_q_modinv"), c.d64("m2_md_G"), c.d64("m2_md_C"), c.n_power, rc, l, Qp, Q,
+                                    P, batch, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = a.out = scratch; a.mod_count = l; a.polys_per_item = 2 * l;
+    a.in_item_stride = a.out_item_stride = per;
+    a.epi.on = 1;
+    a.epi.ks = acc; a.epi.ks_item_stride = per; a.epi.ks_part_limbs = rc;
+    a.epi.ct = ct; a.epi.ct_item_stride = cs; a.epi.ct_parts = add_parts;
+    a.epi.out = out; a.epi.out_item_stride = so;
+    a.epi.inv = c.d64("m2_md_W0");
+    a.epi.limbs = l;
+    a.epi.galois_inv = galois_elt ? (unsigned) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0u;
+    return ntt_launch(a, 2 * l * batch, false, st);
+}
+
 hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,
                                   hipStream_t st)
 {
@@ -475,6 +512,8 @@ hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* 
     a.in = temp1; a.out = temp1; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, rc, l, depth, nullptr, 0, batch, st));          // :1095-1125
+    if (c.fused_moddown) // temp1 ([d][rc][N], the digits) is free again: scratch of the mod-down
+        return ckks_moddown_multi(c, temp2, temp1, per, ct, cs, 0, ct, cs, depth, 0, batch, st);
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));                                          // :1131
     TRY(rns_moddown_extended(temp2, per, nullptr, 0, temp1, per, mods, c.d64("half"), c.d64("half_mod"),
@@ -503,15 +542,23 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
     u64* temp4 = temp3 + (u64) l * rc * n;
     const Mod* mods = c.plan_qp.mods;
     const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
+    const bool ntt_domain = c.fused_moddown && c.ntt_galois;
     NttArgs a = c.ntt_args(0);
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
     a.in_item_stride = cs; a.out_item_stride = per;
-    TRY(ntt_launch(a, 2 * l * batch, true, st));
+    if (ntt_domain) { // c0 stays in the NTT domain (see op_ckks_apply_galois): only c1 is needed as coefficients
+        a.in = ct + (u64) l * n; a.out = temp0 + (u64) l * n; a.polys_per_item = l;
+        TRY(ntt_launch(a, l * batch, true, st));
+    } else {
+        TRY(ntt_launch(a, 2 * l * batch, true, st));
+    }
     TRY(dtoq(c, depth, temp0 + (u64) l * n, per, temp3, per, l, depth, batch, st));
     a = c.ntt_args(0);
     a.in = temp3; a.out = temp3; a.mod_count = rc; a.polys_per_item = d * rc; a.mod_order = order;
     a.in_item_stride = a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp4, per, d, rc, l, depth, nullptr, 0, batch, st));
+    if (ntt_domain) // temp0 is free again: scratch of the mod-down; c0 added and the automorphism applied by its epilogue
+        return ckks_moddown_multi(c, temp4, temp0, per, ct, cs, 1, out, so, depth, galois_elt, batch, st);
     a.in = temp4; a.out = temp4; a.polys_per_item = 2 * rc;
     TRY(ntt_launch(a, 2 * rc * batch, true, st));
     TRY(rns_moddown_permute(temp4, per, temp0, per, out, so, mods, c.d64("half"), c.d64("half_mod"),

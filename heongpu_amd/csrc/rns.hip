@@ -548,6 +548,80 @@ __global__ __launch_bounds__(RNS_THREADS) void k_moddown_extended(
     }
 }
 
+// First half of the same mod-down for the NTT-domain form (context.cpp: m2_md_*): from the special limbs of one
+// coefficient (coefficient domain) the value u_y = sum_i lh_i G_i[y] - C[y] for every limb y of Q; its transform
+// is what the forward pass's epilogue subtracts from the accumulated limb before multiplying by W0[y].
+// in: [2][Qp_cur][N] per item (only the P_size special slots are read), out: [2][Q_cur][N].
+template <int PMAX>
+__global__ __launch_bounds__(RNS_THREADS) void k_moddown_multi_stage_one(
+    const u64* __restrict__ in, u64 in_stride, u64* __restrict__ out, u64 out_stride, const Mod* __restrict__ mods,
+    const u64* __restrict__ half, const u64* __restrict__ half_mod, const u64* __restrict__ last_q_modinv,
+    const u64* __restrict__ G, const u64* __restrict__ C, int n_power, int Qp_cur, int Q_cur, int first_Qp,
+    int first_Q, int P_size)
+{
+    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int z = blockIdx.z & 1, b = blockIdx.z >> 1;
+    const u64* pin = in + in_stride * b + (((u64) Qp_cur << n_power) * z) + idx;
+    u64 r[PMAX];
+#pragma unroll
+    for (int k = 0; k < PMAX; k++) r[k] = pin[(u64) (Q_cur + (k < P_size ? P_size - 1 - k : 0)) << n_power];
+    int loc[PMAX];
+    {
+        int location_ = 0;
+#pragma unroll
+        for (int i = 0; i < PMAX; i++) {
+            loc[i] = location_;
+            location_ += first_Qp - 1 - i;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PMAX; i++) {
+        if (i < P_size) {
+            r[i] = add_mod(r[i], half[i], mods[first_Qp - 1 - i].q); // lh_i
+#pragma unroll
+            for (int k = i + 1; k < PMAX; k++) {
+                if (k < P_size) {
+                    const int j = P_size - 1 - k;
+                    const Mod mj = mods[first_Q + j];
+                    u64 t1 = reduce64(r[i], mj);
+                    t1 = sub_mod(t1, half_mod[loc[i] + first_Q + j], mj.q);
+                    t1 = sub_mod(r[k], t1, mj.q);
+                    r[k] = mul_barrett(t1, last_q_modinv[loc[i] + first_Q + j], mj);
+                }
+            }
+        } else {
+            r[i] = 0;
+        }
+    }
+    u64* po = out + out_stride * b + (((u64) Q_cur << n_power) * z) + idx;
+#pragma unroll 1
+    for (int y = 0; y < Q_cur; y++) {
+        const Mod m = mods[y];
+        u64 hi, lo;
+        dot128(r, G + (u64) y * P_size, P_size, hi, lo); // lh_i, G_i < 2^61: un-reduced factors of the lazy sum
+        po[(u64) y << n_power] = sub_mod(reduce128(hi, lo, m), C[y], m.q);
+    }
+}
+
+hipError_t rns_moddown_multi_stage_one(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                                       const u64* half, const u64* half_mod, const u64* last_q_modinv, const u64* G,
+                                       const u64* C, int n_power, int Qp_cur, int Q_cur, int first_Qp, int first_Q,
+                                       int P_size, int batch, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (P_size > 15 || P_size < 2) return hipErrorInvalidValue;
+    dim3 g((1u << n_power) / RNS_THREADS, 1, 2 * batch);
+#define LAUNCH(M)                                                                                                  \
+    hipLaunchKernelGGL(k_moddown_multi_stage_one<M>, g, dim3(RNS_THREADS), 0, st, in, in_stride, out, out_stride, mods, \
+                       half, half_mod, last_q_modinv, G, C, n_power, Qp_cur, Q_cur, first_Qp, first_Q, P_size)
+    if (P_size <= 2) LAUNCH(2);
+    else if (P_size <= 4) LAUNCH(4);
+    else if (P_size <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
                                 u64 out_stride, const Mod* mods, const u64* half, const u64* half_mod,
                                 const u64* last_q_modinv, int n_power, int Qp_cur, int Q_cur, int first_Qp,

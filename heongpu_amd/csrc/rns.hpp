@@ -43,6 +43,11 @@ hipError_t rns_base_conversion_DtoQtilde(const u64* in, u64 in_stride, u64* out,
                                          const int* I_location, int n_power, int d, int rc, int l, int level,
                                          int max_cnt /* widest digit */, int batch, hipStream_t st);
 
+// first half of the multi-prime mod-down in its NTT-domain form (context.cpp m2_md_*; ops.cpp ckks_moddown_multi)
+hipError_t rns_moddown_multi_stage_one(const u64* in, u64 in_stride, u64* out, u64 out_stride, const Mod* mods,
+                                       const u64* half, const u64* half_mod, const u64* last_q_modinv, const u64* G,
+                                       const u64* C, int n_power, int Qp_cur, int Q_cur, int first_Qp, int first_Q,
+                                       int P_size, int batch, hipStream_t st);
 // reference switchkey.cu:480-611 / 1222-1282 (mod-down by P_size primes);
 // with_ct: 0 none, 1 both parts, 2 part 0 only
 hipError_t rns_moddown_extended(const u64* in, u64 in_stride, const u64* ct, u64 ct_stride, u64* out,
