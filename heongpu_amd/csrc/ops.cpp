@@ -614,10 +614,10 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
         }
     }
 
-    // Method I with the mod-down fused into its transform: every element stays in the NTT domain -- inner product,
-    // INTT of the two P limbs, mod-down transform whose epilogue adds c0 and scatters through the automorphism
-    // (see op_ckks_apply_galois).  c0 is never transformed, so only c1 goes through the shared INTT.
-    const bool ntt_domain = !m2 && c.fused_moddown && c.ntt_galois;
+    // With the mod-down fused into its transform every element stays in the NTT domain -- inner product, INTT of
+    // the special limbs, mod-down transform whose epilogue adds c0 and scatters through the automorphism (see
+    // op_ckks_apply_galois / ckks_moddown_multi).  c0 is never transformed, so only c1 goes through the shared INTT.
+    const bool ntt_domain = c.fused_moddown && c.ntt_galois;
     // ---- shared: INTT of both parts (of c1 only: ntt_domain), digits, forward NTT of the digits
     NttArgs a = c.ntt_args(0);
     a.in = ct; a.out = temp0; a.mod_count = l; a.polys_per_item = 2 * l;
@@ -648,8 +648,10 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
         TRY(rns_keyswitch_mac(temp2, per, keys[i], temp3, per, mods, np, digits, rc, Qp, l, depth, batch, st));
         if (ntt_domain) {
             // temp0 is free once the digits exist: scratch of the mod-down transform
-            TRY(ckks_keyswitch_core(c, nullptr, 0, ct, cs, 1, oi, so, nullptr, depth, batch, temp0, temp3, per, st,
-                                    RELIN_PHASE_INTT_P | RELIN_PHASE_MODDOWN, galois_elts[i]));
+            if (m2) TRY(ckks_moddown_multi(c, temp3, temp0, per, ct, cs, 1, oi, so, depth, galois_elts[i], batch, st));
+            else
+                TRY(ckks_keyswitch_core(c, nullptr, 0, ct, cs, 1, oi, so, nullptr, depth, batch, temp0, temp3, per, st,
+                                        RELIN_PHASE_INTT_P | RELIN_PHASE_MODDOWN, galois_elts[i]));
             continue;
         }
         NttArgs b = c.ntt_args(0);
