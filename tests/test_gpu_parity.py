@@ -337,14 +337,22 @@ def test_c3_bfv_rotate_batch64_full_size(hg, oracle, torch):
         assert np.array_equal(got[b], got[b % uniq]), f"batch item {b} differs from its twin"
 
 
+@pytest.mark.parametrize("p_bits,reference_order", [([40, 40], False), ([40, 40], True), ([40, 41, 40], False),
+                                                     ([60, 36, 45, 50], False)],
+                         ids=["P2", "P2-reference-order", "P3", "P4-mixed-widths"])
 @pytest.mark.parametrize("depth", [0, 1, 3])
-def test_ckks_method_II(hg, oracle, torch, depth):
-    """key-switching method II (P_size = 2): relinearize + rotate, leveled."""
+def test_ckks_method_II(hg, oracle, torch, depth, p_bits, reference_order, monkeypatch):
+    """key-switching method II (P_size = 2, 3, 4): relinearize + rotate, leveled.  By default the multi-prime
+    mod-down runs in the NTT domain (ops.cpp: ckks_moddown_multi); HEGPU_FUSED_MODDOWN=0 keeps the reference's
+    order (INTT of every limb, k_moddown_extended in both its forms, NTT, addition)."""
     n = 8192
-    c, o, primes = _ckks_pair(hg, oracle, n, [40, 35, 35, 35, 35], [40, 40], sec=hg.SEC_NONE)
-    Q, Qp = 5, 7
+    if reference_order:
+        monkeypatch.setenv("HEGPU_FUSED_MODDOWN", "0")  # read when the context is uploaded
+    c, o, primes = _ckks_pair(hg, oracle, n, [40, 35, 35, 35, 35], p_bits, sec=hg.SEC_NONE)
+    P = len(p_bits)
+    Q, Qp = 5, 5 + P
     l = Q - depth
-    d0 = (Q + 1) // 2
+    d0 = -(-Q // P)
     batch = 2
     key = synth_key(primes, d0, Qp, n, 3)
     ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
