@@ -164,7 +164,7 @@ def hoisted_rotation_block(torch, hg, timer, ctx, B=16):
     stream = torch.cuda.current_stream().cuda_stream
     words = 2 * Q * n
     ct = rnd(torch, B * words, 1 << 49)
-    ws = ctx.workspace(hg.OP_CKKS_GALOIS, 0, B)
+    ws = ctx.workspace(hg.OP_CKKS_ROTATE_HOISTED, 0, B)  # room for four accumulators (>= OP_CKKS_GALOIS)
     kmax = 8
     keys = [rnd(torch, Q * 2 * Qp * n, 1 << 49) for _ in range(kmax)]
     elts = [hg.steps_to_galois_elt(i + 1, n, 5) for i in range(kmax)]

@@ -6,7 +6,7 @@ tests/ and bench.py; importing it without the built library fails loudly.
 """
 from . import _lib
 from .api import (BFV, CKKS, SEC_NONE, SEC_128, SEC_192, SEC_256, TABLES_QP, TABLES_Q_BSK, OP_CKKS_RELIN, OP_CKKS_RESCALE,
-                  OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS, E_INVALID, E_LOGIC, E_RUNTIME,
+                  OP_CKKS_GALOIS, OP_CKKS_ROTATE_HOISTED, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS, E_INVALID, E_LOGIC, E_RUNTIME,
                   E_NODEVICE, Context, HEError, Rng, TfheContext, OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC,
                   OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE, OP_CKKS_ENCODE,
                   OP_CKKS_DECODE, OP_BFV_MULTIPLY_PLAIN, GATE_NAND, GATE_AND, GATE_AND_FIRST_NOT,

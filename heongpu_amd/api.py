@@ -15,6 +15,7 @@ BFV, CKKS = 1, 2
 SEC_NONE, SEC_128, SEC_192, SEC_256 = 0, 128, 192, 256
 TABLES_QP, TABLES_Q_BSK = 0, 1
 OP_CKKS_RELIN, OP_CKKS_RESCALE, OP_CKKS_GALOIS, OP_BFV_MULTIPLY, OP_BFV_RELIN, OP_BFV_GALOIS = 1, 2, 3, 4, 5, 6
+OP_CKKS_ROTATE_HOISTED = 17
 OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC, OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE = 7, 8, 9, 10, 11, 12, 13
 OP_CKKS_ENCODE, OP_CKKS_DECODE = 14, 15
 OP_BFV_MULTIPLY_PLAIN = 16

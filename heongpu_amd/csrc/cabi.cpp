@@ -513,8 +513,12 @@ int hegpu_ckks_rotate_hoisted(hegpu_context* ctx, const uint64_t* ct, uint64_t c
             return fail(HEGPU_E_INVALID, "rotate_hoisted: Galois elements are odd and below 2N");
         if (!keys[i]) return fail(HEGPU_E_INVALID, "rotate_hoisted: Galois key not present!");
     }
+    // a workspace of HEGPU_OP_CKKS_ROTATE_HOISTED size holds four accumulators: the inner products of four
+    // elements then share one read of the digits
+    const bool big = ws_bytes >= hegpu_workspace_bytes(ctx, OP_CKKS_ROTATE_HOISTED, depth, batch) && ctx->c.fused_moddown &&
+                     ctx->c.ntt_galois;
     return hip_ret(op_ckks_rotate_hoisted(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64* const*) keys,
-                                          galois_elts, count, depth, batch, (u64*) ws, (hipStream_t) stream),
+                                          galois_elts, count, depth, batch, (u64*) ws, (hipStream_t) stream, big ? 4 : 1),
                    "hegpu_ckks_rotate_hoisted");
 }
 

@@ -103,6 +103,7 @@ size_t ops_workspace_elems(const Context& c, int op, int depth, int batch)
         case OP_CKKS_RELIN: per = ((u64) l * rc + 2 * rc) * n; break;
         case OP_CKKS_RESCALE: per = ((u64) 2 * (l - 1) + 2 * l) * n; break;
         case OP_CKKS_GALOIS: per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n; break;
+        case OP_CKKS_ROTATE_HOISTED: per = ((u64) 2 * l + (u64) l * rc + 4 * 2 * rc) * n; break; // four accumulators
         case OP_BFV_MULTIPLY: per = (u64) 7 * L * n; break;
         case OP_BFV_RELIN: per = ((u64) Q * Qp + 2 * Qp) * n; break;
         case OP_BFV_GALOIS: per = ((u64) Q * Qp + 2 * Qp) * n; break;
@@ -579,7 +580,8 @@ hipError_t op_ckks_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64*
 // out: [count][2][l][N] per ciphertext (`so` apart), entry i at i * 2 l N; galois_elts[i] == 0 copies the input
 // (global_memory_replace_kernel, :4708 / :5141).  Workspace: OP_CKKS_GALOIS.
 hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* const* keys,
-                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st)
+                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st,
+                                  int group)
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     const int np = c.n_power;
@@ -588,10 +590,13 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
     const int l = Q - depth, rc = Qp - depth;
     const bool m2 = c.P_size > 1;
     const int digits = m2 ? c.m2_levels[depth].d : l;
-    const u64 per = ((u64) 2 * l + (u64) l * rc + 2 * rc) * n;
+    if (group != 1 && group != 4) return hipErrorInvalidValue;
+    if (digits > 16) group = 1; // rns_keyswitch_mac_keys keeps the digits of a coefficient in 16 registers
+    const u64 acc_words = (u64) 2 * rc * n;
+    const u64 per = ((u64) 2 * l + (u64) l * rc) * n + group * acc_words;
     u64* temp0 = ws;                       // [2][l][N] coefficient-domain copy of ct
     u64* temp2 = temp0 + (u64) 2 * l * n;  // [digits][rc][N] NTT-domain digits
-    u64* temp3 = temp2 + (u64) l * rc * n; // [2][rc][N]
+    u64* temp3 = temp2 + (u64) l * rc * n; // [group][2][rc][N]
     const Mod* mods = c.plan_qp.mods;
     const int* order = c.d32("new_prime_locations") + prime_loc_offset(c, depth);
     const u64 ct_words = (u64) 2 * l * n;
@@ -641,19 +646,36 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
     }
     TRY(ntt_launch(a, digits * rc * batch, false, st));
 
-    // ---- per Galois element
+    // ---- per Galois element; with room for four accumulators the inner products of four elements share one read
+    // of the digits (rns_keyswitch_mac_keys)
+    int pending[4], npend = 0, next = 0;
     for (int i = 0; i < count; i++) {
         if (galois_elts[i] == 0) continue;
         u64* oi = out + (u64) i * ct_words;
-        TRY(rns_keyswitch_mac(temp2, per, keys[i], temp3, per, mods, np, digits, rc, Qp, l, depth, batch, st));
+        u64* acc = temp3;
+        if (group > 1) {
+            if (npend == next) { // start a new group
+                npend = next = 0;
+                const u64* gk[4];
+                for (int j = i; j < count && npend < group; j++)
+                    if (galois_elts[j] != 0) { pending[npend] = j; gk[npend++] = keys[j]; }
+                TRY(rns_keyswitch_mac_keys(temp2, per, gk, npend, temp3, per, acc_words, mods, np, digits, rc, Qp, l, depth,
+                                           batch, st));
+            }
+            acc = temp3 + (u64) next * acc_words; // pending[next] == i
+            next++;
+        } else {
+            TRY(rns_keyswitch_mac(temp2, per, keys[i], temp3, per, mods, np, digits, rc, Qp, l, depth, batch, st));
+        }
         if (ntt_domain) {
             // temp0 is free once the digits exist: scratch of the mod-down transform
-            if (m2) TRY(ckks_moddown_multi(c, temp3, temp0, per, ct, cs, 1, oi, so, depth, galois_elts[i], batch, st));
+            if (m2) TRY(ckks_moddown_multi(c, acc, temp0, per, ct, cs, 1, oi, so, depth, galois_elts[i], batch, st));
             else
-                TRY(ckks_keyswitch_core(c, nullptr, 0, ct, cs, 1, oi, so, nullptr, depth, batch, temp0, temp3, per, st,
+                TRY(ckks_keyswitch_core(c, nullptr, 0, ct, cs, 1, oi, so, nullptr, depth, batch, temp0, acc, per, st,
                                         RELIN_PHASE_INTT_P | RELIN_PHASE_MODDOWN, galois_elts[i]));
             continue;
         }
+        if (group > 1) return hipErrorInvalidValue; // the reference-order tail works on one accumulator
         NttArgs b = c.ntt_args(0);
         b.in = temp3; b.out = temp3; b.mod_count = rc; b.polys_per_item = 2 * rc; b.mod_order = order;
         b.in_item_stride = b.out_item_stride = per;

@@ -8,7 +8,7 @@ namespace hegpu {
 enum { OP_CKKS_RELIN = 1, OP_CKKS_RESCALE = 2, OP_CKKS_GALOIS = 3, OP_BFV_MULTIPLY = 4, OP_BFV_RELIN = 5,
        OP_BFV_GALOIS = 6, OP_KEYGEN_SECRET = 7, OP_KEYGEN_PUBLIC = 8, OP_KEYGEN_SWITCH = 9, OP_CKKS_ENCRYPT = 10, OP_BFV_ENCRYPT = 11,
        OP_BFV_DECRYPT = 12, OP_BFV_DECODE = 13, OP_CKKS_ENCODE = 14,
-       OP_CKKS_DECODE = 15, OP_BFV_MULTIPLY_PLAIN = 16 };
+       OP_CKKS_DECODE = 15, OP_BFV_MULTIPLY_PLAIN = 16, OP_CKKS_ROTATE_HOISTED = 17 };
 
 size_t ops_workspace_elems(const Context& c, int op, int depth, int batch);
 
@@ -32,7 +32,8 @@ hipError_t op_bfv_apply_galois(const Context& c, const u64* ct, u64 cs, u64* out
 // fast_single_hoisting_rotation_ckks_method_I / _II (ckks/operator.cu:4674-5446): `count` rotations of one
 // ciphertext with the decomposition and the digit NTT shared; keys / galois_elts are HOST arrays
 hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* out, u64 so, const u64* const* keys,
-                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st);
+                                  const int* galois_elts, int count, int depth, int batch, u64* ws, hipStream_t st,
+                                  int group = 1 /* accumulators in ws: 1 (OP_CKKS_GALOIS) or 4 (OP_CKKS_ROTATE_HOISTED) */);
 
 // key-switching method II (P_size > 1)
 hipError_t op_ckks_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int depth, int batch, u64* ws,

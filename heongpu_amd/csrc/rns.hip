@@ -251,6 +251,152 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac(const u64* __rest
     }
 }
 
+// The same inner product for up to KSM_KEYS evaluation keys at once (hoisted rotations: the NTT-domain digits of a
+// ciphertext are shared by all Galois elements): every digit value is loaded once and multiplied into the
+// accumulators of every key, so the digits -- 272 limbs per ciphertext at C4, the largest stream of the per-element
+// part -- are read once per group of keys instead of once per key.  Result of key e at out + e * out_key_stride.
+#define KSM_KEYS 4
+struct KsmKeys { const u64* k[KSM_KEYS]; };
+// One coefficient per thread.  The products are summed by partial-product weight, eight digits at a time (see
+// dot128: operands below 2^61, only a0*b0 needs a carry count) -- 6 instead of ~19 instructions per term, which is
+// what makes four keys per digit load affordable.
+struct ColSum {
+    u64 s00, s01, s10, s11;
+    u32 c00;
+};
+__device__ __forceinline__ void col_clear(ColSum& s) { s.s00 = s.s01 = s.s10 = s.s11 = 0; s.c00 = 0; }
+__device__ __forceinline__ void col_mad(ColSum& s, u64 a, u64 b)
+{
+    const u32 a0 = (u32) a, a1 = (u32) (a >> 32), b0 = (u32) b, b1 = (u32) (b >> 32);
+    const u64 p = (u64) a0 * b0;
+    s.s00 += p;
+    s.c00 += s.s00 < p;
+    s.s01 += (u64) a0 * b1;
+    s.s10 += (u64) a1 * b0;
+    s.s11 += (u64) a1 * b1;
+}
+__device__ __forceinline__ void col_fold(const ColSum& s, u64& hi, u64& lo)
+{
+    const u64 mid = s.s01 + s.s10;
+    const u64 cm = mid < s.s01;
+    const u64 l = s.s00 + (mid << 32);
+    const u64 h = s.s11 + (mid >> 32) + (cm << 32) + s.c00 + (l < s.s00);
+    lo += l;
+    hi += h + (lo < l);
+}
+// Key-stationary: a workgroup owns the key tiles of E keys for one limb and 256 / E coefficients -- all `digits`
+// digits, both parts: digits x 4 KiB of LDS whatever E is -- and walks the ciphertexts (E at a time, one per
+// group of 256 / E lanes).  Per ciphertext and coefficient a thread requests its `digits` digit values at once
+// (independent loads: nothing else keeps this kernel from running at memory speed at two waves per SIMD) and
+// multiplies them into the accumulators of the E keys out of LDS.
+template <int E>
+__global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac_keys(const u64* __restrict__ in, u64 in_stride, KsmKeys keys,
+                                                                    u64* __restrict__ out, u64 out_stride,
+                                                                    u64 out_key_stride, const Mod* __restrict__ mods,
+                                                                    int n_power, int digits, int nmods, int key_limbs,
+                                                                    int split, int level, int items, int items_per_wg)
+{
+    constexpr int TILE = RNS_THREADS / E;
+    extern __shared__ __attribute__((aligned(16))) u64 kl[]; // [E][2][digits][TILE]
+    const int t = threadIdx.x, coef = t % TILE, lane = t / TILE;
+    const int y = blockIdx.y;
+    const int kidx = (y < split) ? y : y + level;
+    const Mod m = mods[kidx];
+    const u64 c0 = (u64) blockIdx.x * TILE;
+    const u64 key_off1 = (u64) key_limbs << n_power;
+    const u64 key_off2 = (u64) key_limbs << (n_power + 1);
+    const u64 dig_off = (u64) nmods << n_power;
+    // fill: (key, part, digit) rows of TILE coefficients; eight rows' worth of loads in flight per thread (a
+    // load -> LDS store chain per element would cost one memory latency each)
+    {
+        const int rows = E * 2 * digits;              // a multiple of 2 E
+        const int row0 = t / TILE, cf = t % TILE;     // this thread's first row; it takes rows row0 + k * E
+        for (int r0 = row0; r0 < rows; r0 += 8 * E) {
+            u64 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = (r0 + k * E < rows) ? r0 + k * E : row0;
+                const int i = r % digits, ep = r / digits;
+                v[k] = keys.k[ep >> 1][((u64) kidx << n_power) + c0 + cf + key_off2 * i + key_off1 * (ep & 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (r0 + k * E < rows) kl[(size_t) (r0 + k * E) * TILE + cf] = v[k];
+        }
+    }
+    __syncthreads();
+    const int item_end = min(items, (int) (blockIdx.z + 1) * items_per_wg);
+    const int item_first = blockIdx.z * items_per_wg + lane;
+    u64 dn[16]; // the digits of the NEXT ciphertext of this lane are requested before the products of this one
+    auto fetch = [&](int item) {
+        const u64* pin = in + in_stride * (item < item_end ? item : item_first) + ((u64) y << n_power) + c0 + coef;
+#pragma unroll
+        for (int i = 0; i < 16; i++) dn[i] = pin[dig_off * (i < digits ? i : digits - 1)];
+    };
+    if (item_first < item_end) fetch(item_first);
+    for (int item = item_first; item < item_end; item += E) {
+        u64 d[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) d[i] = (i < digits) ? dn[i] : 0;
+        fetch(item + E);
+        // (run-time loops over key and part: unrolled, the compiler requests all 2 E x 16 key values from LDS up
+        // front -- 256 registers, one wave per SIMD and scratch)
+#pragma unroll 1
+        for (int e = 0; e < E; e++) {
+#pragma unroll 1
+            for (int part = 0; part < 2; part++) {
+                const u64* kp = kl + (size_t) ((e * 2 + part) * digits) * TILE + coef;
+                u64 hi = 0, lo = 0;
+#pragma unroll
+                for (int i0 = 0; i0 < 16; i0 += 8) {
+                    ColSum cs;
+                    col_clear(cs);
+#pragma unroll
+                    for (int ii = 0; ii < 8; ii++) col_mad(cs, d[i0 + ii], kp[(size_t) (i0 + ii < digits ? i0 + ii : 0) * TILE]);
+                    col_fold(cs, hi, lo);
+                }
+                out[out_key_stride * e + out_stride * item + ((u64) y << n_power) + c0 + coef + dig_off * part] =
+                    reduce128(hi, lo, m);
+            }
+        }
+    }
+}
+
+hipError_t rns_keyswitch_mac_keys(const u64* in, u64 in_stride, const u64* const* keys, int key_count, u64* out,
+                                  u64 out_stride, u64 out_key_stride, const Mod* mods, int n_power, int digits, int nmods,
+                                  int key_limbs, int split, int level, int batch, hipStream_t st)
+{
+    if (batch <= 0 || key_count <= 0) return hipSuccess;
+    if (digits > 16 || key_count > KSM_KEYS) return hipErrorInvalidValue; // digits x 4 KiB of LDS, 16 digit registers
+    KsmKeys kk;
+    for (int e = 0; e < KSM_KEYS; e++) kk.k[e] = keys[e < key_count ? e : 0];
+    const int E = key_count >= 4 ? 4 : key_count >= 2 ? 2 : 1; // three keys: a pair and a single one
+    // enough workgroups to fill the chip: the ciphertexts of a (tile, limb) are split over blockIdx.z if needed
+    const unsigned tiles = (1u << n_power) / (RNS_THREADS / E);
+    int zsplit = 1;
+    while (zsplit * 2 * E <= batch && (unsigned long) tiles * nmods * zsplit < 2048) zsplit *= 2;
+    const int per_wg = (batch + zsplit - 1) / zsplit;
+    const size_t lds = (size_t) digits * 4096;
+#define LAUNCH(EE, KOFF)                                                                                                   \
+    do {                                                                                                                   \
+        KsmKeys k2 = kk;                                                                                                   \
+        for (int e = 0; e < KSM_KEYS; e++) k2.k[e] = kk.k[(KOFF) + e < KSM_KEYS ? (KOFF) + e : KSM_KEYS - 1];              \
+        hipLaunchKernelGGL(k_keyswitch_mac_keys<EE>, dim3((1u << n_power) / (RNS_THREADS / (EE)), nmods, (batch + per_wg - 1) / per_wg), \
+                           dim3(RNS_THREADS), lds, st, in, in_stride, k2, out + (u64) (KOFF) * out_key_stride, out_stride,     \
+                           out_key_stride, mods, n_power, digits, nmods, key_limbs, split, level, batch, per_wg);          \
+    } while (0)
+    (void) E;
+    (void) tiles;
+    switch (key_count) {
+        case 1: LAUNCH(1, 0); break;
+        case 2: LAUNCH(2, 0); break;
+        case 3: LAUNCH(2, 0); LAUNCH(1, 2); break;
+        default: LAUNCH(4, 0); break;
+    }
+#undef LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
                              const Mod* mods, int n_power, int digits, int nmods, int key_limbs, int split,
                              int level, int batch, hipStream_t st)

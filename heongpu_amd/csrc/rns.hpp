@@ -32,6 +32,11 @@ hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride,
 // key strides use key_limbs (= Q' at depth 0); kidx(y) = (y < split) ? y : y + level
 // (method I leveled: split = l, level = depth maps row l to the P limb; method II,
 // switchkey.cu:287-398: rows >= l are the P limbs).
+// the same for up to 4 keys sharing one read of the digits (hoisted rotations); result of key e at
+// out + e * out_key_stride
+hipError_t rns_keyswitch_mac_keys(const u64* in, u64 in_stride, const u64* const* keys, int key_count, u64* out,
+                                  u64 out_stride, u64 out_key_stride, const Mod* mods, int n_power, int digits, int nmods,
+                                  int key_limbs, int split, int level, int batch, hipStream_t st);
 hipError_t rns_keyswitch_mac(const u64* in, u64 in_stride, const u64* key, u64* out, u64 out_stride,
                              const Mod* mods, int n_power, int digits, int nmods, int key_limbs,
                              int split, int level, int batch, hipStream_t st);

@@ -175,7 +175,8 @@ enum {
     HEGPU_OP_BFV_DECODE = 13,
     HEGPU_OP_CKKS_ENCODE = 14,
     HEGPU_OP_CKKS_DECODE = 15, /* depth-dependent */
-    HEGPU_OP_BFV_MULTIPLY_PLAIN = 16
+    HEGPU_OP_BFV_MULTIPLY_PLAIN = 16,
+    HEGPU_OP_CKKS_ROTATE_HOISTED = 17 /* hegpu_ckks_rotate_hoisted with room for four accumulators */
 };
 size_t hegpu_workspace_bytes(const hegpu_context* ctx, int op, int depth, int batch);
 
@@ -214,7 +215,9 @@ int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_
  * out + i * 2 l N (per item: out_stride apart), l = Q - depth; galois_elts[i] == 0 copies the input (the
  * reference's result[0] / a zero shift).  galois_keys / galois_elts are HOST arrays of length count;
  * galois_keys[i] is the DEVICE key of element i (ignored for 0).  Every entry is bit-identical to
- * hegpu_ckks_apply_galois with the same element and key.  Workspace: HEGPU_OP_CKKS_GALOIS. */
+ * hegpu_ckks_apply_galois with the same element and key.  Workspace: HEGPU_OP_CKKS_GALOIS is enough; with
+ * HEGPU_OP_CKKS_ROTATE_HOISTED (room for four accumulators) the inner products of four elements at a time share one
+ * read of the digits. */
 int hegpu_ckks_rotate_hoisted(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
                               uint64_t out_stride, const uint64_t* const* galois_keys, const int* galois_elts,
                               int count, int depth, int batch, void* ws, size_t ws_bytes, hegpu_stream stream);

@@ -2181,7 +2181,7 @@ template <Scheme S> class HEArithmeticOperator { // host/{bfv,ckks}/operator.cuh
                 chained.push_back(i);
             }
         }
-        const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_GALOIS, input1.depth_, 1);
+        const size_t wsb = hegpu_workspace_bytes(context_->handle(), HEGPU_OP_CKKS_ROTATE_HOISTED, input1.depth_, 1);
         DeviceVector<Data64> ws(wsb / 8, stream);
         detail::check(hegpu_ckks_rotate_hoisted(context_->handle(), (const uint64_t*) input1.data(), 0,
                                                 (uint64_t*) result.data(), 0, keys.data(), elts.data(), n1,

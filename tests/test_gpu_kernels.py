@@ -567,7 +567,8 @@ def test_six_gpuntt_entry_points_by_name(hg, oracle, torch):
 # ------------------------------------------------------------------ hoisted rotations
 @pytest.mark.parametrize("depth", [0, 2])
 @pytest.mark.parametrize("method", ["I", "II"])
-def test_hoisted_rotations(hg, oracle, torch, depth, method):
+@pytest.mark.parametrize("grouped", [False, True], ids=["one_accumulator", "four_accumulators"])
+def test_hoisted_rotations(hg, oracle, torch, depth, method, grouped):
     """hegpu_ckks_rotate_hoisted (fast_single_hoisting_rotation_ckks_method_I / _II, ckks/operator.cu:4674-5446):
     one decomposition + digit NTT shared by several Galois elements; every entry bit-identical to the oracle's
     restatement of the reference loop AND to separate hegpu_ckks_apply_galois calls.  CKKS N=2^13, batch 2,
@@ -579,14 +580,16 @@ def test_hoisted_rotations(hg, oracle, torch, depth, method):
     l = Q - depth
     digits = Q if method == "I" else -(-Q // 2)
     batch = 2
-    elts = [0, hg.steps_to_galois_elt(1, n, 5), hg.steps_to_galois_elt(-2, n, 5), hg.steps_to_galois_elt(5, n, 5), 2 * n - 1]
-    keys = [None] + [synth_key(primes, digits, Qp, n, 20 + i) for i in range(1, len(elts))]
-    dkeys = [None] + [hg.to_device(k) for k in keys[1:]]
+    elts = [0, hg.steps_to_galois_elt(1, n, 5), hg.steps_to_galois_elt(-2, n, 5), hg.steps_to_galois_elt(5, n, 5), 2 * n - 1,
+            hg.steps_to_galois_elt(3, n, 5), 0, hg.steps_to_galois_elt(-1, n, 5)]  # six keys: a group of four and one of two
+    keys = [None if g == 0 else synth_key(primes, digits, Qp, n, 20 + i) for i, g in enumerate(elts)]
+    dkeys = [None if k is None else hg.to_device(k) for k in keys]
     cts = [synth_ct(primes, range(l), 2, n, 5 + b) for b in range(batch)]
     d = hg.to_device(np.concatenate(cts))
     words = 2 * l * n
     out = torch.empty(batch * len(elts) * words, dtype=torch.int64, device="cuda")
-    ws = c.workspace(hg.OP_CKKS_GALOIS, depth, batch)
+    # the larger workspace holds four accumulators: four inner products per read of the digits
+    ws = c.workspace(hg.OP_CKKS_ROTATE_HOISTED if grouped else hg.OP_CKKS_GALOIS, depth, batch)
     c.ckks_rotate_hoisted(d, words, out, len(elts) * words, dkeys, elts, depth, batch, ws)
     torch.cuda.synchronize()
     got = hg.to_host(out).reshape(batch, len(elts), words)
@@ -596,6 +599,8 @@ def test_hoisted_rotations(hg, oracle, torch, depth, method):
         for i in range(len(elts)):
             assert np.array_equal(got[b, i], want[i]), (method, depth, b, i)
     for i in range(1, len(elts)):  # the same elements one by one through the plain operator
+        if elts[i] == 0:
+            continue
         c.ckks_apply_galois(d, words, one, words, dkeys[i], elts[i], depth, batch, ws)
         torch.cuda.synchronize()
         assert np.array_equal(hg.to_host(one).reshape(batch, words), got[:, i]), ("vs apply_galois", i)
