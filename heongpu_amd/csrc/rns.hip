@@ -370,7 +370,7 @@ hipError_t rns_keyswitch_mac_keys(const u64* in, u64 in_stride, const u64* const
     if (digits > 16 || key_count > KSM_KEYS) return hipErrorInvalidValue; // digits x 4 KiB of LDS, 16 digit registers
     KsmKeys kk;
     for (int e = 0; e < KSM_KEYS; e++) kk.k[e] = keys[e < key_count ? e : 0];
-    const int E = key_count >= 4 ? 4 : key_count >= 2 ? 2 : 1; // three keys: a pair and a single one
+    const int E = key_count >= 4 ? 4 : key_count >= 2 ? 2 : 1; // three keys: a pair, then a single one
     // enough workgroups to fill the chip: the ciphertexts of a (tile, limb) are split over blockIdx.z if needed
     const unsigned tiles = (1u << n_power) / (RNS_THREADS / E);
     int zsplit = 1;
@@ -385,8 +385,6 @@ hipError_t rns_keyswitch_mac_keys(const u64* in, u64 in_stride, const u64* const
                            dim3(RNS_THREADS), lds, st, in, in_stride, k2, out + (u64) (KOFF) * out_key_stride, out_stride,     \
                            out_key_stride, mods, n_power, digits, nmods, key_limbs, split, level, batch, per_wg);          \
     } while (0)
-    (void) E;
-    (void) tiles;
     switch (key_count) {
         case 1: LAUNCH(1, 0); break;
         case 2: LAUNCH(2, 0); break;
