@@ -22,11 +22,21 @@ static int prime_loc_offset(const Context& c, int depth)
 
 // The fused row pass + inner product runs one workgroup per (ciphertext, target modulus, 16-row tile) that walks
 // all digits; a launch too small to fill the chip finishes sooner as the reference's sequence -- the transform of
-// all digits x moduli as independent limbs, then the element-wise inner product (C2, one ciphertext: 39 -> 27 us).
+// all digits x moduli as independent limbs, then the element-wise inner product.  512 workgroups of this kernel are
+// resident at a time (two per CU); measured crossover (tools/relin_sweep.py, relinearize of B ciphertexts, fused
+// against unfused): N = 2^14, Q = 8: beyond B = 16 (36 B workgroups); N = 2^15, Q = 15: B = 4 388 / 360 us, B = 8
+// 609 / 685 (128 B); N = 2^16, Q = 16: B = 1 401 / 288, B = 2 476 / 452, B = 4 688 / 788 (272 B); Q = 30: B = 1
+// 804 / 758, B = 2 1098 / 1194 (496 B) -- one and a half rounds of resident workgroups.  Chains of integer-butterfly
+// moduli (the 58/59-bit default chains) cross earlier, their transforms being the larger part of either path:
+// N = 2^15, Q = 14: B = 2 242 / 220, B = 4 361 / 377 (120 B); N = 2^16, Q = 14: B = 1 287 / 274, B = 2 388 / 426
+// (240 B); Q = 29: B = 1 756 / 866 (480 B).
 static bool use_fused_row_mac(const Context& c, int rc, int batch)
 {
     if (c.fused_row_mac >= 0) return c.fused_row_mac != 0;
-    return (long) batch * rc * (long) (c.n >> 12) >= 128;
+    size_t fp = 0;
+    for (unsigned char f : c.plan_qp.fp) fp += f ? 1 : 0;
+    const long need = (2 * fp > c.plan_qp.fp.size()) ? 768 : 400;
+    return (long) batch * rc * (long) (c.n >> 12) >= need;
 }
 
 // The target slots of a decomposing launch over the Q' chain whose moduli run on the integer butterflies
