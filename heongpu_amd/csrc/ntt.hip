@@ -1629,10 +1629,22 @@ static void launch_col_multi(const NttArgs& a, int batch, hipStream_t st)
     }
 }
 
-#define NTT_SINGLE_PASS_MIN_LIMBS 256
+// One LDS-resident workgroup per limb against the two passes, by launch size (tools/single_pass_sweep.py, us per
+// forward transform, single / two passes): N = 2^12 (four workgroups per CU): 7.3 / 10.0 at 9..144 limbs, 10.3 / 14.0
+// at 288 -- always; N = 2^13 (two per CU): 10.2 / 10.6 at 36, 10.3 / 11.8 at 72, 11.5 / 16.7 at 144 -- from 64 limbs;
+// N = 2^14 (one per CU, 14 stages in a row): 16.1 / 13.1 at 36, 17.0 / 19.7 at 72, 18.8 / 26.6 at 144, but 36.0 / 32.9
+// at 288 (256 CUs: a second round for 32 limbs) and 56.0 / 57.6 at 576 -- from 48 limbs, when the last round of
+// workgroups is not mostly empty.
 static bool use_single_pass(const NttArgs& a, int batch)
 {
-    return a.single_pass == 1 || (a.single_pass != 0 && batch >= NTT_SINGLE_PASS_MIN_LIMBS);
+    if (a.single_pass == 1) return true;
+    if (a.single_pass == 0) return false;
+    const int s1 = a.n_power - 8;
+    if (s1 <= 4) return true;
+    if (s1 == 5) return batch >= 64;
+    if (batch < 48) return false;
+    const long rounds = ((long) batch + 255) / 256;
+    return (long) batch * 4 >= rounds * 256 * 3;
 }
 
 template <int S1>
