@@ -654,16 +654,23 @@ __global__ __launch_bounds__(256) void k_tfhe_gate_pre(int* __restrict__ out_a, 
 // tfhe_key_switching_kernel (bootstrapping.cu:1349-1436): one workgroup per
 // gate, 256 threads x 2 output coefficients (n = 512); the digit of each input
 // coefficient is wave-uniform, key rows are 2 KiB coalesced reads.
+// SPLIT: gridDim.y workgroups share a gate, `chunk` input coefficients each, and add their partial sums into the
+// zeroed output with integer atomics (sums on the 32-bit torus: any order gives the same bits).  The loop over
+// the N k input coefficients is a chain of L2 round trips -- 1.3 ms per gate however few gates there are -- so a
+// launch that does not fill the chip is cut into more workgroups.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restrict__ in_a,
                                                             const int* __restrict__ in_b, int* __restrict__ out_a,
                                                             int* __restrict__ out_b, const int* __restrict__ ks_a,
                                                             const int* __restrict__ ks_b, int bb, int len, int n,
-                                                            int Nk)
+                                                            int Nk, int chunk)
 {
     const int g = blockIdx.x, t = threadIdx.x;
     const int mask = (1 << bb) - 1;
     const u32 precision_offset = 1u << (32 - (1 + bb * len));
-    u32 acc0 = 0, acc1 = 0, accb = (t == 0) ? (u32) in_b[g] : 0u;
+    const int i_begin = SPLIT ? (int) blockIdx.y * chunk : 0;
+    const int i_end = SPLIT ? ((i_begin + chunk < Nk) ? i_begin + chunk : Nk) : Nk;
+    u32 acc0 = 0, acc1 = 0, accb = (t == 0 && i_begin == 0) ? (u32) in_b[g] : 0u;
     const int* pa = in_a + (u64) g * Nk;
     // All `len` key rows of a coefficient are requested before any of them is used, unconditionally: a zero
     // digit (no row in the key) reads row 0 of its digit position and masks the value, a digit position beyond
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
     // dependent L2 round trips per gate, 0.37 us each.
     const int t2 = (t + 256 < n) ? t + 256 : t;
     const u32 m2 = (t + 256 < n) ? 0xffffffffu : 0u;
-    for (int i = 0; i < Nk; i++) {
+    for (int i = i_begin; i < i_end; i++) {
         const u32 a = (u32) pa[i] + precision_offset;
         u32 v0[8], v1[8], vb[8];
 #pragma unroll
@@ -692,9 +699,15 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
             accb -= vb[i2];
         }
     }
-    out_a[(u64) g * n + t] = (int) acc0;
-    if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1;
-    if (t == 0) out_b[g] = (int) accb;
+    if (SPLIT) {
+        atomicAdd(reinterpret_cast<u32*>(&out_a[(u64) g * n + t]), acc0);
+        if (t + 256 < n) atomicAdd(reinterpret_cast<u32*>(&out_a[(u64) g * n + t + 256]), acc1);
+        if (t == 0) atomicAdd(reinterpret_cast<u32*>(&out_b[g]), accb);
+    } else {
+        out_a[(u64) g * n + t] = (int) acc0;
+        if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1;
+        if (t == 0) out_b[g] = (int) accb;
+    }
 }
 
 // ------------------------------------------------------------------ front end: keys, encryption, decryption
@@ -918,8 +931,21 @@ hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b
 {
     if (p.n > 512 || p.ks_length > 8) return hipErrorInvalidValue;
     if (shape <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tfhe_key_switching, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,
-                       p.ks_base_bit, p.ks_length, p.n, p.N * p.k);
+    const int Nk = p.N * p.k;
+    // fewer gates than resident workgroups (eight per CU): cut the coefficient loop, at least 16 coefficients a piece
+    int pieces = 1;
+    while (pieces < 64 && (long) shape * pieces * 2 <= 2048 && Nk / (pieces * 2) >= 16) pieces *= 2;
+    if (pieces > 1) {
+        const int chunk = (Nk + pieces - 1) / pieces;
+        hipError_t e = hipMemsetAsync(out_a, 0, (size_t) shape * p.n * sizeof(int), st);
+        if (e == hipSuccess) e = hipMemsetAsync(out_b, 0, (size_t) shape * sizeof(int), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_tfhe_key_switching<true>, dim3(shape, pieces), dim3(256), 0, st, in_a, in_b, out_a, out_b,
+                           ks_a, ks_b, p.ks_base_bit, p.ks_length, p.n, Nk, chunk);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_tfhe_key_switching<false>, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,
+                       p.ks_base_bit, p.ks_length, p.n, Nk, Nk);
     return hipGetLastError();
 }
 
