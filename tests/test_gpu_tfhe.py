@@ -65,6 +65,27 @@ def test_blind_rotate_and_key_switch(hg, setup):
     assert np.array_equal(kb.cpu().numpy(), ks_want_b)
 
 
+@pytest.mark.parametrize("shape", [1, 33, 1024, 1025])
+def test_key_switching_split_launches(hg, setup, shape):
+    """Key switching alone on random extracted samples, on both sides of the launch-size rule of tfhe_key_switching:
+    up to 1024 gates the coefficient loop of a gate is cut into several workgroups that add their partial sums with
+    integer atomics (64 pieces at 1 gate, 32 at 33, 2 at 1024), from 1025 on one workgroup per gate.  Bit-exact
+    against the oracle either way (sums on the 32-bit torus do not depend on the order)."""
+    import torch
+    t, o, rng, bk, ks_a, ks_b = setup
+    ea = rng.integers(-2**31, 2**31, shape * 1024, dtype=np.int64).astype(np.int32)
+    eb = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
+    sample = list(range(min(shape, 3))) + ([shape - 1] if shape > 3 else [])  # the oracle takes seconds per gate
+    ka = torch.full((shape * 512,), 7, dtype=torch.int32, device="cuda")      # stale contents must not leak in
+    kb = torch.full((shape,), 7, dtype=torch.int32, device="cuda")
+    t.key_switching(_dev32(ea), _dev32(eb), ka, kb, _dev32(ks_a), _dev32(ks_b), shape)
+    torch.cuda.synchronize()
+    got_a, got_b = ka.cpu().numpy().reshape(shape, 512), kb.cpu().numpy()
+    for g in sample:
+        want_a, want_b = o.key_switching(ea[g * 1024:(g + 1) * 1024], eb[g:g + 1], ks_a, ks_b)
+        assert np.array_equal(got_a[g], want_a) and got_b[g] == want_b[0]
+
+
 @pytest.mark.parametrize("gate", [0, 1, 2, 3, 4, 5, 6])
 def test_full_gates(hg, setup, gate):
     import torch
