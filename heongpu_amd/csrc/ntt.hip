@@ -554,6 +554,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
     if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (DECOMP && a.only_int && md.fp) return; // done by ntt_fwd_col_multi
+    if (DECOMP && a.copy_src) {
+        // NttArgs::copy_src: this workgroup's column tile of limb (digit, slot), copied along
+        constexpr int CT = 4096 >> S1;
+        const int t = threadIdx.x, col = t % CT, r1 = t / CT;
+        const u64 limb = ((u64) (ps.digit * a.copy_part_limbs + (ps.j - ps.digit * a.decomp_mods)) << a.n_power) +
+                         blockIdx.x * CT;
+        const u64* __restrict__ cs = a.copy_src + (u64) ps.item * a.copy_src_item_stride + limb;
+        u64* __restrict__ cd = a.copy_dst + (u64) ps.item * a.copy_dst_item_stride + limb;
+        u64 c[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) c[k] = cs[(u64) (16 * r1 + k) * 256 + col];
+#pragma unroll
+        for (int k = 0; k < 16; k++) cd[(u64) (16 * r1 + k) * 256 + col] = c[k];
+    }
     if (md.fp) {
         if (DECOMP && a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52)
             fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds, twl);
@@ -1605,6 +1619,7 @@ static bool use_col_multi(const NttArgs& a, int batch)
 {
     constexpr int CT = 4096 >> S1;
     if (!a.decomp_mods || a.col_multi == 0 || batch % a.decomp_mods) return false;
+    if (a.copy_src) return false; // the copy rides on the per-polynomial kernel only
     if (a.col_multi == 1) return true;
     return (long) (256 / CT) * (batch / a.decomp_mods) >= 2048;
 }
@@ -1798,6 +1813,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (a.n_power < 12 || a.n_power > 16) return hipErrorInvalidValue;
     if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
     if (a.src_inv && (!a.decomp_mods || batch > 65535 || !ntt_decomp_uses_multi(a, batch))) return hipErrorInvalidValue;
+    if (a.copy_src && (!a.decomp_mods || inverse)) return hipErrorInvalidValue;
     if (a.iepi.on && (!inverse || a.poly_order || a.polys_per_item != 2 * (a.iepi.limbs + 1) || batch % a.polys_per_item))
         return hipErrorInvalidValue;
     if (batch > 65535) {
@@ -1813,8 +1829,23 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
             if (chunk > maxc) chunk = maxc;
             NttArgs c = a;
             if (a.polys_per_item) {
-                c.in = a.in + (u64) (done / unit) * a.in_item_stride;
-                c.out = a.out + (u64) (done / unit) * a.out_item_stride;
+                // every per-item pointer of the launch moves with the items of the piece
+                const u64 items_done = (u64) (done / unit);
+                c.in = a.in + items_done * a.in_item_stride;
+                c.out = a.out + items_done * a.out_item_stride;
+                if (a.epi.on) {
+                    c.epi.ks = a.epi.ks + items_done * a.epi.ks_item_stride;
+                    if (a.epi.ct) c.epi.ct = a.epi.ct + items_done * a.epi.ct_item_stride;
+                    c.epi.out = a.epi.out + items_done * a.epi.out_item_stride;
+                }
+                if (a.iepi.on) {
+                    if (a.iepi.ct) c.iepi.ct = a.iepi.ct + items_done * a.iepi.ct_item_stride;
+                    c.iepi.out = a.iepi.out + items_done * a.iepi.out_item_stride;
+                }
+                if (a.copy_src) {
+                    c.copy_src = a.copy_src + items_done * a.copy_src_item_stride;
+                    c.copy_dst = a.copy_dst + items_done * a.copy_dst_item_stride;
+                }
             } else {
                 c.in = a.in + ((u64) done << a.n_power);
                 c.out = a.out + ((u64) done << a.n_power);

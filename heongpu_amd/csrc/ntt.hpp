@@ -134,6 +134,14 @@ struct NttArgs {
     // still to do -- and the kernel finishes their inverse transform itself (in place, the coefficient-domain
     // limbs are stored too).
     int src_inv;
+    // Decomposing launches through the per-polynomial column kernel only (not ntt_decomp_uses_multi): the workgroup
+    // of polynomial (digit d, target slot k) also copies its column tile of limb d * copy_part_limbs + k from
+    // copy_src to copy_dst (items copy_*_item_stride apart) -- the copy of the kept limbs that the rescale's
+    // epilogue reads (it overwrites them in place), without a launch of its own.  NULL: nothing.
+    const u64* copy_src;
+    u64* copy_dst;
+    u64 copy_src_item_stride, copy_dst_item_stride;
+    int copy_part_limbs;
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

@@ -269,13 +269,21 @@ hipError_t op_ckks_rescale(const Context& c, u64* ct, u64 cs, int depth, int bat
         // stage one (:1205) as the load transform and stage two (:1225) as the row-pass epilogue
         // of the forward NTT (:1214); the copy of the kept limbs (:1219) comes first because the
         // epilogue writes the compacted ciphertext over them
-        TRY(rns_copy_limbs(ct, (u64) l * n, cs, temp2, (u64) l * n, per, np, l - 1, 2, batch, st));
         a = c.ntt_args(0);
         a.in = ct; a.out = temp1; a.mod_count = l - 1; a.polys_per_item = 2 * (l - 1);
         a.in_item_stride = cs; a.out_item_stride = per;
         a.decomp_mods = l - 1; a.decomp_in_mul = l; a.decomp_in_add = l - 1;
         a.half_on = 1; a.half_src_mod = l - 1; a.half = c.h64("rescaled_half")[depth];
         a.half_mod = c.d64("rescaled_half_mod") + location;
+        // The copy rides on the column pass when that is the per-polynomial kernel (one workgroup per kept limb
+        // and tile: C2, 4.7 us of launch less); the multi-modulus kernel keeps its own launch for it.
+        if (c.copy_along && !ntt_decomp_uses_multi(a, 2 * (l - 1) * batch)) {
+            a.copy_src = ct; a.copy_src_item_stride = cs;
+            a.copy_dst = temp2; a.copy_dst_item_stride = per;
+            a.copy_part_limbs = l;
+        } else {
+            TRY(rns_copy_limbs(ct, (u64) l * n, cs, temp2, (u64) l * n, per, np, l - 1, 2, batch, st));
+        }
         a.epi.on = 1;
         a.epi.ks = temp2; a.epi.ks_item_stride = per; a.epi.ks_part_limbs = l;
         a.epi.ct = nullptr; a.epi.ct_item_stride = 0;

@@ -138,3 +138,36 @@ def test_batch_beyond_one_grid(hg, oracle, torch):
     c.ntt(y, y, True, limbs, mc)
     torch.cuda.synchronize()
     assert np.array_equal(hg.to_host(y), x)
+
+
+def test_epilogue_launches_beyond_one_grid(hg, oracle, torch):
+    """Relinearize and rescale of so many ciphertexts that their mod-down transforms (2 l resp. 2 (l - 1)
+    polynomials per ciphertext, with per-ciphertext epilogue operands) exceed one grid (65535 polynomials) and are
+    cut into pieces: every per-item pointer of the launch has to move with the piece.  The batch repeats 24
+    distinct ciphertexts, so all of them are checked against the oracle and every other item against its twin."""
+    n = 4096
+    c, o, primes = _ckks(hg, oracle, n, [40, 30, 30], [40])
+    Q, Qp = 3, 4
+    batch, distinct = 16400, 24            # relinearize: 6 * 16400 = 98400, rescale: 4 * 16400 = 65600 polynomials
+    key = synth_key(primes, Q, Qp, n, 3)
+    cts = [synth_ct(primes, range(Q), 3, n, 40 + i) for i in range(distinct)]
+    base = hg.to_device(np.concatenate(cts)).reshape(distinct, 3 * Q * n)
+    d = base.repeat((batch + distinct - 1) // distinct, 1)[:batch].contiguous().reshape(-1)
+    c.ckks_relinearize_inplace(d, 3 * Q * n, hg.to_device(key), 0, batch, c.workspace(hg.OP_CKKS_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = d.reshape(batch, 3 * Q * n)[:, :2 * Q * n]
+    want = []
+    for i in range(distinct):
+        w = cts[i].copy()
+        o.ckks_relinearize(w, key, 0)
+        want.append(w[:2 * Q * n])
+        assert np.array_equal(hg.to_host(got[i]), want[i]), ("relinearize", i)
+    twin = got[:distinct].repeat((batch + distinct - 1) // distinct, 1)[:batch]
+    assert bool((got == twin).all()), "relinearize: an item beyond the first piece differs from its twin"
+    c.ckks_rescale_inplace(d, 3 * Q * n, 0, batch, c.workspace(hg.OP_CKKS_RESCALE, 0, batch))
+    torch.cuda.synchronize()
+    got = d.reshape(batch, 3 * Q * n)[:, :2 * (Q - 1) * n]
+    for i in range(distinct):
+        assert np.array_equal(hg.to_host(got[i]), o.ckks_rescale(want[i].copy(), 0)[:2 * (Q - 1) * n]), ("rescale", i)
+    twin = got[:distinct].repeat((batch + distinct - 1) // distinct, 1)[:batch]
+    assert bool((got == twin).all()), "rescale: an item beyond the first piece differs from its twin"

@@ -117,6 +117,7 @@ _SWITCHES = [
     dict(HEGPU_GALOIS_SCATTER=0),
     dict(HEGPU_FUSED_ROW_MAC=0),
     dict(HEGPU_FUSED_MODDOWN=0),
+    dict(HEGPU_COPY_ALONG=0),  # the rescale's copy of the kept limbs as its own launch
     dict(HEGPU_FP_NTT=0),
     dict(HEGPU_FUSED_ROW_MAC=0, HEGPU_FUSED_MODDOWN=0, HEGPU_FP_NTT=0),
 ]
