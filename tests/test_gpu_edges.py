@@ -171,3 +171,41 @@ def test_epilogue_launches_beyond_one_grid(hg, oracle, torch):
         assert np.array_equal(hg.to_host(got[i]), o.ckks_rescale(want[i].copy(), 0)[:2 * (Q - 1) * n]), ("rescale", i)
     twin = got[:distinct].repeat((batch + distinct - 1) // distinct, 1)[:batch]
     assert bool((got == twin).all()), "rescale: an item beyond the first piece differs from its twin"
+
+
+def test_bfv_epilogue_launch_beyond_one_grid(hg, oracle, torch):
+    """The same for BFV: the inverse transform that carries the mod-down as its epilogue (NttInvEpilogue, 2 (Q + 1)
+    polynomials per ciphertext with per-ciphertext operands) in relinearize and rotate of 11 000 ciphertexts of
+    N = 4096 (66 000 polynomials: two pieces)."""
+    n, t = 4096, 1032193
+    c = hg.Context.from_default(hg.BFV, n, 1, t)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, c.Q_size, c.P_size, t)
+    c.upload()
+    Q, Qp = c.Q_size, c.Q_prime_size
+    batch, distinct = 11000, 16
+    assert 2 * (Q + 1) * batch > 65535
+    key = synth_key(primes, Q, Qp, n, 3)
+    gkey = synth_key(primes, Q, Qp, n, 4)
+    g = hg.steps_to_galois_elt(1, n, 3)
+    cts = [synth_ct(primes, range(Q), 3, n, 60 + i) for i in range(distinct)]
+    base = hg.to_device(np.concatenate(cts)).reshape(distinct, 3 * Q * n)
+    reps = (batch + distinct - 1) // distinct
+    d = base.repeat(reps, 1)[:batch].contiguous().reshape(-1)
+    c.bfv_relinearize_inplace(d, 3 * Q * n, hg.to_device(key), batch, c.workspace(hg.OP_BFV_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = d.reshape(batch, 3 * Q * n)[:, :2 * Q * n]
+    want = []
+    for i in range(distinct):
+        w = o.bfv_relinearize(cts[i].copy(), key)
+        want.append(np.ascontiguousarray(w[:2 * Q * n]))
+        assert np.array_equal(hg.to_host(got[i]), want[i]), ("relinearize", i)
+    assert bool((got == got[:distinct].repeat(reps, 1)[:batch]).all()), "relinearize: an item of the second piece differs"
+    src = got.contiguous().reshape(-1)
+    rot = torch.empty_like(src)
+    c.bfv_apply_galois(src, 2 * Q * n, rot, 2 * Q * n, hg.to_device(gkey), g, batch, c.workspace(hg.OP_BFV_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    gr = rot.reshape(batch, 2 * Q * n)
+    for i in range(distinct):
+        assert np.array_equal(hg.to_host(gr[i]), o.bfv_apply_galois(want[i], gkey, g)), ("rotate", i)
+    assert bool((gr == gr[:distinct].repeat(reps, 1)[:batch]).all()), "rotate: an item of the second piece differs"
