@@ -209,3 +209,125 @@ def test_bfv_epilogue_launch_beyond_one_grid(hg, oracle, torch):
     for i in range(distinct):
         assert np.array_equal(hg.to_host(gr[i]), o.bfv_apply_galois(want[i], gkey, g)), ("rotate", i)
     assert bool((gr == gr[:distinct].repeat(reps, 1)[:batch]).all()), "rotate: an item of the second piece differs"
+
+
+@pytest.mark.parametrize("batch", [3, 40])
+def test_padded_item_strides(hg, oracle, torch, batch):
+    """Ciphertexts that are NOT back to back: every operator takes element strides between the items of a batch.
+    Items 1000 (inputs) / 3000 (outputs) elements further apart than their size, the gaps filled with a sentinel
+    that must survive; results against the oracle.  Both launch-size regimes of the key switch (3 and 40 items)."""
+    n = 8192
+    c, o, primes = _ckks(hg, oracle, n, [50, 40, 40, 40], [50])
+    Q, Qp = 4, 5
+    SENT = 0x5555555555555555
+    key = synth_key(primes, Q, Qp, n, 3)
+    gkey = synth_key(primes, Q, Qp, n, 4)
+    g = hg.steps_to_galois_elt(1, n, 5)
+    dkey, dgkey = hg.to_device(key), hg.to_device(gkey)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
+    s_in, s_out = 2 * Q * n + 1000, 3 * Q * n + 3000
+    def strided(items, stride):
+        buf = torch.full((batch * stride,), SENT, dtype=torch.int64, device="cuda")
+        for b, x in enumerate(items):
+            buf[b * stride:b * stride + len(x)] = hg.to_device(x)
+        return buf
+    def gaps_intact(buf, stride, used):
+        v = buf.reshape(batch, stride)[:, used:]
+        return bool((v == SENT).all())
+    d1, d2 = strided(ct1, s_in), strided(ct2, s_in)
+    out = torch.full((batch * s_out,), SENT, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, s_in, d2, s_in, out, s_out, 0, batch)
+    c.ckks_relinearize_inplace(out, s_out, dkey, 0, batch, c.workspace(hg.OP_CKKS_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, s_out)
+    want = []
+    for b in range(batch):
+        w = o.ckks_multiply(ct1[b], ct2[b], 0)
+        o.ckks_relinearize(w, key, 0)
+        want.append(w)
+        assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), ("relinearize", b)
+    assert gaps_intact(out, s_out, 3 * Q * n) and gaps_intact(d1, s_in, 2 * Q * n) and gaps_intact(d2, s_in, 2 * Q * n)
+    c.ckks_rescale_inplace(out, s_out, 0, batch, c.workspace(hg.OP_CKKS_RESCALE, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, s_out)
+    resc = []
+    for b in range(batch):
+        r = o.ckks_rescale(want[b][:2 * Q * n].copy(), 0)[:2 * (Q - 1) * n]
+        resc.append(r)
+        assert np.array_equal(got[b][:2 * (Q - 1) * n], r), ("rescale", b)
+    assert gaps_intact(out, s_out, 3 * Q * n)
+    s_rot = 2 * (Q - 1) * n + 500
+    rot = torch.full((batch * s_rot,), SENT, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(out, s_out, rot, s_rot, dgkey, g, 1, batch, c.workspace(hg.OP_CKKS_GALOIS, 1, batch))
+    torch.cuda.synchronize()
+    gr = hg.to_host(rot).reshape(batch, s_rot)
+    for b in range(batch):
+        assert np.array_equal(gr[b][:2 * (Q - 1) * n], o.ckks_apply_galois(resc[b], gkey, g, 1)), ("rotate", b)
+    assert gaps_intact(rot, s_rot, 2 * (Q - 1) * n) and gaps_intact(out, s_out, 3 * Q * n)
+
+
+def test_padded_item_strides_method_II_and_bfv(hg, oracle, torch):
+    """Padded item strides (see above) through key switching method II (CKKS, two special primes, depth 1) and the
+    BFV operators (multiply, relinearize, rotate)."""
+    SENT = 0x5555555555555555
+    batch = 3
+    def strided(items, stride):
+        buf = torch.full((batch * stride,), SENT, dtype=torch.int64, device="cuda")
+        for b, x in enumerate(items):
+            buf[b * stride:b * stride + len(x)] = hg.to_device(x)
+        return buf
+    def gaps_intact(buf, stride, used):
+        return bool((buf.reshape(batch, stride)[:, used:] == SENT).all())
+    # ---- CKKS method II
+    n = 8192
+    c = hg.Context.from_bit_sizes(hg.CKKS, n, [40, 35, 35, 35, 35], [40, 40], sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.CKKS, c.n_power, primes, c.Q_size, c.P_size)
+    c.upload()
+    Q, P, depth = 5, 2, 1
+    Qp, l, d0 = Q + P, Q - depth, -(-Q // P)
+    key = synth_key(primes, d0, Qp, n, 3)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b) for b in range(batch)]
+    s_in, s_out = 2 * l * n + 700, 3 * l * n + 900
+    d1, d2 = strided(ct1, s_in), strided(ct2, s_in)
+    out = torch.full((batch * s_out,), SENT, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, s_in, d2, s_in, out, s_out, depth, batch)
+    c.ckks_relinearize_inplace(out, s_out, hg.to_device(key), depth, batch, c.workspace(hg.OP_CKKS_RELIN, depth, batch))
+    g = hg.steps_to_galois_elt(1, n, 5)
+    rot = torch.full((batch * s_in,), SENT, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(d1, s_in, rot, s_in, hg.to_device(key), g, depth, batch, c.workspace(hg.OP_CKKS_GALOIS, depth, batch))
+    torch.cuda.synchronize()
+    got, gr = hg.to_host(out).reshape(batch, s_out), hg.to_host(rot).reshape(batch, s_in)
+    for b in range(batch):
+        w = o.ckks_multiply(ct1[b], ct2[b], depth)
+        o.ckks_relinearize_II(w, key, depth)
+        assert np.array_equal(got[b][:2 * l * n], w[:2 * l * n]), ("method II relinearize", b)
+        assert np.array_equal(gr[b][:2 * l * n], o.ckks_apply_galois_II(ct1[b], key, g, depth)), ("method II rotate", b)
+    assert gaps_intact(out, s_out, 3 * l * n) and gaps_intact(rot, s_in, 2 * l * n) and gaps_intact(d1, s_in, 2 * l * n)
+    # ---- BFV
+    n, t = 4096, 1032193
+    c = hg.Context.from_default(hg.BFV, n, 1, t)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, c.Q_size, c.P_size, t)
+    c.upload()
+    Q, Qp = c.Q_size, c.Q_prime_size
+    key, gkey = synth_key(primes, Q, Qp, n, 3), synth_key(primes, Q, Qp, n, 4)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
+    s_in, s_out = 2 * Q * n + 300, 3 * Q * n + 1100
+    d1, d2 = strided(ct1, s_in), strided(ct2, s_in)
+    out = torch.full((batch * s_out,), SENT, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(d1, s_in, d2, s_in, out, s_out, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+    c.bfv_relinearize_inplace(out, s_out, hg.to_device(key), batch, c.workspace(hg.OP_BFV_RELIN, 0, batch))
+    g = hg.steps_to_galois_elt(1, n, 3)
+    rot = torch.full((batch * s_in,), SENT, dtype=torch.int64, device="cuda")
+    c.bfv_apply_galois(d1, s_in, rot, s_in, hg.to_device(gkey), g, batch, c.workspace(hg.OP_BFV_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    got, gr = hg.to_host(out).reshape(batch, s_out), hg.to_host(rot).reshape(batch, s_in)
+    for b in range(batch):
+        w = o.bfv_relinearize(o.bfv_multiply(ct1[b], ct2[b]), key)
+        assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), ("bfv multiply + relinearize", b)
+        assert np.array_equal(gr[b][:2 * Q * n], o.bfv_apply_galois(ct1[b], gkey, g)), ("bfv rotate", b)
+    assert gaps_intact(out, s_out, 3 * Q * n) and gaps_intact(rot, s_in, 2 * Q * n) and gaps_intact(d1, s_in, 2 * Q * n)
