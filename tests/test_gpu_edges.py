@@ -331,3 +331,27 @@ def test_padded_item_strides_method_II_and_bfv(hg, oracle, torch):
         assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), ("bfv multiply + relinearize", b)
         assert np.array_equal(gr[b][:2 * Q * n], o.bfv_apply_galois(ct1[b], gkey, g)), ("bfv rotate", b)
     assert gaps_intact(out, s_out, 3 * Q * n) and gaps_intact(rot, s_in, 2 * Q * n) and gaps_intact(d1, s_in, 2 * Q * n)
+
+
+def test_c4_chain_beyond_one_column_pass_grid(hg, oracle, torch):
+    """Config C4's chain with more ciphertexts than one launch of the decomposing column pass takes (digits x Q'
+    polynomials per ciphertext: 65535 / 272 = 240): 250 ciphertexts, so the fused key switch runs in two pieces
+    and the inverse transform of c2 on its own.  Five distinct inputs: two checked against the oracle, all items
+    against their twins."""
+    n = 1 << 16
+    c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])
+    Q, Qp = 16, 17
+    batch, distinct = 250, 5
+    key = synth_key(primes, Q, Qp, n, 3)
+    cts = [synth_ct(primes, range(Q), 3, n, 70 + i) for i in range(distinct)]
+    base = hg.to_device(np.concatenate(cts)).reshape(distinct, 3 * Q * n)
+    reps = (batch + distinct - 1) // distinct
+    d = base.repeat(reps, 1)[:batch].contiguous().reshape(-1)
+    c.ckks_relinearize_inplace(d, 3 * Q * n, hg.to_device(key), 0, batch, c.workspace(hg.OP_CKKS_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = d.reshape(batch, 3 * Q * n)[:, :2 * Q * n]
+    for i in (0, 4):
+        w = cts[i].copy()
+        o.ckks_relinearize(w, key, 0)
+        assert np.array_equal(hg.to_host(got[i]), w[:2 * Q * n]), ("relinearize", i)
+    assert bool((got == got[:distinct].repeat(reps, 1)[:batch]).all()), "an item of the second piece differs from its twin"
