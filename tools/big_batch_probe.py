@@ -11,7 +11,7 @@ def rep(x, per): return x.reshape(D, per).repeat((B + D - 1) // D, 1)[:B].contig
 def twins(name, out, per):
     o = out.reshape(B, per)
     ok = bool((o == o[:D].repeat((B + D - 1) // D, 1)[:B]).all())
-    print("%-28s twins equal: %s" % (name, ok))
+    print("%-28s twins equal: %s   nonzero words in the last item: %d of %d" % (name, ok, int((o[B - 1] != 0).sum()), per))
 a, b = rep(r(D * 2 * Q * n), 2 * Q * n), rep(r(D * 2 * Q * n), 2 * Q * n)
 key = r(Q * 2 * Qp * n)
 for name, fn in (
