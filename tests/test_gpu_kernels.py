@@ -164,6 +164,79 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
         assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
 
 
+@pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
+                                dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=0, HEGPU_SINGLE_PASS=1)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+@pytest.mark.parametrize("n_power,depth", [(12, 0), (13, 1), (15, 0), (15, 2)])
+def test_fused_key_switch_at_every_degree(hg, oracle, torch, sw, n_power, depth):
+    """The fused forms (multi-modulus decomposing column pass finishing the inverse transform of its source, row
+    pass + inner product, mod-down as load transform / epilogue) are picked by launch size, which the small tests
+    never reach below N = 2^14: forced here at N = 2^12, 2^13, 2^15 (the kernels index tiles, rows and twiddles by
+    N) on a chain with a 60-bit first prime and a 60-bit special prime next to FP64-path primes, leveled."""
+    n = 1 << n_power
+    with backend_switches(**sw):
+        c, o, primes = _ckks(hg, oracle, n, [60, 45, 45, 45, 45], [60], sec=hg.SEC_NONE)
+    Q, Qp = 5, 6
+    l = Q - depth
+    batch = 2
+    key = synth_key(primes, Q, Qp, n, 3)
+    gkey = synth_key(primes, Q, Qp, n, 5)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * l * n, d2, 2 * l * n, out, 3 * l * n, depth, batch)
+    c.ckks_relinearize_inplace(out, 3 * l * n, hg.to_device(key), depth, batch, c.workspace(hg.OP_CKKS_RELIN, depth, batch))
+    g = hg.steps_to_galois_elt(2, n, 5)
+    rot = torch.empty(batch * 2 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(d1, 2 * l * n, rot, 2 * l * n, hg.to_device(gkey), g, depth, batch,
+                        c.workspace(hg.OP_CKKS_GALOIS, depth, batch))
+    torch.cuda.synchronize()
+    got, got_r = hg.to_host(out).reshape(batch, -1), hg.to_host(rot).reshape(batch, -1)
+    want = [o.ckks_relinearize(o.ckks_multiply(ct1[b], ct2[b], depth), key, depth) for b in range(batch)]
+    for b in range(batch):
+        assert np.array_equal(got[b][:2 * l * n], want[b][:2 * l * n]), "relinearize"
+        assert np.array_equal(got_r[b], o.ckks_apply_galois(ct1[b], gkey, g, depth)), "rotate"
+    if l > 1:
+        c.ckks_rescale_inplace(out, 3 * l * n, depth, batch, c.workspace(hg.OP_CKKS_RESCALE, depth, batch))
+        torch.cuda.synchronize()
+        got = hg.to_host(out).reshape(batch, -1)
+        for b in range(batch):
+            w = o.ckks_rescale(want[b][:2 * l * n].copy(), depth)
+            assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
+
+
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_SINGLE_PASS=0)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
+@pytest.mark.parametrize("n_power", [13, 14, 16])
+def test_bfv_key_switch_at_every_degree(hg, oracle, torch, sw, n_power):
+    """BFV relinearize + rotate on the default chains of N = 2^13, 2^14, 2^16 (C1 covers 2^12, C3 2^15): the
+    inverse transform that carries the mod-down and the Galois permutation as its epilogue exists as a single-pass
+    kernel (N <= 2^14) and as the column pass of the two-pass form, each indexed by N."""
+    n, t = 1 << n_power, 786433
+    with backend_switches(**sw):
+        c, o, primes = _bfv(hg, oracle, n, t)
+    Q, Qp = c.Q_size, c.Q_prime_size
+    batch = 2
+    key, gkey = synth_key(primes, Q, Qp, n, 3), synth_key(primes, Q, Qp, n, 4)
+    ct3 = [synth_ct(primes, range(Q), 3, n, 11 + b) for b in range(batch)]
+    d = hg.to_device(np.concatenate(ct3))
+    c.bfv_relinearize_inplace(d, 3 * Q * n, hg.to_device(key), batch, c.workspace(hg.OP_BFV_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(d).reshape(batch, -1)
+    want = [o.bfv_relinearize(ct3[b].copy(), key)[:2 * Q * n] for b in range(batch)]
+    for b in range(batch):
+        assert np.array_equal(got[b][:2 * Q * n], want[b]), "relinearize"
+    g = hg.steps_to_galois_elt(1, n, 3)
+    src = hg.to_device(np.concatenate(want))
+    rot = torch.empty_like(src)
+    c.bfv_apply_galois(src, 2 * Q * n, rot, 2 * Q * n, hg.to_device(gkey), g, batch, c.workspace(hg.OP_BFV_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    gr = hg.to_host(rot).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(gr[b], o.bfv_apply_galois(np.ascontiguousarray(want[b]), gkey, g)), "rotate"
+
+
 @pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_FUSED_ROW_MAC=0),
                                 dict(HEGPU_FP_NTT=0), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
                                 dict(HEGPU_SINGLE_PASS=0), dict(HEGPU_FUSED_MODDOWN=0),
