@@ -680,6 +680,51 @@ def test_hoisted_rotations(hg, oracle, torch, depth, method, grouped):
         assert np.array_equal(hg.to_host(one).reshape(batch, words), got[:, i]), ("vs apply_galois", i)
 
 
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
+@pytest.mark.parametrize("n_power,log_p", [(12, [60, 50]), (14, [60, 50, 50]), (16, [60, 50])])
+def test_method_II_and_hoisting_at_other_degrees(hg, oracle, torch, sw, n_power, log_p):
+    """Key switching method II (relinearize, rotate, hoisted rotations) away from N = 2^13: the digit -> Q~ base
+    conversion, the multi-prime mod-down in the NTT domain and the key-stationary inner product at N = 2^12, 2^14
+    and 2^16, by launch size and with the fused forms forced; depth 1, a 60-bit prime in Q (and in P at 2^14)."""
+    n = 1 << n_power
+    with backend_switches(**sw):
+        c, o, primes = _ckks(hg, oracle, n, [60, 45, 45, 45, 45, 45], log_p, sec=hg.SEC_NONE)
+    Q, P, depth = 6, len(log_p), 1
+    Qp, l, digits = Q + P, Q - depth, -(-Q // P)
+    batch = 2
+    key = synth_key(primes, digits, Qp, n, 3)
+    ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(l), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * l * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * l * n, d2, 2 * l * n, out, 3 * l * n, depth, batch)
+    c.ckks_relinearize_inplace(out, 3 * l * n, hg.to_device(key), depth, batch, c.workspace(hg.OP_CKKS_RELIN, depth, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        w = o.ckks_multiply(ct1[b], ct2[b], depth)
+        o.ckks_relinearize_II(w, key, depth)
+        assert np.array_equal(got[b][:2 * l * n], w[:2 * l * n]), "method II relinearize"
+    elts = [hg.steps_to_galois_elt(1, n, 5), 0, hg.steps_to_galois_elt(-3, n, 5), 2 * n - 1, hg.steps_to_galois_elt(7, n, 5)]
+    keys = [None if g == 0 else synth_key(primes, digits, Qp, n, 30 + i) for i, g in enumerate(elts)]
+    dkeys = [None if k is None else hg.to_device(k) for k in keys]
+    words = 2 * l * n
+    hout = torch.empty(batch * len(elts) * words, dtype=torch.int64, device="cuda")
+    c.ckks_rotate_hoisted(d1, words, hout, len(elts) * words, dkeys, elts, depth, batch,
+                          c.workspace(hg.OP_CKKS_ROTATE_HOISTED, depth, batch))
+    one = torch.empty(batch * words, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(d1, words, one, words, dkeys[0], elts[0], depth, batch, c.workspace(hg.OP_CKKS_GALOIS, depth, batch))
+    torch.cuda.synchronize()
+    gh = hg.to_host(hout).reshape(batch, len(elts), words)
+    go = hg.to_host(one).reshape(batch, words)
+    for b in range(batch):
+        want = o.ckks_rotate_hoisted(ct1[b], keys, elts, depth).reshape(len(elts), words)
+        for i in range(len(elts)):
+            assert np.array_equal(gh[b, i], want[i]), ("hoisted", b, i)
+        assert np.array_equal(go[b], o.ckks_apply_galois_II(ct1[b], keys[0], elts[0], depth)), "method II rotate"
+
+
 @pytest.mark.parametrize("single", [1, 0], ids=["single_pass", "two_pass"])
 @pytest.mark.parametrize("n_power", [12, 13, 14])
 def test_ntt_small_degrees_both_forms(hg, oracle, torch, n_power, single):
