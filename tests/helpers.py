@@ -22,3 +22,23 @@ def synth_key(primes, Q, Qp, n, seed):
             for j in range(Qp):
                 out[i, c, j] = ob.fill_poly(seed * 100000 + i * 2 + c, j, n, primes[j])
     return out.reshape(-1)
+
+
+import contextlib  # noqa: E402
+import os  # noqa: E402
+
+
+@contextlib.contextmanager
+def backend_switches(**kw):
+    """The switches are read when a context is uploaded (csrc/context.cpp: Context::upload,
+    build_plan), so the context must be created inside the block."""
+    old = {k: os.environ.get(k) for k in kw}
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

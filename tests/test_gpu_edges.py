@@ -355,3 +355,39 @@ def test_c4_chain_beyond_one_column_pass_grid(hg, oracle, torch):
         o.ckks_relinearize(w, key, 0)
         assert np.array_equal(hg.to_host(got[i]), w[:2 * Q * n]), ("relinearize", i)
     assert bool((got == got[:distinct].repeat(reps, 1)[:batch]).all()), "an item of the second piece differs from its twin"
+
+
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_GALOIS_SCATTER=0), dict(HEGPU_NTT_GALOIS=0)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
+def test_arbitrary_galois_elements(hg, oracle, torch, sw):
+    """Any odd Galois element below 2N, not only the powers of 5 and 2N - 1 a rotation key set holds: the slot
+    scatter (default), the slot gather and the reference's coefficient-domain permutation against the oracle for
+    24 random elements plus 1, 3, N - 1, N + 1, 2N - 3 and 2N - 1 (CKKS N = 2^12; BFV N = 2^12)."""
+    from helpers import backend_switches
+    n = 4096
+    rng = np.random.default_rng(5)
+    elts = [1, 3, n - 1, n + 1, 2 * n - 3, 2 * n - 1] + [int(2 * v + 1) for v in rng.integers(0, n, 24)]
+    with backend_switches(**sw):
+        c, o, primes = _ckks(hg, oracle, n, [40, 30, 30], [40])
+        cb = hg.Context.from_default(hg.BFV, n, 1, 1032193)
+        cb.upload()
+    pb = [int(x) for x in cb.table("modulus")]
+    ob = oracle.OracleContext(oracle.BFV, cb.n_power, pb, cb.Q_size, cb.P_size, 1032193)
+    Q, Qp = 3, 4
+    key = synth_key(primes, Q, Qp, n, 9)
+    ct = synth_ct(primes, range(Q), 2, n, 77)
+    d, dk = hg.to_device(ct), hg.to_device(key)
+    out = torch.empty(2 * Q * n, dtype=torch.int64, device="cuda")
+    ws = c.workspace(hg.OP_CKKS_GALOIS, 0, 1)
+    Qb, Qpb = cb.Q_size, cb.Q_prime_size
+    keyb = synth_key(pb, Qb, Qpb, n, 8)
+    ctb = synth_ct(pb, range(Qb), 2, n, 78)
+    db, dkb = hg.to_device(ctb), hg.to_device(keyb)
+    outb = torch.empty(2 * Qb * n, dtype=torch.int64, device="cuda")
+    wsb = cb.workspace(hg.OP_BFV_GALOIS, 0, 1)
+    for g in elts:
+        c.ckks_apply_galois(d, 2 * Q * n, out, 2 * Q * n, dk, g, 0, 1, ws)
+        cb.bfv_apply_galois(db, 2 * Qb * n, outb, 2 * Qb * n, dkb, g, 1, wsb)
+        torch.cuda.synchronize()
+        assert np.array_equal(hg.to_host(out), o.ckks_apply_galois(ct, key, g, 0)), ("ckks", g)
+        assert np.array_equal(hg.to_host(outb), ob.bfv_apply_galois(ctb, keyb, g)), ("bfv", g)

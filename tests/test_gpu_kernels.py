@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import synth_ct, synth_key
+from helpers import backend_switches, synth_ct, synth_key
 
 pytestmark = pytest.mark.gpu
 
@@ -27,22 +27,6 @@ def torch():
     import torch
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     return torch
-
-
-@contextlib.contextmanager
-def backend_switches(**kw):
-    """The switches are read when a context is uploaded (csrc/context.cpp: Context::upload,
-    build_plan), so the context must be created inside the block."""
-    old = {k: os.environ.get(k) for k in kw}
-    os.environ.update({k: str(v) for k, v in kw.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _ckks(hg, oracle, n, log_q, log_p, sec=None):
