@@ -4,7 +4,7 @@ largest (60), a batch beyond one launch's grid -- each compared limb for limb wi
 import numpy as np
 import pytest
 
-from helpers import synth_ct, synth_key
+from helpers import backend_switches, synth_ct, synth_key
 
 pytestmark = pytest.mark.gpu
 
@@ -363,7 +363,6 @@ def test_arbitrary_galois_elements(hg, oracle, torch, sw):
     """Any odd Galois element below 2N, not only the powers of 5 and 2N - 1 a rotation key set holds: the slot
     scatter (default), the slot gather and the reference's coefficient-domain permutation against the oracle for
     24 random elements plus 1, 3, N - 1, N + 1, 2N - 3 and 2N - 1 (CKKS N = 2^12; BFV N = 2^12)."""
-    from helpers import backend_switches
     n = 4096
     rng = np.random.default_rng(5)
     elts = [1, 3, n - 1, n + 1, 2 * n - 3, 2 * n - 1] + [int(2 * v + 1) for v in rng.integers(0, n, 24)]
@@ -391,3 +390,51 @@ def test_arbitrary_galois_elements(hg, oracle, torch, sw):
         torch.cuda.synchronize()
         assert np.array_equal(hg.to_host(out), o.ckks_apply_galois(ct, key, g, 0)), ("ckks", g)
         assert np.array_equal(hg.to_host(outb), ob.bfv_apply_galois(ctb, keyb, g)), ("bfv", g)
+
+
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=0)],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
+def test_long_chain_many_digits(hg, oracle, torch, sw):
+    """40 primes in Q (method I: 40 digits, beyond the 32 up to which the integer row pass stays un-reduced and the
+    16 up to which hoisting groups four keys): a 59-bit first prime (just above 2^58: the lazy row stages) and a
+    60-bit special prime on the integer butterflies, 38 x 30-bit primes and one 50-bit on the FP64 path.
+    multiply -> relinearize -> rescale -> rotate and hoisted rotations, N = 2^12."""
+    n = 4096
+    with backend_switches(**sw):
+        c, o, primes = _ckks(hg, oracle, n, [59] + [30] * 38 + [50], [60])
+    Q, Qp = 40, 41
+    batch = 2
+    key, gkey = synth_key(primes, Q, Qp, n, 3), synth_key(primes, Q, Qp, n, 4)
+    ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.ckks_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, 0, batch)
+    c.ckks_relinearize_inplace(out, 3 * Q * n, hg.to_device(key), 0, batch, c.workspace(hg.OP_CKKS_RELIN, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    want = []
+    for b in range(batch):
+        w = o.ckks_multiply(ct1[b], ct2[b], 0)
+        o.ckks_relinearize(w, key, 0)
+        want.append(w)
+        assert np.array_equal(got[b][:2 * Q * n], w[:2 * Q * n]), ("relinearize", b)
+    c.ckks_rescale_inplace(out, 3 * Q * n, 0, batch, c.workspace(hg.OP_CKKS_RESCALE, 0, batch))
+    g = hg.steps_to_galois_elt(1, n, 5)
+    elts = [g, 2 * n - 1]
+    keys = [gkey, synth_key(primes, Q, Qp, n, 6)]
+    words = 2 * Q * n
+    hout = torch.empty(batch * 2 * words, dtype=torch.int64, device="cuda")
+    c.ckks_rotate_hoisted(d1, words, hout, 2 * words, [hg.to_device(k) for k in keys], elts, 0, batch,
+                          c.workspace(hg.OP_CKKS_ROTATE_HOISTED, 0, batch))
+    rot = torch.empty(batch * words, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(d1, words, rot, words, hg.to_device(gkey), g, 0, batch, c.workspace(hg.OP_CKKS_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    got, gh, gr = hg.to_host(out).reshape(batch, -1), hg.to_host(hout).reshape(batch, 2, words), hg.to_host(rot).reshape(batch, words)
+    for b in range(batch):
+        r = o.ckks_rescale(want[b][:2 * Q * n].copy(), 0)
+        assert np.array_equal(got[b][:2 * (Q - 1) * n], r[:2 * (Q - 1) * n]), ("rescale", b)
+        wr = o.ckks_apply_galois(ct1[b], gkey, g, 0)
+        assert np.array_equal(gr[b], wr), ("rotate", b)
+        wh = o.ckks_rotate_hoisted(ct1[b], keys, elts, 0).reshape(2, words)
+        assert np.array_equal(gh[b, 0], wh[0]) and np.array_equal(gh[b, 1], wh[1]), ("hoisted", b)
