@@ -355,6 +355,26 @@ def test_c4_chain_beyond_one_column_pass_grid(hg, oracle, torch):
         o.ckks_relinearize(w, key, 0)
         assert np.array_equal(hg.to_host(got[i]), w[:2 * Q * n]), ("relinearize", i)
     assert bool((got == got[:distinct].repeat(reps, 1)[:batch]).all()), "an item of the second piece differs from its twin"
+    # the same batch through rotate (key switch first, then the slot scatter) and hoisted rotations (two elements)
+    del d
+    gkeys = [synth_key(primes, Q, Qp, n, 8), synth_key(primes, Q, Qp, n, 9)]
+    elts = [hg.steps_to_galois_elt(1, n, 5), 2 * n - 1]
+    words = 2 * Q * n
+    src = hg.to_device(np.concatenate([x[:words] for x in cts])).reshape(distinct, words).repeat(reps, 1)[:batch].contiguous().reshape(-1)
+    rot = torch.empty(batch * words, dtype=torch.int64, device="cuda")
+    c.ckks_apply_galois(src, words, rot, words, hg.to_device(gkeys[0]), elts[0], 0, batch, c.workspace(hg.OP_CKKS_GALOIS, 0, batch))
+    torch.cuda.synchronize()
+    gr = rot.reshape(batch, words)
+    assert np.array_equal(hg.to_host(gr[3]), o.ckks_apply_galois(np.ascontiguousarray(cts[3][:words]), gkeys[0], elts[0], 0)), "rotate"
+    assert bool((gr == gr[:distinct].repeat(reps, 1)[:batch]).all()), "rotate: an item of the second piece differs"
+    hout = torch.empty(batch * 2 * words, dtype=torch.int64, device="cuda")
+    c.ckks_rotate_hoisted(src, words, hout, 2 * words, [hg.to_device(k) for k in gkeys], elts, 0, batch,
+                          c.workspace(hg.OP_CKKS_ROTATE_HOISTED, 0, batch))
+    torch.cuda.synchronize()
+    gh = hout.reshape(batch, 2 * words)
+    assert bool((gh[:, :words] == gr).all()), "hoisted element 0 differs from apply_galois"
+    assert np.array_equal(hg.to_host(gh[2][words:]), o.ckks_apply_galois(np.ascontiguousarray(cts[2][:words]), gkeys[1], elts[1], 0)), "hoisted"
+    assert bool((gh == gh[:distinct].repeat(reps, 1)[:batch]).all()), "hoisted: an item of the second piece differs"
 
 
 @pytest.mark.parametrize("sw", [dict(), dict(HEGPU_GALOIS_SCATTER=0), dict(HEGPU_NTT_GALOIS=0)],
