@@ -140,16 +140,19 @@ def test_batch_beyond_one_grid(hg, oracle, torch):
     assert np.array_equal(hg.to_host(y), x)
 
 
-def test_epilogue_launches_beyond_one_grid(hg, oracle, torch):
+@pytest.mark.parametrize("log_q,log_p", [([40, 30, 30], [40]), ([40, 30, 30, 30], [40, 40])], ids=["method_I", "method_II"])
+def test_epilogue_launches_beyond_one_grid(hg, oracle, torch, log_q, log_p):
     """Relinearize and rescale of so many ciphertexts that their mod-down transforms (2 l resp. 2 (l - 1)
     polynomials per ciphertext, with per-ciphertext epilogue operands) exceed one grid (65535 polynomials) and are
     cut into pieces: every per-item pointer of the launch has to move with the piece.  The batch repeats 24
     distinct ciphertexts, so all of them are checked against the oracle and every other item against its twin."""
     n = 4096
-    c, o, primes = _ckks(hg, oracle, n, [40, 30, 30], [40])
-    Q, Qp = 3, 4
-    batch, distinct = 16400, 24            # relinearize: 6 * 16400 = 98400, rescale: 4 * 16400 = 65600 polynomials
-    key = synth_key(primes, Q, Qp, n, 3)
+    c, o, primes = _ckks(hg, oracle, n, log_q, log_p)
+    Q, P = len(log_q), len(log_p)
+    Qp = Q + P
+    batch, distinct = 16400, 24            # relinearize: 2 Q * 16400, rescale: 2 (Q - 1) * 16400 >= 65600 polynomials
+    key = synth_key(primes, -(-Q // P), Qp, n, 3)
+    relin = o.ckks_relinearize if P == 1 else o.ckks_relinearize_II
     cts = [synth_ct(primes, range(Q), 3, n, 40 + i) for i in range(distinct)]
     base = hg.to_device(np.concatenate(cts)).reshape(distinct, 3 * Q * n)
     d = base.repeat((batch + distinct - 1) // distinct, 1)[:batch].contiguous().reshape(-1)
@@ -159,7 +162,7 @@ def test_epilogue_launches_beyond_one_grid(hg, oracle, torch):
     want = []
     for i in range(distinct):
         w = cts[i].copy()
-        o.ckks_relinearize(w, key, 0)
+        relin(w, key, 0)
         want.append(w[:2 * Q * n])
         assert np.array_equal(hg.to_host(got[i]), want[i]), ("relinearize", i)
     twin = got[:distinct].repeat((batch + distinct - 1) // distinct, 1)[:batch]
