@@ -316,6 +316,45 @@ def secondary_block(torch, hg, timer):
     return sec
 
 
+def power_sample(torch, step):
+    """Package power and shader clock while the step loops (outside the timed region): the kernels of the step are
+    bound by FP64 issue at the clock the package power limit allows, which this records next to the
+    throughput.  rocm-smi is polled from the host while ~3 s of steps sit in the stream; None if it is not there."""
+    import re
+    import subprocess
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    try:
+        for _ in range(350):
+            step()
+        watts, mhz, limit = [], [], None
+        for _ in range(3):
+            txt = subprocess.run([smi, "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
+                                 timeout=20).stdout
+            m = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+            if m:
+                watts.append(float(m.group(1)))
+            m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+            if m:
+                mhz.append(int(m.group(1)))
+            m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", txt)
+            if m:
+                limit = float(m.group(1))
+        torch.cuda.synchronize()
+        if not watts:
+            return None
+        return {"package_w": max(watts), "package_limit_w": limit, "sclk_mhz": (min(mhz) if mhz else None),
+                "how": "rocm-smi polled three times while 350 extra steps run (not in the timed region); "
+                       "highest power / lowest clock of the polls that fell inside the run"}
+    except Exception as e:  # a missing or slow tool must not cost the line
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return {"error": str(e)[:120]}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -517,6 +556,7 @@ def main():
             line["roofline"]["copy_ceiling_GBps"] = tj["copy_ceiling_GBps"]
 
     if rank == 0 and world == 1 and not args.no_secondary:
+        line["power"] = power_sample(torch, step)
         line["ntt_by_degree"] = ntt_sweep(torch, hg, timer)
         line["secondary"] = secondary_block(torch, hg, timer)
         del ct1, ct2, out, ws
