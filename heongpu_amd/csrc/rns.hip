@@ -9,6 +9,7 @@
 // lazily where it is exact (128-bit accumulation in the key-switch MAC), so
 // outputs are the same canonical residues.
 #include "rns.hpp"
+#include <cstdlib>
 
 namespace hegpu {
 
@@ -941,13 +942,18 @@ hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride,
 // nothing).  Guarding every slot with `if (i < ib)` instead made the compiler carry the whole register
 // array through a chain of conditional blocks -- 236 registers and one wave per SIMD at MAXB = 16 -- so
 // MAXB is kept close to the real size (behz_slots) and the few wasted products are accepted.
-template <int MAXB>
+// SPLIT (launches that leave the chip mostly empty: one ciphertext pair at N = 2^16 is 1024 workgroups of 10 k
+// instructions per thread): the four wavefronts of a workgroup share 64 coefficients; every wavefront repeats the
+// short per-coefficient prologue and takes every fourth row of the base conversion -- four times the threads, a
+// quarter of the rows each, the row tables still wave-uniform.
+template <int MAXB, bool SPLIT>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __restrict__ in1, u64 s1,
                                                                  const u64* __restrict__ in2, u64 s2,
                                                                  u64* __restrict__ out1, u64 so, BehzDev b,
                                                                  int n_power)
 {
-    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const u32 idx = SPLIT ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int row0 = SPLIT ? (int) (threadIdx.x >> 6) : 0, row_step = SPLIT ? 4 : 1;
     const int idy = blockIdx.y;
     const int ib = b.ibase_size, ob = b.obase_size;
     const u64* input = ((idy >> 1) == 0) ? (in1 + s1 * blockIdx.z) : (in2 + s2 * blockIdx.z);
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
         const int ii = i < ib ? i : ib - 1;
         const Mod mi = b.ibase[ii];
         const u64 v = input[location + ((u64) ii << n_power)];
-        po[(u64) ii << n_power] = v; // slots beyond ib rewrite limb ib-1 with its own value
+        if (!SPLIT || (i & 3) == row0) po[(u64) ii << n_power] = v; // slots beyond ib rewrite limb ib-1 with its own value
         const u64 t = mul_barrett(v, b.mtilde_inv_punct[ii], mi); // x * m_tilde * (q/q_i)^-1, one product
         temp[i] = i < ib ? t : 0;
     }
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     u64 r_mt = (u64) (u32) (acc_mt32 * (u32) b.inv_prod_q_mod_m_tilde);
     r_mt = mt - r_mt;
 #pragma unroll 1
-    for (int i = 0; i < ob; i++) {
+    for (int i = row0; i < ob; i += row_step) {
         const Mod mo = b.obase[i];
         const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
         u64 hi, lo;
@@ -1006,13 +1012,31 @@ static int behz_slots(int m)
         default: LAUNCH(64); break;                                                          \
     }
 
+// The split forms when the plain launch has fewer than 320 workgroups (measured, one ciphertext pair, plain / split:
+// N = 2^14 fast_floor 20.2 / 15.3 us, fast_convertion 14.7 / 13.6; N = 2^15 55 / 58, 35 / 39; N = 2^16 288 / 395,
+// 169 / 279 -- from 384 workgroups on the kernels are bound by their instruction count, which the split raises);
+// HEGPU_BEHZ_SPLIT=0/1
+// forces the choice (read at every call: the tests run both forms on the same context).
+static bool behz_split(int n_power, int polys, int batch)
+{
+    if (const char* e = getenv("HEGPU_BEHZ_SPLIT")) return e[0] != '0';
+    return ((long) (1u << n_power) / RNS_THREADS) * polys * batch < 320;
+}
+
 hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
                                const BehzDev& b, int n_power, int batch, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1) return hipErrorInvalidValue;
+    if (behz_split(n_power, 4, batch)) {
+        dim3 g((1u << n_power) / 64, 4, batch);
+#define LAUNCH(M) hipLaunchKernelGGL((k_fast_convertion<M, true>), g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
+        BEHZ_DISPATCH(b.ibase_size)
+#undef LAUNCH
+        return hipGetLastError();
+    }
     dim3 g((1u << n_power) / RNS_THREADS, 4, batch);
-#define LAUNCH(M) hipLaunchKernelGGL(k_fast_convertion<M>, g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
+#define LAUNCH(M) hipLaunchKernelGGL((k_fast_convertion<M, false>), g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
     BEHZ_DISPATCH(b.ibase_size)
 #undef LAUNCH
     return hipGetLastError();
@@ -1021,11 +1045,15 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
 #ifndef FF_UNROLL_MAX
 #define FF_UNROLL_MAX 0
 #endif
-template <int MAXB>
+// SPLIT: as in k_fast_convertion; the rows of the first conversion computed by the four wavefronts meet in LDS
+// ([row][coefficient], one barrier) before every wavefront runs its quarter of the second one.
+template <int MAXB, bool SPLIT>
 __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restrict__ in, u64 si,
                                                             u64* __restrict__ out1, u64 so, BehzDev b, int n_power)
 {
-    const u32 idx = blockIdx.x * RNS_THREADS + threadIdx.x;
+    const u32 idx = SPLIT ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * RNS_THREADS + threadIdx.x;
+    const int row0 = SPLIT ? (int) (threadIdx.x >> 6) : 0, row_step = SPLIT ? 4 : 1;
+    __shared__ u64 meet[SPLIT ? (MAXB + 1) * 64 : 1];
     const int idy = blockIdx.y;
     const int ib = b.ibase_size, ob = b.obase_size;
     const u64 t = b.plain.q;
@@ -1041,7 +1069,26 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     // rows 0 .. ob-2: the moduli of B (-> temp3), row ob-1: m_sk.  (The two forms are written out: sharing
     // the row computation through a lambda cost 30 registers.)
     u64 reg_Bsk_last = 0;
-    if constexpr (MAXB <= FF_UNROLL_MAX) {
+    if constexpr (SPLIT) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll 1
+        for (int i = row0; i < ob; i += row_step) {
+            const Mod mo = b.obase[i];
+            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
+            const u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
+            u64 hi, lo;
+            dot128(reg_q, row, ib, hi, lo);
+            const u64 tmp = reduce128(hi, lo, mo);
+            u64 t2 = sub_mod(mo.q, tmp, mo.q);
+            t2 = add_mod(t2, rb, mo.q);
+            const bool last = i == ob - 1;
+            meet[i * 64 + lane] = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[i] : b.invq_inv_punct_B[i], mo);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXB; k++) temp3[k] = (k < ob - 1) ? meet[k * 64 + lane] : 0;
+        reg_Bsk_last = meet[(ob - 1) * 64 + lane];
+    } else if constexpr (MAXB <= FF_UNROLL_MAX) {
         // MAXB + 1 unrolled iterations on a clamped row index cover ob <= MAXB + 1 (the surplus ones
         // recompute the m_sk row): static register indices, no selects
 #pragma unroll
@@ -1092,7 +1139,7 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     const bool neg = alpha_sk > (msk.q >> 1);
     u64* po = out1 + so * blockIdx.z + idx + ((u64) (idy * ib) << n_power);
 #pragma unroll 1
-    for (int i = 0; i < ib; i++) {
+    for (int i = row0; i < ib; i += row_step) {
         const Mod mi = b.ibase[i];
         const u64* __restrict__ row = b.base_change_matrix_q + i * (ob - 1);
         u64 h2, l2;
@@ -1118,9 +1165,16 @@ hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1 || b.obase_size < 2)
         return hipErrorInvalidValue;
-    dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
     const int m = b.ibase_size > b.obase_size - 1 ? b.ibase_size : b.obase_size - 1;
-#define LAUNCH(M) hipLaunchKernelGGL(k_fast_floor<M>, g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
+    if (behz_split(n_power, 3, batch)) {
+        dim3 g((1u << n_power) / 64, 3, batch);
+#define LAUNCH(M) hipLaunchKernelGGL((k_fast_floor<M, true>), g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
+        BEHZ_DISPATCH(m)
+#undef LAUNCH
+        return hipGetLastError();
+    }
+    dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
+#define LAUNCH(M) hipLaunchKernelGGL((k_fast_floor<M, false>), g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
     BEHZ_DISPATCH(m)
 #undef LAUNCH
     return hipGetLastError();

@@ -190,6 +190,28 @@ def test_fused_key_switch_at_every_degree(hg, oracle, torch, sw, n_power, depth)
             assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), "rescale"
 
 
+@pytest.mark.parametrize("split", [0, 1], ids=["one_thread_per_coefficient", "rows_over_four_wavefronts"])
+@pytest.mark.parametrize("n_power", [12, 14, 15])
+def test_bfv_multiply_both_behz_forms(hg, oracle, torch, split, n_power):
+    """BFV multiply on the default chains (Q = 2 / 8 / 14 with 3 / 9 / 15 auxiliary primes): the two BEHZ kernels
+    with one thread per coefficient and with the rows of the base conversions spread over the four wavefronts of a
+    workgroup (picked for launches below 320 workgroups; HEGPU_BEHZ_SPLIT is read at every call)."""
+    n, t = 1 << n_power, 786433
+    c, o, primes = _bfv(hg, oracle, n, t)
+    Q = c.Q_size
+    batch = 2
+    ct1 = [synth_ct(primes, range(Q), 2, n, 21 + b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 31 + b) for b in range(batch)]
+    d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    with backend_switches(HEGPU_BEHZ_SPLIT=split):
+        c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+        torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.bfv_multiply(ct1[b], ct2[b])), b
+
+
 @pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_SINGLE_PASS=0)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
 @pytest.mark.parametrize("n_power", [13, 14, 16])
@@ -540,7 +562,8 @@ def test_c5_tfhe_4096_gates(hg, oracle, torch):
     assert np.array_equal(gb, np.tile(gb[:uniq], rep))
 
 
-def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch):
+@pytest.mark.parametrize("split", [0, 1], ids=["one_thread_per_coefficient", "rows_over_four_wavefronts"])
+def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split):
     """BEHZ with Q + |Bsk| beyond 40 moduli (the reference allows MAX_BSK_SIZE = 64, defines.h:26):
     BFV N=2^12, 42 primes of 30 bits + one special prime, multiply + relinearize against the oracle."""
     n, t, Q = 4096, 65537, 42
@@ -553,9 +576,10 @@ def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch):
     ct1 = synth_ct(primes, range(Q), 2, n, 1)
     ct2 = synth_ct(primes, range(Q), 2, n, 2)
     out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
-    c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
-                   c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
-    torch.cuda.synchronize()
+    with backend_switches(HEGPU_BEHZ_SPLIT=split):
+        c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
+                       c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+        torch.cuda.synchronize()
     want = o.bfv_multiply(ct1, ct2)
     assert np.array_equal(hg.to_host(out), want)
 
