@@ -81,6 +81,40 @@ def h():
 soak("CKKS N=2^14 relin + rescale + rotate, 8", h, rot)
 del ctx
 
+# two streams on ONE context at the same time, each with its own data and workspace: results must equal the serial ones
+n, B = 1 << 14, 4
+ctx = hg.Context.from_bit_sizes(hg.CKKS, n, [50] + [40] * 7, [50]); ctx.upload()
+Q, Qp = ctx.Q_size, ctx.Q_prime_size
+key = r(Q * 2 * Qp * n)
+gal = hg.steps_to_galois_elt(1, n, 5)
+srcs = [r(3 * Q * n * B) for _ in range(2)]
+works = [torch.empty_like(srcs[0]) for _ in range(2)]
+rots = [torch.empty(2 * (Q - 1) * n * B, dtype=torch.int64, device="cuda") for _ in range(2)]
+wss = [(ctx.workspace(hg.OP_CKKS_RELIN, 0, B), ctx.workspace(hg.OP_CKKS_RESCALE, 0, B), ctx.workspace(hg.OP_CKKS_GALOIS, 1, B)) for _ in range(2)]
+def seq(i, stream=None):
+    works[i].copy_(srcs[i])
+    ctx.ckks_relinearize_inplace(works[i], 3 * Q * n, key, 0, B, wss[i][0], stream=stream)
+    ctx.ckks_rescale_inplace(works[i], 3 * Q * n, 0, B, wss[i][1], stream=stream)
+    ctx.ckks_apply_galois(works[i], 3 * Q * n, rots[i], 2 * (Q - 1) * n, key, gal, 1, B, wss[i][2], stream=stream)
+for i in range(2):
+    seq(i)
+torch.cuda.synchronize()
+refs = [x.clone() for x in rots]
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+diff = 0
+for _ in range(REPS):
+    for i in range(2):
+        rots[i].fill_(-1)
+    torch.cuda.synchronize()
+    for i in range(2):
+        with torch.cuda.stream(streams[i]):
+            seq(i, stream=streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    diff += int(any(bool((rots[i] != refs[i]).any()) for i in range(2)))
+print("%-40s %d / %d repetitions differ" % ("two streams on one context (CKKS N=2^14)", diff, REPS))
+bad += diff
+del ctx
+
 t = hg.TfheContext()
 S = 300
 bk = r(t.int("bootkey_elems"), 1 << 31)
