@@ -568,6 +568,7 @@ hipError_t Context::upload()
     if (const char* e = getenv("HEGPU_GALOIS_SCATTER")) galois_scatter = (e[0] != '0');
     if (const char* e = getenv("HEGPU_FUSE_INVERSE")) fuse_inverse = (e[0] != '0');
     if (const char* e = getenv("HEGPU_COPY_ALONG")) copy_along = (e[0] != '0');
+    if (const char* e = getenv("HEGPU_DIGIT_SPLIT")) digit_split = atoi(e);
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)
         gauss_cdt.t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);

@@ -60,6 +60,7 @@ struct Context {
     int single_pass = -1;      // HEGPU_SINGLE_PASS: 1 / 0 force the single pass / the two passes for N <= 2^14, otherwise by launch size (NttArgs::single_pass)
     bool ntt_galois = true;    // HEGPU_NTT_GALOIS=0: CKKS rotations in the reference's order (permutation in the coefficient domain)
     bool galois_scatter = true; // HEGPU_GALOIS_SCATTER=0: the NTT-domain permutation as a kernel of its own (gather) instead of the mod-down epilogue's store
+    int digit_split = -1;      // HEGPU_DIGIT_SPLIT: 0 never, 2 / 4 always that many workgroups per fused key-switch unit, -1 by launch size
     bool copy_along = true;    // HEGPU_COPY_ALONG=0: the rescale's copy of the kept limbs always has its own launch
     bool fuse_inverse = true;  // HEGPU_FUSE_INVERSE=0: the INTT feeding a decomposing launch runs on its own
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)

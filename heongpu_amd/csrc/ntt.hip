@@ -930,11 +930,16 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
 // `items` workgroups of a group share the key tiles of that group (1 MiB at 16 digits) and nothing
 // else is re-used, so they are placed on ONE XCD (workgroup b runs on XCD b % 8): group g goes to XCD
 // g % 8 and its ciphertexts run there back to back -- one L2 instead of eight fetches every key tile.
-struct KsIdx { int item, tile, slot; bool valid; };
+struct KsIdx { int item, tile, slot; bool valid; int d0, d1; };
+template <bool SPLIT>
 __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
 {
     const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
-    const unsigned gi = j / (unsigned) a.items, item = j - gi * (unsigned) a.items;
+    // with digit splits (item, split) takes the place of the item: splits of one item sit next to each other
+    const unsigned splits = SPLIT ? (unsigned) a.splits : 1u;
+    const unsigned units = (unsigned) a.items * splits;
+    const unsigned gi = j / units, unit = j - gi * units;
+    const unsigned item = SPLIT ? unit / splits : unit, sp = SPLIT ? unit - item * splits : 0u;
     const unsigned g = gi * 8u + xcd;
     const unsigned tiles = 1u << (a.n_power - 12);
     KsIdx r;
@@ -942,14 +947,17 @@ __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
     r.slot = (int) (g >> (a.n_power - 12));
     r.tile = (int) (g & (tiles - 1));
     r.valid = r.slot < a.rc;
+    r.d0 = SPLIT ? (int) (sp * (unsigned) a.digits / splits) : 0;
+    r.d1 = SPLIT ? (int) ((sp + 1) * (unsigned) a.digits / splits) : a.digits;
     return r;
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
+template <bool SPLIT>
+__global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const KsIdx ki = ks_index(a);
+    const KsIdx ki = ks_index<SPLIT>(a);
     if (!ki.valid) return;
     const int item = ki.item, tile = ki.tile, slot = ki.slot;
     const int midx = a.mod_order ? a.mod_order[slot] : slot;
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
     u64 h0[16], l0[16], h1[16], l1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) h0[k] = l0[k] = h1[k] = l1[k] = 0;
-    for (int i = 0; i < a.digits; i++) {
+    for (int i = ki.d0; i < ki.d1; i++) {
         u64 x[16];
         const u64* p = pin + dig_off * i;
         if (a.skip_identity && i == midx) {
@@ -1000,7 +1008,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
             acc128(h1[k], l1[k], x[k], k1[16 * k]);
         }
     }
-    u64* po = a.out + a.out_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+    // split launches: the partial sums over the first two digits of this workgroup's own range (KsMacArgs::splits)
+    u64* po = (SPLIT ? const_cast<u64*>(pin) + dig_off * ki.d0 - (u64) tile * 4096
+                     : a.out + a.out_item_stride * item + ((u64) slot << a.n_power)) +
+              (u64) tile * 4096 + row * 256 + i0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         po[16 * k] = reduce128(h0[k], l0[k], md);
@@ -1015,11 +1026,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac(KsMacArgs a)
 // every fourth digit (|acc| < 3.5 q < 2^53) and made canonical once at the end.
 // Two double accumulators per coefficient instead of two 128-bit integers
 // halve the register footprint (3 waves per SIMD instead of 2).
+template <bool SPLIT>
 __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const KsIdx ki = ks_index(a);
+    const KsIdx ki = ks_index<SPLIT>(a);
     if (!ki.valid) return;
     const int item = ki.item, tile = ki.tile, slot = ki.slot;
     const int midx = a.mod_order ? a.mod_order[slot] : slot;
@@ -1058,7 +1070,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
     double a0[16], a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a0[k] = a1[k] = 0.0;
-    for (int i = 0; i < a.digits; i++) {
+    for (int i = ki.d0; i < ki.d1; i++) {
         double x[16];
         const u64* p = pin + dig_off * i;
         // The digit first, then the key tile of this digit: vmcnt counts in order, so the wait for the
@@ -1146,7 +1158,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
             }
         }
     }
-    u64* po = a.out + a.out_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
+    u64* po = (SPLIT ? const_cast<u64*>(pin) + dig_off * ki.d0 - (u64) tile * 4096
+                     : a.out + a.out_item_stride * item + ((u64) slot << a.n_power)) +
+              (u64) tile * 4096 + row * 256 + i0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         po[16 * k] = fp_to_u64(fp_canon(a0[k], fc));
@@ -1157,13 +1171,19 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
 {
     if (a.digits > 64 || items <= 0) return hipErrorInvalidValue;
+    if (a.splits > 1 && a.digits < 2 * a.splits) return hipErrorInvalidValue;
     KsMacArgs k = a;
     k.items = items;
     const unsigned groups = ((1u << a.n_power) / 4096) * (unsigned) a.rc;
-    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned) items;
+    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned) items * (a.splits > 1 ? (unsigned) a.splits : 1u);
     // both kernels cover the whole grid; each exits at once on the other's moduli
-    hipLaunchKernelGGL(ks_row_mac_fp, dim3(grid), dim3(NTT_THREADS), 0, st, k);
-    hipLaunchKernelGGL(ks_row_mac, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+    if (a.splits > 1) {
+        hipLaunchKernelGGL(ks_row_mac_fp<true>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        hipLaunchKernelGGL(ks_row_mac<true>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+    } else {
+        hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        hipLaunchKernelGGL(ks_row_mac<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+    }
     return hipGetLastError();
 }
 

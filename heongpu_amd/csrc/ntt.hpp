@@ -176,6 +176,11 @@ struct KsMacArgs {
     const u64* ident;       // [item][digit][N] NTT-domain limbs (the polynomial that was decomposed)
     u64 ident_item_stride;
     int items;              // set by ks_row_mac_launch
+    // Launches too small for one workgroup per (ciphertext, limb slot, tile) to fill the chip: `splits` workgroups
+    // share such a unit, each takes the digits [s * digits / splits, (s + 1) * digits / splits) and leaves its two
+    // partial sums (canonical residues) IN PLACE of the first two digits of its range in `in` (those regions are
+    // read by this workgroup alone; digits >= 2 * splits); rns_sum_partials adds them into `out` afterwards.
+    int splits;             // 0 / 1: none
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 

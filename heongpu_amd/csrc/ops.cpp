@@ -30,13 +30,31 @@ static int prime_loc_offset(const Context& c, int depth)
 // moduli (the 58/59-bit default chains) cross earlier, their transforms being the larger part of either path:
 // N = 2^15, Q = 14: B = 2 242 / 220, B = 4 361 / 377 (120 B); N = 2^16, Q = 14: B = 1 287 / 274, B = 2 388 / 426
 // (240 B); Q = 29: B = 1 756 / 866 (480 B).
+static long fused_row_mac_need(const Context& c)
+{
+    size_t fp = 0;
+    for (unsigned char f : c.plan_qp.fp) fp += f ? 1 : 0;
+    return (2 * fp > c.plan_qp.fp.size()) ? 768 : 400;
+}
+// Between the two: the fused kernel with 2 (or, forced, 4) workgroups per (ciphertext, limb slot, tile), each over a
+// part of the digits, and a pass that adds the partial sums (KsMacArgs::splits).  Measured (tools/relin_sweep.py,
+// us per launch, unfused / fused / two pieces / four pieces): N = 2^16, Q = 16: B = 1 289 / 368 / 307 / 289, B = 2
+// 456 / 457 / 410 / 410; Q = 30: B = 1 766 / 810 / 718 / 687, B = 2 1217 / 1123 / 1044 / 1027; N = 2^15, Q = 15: B = 1
+// 154 / 251 / 195 / 171, B = 2 219 / 307 / 255 / 234; chains of integer-butterfly moduli: never ahead, and the order
+// of fused and unfused changes from box to box there.  So: two pieces, on FP64-path chains at N = 2^16, for launches
+// that reach the fused path's size that way.  Returns 0 (no split) or the number of pieces.
+static int fused_digit_splits(const Context& c, int rc, int digits, int batch)
+{
+    if (c.digit_split == 0) return 0;
+    if (c.digit_split > 0) return digits >= 2 * c.digit_split ? c.digit_split : 0;
+    if (c.fused_row_mac >= 0 || c.n_power < 16 || digits < 8) return 0;
+    const long wgs = (long) batch * rc * (long) (c.n >> 12), need = fused_row_mac_need(c);
+    return (need == 768 && wgs < need && 2 * wgs >= need) ? 2 : 0;
+}
 static bool use_fused_row_mac(const Context& c, int rc, int batch)
 {
     if (c.fused_row_mac >= 0) return c.fused_row_mac != 0;
-    size_t fp = 0;
-    for (unsigned char f : c.plan_qp.fp) fp += f ? 1 : 0;
-    const long need = (2 * fp > c.plan_qp.fp.size()) ? 768 : 400;
-    return (long) batch * rc * (long) (c.n >> 12) >= need;
+    return (long) batch * rc * (long) (c.n >> 12) >= fused_row_mac_need(c);
 }
 
 // The target slots of a decomposing launch over the Q' chain whose moduli run on the integer butterflies
@@ -71,7 +89,8 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
     const int ppi = digits * rc;
     const int skip_identity = ident ? 1 : 0;
     a.skip_identity = skip_identity;
-    if (!use_fused_row_mac(c, rc, batch)) {
+    const int splits = fused_digit_splits(c, rc, digits, batch);
+    if (!splits && !use_fused_row_mac(c, rc, batch)) {
         // identity digits (digit d at modulus d: the transform gives back the NTT-domain limb): copied instead of
         // transformed -- unless this path was chosen for a small launch, where one kernel less is worth more than
         // one transform in ten (same residues either way)
@@ -97,7 +116,11 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         k.mods = c.plan_qp.mods; k.tw = c.plan_qp.tw; k.twB = c.plan_qp.twB; k.mod_order = a.mod_order;
         k.n_power = c.n_power; k.digits = digits; k.rc = rc; k.key_limbs = c.Qp_size; k.skip_identity = skip_identity;
         k.ident = ident ? ident + (u64) b0 * ident_stride : nullptr; k.ident_item_stride = ident_stride;
+        k.splits = splits;
         TRY(ks_row_mac_launch(k, nb, st));
+        if (splits > 1)
+            TRY(rns_sum_partials(ca.out, a.out_item_stride, k.out, acc_stride, c.plan_qp.mods, a.mod_order, c.n_power,
+                                 digits, rc, splits, nb, st));
     }
     return hipSuccess;
 }

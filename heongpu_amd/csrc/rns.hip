@@ -156,6 +156,42 @@ hipError_t rns_decompose(const u64* in, u64 in_stride, u64* out, u64 out_stride,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- partial sums of a digit-split key switch
+__global__ __launch_bounds__(RNS_THREADS) void k_sum_partials(const u64* __restrict__ buf, u64 buf_item_stride,
+                                                              u64* __restrict__ out, u64 out_item_stride,
+                                                              const Mod* __restrict__ mods, const int* __restrict__ mod_order,
+                                                              int n_power, int digits, int rc, int splits)
+{
+    const u64 c = coeff0();
+    const int part = blockIdx.y / rc, slot = blockIdx.y - part * rc;
+    const u64 q = mods[mod_order ? mod_order[slot] : slot].q;
+    const u64* pb = buf + buf_item_stride * blockIdx.z + ((u64) slot << n_power) + c;
+    ulonglong2 v[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int d = ((s < splits ? s : 0) * digits) / splits + part;
+        v[s] = ld2(pb + (((u64) d * rc) << n_power));
+    }
+    ulonglong2 r = v[0];
+#pragma unroll
+    for (int s = 1; s < 8; s++)
+        if (s < splits) {
+            r.x = add_mod(r.x, v[s].x, q);
+            r.y = add_mod(r.y, v[s].y, q);
+        }
+    st2(out + out_item_stride * blockIdx.z + ((u64) (part * rc + slot) << n_power) + c, r);
+}
+
+hipError_t rns_sum_partials(const u64* buf, u64 buf_item_stride, u64* out, u64 out_item_stride, const Mod* mods,
+                            const int* mod_order, int n_power, int digits, int rc, int splits, int batch, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    if (splits < 2 || splits > 8 || digits < 2 * splits) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sum_partials, grid3(n_power, 2 * rc, batch), dim3(RNS_THREADS), 0, st, buf, buf_item_stride, out,
+                       out_item_stride, mods, mod_order, n_power, digits, rc, splits);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- key-switch inner product
 __device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
 {

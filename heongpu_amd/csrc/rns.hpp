@@ -126,6 +126,13 @@ struct BehzDev {
     int ibase_size, obase_size;
 };
 
+// Sum of the partial inner products of a digit-split ks_row_mac launch (KsMacArgs::splits): part p of split s sits in
+// the digit buffer `buf` ([digit][rc][N] per item) at digit s * digits / splits + p; out[item][p][slot] = their sum
+// modulo the modulus of the slot (mod_order as in the launch, NULL: slot k is modulus k).
+hipError_t rns_sum_partials(const u64* buf, u64 buf_item_stride, u64* out, u64 out_item_stride, const Mod* mods,
+                            const int* mod_order, int n_power, int digits, int rc, int splits, int batch,
+                            hipStream_t st);
+
 // reference multiplication.cu:10-100
 hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u64* out, u64 so,
                                const BehzDev& b, int n_power, int batch, hipStream_t st);

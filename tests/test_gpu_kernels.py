@@ -102,6 +102,8 @@ _SWITCHES = [
     dict(HEGPU_FUSED_ROW_MAC=0),
     dict(HEGPU_FUSED_MODDOWN=0),
     dict(HEGPU_COPY_ALONG=0),  # the rescale's copy of the kept limbs as its own launch
+    dict(HEGPU_DIGIT_SPLIT=2),  # fused key switch, two / four workgroups per unit over parts of the digits
+    dict(HEGPU_DIGIT_SPLIT=4, HEGPU_COL_MULTI=1),
     dict(HEGPU_FP_NTT=0),
     dict(HEGPU_FUSED_ROW_MAC=0, HEGPU_FUSED_MODDOWN=0, HEGPU_FP_NTT=0),
 ]
@@ -149,7 +151,8 @@ def test_ckks_sequence_with_fusions_off(hg, oracle, torch, sw, depth):
 
 
 @pytest.mark.parametrize("sw", [dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=1),
-                                dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=0, HEGPU_SINGLE_PASS=1)],
+                                dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_COL_MULTI=0, HEGPU_SINGLE_PASS=1),
+                                dict(HEGPU_DIGIT_SPLIT=2)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 @pytest.mark.parametrize("n_power,depth", [(12, 0), (13, 1), (15, 0), (15, 2)])
 def test_fused_key_switch_at_every_degree(hg, oracle, torch, sw, n_power, depth):
@@ -212,7 +215,8 @@ def test_bfv_multiply_both_behz_forms(hg, oracle, torch, split, n_power):
         assert np.array_equal(got[b], o.bfv_multiply(ct1[b], ct2[b])), b
 
 
-@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_SINGLE_PASS=0)],
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1), dict(HEGPU_SINGLE_PASS=0),
+                                dict(HEGPU_DIGIT_SPLIT=4)],
                          ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "default")
 @pytest.mark.parametrize("n_power", [13, 14, 16])
 def test_bfv_key_switch_at_every_degree(hg, oracle, torch, sw, n_power):
