@@ -1,0 +1,54 @@
+"""Register / scratch / occupancy budgets of the hot kernels (CPU-only: hipcc cross-compiles for gfx950 and reports
+the resource usage of every kernel).  The two key-switch kernels run two wavefronts per SIMD with 250 / 234 registers;
+a few more live values push them over 256 and halve their speed without any test noticing (it happened in round 2
+when the digit-split variant shared their code), so the budgets are pinned here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+# kernel (substring of the mangled name) -> (minimum waves per SIMD, maximum scratch bytes per lane)
+BUDGETS = {
+    "10ks_row_macILb0EE": (2, 0),          # integer row pass + inner product, main path
+    "13ks_row_mac_fpILb0EE": (2, 0),       # FP64 row pass + inner product, main path
+    "10ks_row_macILb1EE": (2, 0),          # digit-split forms
+    "13ks_row_mac_fpILb1EE": (2, 0),
+    "17ntt_fwd_col_multiILi8EE": (3, 0),   # decomposing column pass, N = 2^16
+    "17ntt_fwd_col_multiILi7EE": (4, 0),
+    "11ntt_fwd_colILi8ELb0EE": (4, 0),     # plain passes
+    "11ntt_fwd_colILi8ELb1EE": (4, 0),
+    "11ntt_fwd_rowE": (4, 0),
+    "11ntt_inv_rowE": (4, 0),
+    "11ntt_inv_colILi8ELb0EE": (3, 0),
+    "11ntt_inv_colILi8ELb1EE": (3, 0),     # with the BFV mod-down epilogue
+}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_keep_their_register_budgets(tmp_path):
+    src = os.path.join(ROOT, "heongpu_amd", "csrc", "ntt.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", src, "-o",
+                        str(tmp_path / "ntt.o"), "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    assert usage, "no resource-usage remarks in the compiler output"
+    for key, (min_waves, max_scratch) in BUDGETS.items():
+        hits = [n for n in usage if key in n]
+        assert len(hits) == 1, (key, hits)
+        u = usage[hits[0]]
+        assert u.get("Occupancy", 0) >= min_waves, (hits[0], u)
+        assert u.get("ScratchSize", 0) <= max_scratch, (hits[0], u)
