@@ -1210,8 +1210,11 @@ hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev
         return hipGetLastError();
     }
     dim3 g((1u << n_power) / RNS_THREADS, 3, batch);
+    // the 28-slot instance comes out of the register allocator at 256 registers (one wave per SIMD), the 32-slot one
+    // at 250 (two): bases of 25..28 take the larger one (surplus slots hold zeros)
+    const int m_plain = (behz_slots(m) == 28) ? 29 : m;
 #define LAUNCH(M) hipLaunchKernelGGL((k_fast_floor<M, false>), g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
-    BEHZ_DISPATCH(m)
+    BEHZ_DISPATCH(m_plain)
 #undef LAUNCH
     return hipGetLastError();
 }

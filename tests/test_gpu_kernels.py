@@ -588,6 +588,25 @@ def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split):
     assert np.array_equal(hg.to_host(out), want)
 
 
+@pytest.mark.parametrize("split", [0, 1], ids=["one_thread_per_coefficient", "rows_over_four_wavefronts"])
+@pytest.mark.parametrize("Q", [17, 22, 26, 30])
+def test_bfv_multiply_base_sizes_between_the_kernel_instances(hg, oracle, torch, Q, split):
+    """The BEHZ kernels exist for padded base sizes (steps of 4 between 16 and 32; the plain fast_floor sends 25..28
+    to the 32-slot instance): bases of 17, 22, 26 and 30 primes of 30 bits, N = 2^12, both forms."""
+    n, t = 4096, 65537
+    c = hg.Context.from_bit_sizes(hg.BFV, n, [30] * Q, [31], plain_modulus=t, sec=hg.SEC_NONE)
+    primes = [int(x) for x in c.table("modulus")]
+    o = oracle.OracleContext(oracle.BFV, 12, primes, Q, 1, t)
+    c.upload()
+    ct1, ct2 = synth_ct(primes, range(Q), 2, n, 3), synth_ct(primes, range(Q), 2, n, 4)
+    out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+    with backend_switches(HEGPU_BEHZ_SPLIT=split):
+        c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
+                       c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+        torch.cuda.synchronize()
+    assert np.array_equal(hg.to_host(out), o.bfv_multiply(ct1, ct2))
+
+
 def test_six_gpuntt_entry_points_by_name(hg, oracle, torch):
     """hegpu_GPU_NTT / _Inplace / GPU_INTT / _Inplace / GPU_NTT_Modulus_Ordered_Inplace /
     GPU_NTT_Poly_Ordered_Inplace (include/hegpu.h: the names a maintainer binds call site by call site),

@@ -31,9 +31,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("N=2^%d Q=%d  us per launch by batch  " % (logn, Q) + "  ".join(res))
     sys.exit(0)
 for logn, nq in [(int(a), int(b)) for a, b in (x.split(':') for x in os.environ.get('SWEEP', '14:8,15:15,16:16,16:30').split(','))]:
-    for mode in ("1", "0", "split2", "split4", "auto"):
+    for mode in os.environ.get("MODES", "1,0,split2,split4,auto").split(","):
         env = dict(os.environ)
         if mode in ("1", "0"): env["HEGPU_FUSED_ROW_MAC"] = mode
         if mode.startswith("split"): env["HEGPU_DIGIT_SPLIT"] = mode[5:]
+        if mode.startswith("multi"): env["HEGPU_COL_MULTI"] = mode[5:]
         out = subprocess.run([sys.executable, __file__, "child", str(logn), str(nq)], env=env, capture_output=True, text=True)
         print("fused=%s " % mode + out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])
