@@ -28,11 +28,18 @@ BUDGETS = {
 }
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_hot_kernels_keep_their_register_budgets(tmp_path):
-    src = os.path.join(ROOT, "heongpu_amd", "csrc", "ntt.hip")
+TFHE_BUDGETS = {
+    "22k_tfhe_blind_rotate_fpILi1EE": (2, 0),  # FP64 blind rotate: one wavefront per decomposed polynomial
+    "19k_tfhe_blind_rotateE": (2, 0),          # integer blind rotate (keys beyond int32)
+    "20k_tfhe_key_switchingILb0EE": (4, 0),
+    "20k_tfhe_key_switchingILb1EE": (4, 0),
+}
+
+
+def _usage(source, tmp_path):
+    src = os.path.join(ROOT, "heongpu_amd", "csrc", source)
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", src, "-o",
-                        str(tmp_path / "ntt.o"), "-Rpass-analysis=kernel-resource-usage"],
+                        str(tmp_path / (source + ".o")), "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
     usage, name = {}, None
@@ -46,7 +53,14 @@ def test_hot_kernels_keep_their_register_budgets(tmp_path):
         if m and name:
             usage[name][m.group(1).strip()] = int(m.group(2))
     assert usage, "no resource-usage remarks in the compiler output"
-    for key, (min_waves, max_scratch) in BUDGETS.items():
+    return usage
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("source,budgets", [("ntt.hip", BUDGETS), ("tfhe.hip", TFHE_BUDGETS)], ids=["ntt", "tfhe"])
+def test_hot_kernels_keep_their_register_budgets(tmp_path, source, budgets):
+    usage = _usage(source, tmp_path)
+    for key, (min_waves, max_scratch) in budgets.items():
         hits = [n for n in usage if key in n]
         assert len(hits) == 1, (key, hits)
         u = usage[hits[0]]
