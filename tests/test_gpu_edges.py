@@ -140,14 +140,16 @@ def test_batch_beyond_one_grid(hg, oracle, torch):
     assert np.array_equal(hg.to_host(y), x)
 
 
+@pytest.mark.parametrize("sw", [dict(), dict(HEGPU_COL_MULTI=0)], ids=["default", "per_polynomial_column_pass"])
 @pytest.mark.parametrize("log_q,log_p", [([40, 30, 30], [40]), ([40, 30, 30, 30], [40, 40])], ids=["method_I", "method_II"])
-def test_epilogue_launches_beyond_one_grid(hg, oracle, torch, log_q, log_p):
+def test_epilogue_launches_beyond_one_grid(hg, oracle, torch, log_q, log_p, sw):
     """Relinearize and rescale of so many ciphertexts that their mod-down transforms (2 l resp. 2 (l - 1)
     polynomials per ciphertext, with per-ciphertext epilogue operands) exceed one grid (65535 polynomials) and are
     cut into pieces: every per-item pointer of the launch has to move with the piece.  The batch repeats 24
     distinct ciphertexts, so all of them are checked against the oracle and every other item against its twin."""
     n = 4096
-    c, o, primes = _ckks(hg, oracle, n, log_q, log_p)
+    with backend_switches(**sw):   # per-polynomial column pass: the rescale's copy rides on it (NttArgs::copy_src)
+        c, o, primes = _ckks(hg, oracle, n, log_q, log_p)
     Q, P = len(log_q), len(log_p)
     Qp = Q + P
     batch, distinct = 16400, 24            # relinearize: 2 Q * 16400, rescale: 2 (Q - 1) * 16400 >= 65600 polynomials
