@@ -3,6 +3,8 @@
 Shapes follow BASELINE.json configs C1 (BFV N=2^12 default chain) and C2
 (CKKS N=2^14, Q=8, P=1); the NTT is covered for every supported N.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -602,7 +604,10 @@ def test_operator_sequence_replays_from_a_hip_graph(hg, oracle, torch):
         assert np.array_equal(hg.to_host(rot), o.ckks_apply_galois(w, gkey, gal, 1)), "graph replay: rotate"
 
 
-@pytest.mark.parametrize("seed", range(16))
+_FUZZ = int(os.environ.get("HEGPU_FUZZ", "0"))  # extra seeds for a longer one-off run
+
+
+@pytest.mark.parametrize("seed", range(16 + _FUZZ))
 def test_random_parameter_sets(hg, oracle, torch, seed):
     """Seeded random CKKS parameter sets -- degree, number of primes, prime widths on both sides of the
     FP64 / integer split (2^50) and of the lazy-butterfly split (2^57), key-switching method, depth,
@@ -654,7 +659,7 @@ def test_random_parameter_sets(hg, oracle, torch, seed):
             assert np.array_equal(got[b][:2 * (l - 1) * n], w[:2 * (l - 1) * n]), ("rescale", n, log_q, log_p, depth)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 + _FUZZ))
 def test_random_bfv_parameter_sets(hg, oracle, torch, seed):
     """Seeded random BFV parameter sets (degree, prime count and widths, plain modulus, key-switching method,
     batch) through multiply (BEHZ) -> relinearize -> rotate, bit for bit against the oracle."""
