@@ -46,18 +46,20 @@ def _bfv(hg, oracle, n, t):
 
 
 # ------------------------------------------------------------------ config C4, exact chain
-@pytest.mark.parametrize("col_multi", [None, 1, 0], ids=["auto", "col_multi", "col_per_poly"])
-def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi):
+@pytest.mark.parametrize("col_multi,batch", [(None, 3), (1, 3), (0, 3), (None, 2), (None, 1)],
+                         ids=["auto", "col_multi", "col_per_poly", "two_ciphertexts", "one_ciphertext"])
+def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi, batch):
     """BASELINE.json config C4 / bench.py's workload: CKKS N=2^16, Q = {60, 50 x 15}, P = {60}, depth 0,
     batch 3 (two distinct pairs + a twin): multiply -> relinearize_inplace -> rotate by one slot, every
     limb compared with the oracle.  Both forms of the decomposing column pass (bench.py's batch of 64
-    takes the multi-modulus one, a batch of 3 would not on its own)."""
+    takes the multi-modulus one, a batch of 3 would not on its own); with two ciphertexts the launch-size rules
+    pick the fused key switch in two pieces per unit (ops.cpp: fused_digit_splits), with one the unfused sequence."""
     n = 65536
     with backend_switches(**({} if col_multi is None else dict(HEGPU_COL_MULTI=col_multi))):
         c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])
     Q, Qp = 16, 17
     assert (c.Q_size, c.Q_prime_size) == (Q, Qp)
-    batch, uniq = 3, 2
+    uniq = min(2, batch)
     key = synth_key(primes, Q, Qp, n, 3)
     gkey = synth_key(primes, Q, Qp, n, 4)
     ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(uniq)]
