@@ -49,6 +49,13 @@ SIGNATURES = [
     ("hegpu_divide_round_lastq", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
     ("hegpu_divide_round_lastq_permute", c_int,
      [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq_leveled_stage_one", c_int, [voidp, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq_leveled_stage_two", c_int,
+     [voidp, u64p, u64, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),
+    ("hegpu_move_cipher_leveled", c_int, [voidp, u64p, u64, u64p, u64, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq_rescale", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, voidp]),
+    ("hegpu_divide_round_lastq_extended", c_int,
+     [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, c_int, c_int, voidp]),
     ("hegpu_fast_convertion", c_int, [voidp, u64p, u64, u64p, u64, u64p, u64, c_int, voidp]),
     ("hegpu_fast_floor", c_int, [voidp, u64p, u64, u64p, u64, c_int, voidp]),
     ("hegpu_workspace_bytes", c_size_t, [voidp, c_int, c_int, c_int]),

@@ -200,6 +200,30 @@ class Context:
                                                           s_out, galois_elt, depth, batch,
                                                           stream if stream is not None else _stream()))
 
+    def divide_round_lastq_leveled_stage_one(self, src, s_in, out, s_out, rescale=0, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_divide_round_lastq_leveled_stage_one(self._h, _ptr(src), s_in, _ptr(out), s_out, rescale,
+                                                                    depth, batch,
+                                                                    stream if stream is not None else _stream()))
+
+    def divide_round_lastq_leveled_stage_two(self, last, s_last, src, s_in, ct, s_ct, out, s_out, switchkey=0, depth=0,
+                                             batch=1, stream=None):
+        _check(self._lib.hegpu_divide_round_lastq_leveled_stage_two(self._h, _ptr(last), s_last, _ptr(src), s_in,
+                                                                    _ptr(ct), s_ct, _ptr(out), s_out, switchkey, depth,
+                                                                    batch, stream if stream is not None else _stream()))
+
+    def move_cipher_leveled(self, src, s_in, out, s_out, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_move_cipher_leveled(self._h, _ptr(src), s_in, _ptr(out), s_out, depth, batch,
+                                                   stream if stream is not None else _stream()))
+
+    def divide_round_lastq_rescale(self, last, s_last, src, s_in, out, s_out, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_divide_round_lastq_rescale(self._h, _ptr(last), s_last, _ptr(src), s_in, _ptr(out), s_out,
+                                                          depth, batch, stream if stream is not None else _stream()))
+
+    def divide_round_lastq_extended(self, src, s_in, ct, s_ct, out, s_out, mode=0, depth=0, batch=1, stream=None):
+        _check(self._lib.hegpu_divide_round_lastq_extended(self._h, _ptr(src), s_in, _ptr(ct) if ct is not None else None,
+                                                           s_ct, _ptr(out), s_out, mode, depth, batch,
+                                                           stream if stream is not None else _stream()))
+
     def fast_convertion(self, in1, s1, in2, s2, out, so, batch=1, stream=None):
         _check(self._lib.hegpu_fast_convertion(self._h, _ptr(in1), s1, _ptr(in2), s2, _ptr(out), so, batch,
                                                stream if stream is not None else _stream()))

@@ -398,6 +398,96 @@ int hegpu_divide_round_lastq_permute(hegpu_context* ctx, const uint64_t* in, uin
                    "hegpu_divide_round_lastq_permute");
 }
 
+// location of depth's constants in the triangular rescale tables (reference ckks/operator.cu:1181-1187)
+static int rescale_location(const Context& c, int depth)
+{
+    int counter = c.Q_size - 1, location = 0;
+    for (int i = 0; i < depth; i++) { location += counter; counter--; }
+    return location;
+}
+#define SEAM_CKKS(ctx, depth, batch, min_limbs)                                                                    \
+    NEED_CTX(ctx);                                                                                                 \
+    const Context& c = (ctx)->c;                                                                                   \
+    if (c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "CKKS context required");                            \
+    if ((depth) < 0 || c.Q_size - (depth) < (min_limbs)) return fail(HEGPU_E_INVALID, "invalid depth");            \
+    if ((batch) < 0) return fail(HEGPU_E_INVALID, "batch must not be negative");                                   \
+    if ((batch) == 0) return 0;                                                                                    \
+    const int l = c.Q_size - (depth);                                                                              \
+    (void) l
+
+int hegpu_divide_round_lastq_leveled_stage_one(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                                               uint64_t out_stride, int rescale, int depth, int batch,
+                                               hegpu_stream stream)
+{
+    SEAM_CKKS(ctx, depth, batch, rescale ? 2 : 1);
+    if (rescale)
+        return hip_ret(rns_moddown_stage_one((const u64*) in, in_stride, (u64*) out, out_stride, c.plan_qp.mods,
+                                             c.d64("rescaled_half") + depth,
+                                             c.d64("rescaled_half_mod") + rescale_location(c, depth), c.n_power, l - 1,
+                                             l - 1, batch, (hipStream_t) stream),
+                       "hegpu_divide_round_lastq_leveled_stage_one");
+    if (c.P_size != 1) return fail(HEGPU_E_LOGIC, "the leveled stages serve a single special prime (method I)");
+    return hip_ret(rns_moddown_stage_one((const u64*) in, in_stride, (u64*) out, out_stride, c.plan_qp.mods,
+                                         c.d64("half"), c.d64("half_mod"), c.n_power, c.Q_size, l, batch,
+                                         (hipStream_t) stream),
+                   "hegpu_divide_round_lastq_leveled_stage_one");
+}
+
+int hegpu_divide_round_lastq_leveled_stage_two(hegpu_context* ctx, const uint64_t* in_last, uint64_t last_stride,
+                                               const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                                               uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int switchkey,
+                                               int depth, int batch, hegpu_stream stream)
+{
+    SEAM_CKKS(ctx, depth, batch, 1);
+    if (c.P_size != 1) return fail(HEGPU_E_LOGIC, "the leveled stages serve a single special prime (method I)");
+    if (!ct) return fail(HEGPU_E_INVALID, "ct must not be NULL");
+    return hip_ret(rns_moddown_stage_two((const u64*) in_last, last_stride, (const u64*) in, in_stride, l + 1,
+                                         (const u64*) ct, ct_stride, (u64*) out, out_stride, c.plan_qp.mods,
+                                         c.d64("last_q_modinv"), c.n_power, l, switchkey ? 2 : 1, batch,
+                                         (hipStream_t) stream),
+                   "hegpu_divide_round_lastq_leveled_stage_two");
+}
+
+int hegpu_move_cipher_leveled(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                              uint64_t out_stride, int depth, int batch, hegpu_stream stream)
+{
+    SEAM_CKKS(ctx, depth, batch, 2);
+    return hip_ret(rns_copy_limbs((const u64*) in, (u64) l * c.n, in_stride, (u64*) out, (u64) l * c.n, out_stride,
+                                  c.n_power, l - 1, 2, batch, (hipStream_t) stream),
+                   "hegpu_move_cipher_leveled");
+}
+
+int hegpu_divide_round_lastq_rescale(hegpu_context* ctx, const uint64_t* in_last, uint64_t last_stride,
+                                     const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
+                                     int depth, int batch, hegpu_stream stream)
+{
+    SEAM_CKKS(ctx, depth, batch, 2);
+    return hip_ret(rns_moddown_stage_two((const u64*) in_last, last_stride, (const u64*) in, in_stride, l, nullptr, 0,
+                                         (u64*) out, out_stride, c.plan_qp.mods,
+                                         c.d64("rescaled_last_q_modinv") + rescale_location(c, depth), c.n_power, l - 1,
+                                         0, batch, (hipStream_t) stream),
+                   "hegpu_divide_round_lastq_rescale");
+}
+
+int hegpu_divide_round_lastq_extended(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                                      uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int mode, int depth,
+                                      int batch, hegpu_stream stream)
+{
+    NEED_CTX(ctx);
+    const Context& c = ctx->c;
+    if (mode < 0 || mode > 2) return fail(HEGPU_E_INVALID, "mode must be 0, 1 or 2");
+    if (c.scheme == SCHEME_BFV && depth != 0) return fail(HEGPU_E_INVALID, "BFV ciphertexts have no depth");
+    if (depth < 0 || depth >= c.Q_size) return fail(HEGPU_E_INVALID, "invalid depth");
+    if (mode && !ct) return fail(HEGPU_E_INVALID, "ct must not be NULL");
+    if (batch < 0) return fail(HEGPU_E_INVALID, "batch must not be negative");
+    if (batch == 0) return 0;
+    return hip_ret(rns_moddown_extended((const u64*) in, in_stride, (const u64*) ct, ct_stride, (u64*) out, out_stride,
+                                        c.plan_qp.mods, c.d64("half"), c.d64("half_mod"), c.d64("last_q_modinv"),
+                                        c.n_power, c.Qp_size - depth, c.Q_size - depth, c.Qp_size, c.Q_size, c.P_size,
+                                        mode, batch, (hipStream_t) stream),
+                   "hegpu_divide_round_lastq_extended");
+}
+
 int hegpu_fast_convertion(hegpu_context* ctx, const uint64_t* in1, uint64_t s1, const uint64_t* in2, uint64_t s2,
                           uint64_t* out, uint64_t so, int batch, hegpu_stream stream)
 {

@@ -535,6 +535,12 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     for (int k = 0; k < cnt; k++) (hm[k].fp ? p.has_fp : p.has_int) = 1;
     p.fp.assign(cnt, 0);
     for (int k = 0; k < cnt; k++) p.fp[k] = hm[k].fp ? 1 : 0;
+    // Correction-free forward butterflies add at most 4q to the bound of a value per stage (ntt.hip: ct_bfly), so a
+    // modulus may skip every conditional subtraction when in + 4 * log2(N) * q stays below 2^64; `in` is at most twice
+    // the largest modulus of the plan (canonical inputs, or digits that are residues of another prime of the plan).
+    u64 qmax = 0;
+    for (int k = 0; k < cnt; k++) qmax = mods[k] > qmax ? mods[k] : qmax;
+    p.lazy_q_max = (~0ull - 2 * qmax) / (4ull * (u64) n_power);
     hipError_t e;
     if ((e = to_device(hm, &p.mods)) != hipSuccess) return e;
     if ((e = to_device(htw, &p.tw)) != hipSuccess) return e;
@@ -711,6 +717,7 @@ NttArgs Context::ntt_args(int table_set) const
     a.single_pass = single_pass;
     a.plan_has_fp = p.has_fp;
     a.plan_has_int = p.has_int;
+    a.lazy_q_max = p.lazy_q_max;
     return a;
 }
 

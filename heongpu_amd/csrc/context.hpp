@@ -31,6 +31,8 @@ struct NttPlan {
     int count = 0;
     int has_fp = 0, has_int = 0; // moduli on the FP64 / on the integer butterflies
     std::vector<unsigned char> fp; // host copy of Mod::fp per modulus
+    // integer butterflies: moduli up to this run the whole forward transform correction-free (NttArgs::lazy_q_max)
+    u64 lazy_q_max = 0;
 };
 
 struct Context {

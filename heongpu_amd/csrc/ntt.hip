@@ -146,8 +146,8 @@ __device__ __forceinline__ u64 shoup_full(u64 y, ulonglong2 w, const QC& c)
 
 // Harvey-style CT butterfly.  LAZY == false: x,y in [0,8q) -> [0,8q) (one
 // conditional subtraction per butterfly; needs only q < 2^61).  LAZY == true
-// (q < 2^57): no correction at all -- every stage adds at most 4q to the bound,
-// so 16 stages stay below 65q < 2^64; one exact reduction ends the transform.
+// (q <= NttArgs::lazy_q_max): no correction at all -- every stage adds at most 4q to the
+// bound, which stays below 2^64 over all log2 N stages; one exact reduction ends the transform.
 template <bool LAZY>
 __device__ __forceinline__ void ct_bfly(u64& x, u64& y, ulonglong2 w, const QC& c)
 {
@@ -352,15 +352,17 @@ __device__ __forceinline__ void wave_lds_fence()
 #define ROW_LDS_ELEMS 4096
 
 // ------------------------------------------------------------------ forward
-// Moduli below 2^57 take the correction-free butterflies (see ct_bfly).
-#define NTT_LAZY_BITS 57
+// Moduli up to NttArgs::lazy_q_max take the correction-free butterflies in every stage (see ct_bfly): the bound of a
+// value grows by at most 4q per stage, in + 4 log2(N) q < 2^64 (2^57 for N = 2^16 next to 61-bit primes; the 58/59-bit
+// default chains at N <= 2^15).
+__device__ __forceinline__ bool fwd_stages_lazy(const Mod& md, u64 lazy_q_max) { return md.q <= lazy_q_max; }
 // The ROW stages alone can run correction-free for somewhat larger moduli: the column pass of such a
 // modulus (conditional subtraction per butterfly) hands over values below 8q, eight correction-free
 // stages add at most 4q each, and 40q < 2^64 holds up to q = floor(2^64 / 40) (2^58.67: the 58- and
 // "59"-bit primes of the default chains, which sit just above 2^58).  The one exact reduction at the end
 // (or the 128-bit inner product of ks_row_mac: 64 digits * 40q * q < 2^128) takes any such value.
 #define NTT_ROW_LAZY_MAX_Q 0x0666666666666666ull
-__device__ __forceinline__ bool row_stages_lazy(const Mod& md) { return md.bit <= NTT_LAZY_BITS || md.q <= NTT_ROW_LAZY_MAX_Q; }
+__device__ __forceinline__ bool row_stages_lazy(const Mod& md, u64 lazy_q_max) { return md.q <= lazy_q_max || md.q <= NTT_ROW_LAZY_MAX_Q; }
 
 // Column pass: stages 0..S1-1 (row stride 256).  grid = (256/CT, batch).
 // SREG: the 16 source coefficients of the thread are already in registers (`sreg`, in load order:
@@ -406,6 +408,10 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
     if (DECOMP && a.half_on) {
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = sub_mod(reduce64(add_mod(v[k], a.half, half_qP), md), half_hm, md.q);
+    } else if (DECOMP && !LAZY && a.mods[ps.digit].q > 8 * md.q) {
+        // a digit of a much wider prime (61 bits next to 58): outside the [0, 8q) the correcting butterflies keep
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = reduce64(v[k], md);
     }
     if constexpr (NSA > 0) {
         // round A: G groups of radix RA, rows rbase + 16k
@@ -416,10 +422,10 @@ __device__ __forceinline__ void fwd_col_body(const NttArgs& a, const PolySel& ps
             u64 y[RA];
 #pragma unroll
             for (int k = 0; k < RA; k++) y[k] = v[g * RA + k];
-            // DECOMP: the digit (< 2^60, a residue of another prime) is NOT reduced
-            // first: the lazy butterflies only need x < 8q (q >= 2^57 here) or, on
-            // the correction-free path, x + 64q < 2^64; congruence mod q is kept
-            // and the row pass ends with an exact reduction.
+            // DECOMP: the digit (a residue of another prime of the plan) is NOT reduced
+            // first: the correcting butterflies only need x < 8q (guarded above) and the
+            // correction-free path x + 4 log2(N) q < 2^64 (lazy_q_max); congruence mod q is
+            // kept and the row pass ends with an exact reduction.
             ct_radix<NSA, LAZY>(y, tw, 1u, qc);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = y[k];
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col(NttArgs a)
         if (DECOMP && a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52)
             fwd_col_body_fp<S1, DECOMP, true>(a, ps, md, lds, twl);
         else fwd_col_body_fp<S1, DECOMP, false>(a, ps, md, lds, twl);
-    } else if (md.bit <= NTT_LAZY_BITS) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
+    } else if (fwd_stages_lazy(md, a.lazy_q_max)) fwd_col_body<S1, DECOMP, true>(a, ps, md, lds);
     else fwd_col_body<S1, DECOMP, false>(a, ps, md, lds);
 }
 
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_row(NttArgs a)
     if (a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
     if (md.fp) fwd_row_body_fp(a, ps, md, lds);
-    else if (row_stages_lazy(md)) fwd_row_body<true>(a, ps, md, lds);
+    else if (row_stages_lazy(md, a.lazy_q_max)) fwd_row_body<true>(a, ps, md, lds);
     else fwd_row_body<false>(a, ps, md, lds);
 }
 
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(16 << S1, 4) void ntt_fwd_single(NttArgs a)
     const PolySel ps = select_poly(a, blockIdx.x);
     const Mod md = a.mods[ps.mod];
     if (md.fp) fwd_single_body<S1, true, false>(a, ps, md, limb);
-    else if (md.bit <= NTT_LAZY_BITS) fwd_single_body<S1, false, true>(a, ps, md, limb);
+    else if (fwd_stages_lazy(md, a.lazy_q_max)) fwd_single_body<S1, false, true>(a, ps, md, limb);
     else fwd_single_body<S1, false, false>(a, ps, md, limb);
 }
 
@@ -908,13 +914,12 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
     }
     ct_radix16_tb<LAZY>(x, tb, qc);
     if (!LAZY) {
-        // q >= 2^57: bring [0,8q) down to [0,q) so that 64 products stay below 2^128
+        // bring [0,8q) down to [0,q) so that 64 products stay below 2^128
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
     }
-    // LAZY (q < 2^57): the transform output stays un-reduced (< 65q < 2^64);
-    // x * key < 2^121, so even 64 digits fit the 128-bit accumulator and the one
-    // exact reduction happens on the accumulated sum.
+    // LAZY: the transform output stays un-reduced (any 64-bit value); the caller checked that
+    // digits * 2^64 * q fits the 128-bit accumulator, the one exact reduction happens on the sum.
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -974,8 +979,8 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
     const u64* __restrict__ pk = a.key + ((u64) midx << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
     const u64 dig_off = (u64) a.rc << a.n_power;
     const u64 key_off1 = (u64) a.key_limbs << a.n_power, key_off2 = (u64) a.key_limbs << (a.n_power + 1);
-    // beyond 2^57 the un-reduced output (< 40q) times a key residue is below 2^122.7: 32 digits fit 128 bits
-    const bool lazy = md.bit <= NTT_LAZY_BITS || (row_stages_lazy(md) && a.digits <= 32);
+    // the un-reduced output (any 64-bit value) times a key residue (< q) summed over the digits has to fit 128 bits
+    const bool lazy = row_stages_lazy(md, a.lazy_q_max) && md.q <= ~0ull / (u64) a.digits;
     // digit-invariant twiddles of the first four stages, shared by the 16 lanes of a row (see
     // ks_row_mac_fp; the per-lane ones of the last four stages would need 61 KiB as pairs)
     __shared__ ulonglong2 twa[15 * 16];

@@ -121,6 +121,9 @@ struct NttArgs {
     // of four times as many workgroups (C2, one ciphertext: inverse of 8 limbs 19.6 us against 6.0 + 5.5 us).
     int single_pass;
     int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
+    // Integer butterflies: a modulus up to this bound runs ALL log2 N forward stages without a conditional
+    // subtraction (set from the plan: (2^64 - 1 - 2 max q) / (4 log2 N), see context.cpp build_plan)
+    u64 lazy_q_max;
     int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
     // Decomposing launches whose FP64 targets go through ntt_fwd_col_multi: the target slots (index into the
     // decomp_mods moduli of a digit) that have INTEGER moduli, if the caller knows them -- the per-polynomial kernel
@@ -172,6 +175,7 @@ struct KsMacArgs {
     const ulonglong2* twB;
     const int* mod_order;   // modulus index of limb slot k (NULL: k)
     int n_power, digits, rc, key_limbs;
+    u64 lazy_q_max;         // as NttArgs::lazy_q_max (the column pass that wrote `in` used the same bound)
     int skip_identity;      // digit d at modulus d is not transformed: its NTT-domain limb is read from `ident`
     const u64* ident;       // [item][digit][N] NTT-domain limbs (the polynomial that was decomposed)
     u64 ident_item_stride;

@@ -147,6 +147,40 @@ int hegpu_divide_round_lastq_permute(hegpu_context* ctx, const uint64_t* in, uin
                                      const uint64_t* in2, uint64_t in2_stride, uint64_t* out,
                                      uint64_t out_stride, int galois_elt, int depth, int batch,
                                      hegpu_stream stream);
+/* ---- the leveled (CKKS) mod-down, rescale and multi-prime mod-down kernels, launch by launch.  l = Q - depth is the
+ * reference's current_decomp_count; every layout is [2][limbs][N] per item.
+ * divide_round_lastq_leveled_stage_one_kernel (switchkey.cu:678-705): the last limb of each part of `in`, + half,
+ * reduced into every kept modulus, - half_mod.
+ *   rescale == 0 (relinearize / rotate, ckks/operator.cu:1003): in [2][l+1][N] with the special-prime limb at slot l,
+ *                out [2][l][N], tables half / half_mod;
+ *   rescale != 0 (rescale, ckks/operator.cu:1205): in [2][l][N] with q_{l-1} at slot l-1, out [2][l-1][N], tables
+ *                rescaled_half + depth / rescaled_half_mod + location(depth). */
+int hegpu_divide_round_lastq_leveled_stage_one(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                                               uint64_t out_stride, int rescale, int depth, int batch,
+                                               hegpu_stream stream);
+/* divide_round_lastq_leveled_stage_two_kernel / _switchkey_kernel (switchkey.cu:707-771): out = (in - in_last) *
+ * P^-1 + ct over [2][l][N]; in_last [2][l][N] (the NTT of stage one's output), in [2][l+1][N]; switchkey != 0 adds
+ * ct to part 0 only.  ct may alias out. */
+int hegpu_divide_round_lastq_leveled_stage_two(hegpu_context* ctx, const uint64_t* in_last, uint64_t last_stride,
+                                               const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                                               uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int switchkey,
+                                               int depth, int batch, hegpu_stream stream);
+/* move_cipher_leveled_kernel (switchkey.cu:776-790, ckks/operator.cu:1219): the l-1 kept limbs of both parts,
+ * [2][l][N] -> [2][l][N] (part stride l on both sides) */
+int hegpu_move_cipher_leveled(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, uint64_t* out,
+                              uint64_t out_stride, int depth, int batch, hegpu_stream stream);
+/* divide_round_lastq_rescale_kernel (switchkey.cu:792-815, ckks/operator.cu:1225): out [2][l-1][N] =
+ * (in - in_last) * q_{l-1}^-1; in_last [2][l-1][N], in [2][l][N]; tables rescaled_last_q_modinv + location(depth) */
+int hegpu_divide_round_lastq_rescale(hegpu_context* ctx, const uint64_t* in_last, uint64_t last_stride,
+                                     const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
+                                     int depth, int batch, hegpu_stream stream);
+/* divide_round_lastq_extended_kernel (switchkey.cu:480-543: + ct on both parts, BFV method II relinearize),
+ * _extended_switchkey_kernel (:545-611: + ct on part 0) and _extended_leveled_kernel (:1222-1282: no ct, CKKS
+ * method II): mod-down by the P_size special primes, one after the other.  in [2][rc][N] (rc = Q' - depth,
+ * coefficient domain), out / ct [2][l][N].  mode 0 leveled (ct ignored), 1 ct on both parts, 2 ct on part 0. */
+int hegpu_divide_round_lastq_extended(hegpu_context* ctx, const uint64_t* in, uint64_t in_stride, const uint64_t* ct,
+                                      uint64_t ct_stride, uint64_t* out, uint64_t out_stride, int mode, int depth,
+                                      int batch, hegpu_stream stream);
 /* src/lib/kernel/multiplication.cu:10-100 / 128-272 (BFV BEHZ) */
 int hegpu_fast_convertion(hegpu_context* ctx, const uint64_t* in1, uint64_t in1_stride, const uint64_t* in2,
                           uint64_t in2_stride, uint64_t* out, uint64_t out_stride, int batch,

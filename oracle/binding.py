@@ -116,6 +116,11 @@ def lib():
     L.o_keyswitch_mac_leveled.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.o_divide_round_lastq_permute.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci]
     L.o_base_conversion_DtoQtilde.argtypes = [vp, vp, vp, ci]
+    L.o_divide_round_lastq_extended.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.o_divide_round_lastq_leveled_stage_one.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci]
+    L.o_divide_round_lastq_leveled_stage_two.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    L.o_move_cipher_leveled.argtypes = [vp, vp, ci, ci]
+    L.o_divide_round_lastq_rescale.argtypes = [vp, vp, vp, vp, vp, ci, ci]
     i32p = ctypes.c_void_p
     L.o_tfhe_create.restype = ctypes.c_void_p
     L.o_tfhe_free.argtypes = [vp]

@@ -142,6 +142,9 @@ typedef struct o_m2 {
 void o_m2_build(octx_t* c);
 void o_m2_free(octx_t* c);
 void o_base_conversion_DtoQtilde(const octx_t* c, const u64* in, u64* out, int depth);
+/* switchkey.cu:480-611, 1222-1282; rc / l = current Q' / Q sizes; mode 0 no ct, 1 ct on both parts, 2 ct on part 0 */
+void o_divide_round_lastq_extended(const octx_t* c, const u64* input, const u64* ct, u64* output, int rc, int l,
+                                   int mode);
 
 /* primes given explicitly (Q then P); plain_modulus used for BFV only */
 octx_t* o_ctx_create(int scheme, int n_power, const u64* primes, int Q_size,

@@ -151,9 +151,15 @@ static void keyswitch_mac_II(const u64* input, const u64* key, u64* output, cons
     }
 }
 
-/* switchkey.cu:480-545 (bfv: + ct) / 1222-1282 (leveled: no ct); mode 0 = no
- * ct, 1 = ct on both parts */
+/* switchkey.cu:480-545 (bfv: + ct) / 545-611 (switchkey: + ct on part 0) / 1222-1282 (leveled: no ct);
+ * mode 0 = no ct, 1 = ct on both parts, 2 = ct on part 0 only */
+void o_divide_round_lastq_extended(const octx_t* c, const u64* input, const u64* ct, u64* output, int rc, int l, int mode);
 static void divide_round_lastq_extended(const octx_t* c, const u64* input, const u64* ct, u64* output, int rc, int l,
+                                        int mode)
+{
+    o_divide_round_lastq_extended(c, input, ct, output, rc, l, mode);
+}
+void o_divide_round_lastq_extended(const octx_t* c, const u64* input, const u64* ct, u64* output, int rc, int l,
                                         int mode)
 {
     const int np = c->n_power, P = c->P_size, fQp = c->Qp_size, fQ = c->Q_size;
@@ -183,7 +189,8 @@ static void divide_round_lastq_extended(const octx_t* c, const u64* input, const
                     loc += (fQp - 1 - i);
                 }
                 u64 o = x + ((u64) y << np) + (((u64) l << np) * z);
-                output[o] = mode ? o_add(ct[o], in, &mods[y]) : in;
+                if (mode == 2) output[o] = o_add(z == 0 ? ct[o] : 0ULL, in, &mods[y]);
+                else output[o] = mode ? o_add(ct[o], in, &mods[y]) : in;
             }
 }
 

@@ -473,6 +473,123 @@ def test_kernel_divide_round_lastq_permute(hg, oracle, torch):
         _permute_case(hg, oracle, torch, c, o, primes, n, depth, hg.steps_to_galois_elt(1, n, 5))
 
 
+def _rescale_location(Q, depth):
+    counter, location = Q - 1, 0
+    for _ in range(depth):
+        location += counter
+        counter -= 1
+    return location
+
+
+@pytest.mark.parametrize("depth", [0, 2])
+def test_kernel_leveled_moddown_stages(hg, oracle, torch, depth):
+    """hegpu_divide_round_lastq_leveled_stage_one (relinearize and rescale forms), _stage_two (plain and switchkey),
+    hegpu_move_cipher_leveled and hegpu_divide_round_lastq_rescale (switchkey.cu:678-815), each against the oracle's
+    restatement with the caller-offset tables of ckks/operator.cu:1003-1015 and :1205-1232."""
+    n = 8192
+    c, o, primes = _ckks(hg, oracle, n, [40, 35, 35, 35, 35], [40], sec=hg.SEC_NONE)
+    Q, np_ = c.Q_size, c.n_power
+    l = Q - depth
+    batch = 2
+    dev = lambda parts: hg.to_device(np.concatenate(parts))
+    # ---- stage one, relinearize form: in [2][l+1][N] (limbs 0..l-1 and the special prime), out [2][l][N]
+    ids = list(range(l)) + [Q]
+    src = [_limbs(oracle, primes, ids * 2, n, 5 + b) for b in range(batch)]
+    for s_ in src:
+        s_[l * n:l * n + 3] = [0, primes[Q] - 1, primes[Q] // 2]
+    out = torch.empty(batch * 2 * l * n, dtype=torch.int64, device="cuda")
+    c.divide_round_lastq_leveled_stage_one(dev(src), 2 * (l + 1) * n, out, 2 * l * n, 0, depth, batch)
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    half, half_mod, inv = o.table("half"), o.table("half_mod"), o.table("last_q_modinv")
+    for b in range(batch):
+        w = np.zeros(2 * l * n, dtype=np.uint64)
+        o.L.o_divide_round_lastq_leveled_stage_one(src[b].ctypes.data, w.ctypes.data, o.qp_mods, half.ctypes.data,
+                                                   half_mod.ctypes.data, np_, Q, l)
+        assert np.array_equal(got[b], w), ("stage one", depth, b)
+    # ---- stage two: (in - last) * P^-1 + ct, both parts / part 0 only
+    last = [_limbs(oracle, primes, list(range(l)) * 2, n, 15 + b) for b in range(batch)]
+    cts = [synth_ct(primes, range(l), 2, n, 70 + b) for b in range(batch)]
+    for sk in (0, 1):
+        c.divide_round_lastq_leveled_stage_two(dev(last), 2 * l * n, dev(src), 2 * (l + 1) * n, dev(cts), 2 * l * n, out,
+                                               2 * l * n, sk, depth, batch)
+        torch.cuda.synchronize()
+        got = hg.to_host(out).reshape(batch, -1)
+        for b in range(batch):
+            w = np.zeros(2 * l * n, dtype=np.uint64)
+            o.L.o_divide_round_lastq_leveled_stage_two(last[b].ctypes.data, src[b].ctypes.data, cts[b].ctypes.data,
+                                                       w.ctypes.data, o.qp_mods, inv.ctypes.data, np_, l, sk)
+            assert np.array_equal(got[b], w), ("stage two", depth, sk, b)
+    # ---- rescale: stage one on [2][l][N] -> [2][l-1][N], copy of the kept limbs, divide
+    loc = _rescale_location(Q, depth)
+    rhalf, rhm, rinv = o.table("rescaled_half"), o.table("rescaled_half_mod"), o.table("rescaled_last_q_modinv")
+    ct_in = [synth_ct(primes, range(l), 2, n, 90 + b) for b in range(batch)]
+    for s_ in ct_in:
+        s_[(l - 1) * n:(l - 1) * n + 3] = [0, primes[l - 1] - 1, primes[l - 1] // 2]
+    out1 = torch.empty(batch * 2 * (l - 1) * n, dtype=torch.int64, device="cuda")
+    c.divide_round_lastq_leveled_stage_one(dev(ct_in), 2 * l * n, out1, 2 * (l - 1) * n, 1, depth, batch)
+    torch.cuda.synchronize()
+    got = hg.to_host(out1).reshape(batch, -1)
+    for b in range(batch):
+        w = np.zeros(2 * (l - 1) * n, dtype=np.uint64)
+        o.L.o_divide_round_lastq_leveled_stage_one(ct_in[b].ctypes.data, w.ctypes.data, o.qp_mods,
+                                                   rhalf.ctypes.data + 8 * depth, rhm.ctypes.data + 8 * loc, np_, l - 1,
+                                                   l - 1)
+        assert np.array_equal(got[b], w), ("rescale stage one", depth, b)
+    moved = torch.full((batch * 2 * l * n,), 7, dtype=torch.int64, device="cuda")
+    c.move_cipher_leveled(dev(ct_in), 2 * l * n, moved, 2 * l * n, depth, batch)
+    torch.cuda.synchronize()
+    got = hg.to_host(moved).reshape(batch, -1)
+    for b in range(batch):
+        w = np.full(2 * l * n, 7, dtype=np.uint64)
+        o.L.o_move_cipher_leveled(ct_in[b].ctypes.data, w.ctypes.data, np_, l - 1)
+        assert np.array_equal(got[b], w), ("move", depth, b)   # the dropped limb's slot stays untouched
+    last = [_limbs(oracle, primes, list(range(l - 1)) * 2, n, 25 + b) for b in range(batch)]
+    c.divide_round_lastq_rescale(dev(last), 2 * (l - 1) * n, dev(ct_in), 2 * l * n, out1, 2 * (l - 1) * n, depth, batch)
+    torch.cuda.synchronize()
+    got = hg.to_host(out1).reshape(batch, -1)
+    for b in range(batch):
+        w = np.zeros(2 * (l - 1) * n, dtype=np.uint64)
+        o.L.o_divide_round_lastq_rescale(last[b].ctypes.data, ct_in[b].ctypes.data, w.ctypes.data, o.qp_mods,
+                                         rinv.ctypes.data + 8 * loc, np_, l - 1)
+        assert np.array_equal(got[b], w), ("rescale", depth, b)
+
+
+def test_kernel_divide_round_lastq_extended(hg, oracle, torch):
+    """hegpu_divide_round_lastq_extended: divide_round_lastq_extended_kernel (+ ct, BFV method II relinearize),
+    _extended_switchkey_kernel (+ ct on part 0) and _extended_leveled_kernel (CKKS method II, depth 0 / 1)
+    (switchkey.cu:480-611, 1222-1282) with two and three special primes."""
+    n = 8192
+    cases = []
+    for log_q, log_p in (([40, 35, 35, 35, 35], [40, 40]), ([45, 40, 40, 40, 40, 40], [45, 45, 45])):
+        c, o, primes = _ckks(hg, oracle, n, log_q, log_p, sec=hg.SEC_NONE)
+        cases += [(c, o, primes, depth, (0, 1, 2)) for depth in (0, 1)]
+    cb = hg.Context.from_default(hg.BFV, n, 2, 1032193)   # BFV, two special primes: modes 1 and 2 as its operators use them
+    pb = [int(x) for x in cb.table("modulus")]
+    ob_ = oracle.OracleContext(oracle.BFV, cb.n_power, pb, cb.Q_size, cb.P_size, 1032193)
+    cb.upload()
+    cases.append((cb, ob_, pb, 0, (1, 2)))
+    for c, o, primes, depth, modes in cases:
+        Q, Qp = c.Q_size, c.Q_prime_size
+        l, rc = Q - depth, Qp - depth
+        batch = 2
+        ids = list(range(l)) + list(range(Q, Qp))
+        src = [_limbs(oracle, primes, ids * 2, n, 33 + b) for b in range(batch)]
+        for s_ in src:
+            s_[l * n:l * n + 3] = [0, primes[Q] - 1, primes[Q] // 2]
+        cts = [synth_ct(primes, range(l), 2, n, 44 + b) for b in range(batch)]
+        out = torch.empty(batch * 2 * l * n, dtype=torch.int64, device="cuda")
+        for mode in modes:
+            c.divide_round_lastq_extended(hg.to_device(np.concatenate(src)), 2 * rc * n, hg.to_device(np.concatenate(cts)),
+                                          2 * l * n, out, 2 * l * n, mode, depth, batch)
+            torch.cuda.synchronize()
+            got = hg.to_host(out).reshape(batch, -1)
+            for b in range(batch):
+                w = np.zeros(2 * l * n, dtype=np.uint64)
+                o.L.o_divide_round_lastq_extended(o.h, src[b].ctypes.data, cts[b].ctypes.data, w.ctypes.data, rc, l, mode)
+                assert np.array_equal(got[b], w), (c.P_size, depth, mode, b)
+
+
 @pytest.mark.parametrize("depth", [0, 1, 2])
 def test_kernel_base_conversion_DtoQtilde(hg, oracle, torch, depth):
     """hegpu_base_conversion_DtoQtilde (base_conversion_DtoQtilde_{bfv,leveled}_kernel, switchkey.cu:872-927,
