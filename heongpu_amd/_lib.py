@@ -28,6 +28,9 @@ SIGNATURES = [
      [c_int, c_int, ctypes.POINTER(u64), c_int, c_int, u64, ctypes.POINTER(voidp)]),
     ("hegpu_context_destroy", None, [voidp]),
     ("hegpu_context_upload", c_int, [voidp]),
+    ("hegpu_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),
+    ("hegpu_context_get_option", c_int, [voidp, ctypes.c_char_p, ctypes.POINTER(c_int)]),
+    ("hegpu_tfhe_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),
     ("hegpu_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),
     ("hegpu_context_get", ctypes.c_long, [voidp, ctypes.c_char_p, voidp, ctypes.c_long]),
     ("hegpu_context_device_ptr", voidp, [voidp, ctypes.c_char_p]),

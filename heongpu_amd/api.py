@@ -5,6 +5,7 @@ libhegpu.so.  Polynomial data is held in torch.int64 tensors that carry the
 uint64 bit patterns (torch has no full uint64 support); `to_device`/`to_host`
 convert from/to numpy uint64.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -62,12 +63,38 @@ def to_host(t):
     return t.detach().cpu().numpy().view(np.uint64)
 
 
+_default_options = {}
+
+
+@contextlib.contextmanager
+def default_options(**options):
+    """Options (hegpu_context_set_option) applied to every Context CREATED inside the block -- a convenience of
+    this ctypes layer for tests and measurements; nothing is written to the environment."""
+    old = dict(_default_options)
+    _default_options.update(options)
+    try:
+        yield
+    finally:
+        _default_options.clear()
+        _default_options.update(old)
+
+
 class Context:
     """HEContext<BFV|CKKS>: parameter set + device tables."""
 
     def __init__(self, handle):
         self._lib = _lib.load()
         self._h = handle
+        for k, v in _default_options.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        _check(self._lib.hegpu_context_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int()
+        _check(self._lib.hegpu_context_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
 
     # -- constructors (mirror set_coeff_modulus_* of the reference) --
     @classmethod
@@ -519,6 +546,9 @@ class TfheContext:
         h = ctypes.c_void_p()
         _check(self._lib.hegpu_tfhe_context_create(ctypes.byref(h)))
         self._h = h
+
+    def set_option(self, name, value):
+        _check(self._lib.hegpu_tfhe_context_set_option(self._h, name.encode(), int(value)))
 
     def close(self):
         if self._h:

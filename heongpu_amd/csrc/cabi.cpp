@@ -87,6 +87,7 @@ static int finish_create(hegpu_context* h, int scheme, int n_power, uint64_t pla
     c.plain_modulus = plain_modulus;
     if (scheme == SCHEME_BFV && plain_modulus < 2) throw std::logic_error("plain modulus is not specified");
     c.build_host();
+    c.seed_options_from_env(); // defaults only; hegpu_context_set_option is the interface
     *out = h;
     return 0;
 }
@@ -173,6 +174,24 @@ int hegpu_context_create_from_primes(int scheme, int n, const uint64_t* primes, 
 }
 
 void hegpu_context_destroy(hegpu_context* ctx) { delete ctx; }
+
+int hegpu_context_set_option(hegpu_context* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return fail(HEGPU_E_INVALID, "null argument");
+    switch (ctx->c.set_option(name, value)) {
+        case 0: return 0;
+        case 1: return fail(HEGPU_E_INVALID, std::string("unknown option: ") + name);
+        case 2: return fail(HEGPU_E_INVALID, std::string("value out of range for option ") + name);
+        default: return fail(HEGPU_E_LOGIC, std::string("option ") + name + " must be set before hegpu_context_upload");
+    }
+}
+
+int hegpu_context_get_option(const hegpu_context* ctx, const char* name, int* value)
+{
+    if (!ctx || !name || !value) return fail(HEGPU_E_INVALID, "null argument");
+    if (ctx->c.get_option(name, value)) return fail(HEGPU_E_INVALID, std::string("unknown option: ") + name);
+    return 0;
+}
 
 int hegpu_context_upload(hegpu_context* ctx)
 {
@@ -1040,7 +1059,8 @@ struct hegpu_tfhe_context {
     ulonglong2* dftw = nullptr;
     ulonglong2* dfitw = nullptr;
     bool uploaded = false;
-    bool allow_fp = true; // HEGPU_TFHE_FP=0 keeps the integer blind rotate
+    bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
+    int g4_min = 0x7fffffff;   // option "g4_min": from this many gates four gates share a workgroup's key registers
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
     double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
 };
@@ -1097,12 +1117,27 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
             p.fprime = fq;
             p.fninv = fp_pair(fn, fq);
             p.fw1ninv = fp_pair(host::mul_mod(fi[1], fn, fq), fq);
-            const char* e = getenv("HEGPU_TFHE_FP");
-            h->allow_fp = !(e && e[0] == '0');
+            if (const char* e = getenv("HEGPU_TFHE_FP")) h->allow_fp = e[0] != '0';             // defaults only:
+            if (const char* e = getenv("HEGPU_TFHE_G4_MIN")) h->g4_min = atoi(e);                // hegpu_tfhe_context_set_option
         }
         *out = h;
         return 0;
     });
+}
+
+int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int value)
+{
+    if (!ctx || !name) return fail(HEGPU_E_INVALID, "null argument");
+    if (!strcmp(name, "fp")) {
+        if (value < 0 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option fp");
+        ctx->allow_fp = value != 0;
+    } else if (!strcmp(name, "g4_min")) {
+        if (value < 1) return fail(HEGPU_E_INVALID, "value out of range for option g4_min");
+        ctx->g4_min = value;
+    } else {
+        return fail(HEGPU_E_INVALID, std::string("unknown option: ") + name);
+    }
+    return 0;
 }
 
 void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx)
@@ -1213,7 +1248,7 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
     int r = tfhe_need(ctx);
     if (r) return r;
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
-                                     encode_to_torus32(1, 8), shape, (hipStream_t) stream),
+                                     encode_to_torus32(1, 8), shape, ctx->g4_min, (hipStream_t) stream),
                    "hegpu_tfhe_bootstrapping");
 }
 

@@ -467,7 +467,7 @@ static hipError_t to_device(const std::vector<T>& h, T** d)
 }
 
 static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const vec& inv, const vec& ninv,
-                             int n_power)
+                             int n_power, bool fp_on)
 {
     const u64 n = ((u64) 1) << n_power;
     const int cnt = (int) mods.size();
@@ -475,9 +475,7 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     std::vector<ulonglong2> htw((size_t) cnt * n), hitw((size_t) cnt * n), hn(cnt), hw(cnt);
     const u64 rows = n / 256, perB = rows * 15 * 16; // re-laid entries per modulus
     std::vector<ulonglong2> htwB((size_t) cnt * perB), hitwB((size_t) cnt * perB);
-    // HEGPU_FP_NTT=0 keeps every modulus on the integer butterflies
-    const char* fp_env = getenv("HEGPU_FP_NTT");
-    const bool fp_on = !(fp_env && fp_env[0] == '0');
+    // fp_on == false (option fp_ntt = 0) keeps every modulus on the integer butterflies
     for (int k = 0; k < cnt; k++) {
         const u64 q = mods[k];
         hm[k] = make_mod(q);
@@ -566,22 +564,13 @@ static void free_plan(NttPlan& p)
 hipError_t Context::upload()
 {
     if (uploaded) return hipSuccess;
-    if (const char* e = getenv("HEGPU_FUSED_ROW_MAC")) fused_row_mac = (e[0] != '0') ? 1 : 0;
-    if (const char* e = getenv("HEGPU_FUSED_MODDOWN")) fused_moddown = (e[0] != '0');
-    if (const char* e = getenv("HEGPU_COL_MULTI")) col_multi = atoi(e); // 0 / 1 force a column-pass form
-    if (const char* e = getenv("HEGPU_SINGLE_PASS")) single_pass = atoi(e);
-    if (const char* e = getenv("HEGPU_NTT_GALOIS")) ntt_galois = (e[0] != '0');
-    if (const char* e = getenv("HEGPU_GALOIS_SCATTER")) galois_scatter = (e[0] != '0');
-    if (const char* e = getenv("HEGPU_FUSE_INVERSE")) fuse_inverse = (e[0] != '0');
-    if (const char* e = getenv("HEGPU_COPY_ALONG")) copy_along = (e[0] != '0');
-    if (const char* e = getenv("HEGPU_DIGIT_SPLIT")) digit_split = atoi(e);
     // cdt[k] = floor(2^63 * P(|round(N(0, 3.2^2))| <= k))  (secstdparams.h:22: error_std_dev = 3.2)
     for (int k = 0; k < DRBG_GAUSS_MAX; k++)
         gauss_cdt.t[k] = (u64) (erf(((double) k + 0.5) / (3.2 * 1.4142135623730951)) * 9223372036854775808.0);
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if ((e = build_plan(plan_qp, host["modulus"], host["ntt_table"], host["intt_table"], host["n_inverse"],
-                        n_power)) != hipSuccess)
+                        n_power, fp_ntt)) != hipSuccess)
         return e;
     static const char* u64_tables[] = {"psi_half",
                                        "last_q_modinv",
@@ -640,11 +629,11 @@ hipError_t Context::upload()
     }
     if (scheme == SCHEME_BFV) {
         if ((e = build_plan(plan_merge, host["q_Bsk_merge_modulus"], host["q_Bsk_merge_ntt_tables"],
-                            host["q_Bsk_merge_intt_tables"], host["q_Bsk_n_inverse"], n_power)) != hipSuccess)
+                            host["q_Bsk_merge_intt_tables"], host["q_Bsk_n_inverse"], n_power, fp_ntt)) != hipSuccess)
             return e;
         if (host.count("plain_modulus2") &&
             (e = build_plan(plan_plain, host["plain_modulus2"], host["plain_ntt_tables"], host["plain_intt_tables"],
-                            host["n_plain_inverse"], n_power)) != hipSuccess)
+                            host["n_plain_inverse"], n_power, fp_ntt)) != hipSuccess)
             return e;
         behz.ibase = plan_merge.mods;
         behz.obase = plan_merge.mods + Q_size;
@@ -668,9 +657,79 @@ hipError_t Context::upload()
         behz.msk_mod_q = d64("behz_msk_mod_q");
         behz.ibase_size = Q_size;
         behz.obase_size = bsk_size;
+        behz.split = behz_split;
     }
     uploaded = true;
     return hipDeviceSynchronize();
+}
+
+// ---- options (hegpu_context_set_option).  Environment variables HEGPU_<NAME> only seed the defaults, once, when the
+// context is created; nothing on a call path reads the environment.
+namespace {
+struct OptDesc { const char* name; const char* env; int lo, hi; };
+const OptDesc kOptions[] = {
+    {"fused_row_mac", "HEGPU_FUSED_ROW_MAC", -1, 1}, {"fused_moddown", "HEGPU_FUSED_MODDOWN", 0, 1},
+    {"col_multi", "HEGPU_COL_MULTI", -1, 1},         {"single_pass", "HEGPU_SINGLE_PASS", -1, 1},
+    {"ntt_galois", "HEGPU_NTT_GALOIS", 0, 1},        {"galois_scatter", "HEGPU_GALOIS_SCATTER", 0, 1},
+    {"fuse_inverse", "HEGPU_FUSE_INVERSE", 0, 1},    {"copy_along", "HEGPU_COPY_ALONG", 0, 1},
+    {"digit_split", "HEGPU_DIGIT_SPLIT", -1, 4},     {"fp_ntt", "HEGPU_FP_NTT", 0, 1},
+    {"behz_split", "HEGPU_BEHZ_SPLIT", -1, 1},
+};
+} // namespace
+
+int Context::set_option(const char* name, int value)
+{
+    if (!name) return 1;
+    const OptDesc* d = nullptr;
+    for (const OptDesc& o : kOptions)
+        if (!strcmp(o.name, name)) d = &o;
+    if (!d) return 1;
+    if (value < d->lo || value > d->hi) return 2;
+    const std::string nm(name);
+    if (nm == "fp_ntt") {
+        if (uploaded) return 3; // decides the layout of the twiddle tables
+        fp_ntt = value != 0;
+    } else if (nm == "fused_row_mac") fused_row_mac = value;
+    else if (nm == "fused_moddown") fused_moddown = value != 0;
+    else if (nm == "col_multi") col_multi = value;
+    else if (nm == "single_pass") single_pass = value;
+    else if (nm == "ntt_galois") ntt_galois = value != 0;
+    else if (nm == "galois_scatter") galois_scatter = value != 0;
+    else if (nm == "fuse_inverse") fuse_inverse = value != 0;
+    else if (nm == "copy_along") copy_along = value != 0;
+    else if (nm == "digit_split") {
+        if (value == 1 || value == 3) return 2;
+        digit_split = value;
+    } else if (nm == "behz_split") {
+        behz_split = value;
+        behz.split = value;
+    }
+    return 0;
+}
+
+int Context::get_option(const char* name, int* value) const
+{
+    if (!name || !value) return 1;
+    const std::string nm(name);
+    if (nm == "fp_ntt") *value = fp_ntt;
+    else if (nm == "fused_row_mac") *value = fused_row_mac;
+    else if (nm == "fused_moddown") *value = fused_moddown;
+    else if (nm == "col_multi") *value = col_multi;
+    else if (nm == "single_pass") *value = single_pass;
+    else if (nm == "ntt_galois") *value = ntt_galois;
+    else if (nm == "galois_scatter") *value = galois_scatter;
+    else if (nm == "fuse_inverse") *value = fuse_inverse;
+    else if (nm == "copy_along") *value = copy_along;
+    else if (nm == "digit_split") *value = digit_split;
+    else if (nm == "behz_split") *value = behz_split;
+    else return 1;
+    return 0;
+}
+
+void Context::seed_options_from_env()
+{
+    for (const OptDesc& o : kOptions)
+        if (const char* e = getenv(o.env)) (void) set_option(o.name, atoi(e)); // out-of-range values are ignored
 }
 
 void Context::release_device()

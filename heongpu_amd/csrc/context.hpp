@@ -65,6 +65,14 @@ struct Context {
     int digit_split = -1;      // HEGPU_DIGIT_SPLIT: 0 never, 2 / 4 always that many workgroups per fused key-switch unit, -1 by launch size
     bool copy_along = true;    // HEGPU_COPY_ALONG=0: the rescale's copy of the kept limbs always has its own launch
     bool fuse_inverse = true;  // HEGPU_FUSE_INVERSE=0: the INTT feeding a decomposing launch runs on its own
+    bool fp_ntt = true;        // fp_ntt = 0: every modulus on the integer butterflies (read when the tables are built)
+    int behz_split = -1;       // BFV BEHZ kernels: rows over four wavefronts (1), one thread per coefficient (0), by launch size (-1)
+    // The fields above are options: hegpu_context_set_option (include/hegpu.h); the environment variables named in
+    // the comments only seed their defaults when a context is created (seed_options_from_env).
+    void seed_options_from_env();
+    // 0 ok, 1 unknown name, 2 value out of range, 3 too late (the tables are already on the device)
+    int set_option(const char* name, int value);
+    int get_option(const char* name, int* value) const;
     GaussCdt gauss_cdt{}; // rounded Gaussian, sigma = 3.2 (drbg.hpp)
 
     // ---- device state (valid after upload())

@@ -31,28 +31,17 @@ namespace hegpu {
 
 #define NTT_THREADS 256
 
-// Ablation hooks for tools/exp/ntt_exp.hip (0 in the product build):
-// 1 = memory traffic only (butterflies skipped), 2 = arithmetic only,
-// 3 = data traffic only (no butterflies, no twiddle loads).
-#ifndef NTT_EXP_MODE
-#define NTT_EXP_MODE 0
-#endif
-__device__ __forceinline__ u64 gld(const u64* p)
-{
-#if NTT_EXP_MODE == 2
-    return (u64) (size_t) p * 0x9E3779B97F4A7C15ull >> 4;
+// Measurement builds (tools/exp/ntt_exp.hip) swap the global accessors and the butterflies for knock-outs through a
+// header of their own, tools/exp/ntt_ablation.cuh.  The product has no numeric switch for that: the macro must name
+// that file, so a stray -D cannot turn this library into one that builds and computes garbage.
+#ifdef NTT_ABLATION_HEADER
+#include NTT_ABLATION_HEADER
 #else
-    return *p;
+__device__ __forceinline__ u64 gld(const u64* p) { return *p; }
+__device__ __forceinline__ void gst(u64* p, u64 v) { *p = v; }
+#define NTT_ABLATE_BFLY(x, y, w)
+#define NTT_ABLATE_TW(load, root0, s) (load)
 #endif
-}
-__device__ __forceinline__ void gst(u64* p, u64 v)
-{
-#if NTT_EXP_MODE == 2
-    if (v == 0x123456789abcdefull) *p = v;
-#else
-    *p = v;
-#endif
-}
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
 
@@ -151,9 +140,7 @@ __device__ __forceinline__ u64 shoup_full(u64 y, ulonglong2 w, const QC& c)
 template <bool LAZY>
 __device__ __forceinline__ void ct_bfly(u64& x, u64& y, ulonglong2 w, const QC& c)
 {
-#if NTT_EXP_MODE == 1 || NTT_EXP_MODE == 3
-    x ^= w.x; y ^= w.y; return;
-#endif
+    NTT_ABLATE_BFLY(x, y, w);
     u64 u = LAZY ? x : csub(x, c.q4);
     u64 t = shoup_lazy(y, w, c);
     x = u + t;
@@ -163,9 +150,7 @@ __device__ __forceinline__ void ct_bfly(u64& x, u64& y, ulonglong2 w, const QC& 
 // GS butterfly, x,y in [0,4q) -> [0,4q)
 __device__ __forceinline__ void gs_bfly(u64& x, u64& y, ulonglong2 w, const QC& c)
 {
-#if NTT_EXP_MODE == 1 || NTT_EXP_MODE == 3
-    x ^= w.x; y ^= w.y; return;
-#endif
+    NTT_ABLATE_BFLY(x, y, w);
     u64 s = x + y;
     u64 d = x + c.q4 - y;
     x = csub(s, c.q4);
@@ -183,11 +168,7 @@ __device__ __forceinline__ void ct_radix(u64 (&x)[1 << LOGR], const ulonglong2* 
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-#if NTT_EXP_MODE == 3
-            ulonglong2 w = make_ulonglong2(root0, s);
-#else
-            ulonglong2 w = tw[(root0 << s) + b];
-#endif
+            ulonglong2 w = NTT_ABLATE_TW(tw[(root0 << s) + b], root0, s);
 #pragma unroll
             for (int j = 0; j < half; j++)
                 ct_bfly<LAZY>(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
@@ -223,11 +204,7 @@ __device__ __forceinline__ void gs_radix(u64 (&x)[1 << LOGR], const ulonglong2* 
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-#if NTT_EXP_MODE == 3
-            ulonglong2 w = make_ulonglong2(root0, s);
-#else
-            ulonglong2 w = tw[(root0 << s) + b];
-#endif
+            ulonglong2 w = NTT_ABLATE_TW(tw[(root0 << s) + b], root0, s);
 #pragma unroll
             for (int j = 0; j < half; j++)
                 gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
@@ -262,11 +239,7 @@ __device__ __forceinline__ void gs_radix_last(u64 (&x)[1 << LOGR], const ulonglo
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-#if NTT_EXP_MODE == 3
-            ulonglong2 w = make_ulonglong2(root0, s);
-#else
-            ulonglong2 w = tw[(root0 << s) + b];
-#endif
+            ulonglong2 w = NTT_ABLATE_TW(tw[(root0 << s) + b], root0, s);
 #pragma unroll
             for (int j = 0; j < half; j++)
                 gs_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
@@ -668,12 +641,6 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = csub(csub(csub(x[k], qc.q4), 2 * qc.q), qc.q);
     }
-#if defined(NTT_ROW_DIRECT_STORE)
-    // 16 contiguous results per lane, written as eight 16-byte stores
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        *reinterpret_cast<ulonglong2*>(&p[row * 256 + 16 * i0 + 2 * k]) = make_ulonglong2(x[2 * k], x[2 * k + 1]);
-#else
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -681,7 +648,6 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
             make_ulonglong2(x[2 * k], x[2 * k + 1]);
     wave_lds_fence();
     row_store_all(a, ps, md, a.out + ps.out_off, (u64) blockIdx.x * 4096 + row * 256 + i0, lds, row, i0);
-#endif
 }
 
 // FP64 row pass: raw doubles in (column pass output), canonical u64 out.

@@ -1051,11 +1051,10 @@ static int behz_slots(int m)
 // The split forms when the plain launch has fewer than 320 workgroups (measured, one ciphertext pair, plain / split:
 // N = 2^14 fast_floor 20.2 / 15.3 us, fast_convertion 14.7 / 13.6; N = 2^15 55 / 58, 35 / 39; N = 2^16 288 / 395,
 // 169 / 279 -- from 384 workgroups on the kernels are bound by their instruction count, which the split raises);
-// HEGPU_BEHZ_SPLIT=0/1
-// forces the choice (read at every call: the tests run both forms on the same context).
-static bool behz_split(int n_power, int polys, int batch)
+// the context option behz_split = 0 / 1 forces the choice (BehzDev::split; the tests run both forms on one context).
+static bool behz_split(const BehzDev& b, int n_power, int polys, int batch)
 {
-    if (const char* e = getenv("HEGPU_BEHZ_SPLIT")) return e[0] != '0';
+    if (b.split >= 0) return b.split != 0;
     return ((long) (1u << n_power) / RNS_THREADS) * polys * batch < 320;
 }
 
@@ -1064,7 +1063,7 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
 {
     if (batch <= 0) return hipSuccess; // an empty batch is a no-op, not an invalid launch
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1) return hipErrorInvalidValue;
-    if (behz_split(n_power, 4, batch)) {
+    if (behz_split(b, n_power, 4, batch)) {
         dim3 g((1u << n_power) / 64, 4, batch);
 #define LAUNCH(M) hipLaunchKernelGGL((k_fast_convertion<M, true>), g, dim3(RNS_THREADS), 0, st, in1, s1, in2, s2, out, so, b, n_power)
         BEHZ_DISPATCH(b.ibase_size)
@@ -1202,7 +1201,7 @@ hipError_t rns_fast_floor(const u64* in, u64 si, u64* out, u64 so, const BehzDev
     if (b.ibase_size > BEHZ_MAX || b.obase_size > BEHZ_MAX || b.ibase_size < 1 || b.obase_size < 2)
         return hipErrorInvalidValue;
     const int m = b.ibase_size > b.obase_size - 1 ? b.ibase_size : b.obase_size - 1;
-    if (behz_split(n_power, 3, batch)) {
+    if (behz_split(b, n_power, 3, batch)) {
         dim3 g((1u << n_power) / 64, 3, batch);
 #define LAUNCH(M) hipLaunchKernelGGL((k_fast_floor<M, true>), g, dim3(RNS_THREADS), 0, st, in, si, out, so, b, n_power)
         BEHZ_DISPATCH(m)

@@ -124,6 +124,7 @@ struct BehzDev {
     const u64* invq_inv_punct_B;
     const u64* msk_mod_q; // m_sk mod q_i
     int ibase_size, obase_size;
+    int split; // rows of the base conversions over four wavefronts: 1 / 0 forced, -1 by launch size (option behz_split)
 };
 
 // Sum of the partial inner products of a digit-split ks_row_mac launch (KsMacArgs::splits): part p of split s sits in

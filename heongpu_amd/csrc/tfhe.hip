@@ -900,13 +900,12 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
 }
 
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, hipStream_t st)
+                             int* out_b, int encoded, int shape, int g4_min, hipStream_t st)
 {
     // both kernels cover all gates; the one whose key layout is absent exits at once
     // one gate per workgroup: measured faster than four gates sharing the key registers at every
     // batch size (64 k vs 53 k gates/s at 4096 gates; 7.4 ms for a batch of 8); the shared
-    // variant stays selectable for experiments
-    static const int g4_min = getenv("HEGPU_TFHE_G4_MIN") ? atoi(getenv("HEGPU_TFHE_G4_MIN")) : 0x7fffffff;
+    // variant stays selectable for experiments (context option "g4_min")
     if (shape >= g4_min)
         hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<4>, dim3((shape + 3) / 4), dim3(TF_THREADS), 0, st, in_a, in_b,
                            bk_prepared, out_a, out_b, p, encoded, shape);

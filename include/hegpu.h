@@ -61,6 +61,28 @@ int hegpu_context_create_default(int scheme, int poly_modulus_degree, int p_coun
 int hegpu_context_create_from_primes(int scheme, int poly_modulus_degree, const uint64_t* primes, int q_count,
                                      int p_count, uint64_t plain_modulus, hegpu_context** out);
 void hegpu_context_destroy(hegpu_context* ctx);
+/* Run-time options of a context (the reference configures through objects as well: ExecutionOptions,
+ * src/include/heongpu/util/storagemanager.cuh:34-97; MemoryPoolConfig, util/memorypool.cuh:38-54).  They select
+ * between forms of the same computation -- every setting gives bit-identical results -- and exist for measurements
+ * and for the parity tests, which run each form.  -1 = chosen by launch size (the default of the tri-state ones).
+ *   "fused_row_mac"  -1/0/1  key switch: row pass of the digit NTT fused with the key inner product / the
+ *                            reference's kernel sequence (NTT of all digits, then keyswitch_multiply_accumulate)
+ *   "fused_moddown"  0/1     mod-down stages as load transform / epilogue of the transform between them (1)
+ *   "col_multi"      -1/0/1  decomposing column pass: one workgroup per source tile walking the target moduli
+ *   "single_pass"    -1/0/1  N <= 2^14: one LDS-resident pass per transform instead of two
+ *   "ntt_galois"     0/1     CKKS rotations without leaving the NTT domain (1) / in the reference's order
+ *   "galois_scatter" 0/1     the NTT-domain automorphism as the mod-down epilogue's store (1) / a kernel of its own
+ *   "fuse_inverse"   0/1     the inverse transform feeding a decomposition ends inside it (1)
+ *   "copy_along"     0/1     rescale: the copy of the kept limbs rides on the column pass (1)
+ *   "digit_split"    -1/0/2/4  workgroups per unit of the fused key switch for small launches
+ *   "fp_ntt"         0/1     moduli below 2^50 on the exact FP64 butterflies (1); ONLY before hegpu_context_upload
+ *                            (HEGPU_E_LOGIC afterwards: it decides the layout of the twiddle tables)
+ *   "behz_split"     -1/0/1  BFV base conversions with their rows over four wavefronts
+ * Every option but "fp_ntt" may be changed at any time, but not concurrently with calls on the same context.  The
+ * environment variables HEGPU_<NAME IN CAPITALS> seed the defaults once, when a context is created; no call path
+ * reads the environment.  Unknown name / value out of range: HEGPU_E_INVALID. */
+int hegpu_context_set_option(hegpu_context* ctx, const char* name, int value);
+int hegpu_context_get_option(const hegpu_context* ctx, const char* name, int* value);
 int hegpu_context_upload(hegpu_context* ctx);
 /* integer properties: "n_power","Q_size","P_size","Q_prime_size","bsk_modulus" */
 long hegpu_context_int(const hegpu_context* ctx, const char* name);
@@ -422,6 +444,10 @@ enum {
 /* HEContextImpl<TFHE>::HEContextImpl (tfhe/context.cu:15-57); host only */
 int hegpu_tfhe_context_create(hegpu_tfhe_context** out);
 void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
+/* "fp" 0/1: re-encode a torus32 boot key for the FP64 blind rotate (1, read by hegpu_tfhe_prepare_bootkey);
+ * "g4_min": from this many gates per call four gates share one workgroup's key registers (default: never).
+ * Defaults seeded once from HEGPU_TFHE_FP / HEGPU_TFHE_G4_MIN at creation. */
+int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int value);
 /* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems",
  * "prepared_bootkey_elems","kskey_a_elems","kskey_b_elems" */
 long hegpu_tfhe_context_int(const hegpu_tfhe_context* ctx, const char* name);

@@ -25,20 +25,18 @@ def synth_key(primes, Q, Qp, n, seed):
 
 
 import contextlib  # noqa: E402
-import os  # noqa: E402
 
 
 @contextlib.contextmanager
 def backend_switches(**kw):
-    """The switches are read when a context is uploaded (csrc/context.cpp: Context::upload,
-    build_plan), so the context must be created inside the block."""
-    old = {k: os.environ.get(k) for k in kw}
-    os.environ.update({k: str(v) for k, v in kw.items()})
-    try:
+    """Options for every context CREATED inside the block (hegpu_context_set_option through
+    heongpu_amd.default_options).  The keys are the option names in capitals with the HEGPU_ prefix of the environment
+    variables that seed the same defaults (HEGPU_COL_MULTI=1 -> option "col_multi" = 1); the environment itself is
+    not touched."""
+    import heongpu_amd as hg
+    opts = {}
+    for k, v in kw.items():
+        assert k.startswith("HEGPU_"), k
+        opts[k[len("HEGPU_"):].lower()] = int(v)
+    with hg.default_options(**opts):
         yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v

@@ -125,3 +125,44 @@ def test_entropy_seeded_generators_differ():
     lib.hegpu_rng_destroy(a)
     lib.hegpu_rng_destroy(b)
     assert lib.hegpu_rng_create_seeded(None, ctypes.byref(a)) != 0
+
+
+def test_options_are_an_interface_not_the_environment(hg):
+    """hegpu_context_set_option / get_option (include/hegpu.h): names, ranges, error codes; the environment only seeds
+    the defaults of a context at creation, a later change of the variable does nothing; no product source reads the
+    environment on a call path."""
+    import subprocess
+    import sys
+    c = hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE)
+    defaults = {"fused_row_mac": -1, "fused_moddown": 1, "col_multi": -1, "single_pass": -1, "ntt_galois": 1,
+                "galois_scatter": 1, "fuse_inverse": 1, "copy_along": 1, "digit_split": -1, "fp_ntt": 1, "behz_split": -1}
+    for k, v in defaults.items():
+        assert c.get_option(k) == v, k
+    for k, v in (("fused_row_mac", 0), ("col_multi", 1), ("digit_split", 4), ("fp_ntt", 0), ("behz_split", 1)):
+        c.set_option(k, v)
+        assert c.get_option(k) == v
+    for name, value in (("no_such_option", 1), ("col_multi", 2), ("digit_split", 3), ("fused_moddown", -1)):
+        with pytest.raises(hg.HEError) as e:
+            c.set_option(name, value)
+        assert e.value.code == hg.E_INVALID
+    with hg.default_options(single_pass=0):
+        assert hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE).get_option("single_pass") == 0
+    assert hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE).get_option("single_pass") == -1
+    # the environment seeds defaults at creation (a fresh process: the variable is set before the library reads it)
+    code = ("import os, heongpu_amd as hg\n"
+            "c = hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE)\n"
+            "os.environ['HEGPU_COL_MULTI'] = '0'\n"
+            "d = hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE)\n"
+            "print(c.get_option('col_multi'), c.get_option('fp_ntt'), d.get_option('col_multi'))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                         env=dict(os.environ, HEGPU_COL_MULTI="1", HEGPU_FP_NTT="0"))
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.split() == ["1", "0", "0"]
+    # getenv appears only where defaults are seeded (context / TFHE context creation) and in the class layer's
+    # debugging aids of the memory pool
+    allowed = {"context.cpp": 1, "cabi.cpp": 2}
+    csrc = os.path.join(ROOT, "heongpu_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".hpp", ".cuh")):
+            n = len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read()))
+            assert n == allowed.get(f, 0), (f, n)

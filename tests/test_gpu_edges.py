@@ -463,3 +463,30 @@ def test_long_chain_many_digits(hg, oracle, torch, sw):
         assert np.array_equal(gr[b], wr), ("rotate", b)
         wh = o.ckks_rotate_hoisted(ct1[b], keys, elts, 0).reshape(2, words)
         assert np.array_equal(gh[b, 0], wh[0]) and np.array_equal(gh[b, 1], wh[1]), ("hoisted", b)
+
+
+def test_options_change_the_launches_not_the_result(hg, oracle, torch):
+    """hegpu_context_set_option on an uploaded context: every call-time option may change between calls on the same
+    context and the residues stay the oracle's; fp_ntt (the layout of the uploaded tables) is refused after upload."""
+    n = 8192
+    c, o, primes = _ckks(hg, oracle, n, [50, 40, 40, 40], [50])
+    Q, Qp = 4, 5
+    with pytest.raises(hg.HEError) as e:
+        c.set_option("fp_ntt", 0)
+    assert e.value.code == hg.E_LOGIC
+    ct1, ct2 = synth_ct(primes, range(Q), 2, n, 1), synth_ct(primes, range(Q), 2, n, 2)
+    key = synth_key(primes, Q, Qp, n, 3)
+    want = o.ckks_multiply(ct1, ct2, 0)
+    o.ckks_relinearize(want, key, 0)
+    d1, d2, dk = hg.to_device(ct1), hg.to_device(ct2), hg.to_device(key)
+    ws = c.workspace(hg.OP_CKKS_RELIN, 0, 1)
+    for opts in (dict(), dict(fused_row_mac=1, col_multi=1), dict(fused_row_mac=0, fused_moddown=0), dict(single_pass=0),
+                 dict(fused_row_mac=1, col_multi=0, fuse_inverse=0), dict(fused_row_mac=-1, col_multi=-1, fused_moddown=1,
+                                                                           single_pass=-1, fuse_inverse=1)):
+        for k, v in opts.items():
+            c.set_option(k, v)
+        out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
+        c.ckks_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, 0, 1)
+        c.ckks_relinearize_inplace(out, 3 * Q * n, dk, 0, 1, ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(hg.to_host(out)[:2 * Q * n], want[:2 * Q * n]), opts

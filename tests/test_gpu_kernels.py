@@ -200,7 +200,7 @@ def test_fused_key_switch_at_every_degree(hg, oracle, torch, sw, n_power, depth)
 def test_bfv_multiply_both_behz_forms(hg, oracle, torch, split, n_power):
     """BFV multiply on the default chains (Q = 2 / 8 / 14 with 3 / 9 / 15 auxiliary primes): the two BEHZ kernels
     with one thread per coefficient and with the rows of the base conversions spread over the four wavefronts of a
-    workgroup (picked for launches below 320 workgroups; HEGPU_BEHZ_SPLIT is read at every call)."""
+    workgroup (picked for launches below 320 workgroups; the context option behz_split may be changed between calls)."""
     n, t = 1 << n_power, 786433
     c, o, primes = _bfv(hg, oracle, n, t)
     Q = c.Q_size
@@ -209,9 +209,9 @@ def test_bfv_multiply_both_behz_forms(hg, oracle, torch, split, n_power):
     ct2 = [synth_ct(primes, range(Q), 2, n, 31 + b) for b in range(batch)]
     d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
     out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
-    with backend_switches(HEGPU_BEHZ_SPLIT=split):
-        c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
-        torch.cuda.synchronize()
+    c.set_option("behz_split", split)
+    c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+    torch.cuda.synchronize()
     got = hg.to_host(out).reshape(batch, -1)
     for b in range(batch):
         assert np.array_equal(got[b], o.bfv_multiply(ct1[b], ct2[b])), b
@@ -699,10 +699,10 @@ def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split):
     ct1 = synth_ct(primes, range(Q), 2, n, 1)
     ct2 = synth_ct(primes, range(Q), 2, n, 2)
     out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
-    with backend_switches(HEGPU_BEHZ_SPLIT=split):
-        c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
-                       c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
-        torch.cuda.synchronize()
+    c.set_option("behz_split", split)
+    c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
+                   c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+    torch.cuda.synchronize()
     want = o.bfv_multiply(ct1, ct2)
     assert np.array_equal(hg.to_host(out), want)
 
@@ -719,10 +719,10 @@ def test_bfv_multiply_base_sizes_between_the_kernel_instances(hg, oracle, torch,
     c.upload()
     ct1, ct2 = synth_ct(primes, range(Q), 2, n, 3), synth_ct(primes, range(Q), 2, n, 4)
     out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
-    with backend_switches(HEGPU_BEHZ_SPLIT=split):
-        c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
-                       c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
-        torch.cuda.synchronize()
+    c.set_option("behz_split", split)
+    c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
+                   c.workspace(hg.OP_BFV_MULTIPLY, 0, 1))
+    torch.cuda.synchronize()
     assert np.array_equal(hg.to_host(out), o.bfv_multiply(ct1, ct2))
 
 

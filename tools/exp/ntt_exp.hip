@@ -4,6 +4,7 @@
 #ifndef NTT_EXP_MODE
 #define NTT_EXP_MODE 0
 #endif
+#define NTT_ABLATION_HEADER "../../tools/exp/ntt_ablation.cuh"
 #include "../../heongpu_amd/csrc/ntt.hip"
 #include <cstdio>
 #include <cstdlib>
