@@ -28,6 +28,10 @@ SIGNATURES = [
      [c_int, c_int, ctypes.POINTER(u64), c_int, c_int, u64, ctypes.POINTER(voidp)]),
     ("hegpu_context_destroy", None, [voidp]),
     ("hegpu_context_upload", c_int, [voidp]),
+    ("hegpu_context_clone", c_int, [voidp, ctypes.POINTER(voidp)]),
+    ("hegpu_context_upload_device", c_int, [voidp, c_int]),
+    ("hegpu_context_device", c_int, [voidp]),
+    ("hegpu_broadcast_key", c_int, [ctypes.POINTER(voidp), c_int, ctypes.POINTER(voidp), c_size_t, ctypes.POINTER(voidp)]),
     ("hegpu_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),
     ("hegpu_context_get_option", c_int, [voidp, ctypes.c_char_p, ctypes.POINTER(c_int)]),
     ("hegpu_tfhe_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),

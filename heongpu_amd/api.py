@@ -79,6 +79,16 @@ def default_options(**options):
         _default_options.update(old)
 
 
+def broadcast_key(contexts, keys, elems, streams=None):
+    """hegpu_broadcast_key: keys[0] (a tensor on contexts[0]'s device) -> keys[i] on contexts[i]'s device."""
+    n = len(contexts)
+    lib = _lib.load()
+    hs = (ctypes.c_void_p * n)(*[c._h for c in contexts])
+    ks = (ctypes.c_void_p * n)(*[_ptr(k) for k in keys])
+    ss = (ctypes.c_void_p * n)(*[s for s in streams]) if streams is not None else None
+    _check(lib.hegpu_broadcast_key(hs, n, ks, int(elems), ss))
+
+
 class Context:
     """HEContext<BFV|CKKS>: parameter set + device tables."""
 
@@ -90,6 +100,24 @@ class Context:
 
     def set_option(self, name, value):
         _check(self._lib.hegpu_context_set_option(self._h, name.encode(), int(value)))
+
+    def clone(self):
+        """hegpu_context_clone: the same parameter set and options, not uploaded (one context per device)."""
+        h = ctypes.c_void_p()
+        _check(self._lib.hegpu_context_clone(self._h, ctypes.byref(h)))
+        saved = dict(_default_options)
+        _default_options.clear()  # the clone carries the source's options
+        try:
+            return Context(h)
+        finally:
+            _default_options.update(saved)
+
+    def upload_device(self, device):
+        _check(self._lib.hegpu_context_upload_device(self._h, int(device)))
+
+    @property
+    def device(self):
+        return self._lib.hegpu_context_device(self._h)
 
     def get_option(self, name):
         v = ctypes.c_int()

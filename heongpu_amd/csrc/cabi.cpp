@@ -25,6 +25,23 @@ static int fail(int code, const std::string& msg)
     return code;
 }
 
+// Every device entry point runs on the device its context was uploaded to, whatever the calling thread's current
+// device is (one process driving several GPUs: one context per device, hegpu_context_upload_device); the thread's
+// current device is restored on return.
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(int dev)
+    {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard()
+    {
+        if (switched) (void) hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
 static int hip_ret(hipError_t e, const char* where)
 {
     if (e == hipSuccess) return 0;
@@ -204,6 +221,81 @@ int hegpu_context_upload(hegpu_context* ctx)
     return hip_ret(ctx->c.upload(), "context upload");
 }
 
+int hegpu_context_upload_device(hegpu_context* ctx, int device)
+{
+    if (!ctx) return fail(HEGPU_E_INVALID, "null context");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        (void) hipGetLastError();
+        return fail(HEGPU_E_NODEVICE, "no HIP device available: the HIP backend cannot run (no CPU fallback)");
+    }
+    if (device < 0 || device >= cnt) return fail(HEGPU_E_INVALID, "no such device");
+    if (ctx->c.uploaded)
+        return ctx->c.device == device ? 0 : fail(HEGPU_E_LOGIC, "the context is already uploaded to another device");
+    DevGuard g(device);
+    return hip_ret(ctx->c.upload(), "context upload");
+}
+
+int hegpu_context_device(const hegpu_context* ctx) { return (ctx && ctx->c.uploaded) ? ctx->c.device : -1; }
+
+int hegpu_context_clone(const hegpu_context* src, hegpu_context** out)
+{
+    return guarded([&]() -> int {
+        if (!src || !out) throw std::invalid_argument("null argument");
+        hegpu_context* h = new hegpu_context();
+        Context& c = h->c;
+        const Context& s = src->c;
+        // host state and options only: the clone owns its own device tables once uploaded
+        c.scheme = s.scheme; c.n_power = s.n_power; c.n = s.n;
+        c.Q_size = s.Q_size; c.P_size = s.P_size; c.Qp_size = s.Qp_size; c.bsk_size = s.bsk_size;
+        c.plain_modulus = s.plain_modulus; c.primes = s.primes; c.host = s.host;
+        c.m2_levels = s.m2_levels; c.m2_width = s.m2_width;
+        c.fused_row_mac = s.fused_row_mac; c.fused_moddown = s.fused_moddown; c.col_multi = s.col_multi;
+        c.single_pass = s.single_pass; c.ntt_galois = s.ntt_galois; c.galois_scatter = s.galois_scatter;
+        c.digit_split = s.digit_split; c.copy_along = s.copy_along; c.fuse_inverse = s.fuse_inverse;
+        c.fp_ntt = s.fp_ntt; c.behz_split = s.behz_split;
+        *out = h;
+        return 0;
+    });
+}
+
+// Evaluation keys are the only data every GPU needs a copy of: binomial fan-out over the
+// device-to-device links, copy i -> i + 2^r in round r, each ordered on the destination's stream behind the
+// arrival of the source's copy.
+int hegpu_broadcast_key(hegpu_context* const* ctxs, int n_ctx, uint64_t* const* keys, size_t elems,
+                        const hegpu_stream* streams)
+{
+    if (!ctxs || !keys || n_ctx < 1) return fail(HEGPU_E_INVALID, "null argument");
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i] || !keys[i]) return fail(HEGPU_E_INVALID, "null context or key pointer");
+        if (!ctxs[i]->c.uploaded) return fail(HEGPU_E_LOGIC, "every context must be uploaded (hegpu_context_upload_device)");
+    }
+    if (n_ctx == 1 || elems == 0) return 0;
+    std::vector<hipEvent_t> ready(n_ctx, nullptr);
+    auto stream_of = [&](int i) { return streams ? (hipStream_t) streams[i] : (hipStream_t) nullptr; };
+    hipError_t e = hipSuccess;
+    auto mark = [&](int i) { // keys[i] is complete once stream i reaches this point
+        DevGuard g(ctxs[i]->c.device);
+        if ((e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming)) != hipSuccess) return;
+        e = hipEventRecord(ready[i], stream_of(i));
+    };
+    mark(0);
+    for (int span = 1; span < n_ctx && e == hipSuccess; span <<= 1) {
+        for (int i = 0; i < span && i + span < n_ctx && e == hipSuccess; i++) {
+            const int j = i + span;
+            DevGuard g(ctxs[j]->c.device);
+            if ((e = hipStreamWaitEvent(stream_of(j), ready[i], 0)) != hipSuccess) break;
+            if ((e = hipMemcpyPeerAsync(keys[j], ctxs[j]->c.device, keys[i], ctxs[i]->c.device, elems * sizeof(u64),
+                                        stream_of(j))) != hipSuccess)
+                break;
+            mark(j);
+        }
+    }
+    for (hipEvent_t ev : ready)
+        if (ev) (void) hipEventDestroy(ev); // released by the runtime once the recorded work has completed
+    return hip_ret(e, "hegpu_broadcast_key");
+}
+
 long hegpu_context_int(const hegpu_context* ctx, const char* name)
 {
     if (!ctx || !name) return -1;
@@ -253,13 +345,12 @@ int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order)
 }
 
 #define NEED_CTX(ctx)                                                                      \
-    do {                                                                                   \
-        if (!(ctx)) return fail(HEGPU_E_INVALID, "null context");                          \
-        if (!(ctx)->c.uploaded) {                                                          \
-            int r__ = hegpu_context_upload(ctx);                                           \
-            if (r__) return r__;                                                           \
-        }                                                                                  \
-    } while (0)
+    if (!(ctx)) return fail(HEGPU_E_INVALID, "null context");                              \
+    if (!(ctx)->c.uploaded) {                                                              \
+        int r__ = hegpu_context_upload(ctx);                                               \
+        if (r__) return r__;                                                               \
+    }                                                                                      \
+    DevGuard dev_guard__((ctx)->c.device)
 
 static const Mod* mods_of(const Context& c, int table_set)
 {
@@ -1059,6 +1150,7 @@ struct hegpu_tfhe_context {
     ulonglong2* dftw = nullptr;
     ulonglong2* dfitw = nullptr;
     bool uploaded = false;
+    int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
     int g4_min = 0x7fffffff;   // option "g4_min": from this many gates four gates share a workgroup's key registers
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
@@ -1194,9 +1286,14 @@ static int tfhe_need(hegpu_tfhe_context* ctx)
     ctx->p.itw = ctx->ditw;
     ctx->p.ftw = ctx->dftw;
     ctx->p.fitw = ctx->dfitw;
+    (void) hipGetDevice(&ctx->device);
     ctx->uploaded = true;
     return 0;
 }
+#define TFHE_NEED(ctx)        \
+    int r = tfhe_need(ctx);   \
+    if (r) return r;          \
+    DevGuard dev_guard__((ctx)->device)
 
 // tfhe/operator.cu:317-323
 static int32_t encode_to_torus32(uint32_t mu, uint32_t m_size)
@@ -1209,8 +1306,7 @@ static int32_t encode_to_torus32(uint32_t mu, uint32_t m_size)
 int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
                                hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     const TfheDev& p = ctx->p;
     const u64 polys = (u64) p.n * (p.k + 1) * p.bk_l * (p.k + 1);
     return hip_ret(tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp,
@@ -1222,8 +1318,7 @@ int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a
                                const int32_t* a1, const int32_t* b1, const int32_t* a2, const int32_t* b2,
                                int shape, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     int enc, s1, s2, m = 1;
     const int e8 = encode_to_torus32(1, 8), e4 = encode_to_torus32(1, 4);
     switch (gate) { // tfhe/operator.cu:24-198
@@ -1245,8 +1340,7 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
                              hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
                                      encode_to_torus32(1, 8), shape, ctx->g4_min, (hipStream_t) stream),
                    "hegpu_tfhe_bootstrapping");
@@ -1256,8 +1350,7 @@ int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              int32_t* out_b, const int32_t* ks_a, const int32_t* ks_b, int shape,
                              hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, (hipStream_t) stream),
                    "hegpu_tfhe_key_switching");
 }
@@ -1267,8 +1360,7 @@ int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, con
                     const uint64_t* prepared_boot_key, const int32_t* ks_a, const int32_t* ks_b, int shape, void* ws,
                     size_t ws_bytes, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     const TfheDev& p = ctx->p;
     if (gate == HEGPU_GATE_NOT) // NOT needs no bootstrapping (tfhe/operator.cuh:640-686)
         return hegpu_tfhe_gate_precompute(ctx, gate, out_a, out_b, in1_a, in1_b, nullptr, nullptr, shape, stream);
@@ -1289,8 +1381,7 @@ static const double TFHE_IH = 1.1547005383792517; // sqrt(16/12), see drbg_torus
 int hegpu_tfhe_generate_secret_key(hegpu_tfhe_context* ctx, hegpu_rng* rng, int32_t* lwe_key, int32_t* tlwe_key,
                                    hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
     const u64 s0 = rng->r.stream;
     rng->r.stream += 2;
@@ -1303,8 +1394,7 @@ int hegpu_tfhe_generate_bootstrapping_key(hegpu_tfhe_context* ctx, hegpu_rng* rn
                                           const int32_t* tlwe_key, uint64_t* boot_key, int32_t* ks_a, int32_t* ks_b,
                                           void* ws, size_t ws_bytes, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
     const TfheDev& p = ctx->p;
     if (!ws || ws_bytes < (size_t) p.N * sizeof(u64)) return fail(HEGPU_E_INVALID, "workspace too small");
@@ -1322,8 +1412,7 @@ int hegpu_tfhe_generate_bootstrapping_key(hegpu_tfhe_context* ctx, hegpu_rng* rn
 int hegpu_tfhe_encrypt(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* lwe_key, const int32_t* messages,
                        int shape, int32_t* out_a, int32_t* out_b, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     if (!rng) return fail(HEGPU_E_INVALID, "null random generator");
     if (shape <= 0) return fail(HEGPU_E_INVALID, "shape must be positive");
     const u64 s0 = rng->r.stream;
@@ -1336,8 +1425,7 @@ int hegpu_tfhe_encrypt(hegpu_tfhe_context* ctx, hegpu_rng* rng, const int32_t* l
 int hegpu_tfhe_decrypt_phase(hegpu_tfhe_context* ctx, const int32_t* lwe_key, const int32_t* a, const int32_t* b,
                              int shape, int32_t* phase, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     return hip_ret(tfhe_lwe_phase(a, b, lwe_key, phase, ctx->p.n, shape, (hipStream_t) stream),
                    "hegpu_tfhe_decrypt_phase");
 }
@@ -1347,8 +1435,7 @@ int hegpu_tfhe_mux(hegpu_tfhe_context* ctx, const int32_t* in1_a, const int32_t*
                    const uint64_t* prepared_boot_key, const int32_t* ks_a, const int32_t* ks_b, int shape, void* ws,
                    size_t ws_bytes, hegpu_stream stream)
 {
-    int r = tfhe_need(ctx);
-    if (r) return r;
+    TFHE_NEED(ctx);
     const TfheDev& p = ctx->p;
     const size_t kN = (size_t) p.k * p.N;
     const size_t need = ((size_t) p.n + 1 + 2 * (kN + 1)) * shape * sizeof(int32_t);

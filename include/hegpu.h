@@ -17,7 +17,8 @@
  *  - every call is asynchronous on `stream`; return value 0 = success,
  *    otherwise a hipError_t code (or HEGPU_E_* below); hegpu_last_error()
  *    returns a message for the calling thread;
- *  - device pointers must live on the device the context was uploaded to.
+ *  - device pointers and the stream must belong to the device the context was uploaded to; the call runs there
+ *    whatever the calling thread's current device is (see hegpu_context_upload_device).
  */
 #ifndef HEGPU_H
 #define HEGPU_H
@@ -84,6 +85,21 @@ void hegpu_context_destroy(hegpu_context* ctx);
 int hegpu_context_set_option(hegpu_context* ctx, const char* name, int value);
 int hegpu_context_get_option(const hegpu_context* ctx, const char* name, int* value);
 int hegpu_context_upload(hegpu_context* ctx);
+/* ---- several GPUs in one process (batches of independent ciphertexts shard across the GPUs of a node,
+ * only the evaluation keys are replicated).  One context per device: hegpu_context_clone copies the host-side
+ * parameter set and options (not the device tables), hegpu_context_upload_device puts a context's tables on the
+ * given device (hegpu_context_upload = the calling thread's current device).  Every entry point then runs on its
+ * context's device whatever the caller's current device is (the caller's is restored on return), so a consumer drives
+ * device d from any thread -- one OpenMP thread per device as the reference drives one stream per thread in
+ * example/basic/9_multi_stream_usage_way1.cpp:27-66 -- with buffers and streams that belong to device d.
+ * hegpu_broadcast_key copies keys[0] (on the device of ctxs[0]) to keys[i] on the device of ctxs[i], i = 1..n-1, as a
+ * binomial fan-out of peer copies over xGMI; the copy into keys[i] is ordered on streams[i] (NULL: the default
+ * streams), the source must be complete on streams[0]'s timeline.  hegpu_context_device: -1 before upload. */
+int hegpu_context_clone(const hegpu_context* src, hegpu_context** out);
+int hegpu_context_upload_device(hegpu_context* ctx, int device);
+int hegpu_context_device(const hegpu_context* ctx);
+int hegpu_broadcast_key(hegpu_context* const* ctxs, int n_ctx, uint64_t* const* keys, size_t elems,
+                        const hegpu_stream* streams);
 /* integer properties: "n_power","Q_size","P_size","Q_prime_size","bsk_modulus" */
 long hegpu_context_int(const hegpu_context* ctx, const char* name);
 /* copy the named HOST table (reference member name without trailing '_',

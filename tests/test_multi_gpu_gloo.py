@@ -121,6 +121,24 @@ def test_bench_launches_its_own_ranks():
     assert line["slices"] == [[0, 64], [64, 64]] and line["global_batch"] == 128
 
 
+def test_bench_falls_back_to_one_process_when_the_launch_fails():
+    """The third multi-GPU path of bench.py: when the launch of the ranks fails (forced here), one process drives the
+    N devices itself -- a thread per device, the same contiguous sharding, the key replicated in the fan-out order of
+    hegpu_broadcast_key, a barrier on both sides of the timed region and the maximum over the threads -- and the line
+    still reports n_gpus = 2 and says which path ran."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launcher-selftest",
+                        "--force-launch-failure"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "single-process path" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["key_broadcast_ok"] and "single process" in line["parallelism"]
+    assert line["slices"] == [[0, 64], [64, 64], [128, 64]] and line["global_batch"] == 192
+    assert line["max_elapsed_s"] >= 0.003
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """under a launcher the world size must equal --gpus (the driver passes both)"""
     import subprocess

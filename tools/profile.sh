@@ -25,6 +25,17 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python $REPO/bench.py --step-only --steps $STEPS --warmup $WARM > $OUT/pmcs_${C}_run.txt 2>&1
   find $OUT/pmcs_$C -name '*counter_collection.csv' -exec cp {} $OUT/pmcs_$C.csv \;
 done
+# vector-ALU issue counters, their own passes (SQ counters never share a pass with the traffic counters): the full
+# line (-> the roofline launch pair) and --step-only (-> every kernel of the step)
+SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES"
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/sq -o bench -- \
+    python $REPO/bench.py --no-cpu-baseline --no-secondary "$@" > $OUT/sq_run.txt 2>&1
+find $OUT/sq -name '*counter_collection.csv' -exec cp {} $OUT/sq.csv \;
+find $OUT/sq -name '*kernel_trace.csv' -exec cp {} $OUT/sq_trace.csv \;
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/sqs -o bench -- \
+    python $REPO/bench.py --step-only --steps $STEPS --warmup $WARM > $OUT/sqs_run.txt 2>&1
+find $OUT/sqs -name '*counter_collection.csv' -exec cp {} $OUT/sqs.csv \;
+find $OUT/sqs -name '*kernel_trace.csv' -exec cp {} $OUT/sqs_trace.csv \;
 [ -x $REPO/tools/exp/copy_bw ] && $REPO/tools/exp/copy_bw 16384 5 > $OUT/copy_bw.txt 2>&1
 python3 - <<PY
 import csv, collections, json, re
@@ -78,8 +89,59 @@ res["step_bytes"] = sb
 res["step_batch"] = 64
 res["step_kernels"] = {}
 for (c, k, g), s in step.items():
-    e = res["step_kernels"].setdefault(re.sub(r"\(.*", "", k) + f" grid {g}", {"bytes_per_step": 0.0})
+    e = res["step_kernels"].setdefault(re.sub(r"^void ", "", re.sub(r"\(.*", "", k)) + f" grid {g}", {"bytes_per_step": 0.0})
     e["bytes_per_step"] += (2 if c == "FETCH_SIZE" else 1) * s * 1024 / steps
+# ---- SQ counters per (kernel, grid): wave-level vector instructions, the cycles in which a SIMD issued one, the
+# kernels' own cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs -> / 8) and their durations in the same run
+def norm(k):
+    k = re.sub(r"\(.*", "", k)
+    k = re.sub(r"^void ", "", k)
+    return re.sub(r"(ks_row_mac(?:_fp)?)<(?:false|true)>", r"\\1", k)
+def load_sq(cpath, tpath):
+    dur = {}
+    try:
+        for r in csv.DictReader(open(tpath)):
+            dur[r.get("Dispatch_Id")] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+    except Exception as e:
+        print(tpath, "missing", e)
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    try:
+        for r in csv.DictReader(open(cpath)):
+            key = norm(r.get("Kernel_Name", "?")) + " grid " + r.get("Grid_Size", "0")
+            agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+            d = r.get("Dispatch_Id")
+            if d not in seen[key]:
+                seen[key].add(d)
+                agg[key]["seconds"] += dur.get(d, 0.0)
+                agg[key]["dispatches"] += 1
+    except Exception as e:
+        print(cpath, "missing", e)
+    res_ = {}
+    for key, a in agg.items():
+        if "rocclr" in key or not a.get("GRBM_GUI_ACTIVE"): continue
+        n = a["dispatches"]
+        res_[key] = {"dispatches": n, "valu_wave_insts": a["SQ_INSTS_VALU"] / n,
+                     "valu_busy_cycles_per_simd": a["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / n,
+                     "cycles": a["GRBM_GUI_ACTIVE"] / 8 / n, "seconds": a["seconds"] / n, "waves": a["SQ_WAVES"] / n}
+        res_[key]["valu_busy"] = res_[key]["valu_busy_cycles_per_simd"] / res_[key]["cycles"]
+    return res_
+sqs = load_sq(f"{out}/sqs.csv", f"{out}/sqs_trace.csv")
+res["step_kernels_sq"] = sqs
+res["sq_note"] = ("per dispatch: valu_wave_insts = SQ_INSTS_VALU, valu_busy = SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / cycles, "
+                   "cycles = GRBM_GUI_ACTIVE / 8 XCDs, seconds from the kernel trace of the same (counter) run")
+sqf = load_sq(f"{out}/sq.csv", f"{out}/sq_trace.csv")
+pair = [v for k, v in sqf.items() if (k.startswith("hegpu::ntt_fwd_col<8, false>") or k.startswith("hegpu::ntt_fwd_row"))
+        and k.endswith("grid 71303168")]
+if len(pair) == 2:
+    res["roofline_pair_sq"] = {f: sum(p[f] for p in pair) for f in ("valu_wave_insts", "valu_busy_cycles_per_simd", "cycles", "seconds")}
+with open(f"{out}/pmc_sq_summary.txt", "w") as f:
+    for name, d in (("step", sqs), ("full line", sqf)):
+        f.write("== %s\n" % name)
+        for k, v in sorted(d.items(), key=lambda kv: -kv[1]["seconds"] * kv[1]["dispatches"]):
+            f.write("%-64s x%-4d %8.3f ms  %12.0f wave-insts  busy %.3f  %.3f GHz\n" % (
+                k, v["dispatches"], v["seconds"] * 1e3, v["valu_wave_insts"], v["valu_busy"],
+                v["cycles"] / v["seconds"] / 1e9 if v["seconds"] else 0))
 try:
     rows = [l.split() for l in open(f"{out}/copy_bw.txt") if l.split()[:1] == ["lin16"] and "nt-" not in l]
     res["copy_ceiling_GBps"] = float(rows[-1][-2])
@@ -90,7 +152,8 @@ res["source"] = "profiles/$TAG (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separat
 json.dump(res, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(res)[:600])
 PY
-rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE $OUT/pmc_*.csv.tmp
+rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE $OUT/pmc_*.csv.tmp $OUT/sq $OUT/sqs
+rm -f $OUT/sq.csv $OUT/sqs.csv $OUT/sq_trace.csv $OUT/sqs_trace.csv
 rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmcs_FETCH_SIZE.csv $OUT/pmcs_WRITE_SIZE.csv
 ls -la $OUT
 head -14 $OUT/kernel_stats.csv
