@@ -1,8 +1,10 @@
 // cabi.cpp -- extern "C" entry points declared in include/hegpu.h.
 #include "../../include/hegpu.h"
+#include "../../include/hegpu_bench.h"
 #include "context.hpp"
 #include "host_params.hpp"
 #include "ops.hpp"
+#include <cmath>
 #include "tfhe.hpp"
 #include <cerrno>
 #include <cstring>
@@ -680,13 +682,27 @@ int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, in
                    "hegpu_ckks_rescale_inplace");
 }
 
+// The rotations read the input ciphertext while their epilogue already writes (scatters) results: the result buffer
+// must not contain the input, not even partly.  Spans of the two batches: [p, p + (batch - 1) * stride + item).
+static bool spans_overlap(const uint64_t* a, uint64_t a_stride, uint64_t a_item, const uint64_t* b, uint64_t b_stride,
+                          uint64_t b_item, int batch)
+{
+    const uintptr_t a0 = (uintptr_t) a, a1 = a0 + ((uint64_t) (batch - 1) * a_stride + a_item) * sizeof(uint64_t);
+    const uintptr_t b0 = (uintptr_t) b, b1 = b0 + ((uint64_t) (batch - 1) * b_stride + b_item) * sizeof(uint64_t);
+    return a0 < b1 && b0 < a1;
+}
+
 int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, uint64_t* out, uint64_t so,
                             const uint64_t* key, int galois_elt, int depth, int batch, void* ws, size_t ws_bytes,
                             hegpu_stream stream)
 {
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
-    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
+    {
+        const uint64_t words = (uint64_t) 2 * (ctx->c.Q_size - depth) * ctx->c.n;
+        if (spans_overlap(ct, cs, words, out, so, words, batch))
+            return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct (the result buffer must not contain the input)");
+    }
     if (galois_elt <= 0 || !(galois_elt & 1) || galois_elt >= 2 * (int) ctx->c.n)
         return fail(HEGPU_E_INVALID, "apply_galois: Galois elements are odd and below 2N");
     return hip_ret(ctx->c.P_size == 1
@@ -705,8 +721,9 @@ int hegpu_ckks_rotate_hoisted(hegpu_context* ctx, const uint64_t* ct, uint64_t c
     CHECK_OP(ctx, SCHEME_CKKS, OP_CKKS_GALOIS, depth, batch, ws, ws_bytes);
     if (count <= 0 || !keys || !galois_elts) return fail(HEGPU_E_INVALID, "rotate_hoisted: empty element list");
     const uint64_t words = (uint64_t) 2 * (ctx->c.Q_size - depth) * ctx->c.n;
-    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "rotate_hoisted: out must not alias ct");
     if (batch > 1 && so < (uint64_t) count * words) return fail(HEGPU_E_INVALID, "rotate_hoisted: out_stride too small");
+    if (spans_overlap(ct, cs, words, out, so, (uint64_t) count * words, batch))
+        return fail(HEGPU_E_INVALID, "rotate_hoisted: out must not alias ct (the result buffer must not contain the input)");
     for (int i = 0; i < count; i++) {
         if (galois_elts[i] == 0) continue;
         if (galois_elts[i] < 0 || !(galois_elts[i] & 1) || galois_elts[i] >= 2 * (int) ctx->c.n)
@@ -754,7 +771,11 @@ int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, 
 {
     NEED_CTX(ctx);
     CHECK_OP(ctx, SCHEME_BFV, OP_BFV_GALOIS, 0, batch, ws, ws_bytes);
-    if ((const void*) ct == (const void*) out) return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct");
+    {
+        const uint64_t words = (uint64_t) 2 * ctx->c.Q_size * ctx->c.n;
+        if (spans_overlap(ct, cs, words, out, so, words, batch))
+            return fail(HEGPU_E_INVALID, "apply_galois: out must not alias ct (the result buffer must not contain the input)");
+    }
     return hip_ret(ctx->c.P_size == 1
                        ? op_bfv_apply_galois(ctx->c, (const u64*) ct, cs, (u64*) out, so, (const u64*) key,
                                              galois_elt, batch, (u64*) ws, (hipStream_t) stream)
@@ -824,7 +845,12 @@ int hegpu_drbg_block(const uint8_t key[32], uint64_t stream, uint64_t index, uin
     return 0;
 }
 
-void hegpu_rng_destroy(hegpu_rng* rng) { delete rng; }
+void hegpu_rng_destroy(hegpu_rng* rng)
+{
+    if (!rng) return;
+    explicit_bzero(&rng->r, sizeof(rng->r)); // the 256-bit key must not stay behind in freed heap memory
+    delete rng;
+}
 
 #define CHECK_KG(ctx, rng, op, ws, ws_bytes)                                                          \
     do {                                                                                              \
@@ -1068,8 +1094,8 @@ int hegpu_ckks_gaussian_integer_op(hegpu_context* ctx, int op, const uint64_t* c
     if (ctx->c.scheme != SCHEME_CKKS) return fail(HEGPU_E_INVALID, "context scheme mismatch");
     if (op < 0 || op > 1) return fail(HEGPU_E_INVALID, "unknown constant operation");
     if (limbs <= 0 || limbs > ctx->c.Q_size || parts < 2 || parts > 3) return fail(HEGPU_E_INVALID, "bad ciphertext shape");
-    for (double v : {re, im})
-        if (!(v == v) || v >= 3.4e38 || v <= -3.4e38) return fail(HEGPU_E_INVALID, "constant out of range");
+    for (double v : {re, im}) // any finite double, as the reference's NTL conversion (ckks/operator.cu:583-617)
+        if (!std::isfinite(v)) return fail(HEGPU_E_INVALID, "constant is not a finite number");
     return guarded([&]() -> int {
         return hip_ret(kg_ckks_gaussian((const u64*) ct, re, im, (u64*) out, ctx->c.d64("psi_half"), ctx->c.plan_qp.mods,
                                         ctx->c.n_power, limbs, parts, op, (hipStream_t) stream),

@@ -435,16 +435,31 @@ hipError_t kg_ckks_constant(const u64* ct, double value, u64* out, const Mod* mo
 // the constant round(re) + round(im) * i in every slot.  In the NTT domain i is +psi^(N/2) on the first half
 // of the positions and -psi^(N/2) on the second, so the slot constant is re +- im * psi^(N/2) mod q_j; op 0
 // adds it to part 0 (the other parts are copied), op 1 multiplies every part by it.  The reference turns the
-// rounded doubles into residues with NTL big integers (ckks/operator.cu:583-617); a double is m * 2^e, so the
-// residue comes from its two 64-bit halves exactly (|value| < 2^128).
+// rounded doubles into residues with NTL big integers (ckks/operator.cu:583-617) and accepts any magnitude; a
+// double is mant * 2^e: below 2^128 the residue comes from its two 64-bit halves, beyond that from
+// (mant mod q) * (2^e mod q) -- exact for every finite double.
 __device__ __forceinline__ u64 residue_of_rounded(double value, const Mod& m)
 {
     double c = round(value);
     const bool neg = signbit(c);
     c = fabs(c);
     const double two64 = 18446744073709551616.0;
-    const u64 lo = (u64) fmod(c, two64), hi = (u64) (c / two64);
-    const u64 r = reduce128(hi, lo, m);
+    u64 r;
+    if (c < two64 * two64) {
+        const u64 lo = (u64) fmod(c, two64), hi = (u64) (c / two64);
+        r = reduce128(hi, lo, m);
+    } else {
+        int e;
+        const double fr = frexp(c, &e);              // c = fr * 2^e, 0.5 <= fr < 1
+        const u64 mant = (u64) ldexp(fr, 53);        // the 53-bit integer mantissa, exact
+        r = reduce64(mant, m);
+        u64 p = reduce64(2, m), acc = reduce64(1, m); // 2^(e - 53) mod q by square and multiply
+        for (int sh = e - 53; sh; sh >>= 1) {
+            if (sh & 1) acc = reduce128(mulhi64(acc, p), acc * p, m);
+            p = reduce128(mulhi64(p, p), p * p, m);
+        }
+        r = reduce128(mulhi64(r, acc), r * acc, m);
+    }
     return (neg && r) ? m.q - r : r; // NTL: (x % q) made non-negative
 }
 __global__ __launch_bounds__(KG_THREADS) void k_kg_ckks_gaussian(const u64* __restrict__ ct, double re, double im,

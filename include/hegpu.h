@@ -265,18 +265,12 @@ int hegpu_ckks_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_st
 int hegpu_ckks_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
                                    const uint64_t* relin_key, int depth, int batch, void* ws, size_t ws_bytes,
                                    hegpu_stream stream);
-/* Measurement seam (bench.py's per-kernel roofline, no reference counterpart): runs only the launches
- * of hegpu_ckks_relinearize_inplace (method I) selected by `phases` -- 1 INTT of c2 (:919), 2 decomposing
- * column pass and 4 row pass + inner product (:932-988), 8 INTT of the P limbs (:996), 16 mod-down NTT
- * (:1003-1015) -- on whatever the buffers hold; results are meaningful only with all five (31). */
-int hegpu_probe_ckks_relinearize(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride, const uint64_t* relin_key,
-                                 int depth, int batch, void* ws, size_t ws_bytes, unsigned phases,
-                                 hegpu_stream stream);
 /* rescale_inplace_ckks_leveled (ckks/operator.cu:1156-1244):
  * ct [2][l][N] -> [2][l-1][N] in place (caller then uses depth+1) */
 int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride, int depth, int batch,
                                void* ws, size_t ws_bytes, hegpu_stream stream);
-/* apply_galois_ckks_method_I (ckks/operator.cu:1422-1559); out != ct */
+/* apply_galois_ckks_method_I (ckks/operator.cu:1422-1559); the result buffer must not contain the input: HEGPU_E_INVALID
+ * if the address ranges of the two batches overlap (the epilogue scatters results while c0 is still being read) */
 int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
                             uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int depth,
                             int batch, void* ws, size_t ws_bytes, hegpu_stream stream);
@@ -302,7 +296,7 @@ int hegpu_bfv_multiply(hegpu_context* ctx, const uint64_t* ct1, uint64_t ct1_str
 int hegpu_bfv_relinearize_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t ct_stride,
                                   const uint64_t* relin_key, int batch, void* ws, size_t ws_bytes,
                                   hegpu_stream stream);
-/* apply_galois_method_I (bfv/operator.cu:771-864); out != ct */
+/* apply_galois_method_I (bfv/operator.cu:771-864); the result buffer must not contain the input (as above) */
 int hegpu_bfv_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t ct_stride, uint64_t* out,
                            uint64_t out_stride, const uint64_t* galois_key, int galois_elt, int batch, void* ws,
                            size_t ws_bytes, hegpu_stream stream);

@@ -485,7 +485,7 @@ template <typename T> using HostVector = std::vector<T, PinnedAllocator<T>>;
 namespace detail {
 class StoredBuffer;
 struct OpScope {
-    explicit OpScope(const ExecutionOptions& o) : o_(o), outer_(current() == nullptr)
+    explicit OpScope(const ExecutionOptions& o) : o_(o), outer_(current() == nullptr), exceptions_(std::uncaught_exceptions())
     {
         if (outer_) current() = this;
     }
@@ -497,11 +497,26 @@ struct OpScope {
     }
     void staged(StoredBuffer* b) { if (std::find(staged_.begin(), staged_.end(), b) == staged_.end()) staged_.push_back(b); }
     void written(StoredBuffer* b) { if (std::find(written_.begin(), written_.end(), b) == written_.end()) written_.push_back(b); }
+    // a registered buffer that dies (an operator-local temporary) or moves before the operator returns
+    void forget(const StoredBuffer* b)
+    {
+        staged_.erase(std::remove(staged_.begin(), staged_.end(), b), staged_.end());
+        written_.erase(std::remove(written_.begin(), written_.end(), b), written_.end());
+    }
+    void moved(const StoredBuffer* from, StoredBuffer* to)
+    {
+        for (auto* v : {&staged_, &written_})
+            if (std::find(v->begin(), v->end(), from) != v->end()) {
+                v->erase(std::remove(v->begin(), v->end(), from), v->end());
+                if (std::find(v->begin(), v->end(), to) == v->end()) v->push_back(to);
+            }
+    }
     hipStream_t stream() const { return o_.stream_; }
 
   private:
     ExecutionOptions o_;
     bool outer_;
+    int exceptions_; // uncaught exceptions when the operator started: more of them in the destructor = unwinding
     std::vector<StoredBuffer*> staged_, written_;
 };
 
@@ -510,13 +525,34 @@ class StoredBuffer {
     StoredBuffer() = default;
     StoredBuffer(DeviceVector<Data64>&& m) : dev_(std::move(m)) {}
     StoredBuffer(const StoredBuffer& o) : dev_(o.dev_), host_(o.host_), st_(o.st_), staged_(o.staged_) {}
+    // Inside an operator (OpScope::current()) an assignment makes this object something the operator wrote: it is
+    // placed per ExecutionOptions::storage_ when the operator returns (`out = in` of a zero shift, `out =
+    // std::move(cur)` at the end of a key chain).  A buffer the scope knows about unregisters itself when it dies or
+    // moves, so the scope never touches an operator-local temporary that is already gone.
     StoredBuffer& operator=(const StoredBuffer& o)
     {
-        if (this != &o) { dev_ = o.dev_; host_ = o.host_; st_ = o.st_; staged_ = o.staged_; }
+        if (this != &o) {
+            dev_ = o.dev_; host_ = o.host_; st_ = o.st_; staged_ = o.staged_;
+            if (OpScope* sc = OpScope::current()) sc->written(this);
+        }
         return *this;
     }
-    StoredBuffer(StoredBuffer&&) = default;
-    StoredBuffer& operator=(StoredBuffer&&) = default;
+    StoredBuffer(StoredBuffer&& o) noexcept : dev_(std::move(o.dev_)), host_(std::move(o.host_)), st_(o.st_), staged_(o.staged_)
+    {
+        if (OpScope* sc = OpScope::current()) sc->moved(&o, this);
+    }
+    StoredBuffer& operator=(StoredBuffer&& o)
+    {
+        if (this != &o) {
+            dev_ = std::move(o.dev_); host_ = std::move(o.host_); st_ = o.st_; staged_ = o.staged_;
+            if (OpScope* sc = OpScope::current()) { sc->forget(&o); sc->written(this); }
+        }
+        return *this;
+    }
+    ~StoredBuffer()
+    {
+        if (OpScope* sc = OpScope::current()) sc->forget(this);
+    }
     // fresh residues from an operator: they are on the device, whatever the object held before is gone
     StoredBuffer& operator=(DeviceVector<Data64>&& m)
     {
@@ -605,6 +641,9 @@ inline OpScope::~OpScope() noexcept(false)
 {
     if (!outer_) return;
     current() = nullptr;
+    // the operator is leaving through an exception: no copies, no synchronisation (a second throw from here would be
+    // std::terminate); staged operands simply stay where they are
+    if (std::uncaught_exceptions() > exceptions_) return;
     for (StoredBuffer* b : written_)
         if (o_.storage_ == storage_type::HOST) b->store_in_host(o_.stream_);
     for (StoredBuffer* b : staged_) {

@@ -288,8 +288,21 @@ static u64 zz_residue(double value, u64 q)
     const int neg = signbit(v) != 0;
     v = fabs(v);
     const double two64 = 18446744073709551616.0;
-    const u128 wide = ((u128) (u64) (v / two64) << 64) | (u64) fmod(v, two64);
-    u64 r = (u64) (wide % q);
+    u64 r;
+    if (v < two64 * two64) {
+        const u128 wide = ((u128) (u64) (v / two64) << 64) | (u64) fmod(v, two64);
+        r = (u64) (wide % q);
+    } else { /* NTL takes any magnitude: v = mant * 2^(e - 53) exactly */
+        int e;
+        const double fr = frexp(v, &e);
+        const u64 mant = (u64) ldexp(fr, 53);
+        u128 acc = 1 % q, p = 2 % q;
+        for (int sh = e - 53; sh; sh >>= 1) {
+            if (sh & 1) acc = acc * p % q;
+            p = p * p % q;
+        }
+        r = (u64) ((u128) (mant % q) * acc % q);
+    }
     if (neg && r) r = q - r; /* real_mod < 0 -> += q */
     return r;
 }

@@ -913,6 +913,47 @@ static void storage_manager()
     ok = true;
     for (size_t i = 0; ok && i < n; i++) ok = slots[i] == a[i];
     EXPECT(ok, "the copy decrypts to the same message");
+
+    // ---- rotations through the storage manager: operator-local temporaries (rotate_rows_inplace's copy, the key
+    // chain's intermediate ciphertexts) die before the operator's scope does; results assigned by copy / move (a zero
+    // shift, the end of a chain) are placed per ExecutionOptions::storage_ like any other result
+    Galoiskey<S> gk(ctx, std::vector<int>{1, 2});
+    keygen.generate_galois_key(gk, sk);
+    auto rotated = [&](const HostVector<uint64_t>& v, int shift) { // BFV batching: two rows of n / 2 slots
+        HostVector<uint64_t> r(n);
+        const size_t h = n / 2;
+        for (size_t i = 0; i < h; i++) { r[i] = v[(i + shift) % h]; r[h + i] = v[h + (i + shift) % h]; }
+        return r;
+    };
+    auto decrypts_to = [&](Ciphertext<S>& c, const HostVector<uint64_t>& want) {
+        dec.decrypt(pr, c);
+        encoder.decode(slots, pr);
+        bool same = slots.size() == n;
+        for (size_t i = 0; same && i < n; i++) same = slots[i] == want[i];
+        return same;
+    };
+    Ciphertext<S> r1(ctx);
+    enc.encrypt(r1, pa);
+    r1.store_in_host();
+    op.rotate_rows_inplace(r1, gk, 1); // direct key; HOST input, default options
+    EXPECT(decrypts_to(r1, rotated(a, 1)), "rotate_rows_inplace on a HOST-stored ciphertext rotates by one");
+    r1.store_in_host();
+    op.rotate_rows_inplace(r1, gk, 3, ExecutionOptions().set_storage_type(storage_type::HOST)); // chain 2 + 1
+    EXPECT(!r1.is_on_device(), "key-chain rotation with storage_ = HOST leaves the result in host memory");
+    EXPECT(decrypts_to(r1, rotated(a, 4)), "chain rotation of a HOST-stored ciphertext (1, then 2 + 1) gives shift 4");
+    Ciphertext<S> r2(ctx), r3(ctx);
+    enc.encrypt(r2, pb);
+    op.rotate_rows(r2, r3, gk, 0, ExecutionOptions().set_storage_type(storage_type::HOST)); // zero shift: out = in
+    EXPECT(!r3.is_on_device() && r2.is_on_device(), "zero-shift result obeys storage_ = HOST, the input stays put");
+    EXPECT(decrypts_to(r3, b), "zero shift copies the ciphertext");
+    op.rotate_rows(r2, r3, gk, 3, ExecutionOptions().set_storage_type(storage_type::HOST));
+    EXPECT(!r3.is_on_device() && decrypts_to(r3, rotated(b, 3)), "chain rotation into a HOST-placed result");
+    // an operator that throws while a HOST operand is staged: the scope unwinds without copies or a second throw
+    r2.store_in_host();
+    bool thrown = false;
+    try { op.rotate_rows(r2, r3, gk, 4); } catch (const std::logic_error&) { thrown = true; } // no key for 4
+    EXPECT(thrown, "missing Galois key throws std::logic_error through the storage scope");
+    EXPECT(decrypts_to(r2, b), "the staged operand is intact after the exception");
 }
 
 int main()

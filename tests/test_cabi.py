@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "hegpu.h")).read()
+    # the drop-in boundary + the bench-only measurement seam (hegpu_bench.h, one entry)
+    src = open(os.path.join(ROOT, "include", "hegpu.h")).read() + open(os.path.join(ROOT, "include", "hegpu_bench.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hegpu_[A-Za-z0-9_]+)\s*\(", src)))
 

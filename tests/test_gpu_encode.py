@@ -150,9 +150,18 @@ def test_gaussian_integer_constant_ops(hg, oracle, parts):
         l = 3 - depth
         ct = synth_ct(primes, range(l), parts, n, 21 + depth)
         d = hg.to_device(ct)
-        for re, im in ((3.0, 0.0), (-7.49, 2.5), (1.5 * 2**40, -3.25 * 2**40), (2.0**70 + 12345.0, -(2.0**66)), (0.0, -1.0)):
+        # (the last two: beyond 2^128 -- a constant times the scale of an un-rescaled ciphertext -- where the residue is
+        # taken from mantissa and exponent; the reference's NTL conversion accepts any magnitude)
+        for re, im in ((3.0, 0.0), (-7.49, 2.5), (1.5 * 2**40, -3.25 * 2**40), (2.0**70 + 12345.0, -(2.0**66)), (0.0, -1.0),
+                       (1.37 * 2.0**130, -(2.0**200 + 2.0**160)), (-1.7976931348623157e308, 3.0 * 2.0**127)):
             for op in (0, 1):
                 got = hg.to_host(c.ckks_gaussian_integer_op(op, d, re, im, l, parts))
                 torch.cuda.synchronize()
                 want = o.ckks_gaussian_integer_op(op, ct, re, im, l, parts)
                 assert np.array_equal(got, want), (depth, re, im, op)
+    # the oracle's mantissa / exponent path against Python's big integers (limb 0 of a zero ciphertext + constant)
+    for v in (1.37 * 2.0**130, 2.0**200 + 2.0**160, 1.7976931348623157e308):
+        got = o.ckks_gaussian_integer_op(0, np.zeros(2 * n, dtype=np.uint64), v, 0.0, 1, 2)
+        assert int(got[0]) == int(v) % primes[0], v
+    with pytest.raises(hg.HEError):
+        c.ckks_gaussian_integer_op(0, d, float("inf"), 0.0, l, parts)

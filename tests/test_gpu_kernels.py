@@ -652,8 +652,8 @@ def test_kernel_fast_convertion_and_fast_floor(hg, oracle, torch):
 # ------------------------------------------------------------------ config C5 at a grid that fills the GPU
 def test_c5_tfhe_4096_gates(hg, oracle, torch):
     """Config C5 per-GPU share and more: 4096 concurrent NAND gates (pre-computation -> blind rotate ->
-    sample extraction -> key switching) with a real torus32 boot key (FP64 blind rotate).  A sample of the
-    gates is compared with the oracle bit for bit; the rest through twin consistency (inputs repeat with
+    sample extraction -> key switching) with a real torus32 boot key (FP64 blind rotate).  64 distinct input pairs;
+    16 gates are compared with the oracle bit for bit, the rest through twin consistency (inputs repeat with
     period `uniq`, so gate i must equal gate i mod uniq)."""
     t = hg.TfheContext()
     o = oracle.OracleTfhe()
@@ -665,7 +665,7 @@ def test_c5_tfhe_4096_gates(hg, oracle, torch):
     assert t.prepared_is_fp64(prepared)
     ks_a = rng.integers(-2**31, 2**31, t.int("kskey_a_elems"), dtype=np.int64).astype(np.int32)
     ks_b = rng.integers(-2**31, 2**31, t.int("kskey_b_elems"), dtype=np.int64).astype(np.int32)
-    shape, uniq, checked = 4096, 16, 4
+    shape, uniq, checked = 4096, 64, 16
     r32 = lambda k: rng.integers(-2**31, 2**31, k, dtype=np.int64).astype(np.int32)
     a1u, a2u, b1u, b2u = r32(uniq * 512), r32(uniq * 512), r32(uniq), r32(uniq)
     rep = shape // uniq
@@ -683,6 +683,44 @@ def test_c5_tfhe_4096_gates(hg, oracle, torch):
     assert np.array_equal(ga[:checked].reshape(-1), want_a) and np.array_equal(gb[:checked], want_b)
     assert np.array_equal(ga, np.tile(ga[:uniq], (rep, 1))), "a gate differs from its twin"
     assert np.array_equal(gb, np.tile(gb[:uniq], rep))
+
+
+def test_bfv_n14_multiply_at_the_bench_shape(hg, oracle, torch):
+    """North-star target 2 at the shape bench.py times: BFV N=2^14, default chain (Q=8, Bsk=9), 256 pairs in one call
+    (single-pass transforms of 4 x 17 x 256 limbs, the one-thread-per-coefficient BEHZ kernels).  Four distinct
+    pairs against the oracle, the other 252 against their twins."""
+    n, t, B, U = 1 << 14, 786433, 256, 4
+    c, o, primes = _bfv(hg, oracle, n, t)
+    Q = c.Q_size
+    a = [synth_ct(primes, range(Q), 2, n, 1 + 10 * u) for u in range(U)]
+    b = [synth_ct(primes, range(Q), 2, n, 2 + 10 * u) for u in range(U)]
+    d1 = hg.to_device(np.concatenate(a)).repeat(B // U)
+    d2 = hg.to_device(np.concatenate(b)).repeat(B // U)
+    out = torch.empty(B * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(d1, 2 * Q * n, d2, 2 * Q * n, out, 3 * Q * n, B, c.workspace(hg.OP_BFV_MULTIPLY, 0, B))
+    torch.cuda.synchronize()
+    v = out.view(B // U, U, 3 * Q * n)
+    assert bool(torch.equal(v, v[:1].expand(B // U, U, 3 * Q * n))), "an item differs from its twin"
+    got = hg.to_host(v[0])
+    for u in range(U):
+        assert np.array_equal(got[u], o.bfv_multiply(a[u], b[u])), u
+
+
+def test_bench_line_proves_its_own_work():
+    """`bench.py --steps 1 --warmup 0 --no-secondary` on this GPU: rc 0 and a line whose every timed output was
+    checked -- all 64 against the CPU oracle, 60 of them also against their twins."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-secondary"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["cpu_baseline"]["gpu_matches_cpu_bit_exact"] and line["cpu_baseline"]["kind"] == "port"
+    chk = line["checked_items"]
+    assert chk["oracle_equal"] and chk["twins_equal"] and chk["total"] == 64 and chk["oracle_compared"] >= 2
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["roofline"]["unit"] == "GB/s"
 
 
 @pytest.mark.parametrize("split", [0, 1], ids=["one_thread_per_coefficient", "rows_over_four_wavefronts"])

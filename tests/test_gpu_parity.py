@@ -188,14 +188,16 @@ def test_add_sub_neg(hg, oracle, torch):
     assert np.array_equal(hg.to_host(out), want)
 
 
+@pytest.mark.parametrize("batch", [1, 2], ids=["batch1", "batch2"])
 @pytest.mark.parametrize("depth", [0, 1, 3])
-def test_ckks_mul_relin_rescale(hg, oracle, torch, depth):
-    """Config C2: CKKS N=2^14, Q{50,40x7} P{50}: multiply -> relinearize -> rescale."""
+def test_ckks_mul_relin_rescale(hg, oracle, torch, depth, batch):
+    """Config C2: CKKS N=2^14, Q{50,40x7} P{50}: multiply -> relinearize -> rescale.  Batch 1 is the configuration
+    itself (the launch-size rules pick other kernels there than at batch 2: the unfused key switch, the copy riding on
+    the per-polynomial column pass)."""
     n = 16384
     c, o, primes = _ckks_pair(hg, oracle, n, [50] + [40] * 7, [50])
     Q, Qp = 8, 9
     l = Q - depth
-    batch = 2
     key = synth_key(primes, Q, Qp, n, 3)
     dkey = hg.to_device(key)
     ct1 = [synth_ct(primes, range(l), 2, n, 1 + 10 * b) for b in range(batch)]
