@@ -63,7 +63,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     with open(f"{out}/pmc_step_{c}_summary.csv", "w") as f:
         f.write("kernel,grid_size,dispatches,sum_KiB,avg_KiB_per_dispatch\n")
         for (k, g), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            if "rocclr" in k: continue   # input upload before the timed region
+            if "hegpu::" not in k: continue   # input synthesis / verification (torch kernels, copies) outside the timed region
             f.write(f'"{k}",{g},{n},{s},{s/n}\n')
             step[(c, k, g)] = s
 # HBM traffic per launch of the roofline kernel pair (largest forward-NTT dispatches):
@@ -119,7 +119,7 @@ def load_sq(cpath, tpath):
         print(cpath, "missing", e)
     res_ = {}
     for key, a in agg.items():
-        if "rocclr" in key or not a.get("GRBM_GUI_ACTIVE"): continue
+        if "hegpu::" not in key or not a.get("GRBM_GUI_ACTIVE"): continue
         n = a["dispatches"]
         res_[key] = {"dispatches": n, "valu_wave_insts": a["SQ_INSTS_VALU"] / n,
                      "valu_busy_cycles_per_simd": a["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / n,
