@@ -1318,23 +1318,27 @@ struct InvEpi {
     Mod md;
     u64 half, qP, hm, inv;
     int galois, n_power;
+    bool pre; // `last` already holds the value to subtract (several special primes, NttInvEpilogue::u)
 };
 __device__ __forceinline__ bool inv_epi_setup(const NttArgs& a, const PolySel& ps, InvEpi& e, bool& skip)
 {
     skip = false;
     if (!a.iepi.on) return false;
     const NttInvEpilogue& ep = a.iepi;
-    const int part = udiv16(ps.j, ep.mg_slots), limb = ps.j - part * (ep.limbs + 1);
-    if (limb == ep.limbs) { skip = true; return true; } // the P limb: transformed by its own launch
+    const int pc = ep.p_count ? ep.p_count : 1;
+    const int part = udiv16(ps.j, ep.mg_slots), limb = ps.j - part * (ep.limbs + pc);
+    if (limb >= ep.limbs) { skip = true; return true; } // the special limbs: transformed by their own launch
     const u64 item_in = a.out_item_stride * ps.item;
-    e.last = a.out + item_in + ((u64) (part * (ep.limbs + 1) + ep.limbs) << a.n_power);
     const u64 off = (u64) (part * ep.limbs + limb) << a.n_power;
+    e.pre = ep.u != nullptr;
+    e.last = e.pre ? ep.u + ep.u_item_stride * ps.item + off
+                   : a.out + item_in + ((u64) (part * (ep.limbs + 1) + ep.limbs) << a.n_power);
     e.ct = (ep.ct && part < ep.add_parts) ? ep.ct + ep.ct_item_stride * ps.item + off : nullptr;
     e.out = ep.out + ep.out_item_stride * ps.item + off;
     e.md = a.mods[ps.mod];
     e.half = ep.half;
     e.qP = a.mods[ep.p_mod].q;
-    e.hm = ep.half_mod[limb];
+    e.hm = e.pre ? 0 : ep.half_mod[limb];
     e.inv = ep.inv[limb];
     e.galois = ep.galois_elt;
     e.n_power = a.n_power;
@@ -1359,13 +1363,16 @@ __device__ __forceinline__ void inv_store(const InvEpi& epr, u64* __restrict__ p
 #pragma unroll
         for (int k = 0; k < CNT; k++) cv[k] = ep->ct[e0 + pos(k)];
     }
+    if (!ep->pre) { // (uniform condition around a whole loop)
 #pragma unroll
-    for (int k = 0; k < CNT; k++) {
-        u64 l = add_mod(lv[k], ep->half, ep->qP);
-        l = reduce64(l, ep->md);
-        l = sub_mod(l, ep->hm, ep->md.q);
-        r[k] = mul_barrett(sub_mod(o[k], l, ep->md.q), ep->inv, ep->md);
+        for (int k = 0; k < CNT; k++) {
+            u64 l = add_mod(lv[k], ep->half, ep->qP);
+            l = reduce64(l, ep->md);
+            lv[k] = sub_mod(l, ep->hm, ep->md.q);
+        }
     }
+#pragma unroll
+    for (int k = 0; k < CNT; k++) r[k] = mul_barrett(sub_mod(o[k], lv[k], ep->md.q), ep->inv, ep->md);
     if (ep->ct) {
 #pragma unroll
         for (int k = 0; k < CNT; k++) r[k] = add_mod(cv[k], r[k], ep->md.q);
@@ -1459,7 +1466,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const PolySel ps = select_poly(a, blockIdx.y);
-    if (a.iepi.on && ps.j - udiv16(ps.j, a.iepi.mg_slots) * (a.iepi.limbs + 1) == a.iepi.limbs) return; // P limb: own launch
+    if (a.iepi.on && ps.j - udiv16(ps.j, a.iepi.mg_slots) * (a.iepi.limbs + (a.iepi.p_count ? a.iepi.p_count : 1)) >= a.iepi.limbs)
+        return; // special limbs: own launch
     const Mod md = a.mods[ps.mod];
     const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
     u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
@@ -1730,7 +1738,7 @@ static void fill_magics(NttArgs& g)
     g.mg_polys_per_item = magic16(g.polys_per_item);
     g.mg_decomp_mods = magic16(g.decomp_mods);
     g.epi.mg_limbs = magic16(g.epi.limbs);
-    g.iepi.mg_slots = magic16(g.iepi.limbs + 1);
+    g.iepi.mg_slots = magic16(g.iepi.limbs + (g.iepi.p_count ? g.iepi.p_count : 1));
 }
 
 bool ntt_decomp_uses_multi(const NttArgs& a, int batch)
@@ -1805,7 +1813,9 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
     if (a.src_inv && (!a.decomp_mods || batch > 65535 || !ntt_decomp_uses_multi(a, batch))) return hipErrorInvalidValue;
     if (a.copy_src && (!a.decomp_mods || inverse)) return hipErrorInvalidValue;
-    if (a.iepi.on && (!inverse || a.poly_order || a.polys_per_item != 2 * (a.iepi.limbs + 1) || batch % a.polys_per_item))
+    if (a.iepi.on && (!inverse || a.poly_order || batch % a.polys_per_item ||
+                      a.polys_per_item != 2 * (a.iepi.limbs + (a.iepi.p_count ? a.iepi.p_count : 1)) ||
+                      ((a.iepi.p_count > 1) != (a.iepi.u != nullptr))))
         return hipErrorInvalidValue;
     if (batch > 65535) {
         // gridDim.y limit: split (poly_order / mod_order semantics need the
@@ -1832,6 +1842,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
                 if (a.iepi.on) {
                     if (a.iepi.ct) c.iepi.ct = a.iepi.ct + items_done * a.iepi.ct_item_stride;
                     c.iepi.out = a.iepi.out + items_done * a.iepi.out_item_stride;
+                    if (a.iepi.u) c.iepi.u = a.iepi.u + items_done * a.iepi.u_item_stride;
                 }
                 if (a.copy_src) {
                     c.copy_src = a.copy_src + items_done * a.copy_src_item_stride;

@@ -54,6 +54,13 @@ struct NttInvEpilogue {
     u64 ct_item_stride;
     u64* out;          // [2][limbs][N] per item
     u64 out_item_stride;
+    // Several special primes (key switching method II, divide_round_lastq_extended*_kernel, switchkey.cu:480-611):
+    // an item is [2][limbs + p_count][N], the p_count special slots of a part are skipped, and the value subtracted
+    // from x is not formed from the P limb but read from `u` ([2][limbs][N] per item, coefficient domain:
+    // rns_moddown_multi_stage_one), v = (x - u) * inv[j] with inv = the product of the special primes' inverses.
+    int p_count;       // 0 means 1
+    const u64* u;      // nullptr: one special prime, the P limb is read from the item itself
+    u64 u_item_stride;
 };
 
 struct NttArgs {

@@ -731,6 +731,41 @@ hipError_t op_ckks_rotate_hoisted(const Context& c, const u64* ct, u64 cs, u64* 
     return hipSuccess;
 }
 
+// BFV key switching with several special primes, tail: acc [2][Q'][N] (NTT domain) -> out [2][Q][N] = moddown(acc) + ct
+// (parts below add_parts) [-> Galois permutation].  The reference inverse-transforms all 2 Q' limbs and runs
+// divide_round_lastq_extended_kernel / divide_round_lastq_permute_bfv_kernel (bfv/operator.cu:657-667, 948-963).  Here
+// the 2 P special limbs are inverse-transformed first, one kernel forms u = sum_i lh_i G_i - C per limb of Q from them
+// (the chain among the special limbs run once per coefficient, context.cpp m2_md_*), and the division (x - u) * W0,
+// the added ciphertext and the permutation are the epilogue of the Q limbs' inverse transform (NttInvEpilogue::u):
+// the same exact integer function, the coefficient-domain accumulator is never written or read back.
+// scratch: [2][Q][N] per item (`per` apart).
+static hipError_t bfv_intt_moddown_multi(const Context& c, u64* acc, u64* scratch, u64 per, const u64* ct, u64 cs,
+                                         int add_parts, u64* out, u64 so, int galois_elt, int batch, hipStream_t st)
+{
+    const u64 n = c.n;
+    const int Q = c.Q_size, Qp = c.Qp_size, P = c.P_size;
+    for (int part = 0; part < 2; part++) {
+        NttArgs a = c.ntt_args(0);
+        a.in = a.out = acc + (u64) (part * Qp + Q) * n;
+        a.mod_count = P; a.mod_offset = Q; a.polys_per_item = P;
+        a.in_item_stride = a.out_item_stride = per;
+        TRY(ntt_launch(a, P * batch, true, st));
+    }
+    TRY(rns_moddown_multi_stage_one(acc, per, scratch, per, c.plan_qp.mods, c.d64("half"), c.d64("half_mod"),
+                                    c.d64("last_q_modinv"), c.d64("m2_md_G"), c.d64("m2_md_C"), c.n_power, Qp, Q, Qp, Q, P,
+                                    batch, st));
+    NttArgs a = c.ntt_args(0);
+    a.in = a.out = acc; a.mod_count = Qp; a.polys_per_item = 2 * Qp;
+    a.in_item_stride = a.out_item_stride = per;
+    a.iepi.on = 1; a.iepi.limbs = Q; a.iepi.p_count = P; a.iepi.add_parts = add_parts; a.iepi.p_mod = Q;
+    a.iepi.galois_elt = galois_elt;
+    a.iepi.inv = c.d64("m2_md_W0");
+    a.iepi.u = scratch; a.iepi.u_item_stride = per;
+    a.iepi.ct = ct; a.iepi.ct_item_stride = cs;
+    a.iepi.out = out; a.iepi.out_item_stride = so;
+    return ntt_launch(a, 2 * Qp * batch, true, st);
+}
+
 // reference bfv/operator.cu:585-672
 hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* key, int batch, u64* ws,
                                  hipStream_t st)
@@ -749,6 +784,8 @@ hipError_t op_bfv_relinearize_II(const Context& c, u64* ct, u64 cs, const u64* k
     a.in = temp1; a.out = temp1; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp2, per, d, Qp, Qp, 0, nullptr, 0, batch, st));             // :619-650
+    if (c.fused_moddown) // temp1 (the digits) is free again: scratch of the mod-down
+        return bfv_intt_moddown_multi(c, temp2, temp1, per, ct, cs, 2, ct, cs, 0, batch, st);        // :657-667 in one transform
     a.in = temp2; a.out = temp2; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));                                          // :657
     return rns_moddown_extended(temp2, per, ct, cs, ct, cs, mods, c.d64("half"), c.d64("half_mod"),
@@ -773,6 +810,8 @@ hipError_t op_bfv_apply_galois_II(const Context& c, const u64* ct, u64 cs, u64* 
     a.in = temp2; a.out = temp2; a.mod_count = Qp; a.polys_per_item = d * Qp;
     a.in_item_stride = a.out_item_stride = per;
     TRY(keyswitch_ntt_mac(c, a, key, temp3, per, d, Qp, Qp, 0, nullptr, 0, batch, st));
+    if (c.fused_moddown) // temp2 (the digits) is free again; c0 added to part 0, the permutation as the scatter of the store
+        return bfv_intt_moddown_multi(c, temp3, temp2, per, ct, cs, 1, out, so, galois_elt, batch, st);
     a.in = temp3; a.out = temp3; a.polys_per_item = 2 * Qp;
     TRY(ntt_launch(a, 2 * Qp * batch, true, st));
     return rns_moddown_permute(temp3, per, ct, cs, out, so, mods, c.d64("half"), c.d64("half_mod"),

@@ -382,14 +382,24 @@ def test_ckks_method_II(hg, oracle, torch, depth, p_bits, reference_order, monke
         assert np.array_equal(got[b], o.ckks_apply_galois_II(ct1[b], key, g, depth)), "method II rotate"
 
 
-def test_bfv_method_II(hg, oracle, torch):
-    n, t = 4096, 1032193
-    c = hg.Context.from_bit_sizes(hg.BFV, n, [36, 36, 36], [37, 37], plain_modulus=t, sec=hg.SEC_NONE)
+@pytest.mark.parametrize("shape", [(4096, [36, 36, 36], [37, 37], 1), (4096, [36, 36, 36], [37, 37], 0),
+                                   (16384, [50, 59, 45, 50, 50], [59, 50, 60], 1), (32768, [58] * 6, [59, 59], 1)],
+                         ids=["n12_fused", "n12_reference_order", "n14_three_special_primes", "n15_two_passes"])
+def test_bfv_method_II(hg, oracle, torch, shape):
+    """BFV key switching with several special primes (relinearize_external_product_method2_inplace / apply_galois
+    method II, bfv/operator.cu:585-672, 866-973).  fused_moddown = 1: the mod-down by the special primes is the epilogue
+    of the inverse transform of the Q limbs (NttInvEpilogue::u; single pass and two passes, FP64 and integer moduli);
+    = 0: the reference's order with divide_round_lastq_extended / _permute kernels of their own."""
+    n, log_q, log_p, fused = shape
+    t = 1032193
+    from helpers import backend_switches
+    with backend_switches(HEGPU_FUSED_MODDOWN=fused):
+        c = hg.Context.from_bit_sizes(hg.BFV, n, log_q, log_p, plain_modulus=t, sec=hg.SEC_NONE)
     primes = [int(x) for x in c.table("modulus")]
-    o = oracle.OracleContext(oracle.BFV, 12, primes, 3, 2, t)
+    Q, Qp, batch = len(log_q), len(log_q) + len(log_p), 2
+    o = oracle.OracleContext(oracle.BFV, c.n_power, primes, Q, len(log_p), t)
     c.upload()
-    Q, Qp, batch = 3, 5, 2
-    key = synth_key(primes, 2, Qp, n, 3)
+    key = synth_key(primes, -(-Q // 2), Qp, n, 3)
     ct1 = [synth_ct(primes, range(Q), 2, n, 1 + 10 * b) for b in range(batch)]
     ct2 = [synth_ct(primes, range(Q), 2, n, 2 + 10 * b) for b in range(batch)]
     d1, d2 = hg.to_device(np.concatenate(ct1)), hg.to_device(np.concatenate(ct2))
