@@ -348,6 +348,39 @@ void Context::build_host()
             vec msk_q;
             for (int i = 0; i < Q; i++) msk_q.push_back(msk % primes[i]);
             host["behz_msk_mod_q"] = msk_q;
+            // whole rows with their trailing factors multiplied in (rns.hpp BehzDev::fc_matrix ...): a row of either base
+            // conversion becomes one lazy 128-bit sum and one reduction; every value the kernels store is the canonical
+            // residue of the same integer expression as in the reference (multiplication.cu:37-90, 160-205)
+            // ... and every such table carries a factor 2^64 (mod its modulus): the kernels bring a lazy sum down with a
+            // Montgomery reduction (modarith.cuh redc128), which divides by 2^64
+            auto R = [](u64 m) { return (u64) ((((unsigned __int128) 1) << 64) % m); };
+            vec fc_m, fc_c1, ff_m, ff_tc, ff_qm, ff_mskm, ff_pB, ff_npB;
+            for (int i = 0; i < bsk; i++) {
+                const u64 p = B[i], r = R(p);
+                const u64 c = i < bsk - 1 ? ff_mid[i] : inv_prod_q_B[i];
+                for (int j = 0; j < Q; j++) {
+                    const u64 m = m_q_Bsk[(size_t) i * Q + j];
+                    fc_m.push_back(mul_mod(mul_mod(m, inv_mt_B[i], p), r, p));
+                    ff_m.push_back(mul_mod((p - mul_mod(m, c, p)) % p, r, p));
+                }
+                fc_c1.push_back(mul_mod(mul_mod(prod_q_B[i], inv_mt_B[i], p), r, p));
+                ff_tc.push_back(mul_mod(mul_mod(plain_modulus % p, c, p), r, p));
+            }
+            for (int k = 0; k < Q; k++) {
+                const u64 q = primes[k], r = R(q);
+                for (int i = 0; i < bsk - 1; i++) ff_qm.push_back(mul_mod(m_B_q[(size_t) k * (bsk - 1) + i], r, q));
+                ff_pB.push_back(mul_mod(prod_B_q[k], r, q));
+                ff_npB.push_back(mul_mod(q - prod_B_q[k], r, q));
+            }
+            for (int i = 0; i < bsk - 1; i++) ff_mskm.push_back(mul_mod(m_msk[i], R(msk), msk));
+            host["behz_fc_matrix"] = fc_m;
+            host["behz_fc_c1"] = fc_c1;
+            host["behz_ff_matrix"] = ff_m;
+            host["behz_ff_tc"] = ff_tc;
+            host["behz_ff_q_matrix"] = ff_qm;
+            host["behz_ff_msk_matrix"] = ff_mskm;
+            host["behz_ff_prod_B"] = ff_pB;
+            host["behz_ff_neg_prod_B"] = ff_npB;
         }
 
         // merged base [q | Bsk] with its NTT tables (bfv/context.cu:1210-1241)
@@ -596,6 +629,14 @@ hipError_t Context::upload()
                                        "behz_t_inv_punct",
                                        "behz_invq_inv_punct_B",
                                        "behz_msk_mod_q",
+                                       "behz_fc_matrix",
+                                       "behz_fc_c1",
+                                       "behz_ff_matrix",
+                                       "behz_ff_tc",
+                                       "behz_ff_q_matrix",
+                                       "behz_ff_msk_matrix",
+                                       "behz_ff_prod_B",
+                                       "behz_ff_neg_prod_B",
                                        "prod_B_mod_q",
                                        "Mi",
                                        "Mi_inv",
@@ -655,6 +696,14 @@ hipError_t Context::upload()
         behz.t_inv_punct = d64("behz_t_inv_punct");
         behz.invq_inv_punct_B = d64("behz_invq_inv_punct_B");
         behz.msk_mod_q = d64("behz_msk_mod_q");
+        behz.fc_matrix = d64("behz_fc_matrix");
+        behz.fc_c1 = d64("behz_fc_c1");
+        behz.ff_matrix = d64("behz_ff_matrix");
+        behz.ff_tc = d64("behz_ff_tc");
+        behz.ff_q_matrix = d64("behz_ff_q_matrix");
+        behz.ff_msk_matrix = d64("behz_ff_msk_matrix");
+        behz.ff_prod_B = d64("behz_ff_prod_B");
+        behz.ff_neg_prod_B = d64("behz_ff_neg_prod_B");
         behz.ibase_size = Q_size;
         behz.obase_size = bsk_size;
         behz.split = behz_split;

@@ -207,6 +207,23 @@ __device__ __forceinline__ void acc_mad(u64& hi, u64& lo, u64 a, u64 b)
 // partial products of eight terms at a time are summed by weight instead -- a0*b1, a1*b0 < 2^61 and
 // a1*b1 < 2^58 cannot overflow 64 bits in eight terms, so each is one v_mad_u64_u32 with a 64-bit addend; only
 // a0*b0 needs a carry count -- and the columns are put together once per eight terms: 6 instructions per term.
+// One term in five instructions: every partial product accumulates straight into its 64-bit column (v_mad_u64_u32
+// takes the column as its addend), a0*b0 hands its carry to the count c00.  hipcc's own code for the same statements
+// spends ~15 (a 64-bit add, a 64-bit compare and a select for the carry, moves that rebuild operands in VGPRs); the
+// base-conversion kernels built on this are bound by nothing but their instruction count (vector ALU > 100 % busy by
+// the 4-cycles-per-instruction measure).  b0 / b1: wave-uniform table entries (scalar registers).
+__device__ __forceinline__ void col_mad_uniform(u64& s00, u64& s01, u64& s10, u64& s11, u32& c00, u32 a0, u32 a1, u32 b0,
+                                                u32 b1)
+{
+    asm("v_mad_u64_u32 %0, vcc, %5, %7, %0\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %6, %8, %3"
+        : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11), "+v"(c00)
+        : "v"(a0), "v"(a1), "s"(b0), "s"(b1)
+        : "vcc");
+}
 template <int M>
 __device__ __forceinline__ void dot128(const u64 (&v)[M], const u64* __restrict__ row, int valid, u64& hi, u64& lo)
 {
@@ -218,13 +235,7 @@ __device__ __forceinline__ void dot128(const u64 (&v)[M], const u64* __restrict_
 #pragma unroll
         for (int j = j0; j < j0 + 8 && j < M; j++) {
             const u64 b = row[j < valid ? j : 0];
-            const u32 a0 = (u32) v[j], a1 = (u32) (v[j] >> 32), b0 = (u32) b, b1 = (u32) (b >> 32);
-            const u64 p = (u64) a0 * b0;
-            s00 += p;
-            c00 += s00 < p;
-            s01 += (u64) a0 * b1;
-            s10 += (u64) a1 * b0;
-            s11 += (u64) a1 * b1;
+            col_mad_uniform(s00, s01, s10, s11, c00, (u32) v[j], (u32) (v[j] >> 32), (u32) b, (u32) (b >> 32));
         }
         const u64 mid = s01 + s10;
         const u64 cm = mid < s01;
@@ -964,6 +975,15 @@ hipError_t rns_copy_diag(const u64* in, u64 in_stride, u64* out, u64 out_stride,
     return hipGetLastError();
 }
 
+// hi:lo += a * b (a, b < 2^61: the running sum of a few dozen such products stays below 2^128)
+__device__ __forceinline__ void acc128(u64& hi, u64& lo, u64 a, u64 b)
+{
+    u64 h, l;
+    mul64wide(a, b, h, l);
+    lo += l;
+    hi += h + (lo < l);
+}
+
 // ---------------------------------------------------------------- BFV BEHZ kernels
 // One thread per coefficient; the per-coefficient vectors (ibase / Bsk
 // residues) must stay in registers, so the kernels are instantiated for a
@@ -1013,21 +1033,21 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_convertion(const u64* __re
     const u64 mt = b.m_tilde.q;
     u64 r_mt = (u64) (u32) (acc_mt32 * (u32) b.inv_prod_q_mod_m_tilde);
     r_mt = mt - r_mt;
+    // Row i of the conversion into Bsk with its trailing factors folded into the constants (BehzDev::fc_matrix):
+    //   out_i = ((sum_j temp_j M_ij) + t3_i prod_q_i) * inv_m_tilde_i = sum_j temp_j M'_ij + t3_i c1_i   (mod Bsk_i),
+    // t3_i = r_mt, or r_mt - m_tilde (as Bsk_i - m_tilde + r_mt) when r_mt is in the upper half: one lazy 128-bit
+    // sum and ONE reduction per row instead of a reduction and two Barrett products (the stored value is the
+    // canonical residue of the same integer either way, multiplication.cu:66-90).
+    const bool mt_neg = r_mt >= (mt >> 1);
 #pragma unroll 1
     for (int i = row0; i < ob; i += row_step) {
         const Mod mo = b.obase[i];
-        const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
+        const u64* __restrict__ row = b.fc_matrix + i * ib;
         u64 hi, lo;
         dot128(temp, row, ib, hi, lo);
-        u64 t2 = reduce128(hi, lo, mo);
-        u64 t3 = r_mt;
-        if (t3 >= (mt >> 1)) {
-            t3 = mo.q - mt;
-            t3 = add_mod(t3, r_mt, mo.q);
-        }
-        t3 = mul_barrett(t3, b.prod_q_mod_Bsk[i], mo);
-        t3 = add_mod(t2, t3, mo.q);
-        po[(u64) (i + ib) << n_power] = mul_barrett(t3, b.inv_m_tilde_mod_Bsk[i], mo);
+        const u64 t3 = mt_neg ? mo.q - mt + r_mt : r_mt; // < 2^61: a valid factor of the lazy sum
+        acc128(hi, lo, t3, b.fc_c1[i]);
+        po[(u64) (i + ib) << n_power] = redc128(hi, lo, mo); // the tables carry the 2^64
     }
 }
 
@@ -1091,7 +1111,6 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     __shared__ u64 meet[SPLIT ? (MAXB + 1) * 64 : 1];
     const int idy = blockIdx.y;
     const int ib = b.ibase_size, ob = b.obase_size;
-    const u64 t = b.plain.q;
     const u64* pq = in + si * blockIdx.z + idx + ((u64) (idy * (ib + ob)) << n_power);
     const u64* pB = pq + ((u64) ib << n_power);
     u64 reg_q[MAXB], temp3[MAXB];
@@ -1101,23 +1120,22 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
         const u64 v = mul_barrett(pq[(u64) ii << n_power], b.t_inv_punct[ii], b.ibase[ii]); // x * t * (q/q_i)^-1
         reg_q[i] = i < ib ? v : 0;
     }
-    // rows 0 .. ob-2: the moduli of B (-> temp3), row ob-1: m_sk.  (The two forms are written out: sharing
-    // the row computation through a lambda cost 30 registers.)
+    // rows 0 .. ob-2: the moduli of B (-> temp3), row ob-1: m_sk.  (The forms are written out: sharing
+    // the row computation through a lambda cost 30 registers.)  A row with its trailing factors folded into the
+    // constants (BehzDev::ff_matrix, ff_tc):
+    //   v_i = (x_Bsk_i t - sum_j reg_q_j M_ij) c_i = x_Bsk_i (t c_i) + sum_j reg_q_j (-M_ij c_i)   (mod Bsk_i)
+    // -- one lazy 128-bit sum and one reduction instead of a reduction and two Barrett products; the canonical residue
+    // of the same integer as the reference's chain (multiplication.cu:160-205).
     u64 reg_Bsk_last = 0;
     if constexpr (SPLIT) {
         const int lane = threadIdx.x & 63;
 #pragma unroll 1
         for (int i = row0; i < ob; i += row_step) {
             const Mod mo = b.obase[i];
-            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
-            const u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
             u64 hi, lo;
-            dot128(reg_q, row, ib, hi, lo);
-            const u64 tmp = reduce128(hi, lo, mo);
-            u64 t2 = sub_mod(mo.q, tmp, mo.q);
-            t2 = add_mod(t2, rb, mo.q);
-            const bool last = i == ob - 1;
-            meet[i * 64 + lane] = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[i] : b.invq_inv_punct_B[i], mo);
+            dot128(reg_q, b.ff_matrix + i * ib, ib, hi, lo);
+            acc128(hi, lo, pB[(u64) i << n_power], b.ff_tc[i]);
+            meet[i * 64 + lane] = redc128(hi, lo, mo);
         }
         __syncthreads();
 #pragma unroll
@@ -1131,14 +1149,10 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
             const int ii = i < ob - 1 ? i : ob - 1;
             const bool last = i >= ob - 1;
             const Mod mo = b.obase[ii];
-            const u64* __restrict__ row = b.base_change_matrix_Bsk + ii * ib;
-            const u64 rb = mul_barrett(pB[(u64) ii << n_power], t, mo);
             u64 hi, lo;
-            dot128(reg_q, row, ib, hi, lo);
-            const u64 tmp = reduce128(hi, lo, mo);
-            u64 t2 = sub_mod(mo.q, tmp, mo.q);
-            t2 = add_mod(t2, rb, mo.q);
-            const u64 v = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[ii] : b.invq_inv_punct_B[ii], mo); // * q^-1 [* (B/b_i)^-1]
+            dot128(reg_q, b.ff_matrix + ii * ib, ib, hi, lo);
+            acc128(hi, lo, pB[(u64) ii << n_power], b.ff_tc[ii]);
+            const u64 v = redc128(hi, lo, mo); // (x_Bsk t - sum) * q^-1 [* (B/b_i)^-1]
             if (i < MAXB) temp3[i] = last ? 0 : v;
             reg_Bsk_last = last ? v : reg_Bsk_last;
         }
@@ -1150,15 +1164,11 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
 #pragma unroll 1
         for (int i = 0; i < ob; i++) {
             const Mod mo = b.obase[i];
-            const u64* __restrict__ row = b.base_change_matrix_Bsk + i * ib;
-            const u64 rb = mul_barrett(pB[(u64) i << n_power], t, mo);
             u64 hi, lo;
-            dot128(reg_q, row, ib, hi, lo);
-            const u64 tmp = reduce128(hi, lo, mo);
-            u64 t2 = sub_mod(mo.q, tmp, mo.q);
-            t2 = add_mod(t2, rb, mo.q);
+            dot128(reg_q, b.ff_matrix + i * ib, ib, hi, lo);
+            acc128(hi, lo, pB[(u64) i << n_power], b.ff_tc[i]);
             const bool last = i == ob - 1;
-            const u64 v = mul_barrett(t2, last ? b.inv_prod_q_mod_Bsk[i] : b.invq_inv_punct_B[i], mo);
+            const u64 v = redc128(hi, lo, mo);
             if (last) reg_Bsk_last = v;
 #pragma unroll
             for (int k = 0; k < MAXB; k++) temp3[k] = (!last && k == i) ? v : temp3[k];
@@ -1166,8 +1176,8 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
     }
     const Mod msk = b.obase[ob - 1];
     u64 hi, lo;
-    dot128(temp3, b.base_change_matrix_msk, ob - 1, hi, lo);
-    u64 t4sk = reduce128(hi, lo, msk);
+    dot128(temp3, b.ff_msk_matrix, ob - 1, hi, lo);
+    u64 t4sk = redc128(hi, lo, msk);
     u64 alpha_sk = sub_mod(msk.q, reg_Bsk_last, msk.q);
     alpha_sk = add_mod(alpha_sk, t4sk, msk.q);
     alpha_sk = mul_barrett(alpha_sk, b.inv_prod_B_mod_m_sk, msk);
@@ -1176,21 +1186,14 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
 #pragma unroll 1
     for (int i = row0; i < ib; i += row_step) {
         const Mod mi = b.ibase[i];
-        const u64* __restrict__ row = b.base_change_matrix_q + i * (ob - 1);
+        const u64* __restrict__ row = b.ff_q_matrix + i * (ob - 1);
         u64 h2, l2;
         dot128(temp3, row, ob - 1, h2, l2); // un-reduced: 64 terms below 2^122 fit 128 bits
-        u64 t4 = reduce128(h2, l2, mi);
-        u64 obase_ = b.msk_mod_q[i];
-        u64 alpha_ = reduce64(alpha_sk, mi);
-        u64 inner;
-        if (neg) {
-            inner = sub_mod(obase_, alpha_, mi.q);
-            inner = mul_barrett(inner, b.prod_B_mod_q[i], mi);
-        } else {
-            inner = sub_mod(mi.q, b.prod_B_mod_q[i], mi.q);
-            inner = mul_barrett(inner, alpha_, mi);
-        }
-        po[(u64) i << n_power] = add_mod(t4, inner, mi.q);
+        // + the m_sk correction as one more term of the same lazy sum (multiplication.cu:243-262): alpha_sk is in
+        // the upper half: (m_sk - alpha_sk) * prod_B, else alpha_sk * (q_i - prod_B) -- both factors below 2^61, no
+        // reduction of alpha_sk into q_i first
+        acc128(h2, l2, neg ? msk.q - alpha_sk : alpha_sk, neg ? b.ff_prod_B[i] : b.ff_neg_prod_B[i]);
+        po[(u64) i << n_power] = redc128(h2, l2, mi);
     }
 }
 

@@ -123,6 +123,21 @@ struct BehzDev {
     const u64* t_inv_punct;
     const u64* invq_inv_punct_B;
     const u64* msk_mod_q; // m_sk mod q_i
+    // rows with their trailing constant factors multiplied in (context.cpp), so that a row is ONE lazy 128-bit sum and
+    // one reduction: fc_matrix[i][j] = base_change_matrix_Bsk[i][j] * inv_m_tilde_mod_Bsk[i], fc_c1[i] = prod_q_mod_Bsk[i]
+    // * inv_m_tilde_mod_Bsk[i]  (mod Bsk_i);  ff_matrix[i][j] = -base_change_matrix_Bsk[i][j] * c_i, ff_tc[i] = t * c_i
+    // with c_i = inv_prod_q_mod_Bsk[i] [* inv_punctured_prod_mod_B_array[i] for i < |B|]  (mod Bsk_i)
+    // Every one of these also carries the factor 2^64 (mod its modulus) that the Montgomery reduction of the lazy
+    // sum (redc128) divides out: ff_q_matrix = base_change_matrix_q, ff_msk_matrix = base_change_matrix_msk,
+    // ff_prod_B / ff_neg_prod_B = prod_B_mod_q[i] / q_i - prod_B_mod_q[i], each times 2^64.
+    const u64* fc_matrix;
+    const u64* fc_c1;
+    const u64* ff_matrix;
+    const u64* ff_tc;
+    const u64* ff_q_matrix;
+    const u64* ff_msk_matrix;
+    const u64* ff_prod_B;
+    const u64* ff_neg_prod_B;
     int ibase_size, obase_size;
     int split; // rows of the base conversions over four wavefronts: 1 / 0 forced, -1 by launch size (option behz_split)
 };

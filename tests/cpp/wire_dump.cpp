@@ -169,23 +169,24 @@ template <Scheme S> static void objects(const std::string& tag, HEContext<S> ctx
         entry(tag + "_plaintext", "plaintext", join({kv("plain_size", (long long) p.size()), kv("depth", p.depth()), kd("scale", p.scale()),
                                                       kv("in_ntt_domain", 1), kv("encoding", (int) p.encoding_type())}));
         enc.encrypt(c, p);
+        auto words = [&](Ciphertext<S>& x) { return (size_t) x.size() * (x.coeff_modulus_count() - x.depth()) * x.ring_size(); };
         auto cipher_fields = [&](Ciphertext<S>& x) {
             return join({kv("ring_size", x.ring_size()), kv("coeff_modulus_count", x.coeff_modulus_count()), kv("cipher_size", x.size()),
                          kv("depth", x.depth()), kd("scale", x.scale()), kv("in_ntt_domain", x.in_ntt_domain()),
                          kv("encoding", (int) x.encoding_type()), kv("rescale_required", x.rescale_required()),
-                         kv("relinearization_required", x.relinearization_required()), kv("size", (long long) x.memory_size())});
+                         kv("relinearization_required", x.relinearization_required()), kv("size", (long long) words(x))});
         };
         blob(tag + "_ciphertext", c);
-        payload(tag + "_ciphertext", c.data(), c.memory_size());
+        payload(tag + "_ciphertext", c.data(), words(c));
         entry(tag + "_ciphertext", "ciphertext", cipher_fields(c));
         op.multiply(c, c, c3);
         blob(tag + "_ciphertext_product", c3); // three parts, un-rescaled
-        payload(tag + "_ciphertext_product", c3.data(), c3.memory_size());
+        payload(tag + "_ciphertext_product", c3.data(), words(c3));
         entry(tag + "_ciphertext_product", "ciphertext", cipher_fields(c3));
         op.relinearize_inplace(c3, rk);
         op.rescale_inplace(c3);
         blob(tag + "_ciphertext_depth1", c3);
-        payload(tag + "_ciphertext_depth1", c3.data(), c3.memory_size());
+        payload(tag + "_ciphertext_depth1", c3.data(), words(c3)); // the buffer itself stays three parts x four limbs long
         entry(tag + "_ciphertext_depth1", "ciphertext", cipher_fields(c3));
     }
 }
