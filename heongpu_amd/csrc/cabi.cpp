@@ -255,7 +255,7 @@ int hegpu_context_clone(const hegpu_context* src, hegpu_context** out)
         c.fused_row_mac = s.fused_row_mac; c.fused_moddown = s.fused_moddown; c.col_multi = s.col_multi;
         c.single_pass = s.single_pass; c.ntt_galois = s.ntt_galois; c.galois_scatter = s.galois_scatter;
         c.digit_split = s.digit_split; c.copy_along = s.copy_along; c.fuse_inverse = s.fuse_inverse;
-        c.fp_ntt = s.fp_ntt; c.behz_split = s.behz_split;
+        c.fp_ntt = s.fp_ntt; c.behz_split = s.behz_split; c.fused_tensor = s.fused_tensor;
         *out = h;
         return 0;
     });

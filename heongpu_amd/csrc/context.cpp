@@ -722,7 +722,7 @@ const OptDesc kOptions[] = {
     {"ntt_galois", "HEGPU_NTT_GALOIS", 0, 1},        {"galois_scatter", "HEGPU_GALOIS_SCATTER", 0, 1},
     {"fuse_inverse", "HEGPU_FUSE_INVERSE", 0, 1},    {"copy_along", "HEGPU_COPY_ALONG", 0, 1},
     {"digit_split", "HEGPU_DIGIT_SPLIT", -1, 4},     {"fp_ntt", "HEGPU_FP_NTT", 0, 1},
-    {"behz_split", "HEGPU_BEHZ_SPLIT", -1, 1},
+    {"behz_split", "HEGPU_BEHZ_SPLIT", -1, 1},       {"fused_tensor", "HEGPU_FUSED_TENSOR", 0, 1},
 };
 } // namespace
 
@@ -746,6 +746,7 @@ int Context::set_option(const char* name, int value)
     else if (nm == "galois_scatter") galois_scatter = value != 0;
     else if (nm == "fuse_inverse") fuse_inverse = value != 0;
     else if (nm == "copy_along") copy_along = value != 0;
+    else if (nm == "fused_tensor") fused_tensor = value != 0;
     else if (nm == "digit_split") {
         if (value == 1 || value == 3) return 2;
         digit_split = value;
@@ -769,6 +770,7 @@ int Context::get_option(const char* name, int* value) const
     else if (nm == "galois_scatter") *value = galois_scatter;
     else if (nm == "fuse_inverse") *value = fuse_inverse;
     else if (nm == "copy_along") *value = copy_along;
+    else if (nm == "fused_tensor") *value = fused_tensor;
     else if (nm == "digit_split") *value = digit_split;
     else if (nm == "behz_split") *value = behz_split;
     else return 1;

@@ -65,6 +65,7 @@ struct Context {
     int digit_split = -1;      // HEGPU_DIGIT_SPLIT: 0 never, 2 / 4 always that many workgroups per fused key-switch unit, -1 by launch size
     bool copy_along = true;    // HEGPU_COPY_ALONG=0: the rescale's copy of the kept limbs always has its own launch
     bool fuse_inverse = true;  // HEGPU_FUSE_INVERSE=0: the INTT feeding a decomposing launch runs on its own
+    bool fused_tensor = true;  // BFV multiply: the tensor product as the load transform of the inverse transform (0: its own kernel)
     bool fp_ntt = true;        // fp_ntt = 0: every modulus on the integer butterflies (read when the tables are built)
     int behz_split = -1;       // BFV BEHZ kernels: rows over four wavefronts (1), one thread per coefficient (0), by launch size (-1)
     // The fields above are options: hegpu_context_set_option (include/hegpu.h); the environment variables named in

@@ -1271,17 +1271,60 @@ struct ArFp {
 // Row stages of one 16-row tile.  src: 16 x 256 coefficients in global memory (canonical residues); `lds`: the
 // tile's 4096-element exchange buffer.  TO_LDS: leave the result in `lds` (row_phys layout, the single pass)
 // instead of storing it to dst.  crow0 = global index of the tile's first row.
-template <typename AR, bool TO_LDS>
+template <typename AR, bool TO_LDS, bool TENSOR = false>
 __device__ __forceinline__ void inv_row_part(const AR& ar, const NttArgs& a, int mod, int tt, u32 crow0,
-                                             const u64* __restrict__ src, u64* __restrict__ dst, u64* lds)
+                                             const u64* __restrict__ src, u64* __restrict__ dst, u64* lds,
+                                             int tensor_part = 0)
 {
     typedef typename AR::T T;
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.itw + ((u64) mod << a.n_power);
     const int row = tt >> 4, i0 = tt & 15;
     const u32 crow = crow0 + row;
+    if (TENSOR) {
+        // the tile of the tensor product instead of a stored limb (NttArgs::tensor_in): four elements at a time, so
+        // that at most sixteen loads are in flight per lane (the kernel runs at 128 registers)
+        const Mod md = a.mods[mod];
+        const u64 part_off = (u64) a.tensor_limbs << a.n_power;
+        const u64* __restrict__ a0 = src, * __restrict__ a1 = src + part_off, * __restrict__ b0 = src + 2 * part_off,
+                 * __restrict__ b1 = src + 3 * part_off;
 #pragma unroll
-    for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = gld(&src[row * 256 + i0 + 16 * k]);
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            u64 r[4];
+            if (tensor_part == 1) { // (uniform per workgroup)
+                u64 va0[4], va1[4], vb0[4], vb1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = row * 256 + i0 + 16 * (k0 + k);
+                    va0[k] = a0[e]; va1[k] = a1[e]; vb0[k] = b0[e]; vb1[k] = b1[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { // a0 b1 + a1 b0: one 128-bit sum, one reduction
+                    u64 h1, l1, h2, l2;
+                    mul64wide(va0[k], vb1[k], h1, l1);
+                    mul64wide(va1[k], vb0[k], h2, l2);
+                    const u64 lo = l1 + l2;
+                    r[k] = reduce128(h1 + h2 + (lo < l1), lo, md);
+                }
+            } else {
+                const u64* __restrict__ pa = tensor_part == 0 ? a0 : a1;
+                const u64* __restrict__ pb = tensor_part == 0 ? b0 : b1;
+                u64 va[4], vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = row * 256 + i0 + 16 * (k0 + k);
+                    va[k] = pa[e]; vb[k] = pb[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = mul_barrett(va[k], vb[k], md);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) lds[row_phys(row * 256 + i0 + 16 * (k0 + k))] = r[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = gld(&src[row * 256 + i0 + 16 * k]);
+    }
     wave_lds_fence();
     T x[16];
 #pragma unroll
@@ -1475,6 +1518,26 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
     else inv_row_part<ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
 }
 
+// The same with the tensor product as the load transform (NttArgs::tensor_in); a kernel of its own so that the plain
+// row pass keeps its register budget.
+__device__ __forceinline__ const u64* tensor_src(const NttArgs& a, const PolySel& ps, int& part)
+{
+    part = udiv16(ps.j, a.mg_tensor_limbs);
+    const int limb = ps.j - part * a.tensor_limbs;
+    return a.tensor_in + (u64) ps.item * a.tensor_item_stride + ((u64) limb << a.n_power);
+}
+__global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row_tensor(NttArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    const PolySel ps = select_poly(a, blockIdx.y);
+    const Mod md = a.mods[ps.mod];
+    int part;
+    const u64* __restrict__ src = tensor_src(a, ps, part) + (u64) blockIdx.x * 4096;
+    u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
+    if (md.fp) inv_row_part<ArFp, false, true>(ArFp(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds, part);
+    else inv_row_part<ArInt, false, true>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds, part);
+}
+
 // Column pass last, in place on a.out.  grid = (256 / CT, batch).  EPI: with NttArgs::iepi (a kernel of its own:
 // the epilogue's state would cost the plain transform a wave per SIMD).
 template <int S1, bool EPI = false>
@@ -1502,7 +1565,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
 
 // Single pass for N <= 2^14 (see ntt_fwd_single): thread group g runs the row stages of row tile g into the
 // LDS-resident limb, then the column stages of column tile g out of it.  grid = batch, N / 16 threads.
-template <int S1, bool EPI, typename AR>
+template <int S1, bool EPI, bool TENSOR, typename AR>
 __device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, const PolySel& ps, u64* limb)
 {
     constexpr int CT = 4096 >> S1;
@@ -1513,21 +1576,27 @@ __device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, 
         inv_epi_setup(a, ps, epi, skip);
         if (skip) return; // (uniform per workgroup: before any barrier)
     }
-    inv_row_part<AR, true>(ar, a, ps.mod, tt, g * 16, a.in + ps.in_off + (u64) g * 4096, nullptr, limb + g * 4096);
+    if constexpr (TENSOR) {
+        int part;
+        const u64* src = tensor_src(a, ps, part) + (u64) g * 4096;
+        inv_row_part<AR, true, true>(ar, a, ps.mod, tt, g * 16, src, nullptr, limb + g * 4096, part);
+    } else {
+        inv_row_part<AR, true>(ar, a, ps.mod, tt, g * 16, a.in + ps.in_off + (u64) g * 4096, nullptr, limb + g * 4096);
+    }
     __syncthreads();
     u64 unused[16];
     if constexpr (EPI) inv_col_part<S1, AR, true, false, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused, epi, g * CT);
     else inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused);
 }
 
-template <int S1, bool EPI = false>
+template <int S1, bool EPI = false, bool TENSOR = false>
 __global__ __launch_bounds__(16 << S1, 4) void ntt_inv_single(NttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u64 limb[];
     const PolySel ps = select_poly(a, blockIdx.x);
     const Mod md = a.mods[ps.mod];
-    if (md.fp) inv_single_body<S1, EPI>(ArFp(md), a, ps, limb);
-    else inv_single_body<S1, EPI>(ArInt(md), a, ps, limb);
+    if (md.fp) inv_single_body<S1, EPI, TENSOR>(ArFp(md), a, ps, limb);
+    else inv_single_body<S1, EPI, TENSOR>(ArInt(md), a, ps, limb);
 }
 
 // Decomposing column pass, one workgroup per SOURCE tile: the 16 coefficients a thread needs are
@@ -1711,16 +1780,22 @@ static void launch_inv(const NttArgs& a, int batch, hipStream_t st)
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             static const hipError_t attr_e = hipFuncSetAttribute((const void*) ntt_inv_single<S1, true>,
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
+            static const hipError_t attr_t = hipFuncSetAttribute((const void*) ntt_inv_single<S1, false, true>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             (void) attr;
             (void) attr_e;
-            if (a.iepi.on)
+            (void) attr_t;
+            if (a.tensor_in)
+                hipLaunchKernelGGL((ntt_inv_single<S1, false, true>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            else if (a.iepi.on)
                 hipLaunchKernelGGL((ntt_inv_single<S1, true>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
             else
                 hipLaunchKernelGGL((ntt_inv_single<S1, false>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
             return;
         }
     }
-    hipLaunchKernelGGL(ntt_inv_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, a);
+    if (a.tensor_in) hipLaunchKernelGGL(ntt_inv_row_tensor, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(ntt_inv_row, dim3((1u << a.n_power) / 4096, batch), dim3(NTT_THREADS), 0, st, a);
     NttArgs b = a;
     b.in = a.out;
     b.in_item_stride = a.out_item_stride;
@@ -1739,6 +1814,7 @@ static void fill_magics(NttArgs& g)
     g.mg_decomp_mods = magic16(g.decomp_mods);
     g.epi.mg_limbs = magic16(g.epi.limbs);
     g.iepi.mg_slots = magic16(g.iepi.limbs + (g.iepi.p_count ? g.iepi.p_count : 1));
+    g.mg_tensor_limbs = magic16(g.tensor_limbs);
 }
 
 bool ntt_decomp_uses_multi(const NttArgs& a, int batch)
@@ -1813,6 +1889,8 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
     if (a.decomp_mods && (inverse || a.poly_order || !a.polys_per_item)) return hipErrorInvalidValue;
     if (a.src_inv && (!a.decomp_mods || batch > 65535 || !ntt_decomp_uses_multi(a, batch))) return hipErrorInvalidValue;
     if (a.copy_src && (!a.decomp_mods || inverse)) return hipErrorInvalidValue;
+    if (a.tensor_in && (!inverse || a.poly_order || a.iepi.on || a.polys_per_item != 3 * a.tensor_limbs || batch % a.polys_per_item))
+        return hipErrorInvalidValue;
     if (a.iepi.on && (!inverse || a.poly_order || batch % a.polys_per_item ||
                       a.polys_per_item != 2 * (a.iepi.limbs + (a.iepi.p_count ? a.iepi.p_count : 1)) ||
                       ((a.iepi.p_count > 1) != (a.iepi.u != nullptr))))
@@ -1848,6 +1926,7 @@ hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st)
                     c.copy_src = a.copy_src + items_done * a.copy_src_item_stride;
                     c.copy_dst = a.copy_dst + items_done * a.copy_dst_item_stride;
                 }
+                if (a.tensor_in) c.tensor_in = a.tensor_in + items_done * a.tensor_item_stride;
             } else {
                 c.in = a.in + ((u64) done << a.n_power);
                 c.out = a.out + ((u64) done << a.n_power);

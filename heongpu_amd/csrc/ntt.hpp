@@ -152,6 +152,15 @@ struct NttArgs {
     u64* copy_dst;
     u64 copy_src_item_stride, copy_dst_item_stride;
     int copy_part_limbs;
+    // Inverse launches only: the NTT-domain input of polynomial j = (part p, limb) of an item -- polys_per_item = 3 *
+    // tensor_limbs -- is not read from `in` but formed on the load as the degree-2 tensor product of two transformed
+    // ciphertexts held at tensor_in as [4][tensor_limbs][N] per item (a0, a1, b0, b1): p = 0: a0 b0, 1: a0 b1 + a1 b0,
+    // 2: a1 b1 -- cross_multiplication (reference multiplication.cu:102-126) as the load transform of the inverse
+    // transform that follows it in multiply_bfv (bfv/operator.cu:399-414): the [3][L][N] product is never stored.
+    const u64* tensor_in; // nullptr: off
+    u64 tensor_item_stride;
+    int tensor_limbs;
+    unsigned mg_tensor_limbs; // set by ntt_launch
 };
 
 hipError_t ntt_launch(const NttArgs& a, int batch, bool inverse, hipStream_t st);

@@ -393,9 +393,14 @@ hipError_t op_bfv_multiply(const Context& c, const u64* ct1, u64 s1, const u64* 
     a.in = temp1; a.out = temp1; a.mod_count = L; a.polys_per_item = 4 * L;
     a.in_item_stride = a.out_item_stride = per;
     TRY(ntt_launch(a, 4 * L * batch, false, st));                                          // :393
-    TRY(rns_cross_multiplication(temp1, per, temp1 + (u64) 2 * L * n, per, temp2, per, c.plan_merge.mods, np, L,
-                                 batch, st));                                              // :399
     a.in = temp2; a.out = temp2; a.polys_per_item = 3 * L;
+    if (c.fused_tensor) {
+        // the tensor product (:399) as the load transform of the inverse transform (:410): [3][L][N] is never stored
+        a.tensor_in = temp1; a.tensor_item_stride = per; a.tensor_limbs = L;
+    } else {
+        TRY(rns_cross_multiplication(temp1, per, temp1 + (u64) 2 * L * n, per, temp2, per, c.plan_merge.mods, np, L,
+                                     batch, st));                                          // :399
+    }
     TRY(ntt_launch(a, 3 * L * batch, true, st));                                           // :410
     return rns_fast_floor(temp2, per, out, so, c.behz, np, batch, st);                     // :416
 }

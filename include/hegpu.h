@@ -79,6 +79,7 @@ void hegpu_context_destroy(hegpu_context* ctx);
  *   "fp_ntt"         0/1     moduli below 2^50 on the exact FP64 butterflies (1); ONLY before hegpu_context_upload
  *                            (HEGPU_E_LOGIC afterwards: it decides the layout of the twiddle tables)
  *   "behz_split"     -1/0/1  BFV base conversions with their rows over four wavefronts
+ *   "fused_tensor"   0/1     BFV multiply: the tensor product as the load transform of the inverse transform (1)
  * Every option but "fp_ntt" may be changed at any time, but not concurrently with calls on the same context.  The
  * environment variables HEGPU_<NAME IN CAPITALS> seed the defaults once, when a context is created; no call path
  * reads the environment.  Unknown name / value out of range: HEGPU_E_INVALID. */

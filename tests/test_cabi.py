@@ -136,7 +136,7 @@ def test_options_are_an_interface_not_the_environment(hg):
     import sys
     c = hg.Context.from_bit_sizes(hg.CKKS, 4096, [40, 30], [40], sec=hg.SEC_NONE)
     defaults = {"fused_row_mac": -1, "fused_moddown": 1, "col_multi": -1, "single_pass": -1, "ntt_galois": 1,
-                "galois_scatter": 1, "fuse_inverse": 1, "copy_along": 1, "digit_split": -1, "fp_ntt": 1, "behz_split": -1}
+                "galois_scatter": 1, "fuse_inverse": 1, "copy_along": 1, "digit_split": -1, "fp_ntt": 1, "behz_split": -1, "fused_tensor": 1}
     for k, v in defaults.items():
         assert c.get_option(k) == v, k
     for k, v in (("fused_row_mac", 0), ("col_multi", 1), ("digit_split", 4), ("fp_ntt", 0), ("behz_split", 1)):

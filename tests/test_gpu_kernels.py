@@ -685,6 +685,26 @@ def test_c5_tfhe_4096_gates(hg, oracle, torch):
     assert np.array_equal(gb, np.tile(gb[:uniq], rep))
 
 
+@pytest.mark.parametrize("n,fused", [(4096, 0), (8192, 0), (16384, 0), (32768, 1), (32768, 0), (65536, 1)])
+def test_bfv_multiply_tensor_fusion(hg, oracle, torch, n, fused):
+    """multiply_bfv on the default chains with the tensor product as the load transform of the inverse transform
+    (option fused_tensor = 1, the default: single pass at N <= 2^14 -- covered by every other BFV test -- and the
+    two-pass row kernel ntt_inv_row_tensor at 2^15 / 2^16) and as the reference's kernel of its own (= 0)."""
+    t = 786433
+    with backend_switches(HEGPU_FUSED_TENSOR=fused):
+        c, o, primes = _bfv(hg, oracle, n, t)
+    Q, batch = c.Q_size, 2
+    ct1 = [synth_ct(primes, range(Q), 2, n, 5 + b) for b in range(batch)]
+    ct2 = [synth_ct(primes, range(Q), 2, n, 9 + b) for b in range(batch)]
+    out = torch.empty(batch * 3 * Q * n, dtype=torch.int64, device="cuda")
+    c.bfv_multiply(hg.to_device(np.concatenate(ct1)), 2 * Q * n, hg.to_device(np.concatenate(ct2)), 2 * Q * n, out, 3 * Q * n,
+                   batch, c.workspace(hg.OP_BFV_MULTIPLY, 0, batch))
+    torch.cuda.synchronize()
+    got = hg.to_host(out).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.bfv_multiply(ct1[b], ct2[b])), (n, fused, b)
+
+
 def test_bfv_n14_multiply_at_the_bench_shape(hg, oracle, torch):
     """North-star target 2 at the shape bench.py times: BFV N=2^14, default chain (Q=8, Bsk=9), 256 pairs in one call
     (single-pass transforms of 4 x 17 x 256 limbs, the one-thread-per-coefficient BEHZ kernels).  Four distinct
