@@ -143,10 +143,22 @@ struct MemoryPoolConfig {
 
 class MemoryPool {
   public:
-    static MemoryPool& instance()
+    // One pool per device: a block cached by the pool of device d is memory of device d.  instance() is the pool of the
+    // calling thread's current device (one process driving several GPUs, a thread per device as in the reference's
+    // example/basic/9_multi_stream_usage_way1.cpp: every thread works with its own device's pool); a DeviceVector
+    // remembers the device it was allocated on and returns its memory there, whichever thread frees it.
+    static constexpr int kMaxDevices = 64;
+    static MemoryPool& instance(int device)
     {
-        static MemoryPool pool;
-        return pool;
+        static MemoryPool pools[kMaxDevices];
+        return pools[(device >= 0 && device < kMaxDevices) ? device : 0];
+    }
+    static MemoryPool& instance() { return instance(current_device()); }
+    static int current_device()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) { (void) hipGetLastError(); d = 0; }
+        return d;
     }
     void initialize() { initialize(MemoryPoolConfig::Defaults()); }
     void initialize(const MemoryPoolConfig& config) // the first call wins, like the reference
@@ -407,12 +419,15 @@ template <typename T> class DeviceVector {
         if (this != &o) { release(); copy_from(o); }
         return *this;
     }
-    DeviceVector(DeviceVector&& o) noexcept : p_(o.p_), n_(o.n_), s_(o.s_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceVector(DeviceVector&& o) noexcept : p_(o.p_), n_(o.n_), s_(o.s_), dev_(o.dev_) { o.p_ = nullptr; o.n_ = 0; }
     // The buffer being replaced was last read by the work that produced `o` (an in-place operator on
     // o's stream), possibly on another stream than the one it was allocated on: free it ordered after both.
     DeviceVector& operator=(DeviceVector&& o) noexcept
     {
-        if (this != &o) { release(o.s_); p_ = o.p_; n_ = o.n_; s_ = o.s_; o.p_ = nullptr; o.n_ = 0; }
+        if (this != &o) {
+            release(o.dev_ == dev_ ? o.s_ : s_); // a stream of another device cannot order this buffer's release
+            p_ = o.p_; n_ = o.n_; s_ = o.s_; dev_ = o.dev_; o.p_ = nullptr; o.n_ = 0;
+        }
         return *this;
     }
     ~DeviceVector() { release(); }
@@ -421,18 +436,26 @@ template <typename T> class DeviceVector {
         release();
         s_ = s;
         n_ = n;
-        if (n) p_ = (T*) MemoryPool::instance().allocate(n * sizeof(T), s);
+        if (n) {
+            dev_ = MemoryPool::current_device(); // the calling thread's device: `s` is one of its streams
+            p_ = (T*) MemoryPool::instance(dev_).allocate(n * sizeof(T), s);
+        }
     }
     T* data() const { return p_; }
     size_t size() const { return n_; }
     hipStream_t stream() const { return s_; }
     void set_stream(hipStream_t s) { s_ = s; }
+    int device() const { return dev_; } // the device the buffer lives on (-1: empty)
 
   private:
     void release() { release(s_); }
     void release(hipStream_t last_use)
     {
         if (p_) {
+            // events and streams of this buffer belong to its device: freed from a thread that works on another one,
+            // the release runs with that device current
+            const int cur = MemoryPool::current_device();
+            if (cur != dev_) (void) hipSetDevice(dev_);
             if (last_use != s_) { // make the freeing stream wait for the allocation stream's work as well
                 hipEvent_t e = nullptr;
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
@@ -441,19 +464,26 @@ template <typename T> class DeviceVector {
                     (void) hipEventDestroy(e);
                 }
             }
-            MemoryPool::instance().deallocate(p_, n_ * sizeof(T), last_use);
+            MemoryPool::instance(dev_).deallocate(p_, n_ * sizeof(T), last_use);
+            if (cur != dev_) (void) hipSetDevice(cur);
         }
         p_ = nullptr;
         n_ = 0;
     }
+    // A copy lives on the COPYING thread's device: copy-constructing a key on device d from the key on device 0 is how
+    // a multi-device consumer replicates evaluation keys (a peer copy over xGMI); hegpu_broadcast_key is the C-ABI form.
     void copy_from(const DeviceVector& o)
     {
-        resize(o.n_, o.s_);
-        if (n_) detail::hip(hipMemcpyAsync(p_, o.p_, n_ * sizeof(T), hipMemcpyDeviceToDevice, s_));
+        const bool same = o.dev_ < 0 || o.dev_ == MemoryPool::current_device();
+        resize(o.n_, same ? o.s_ : nullptr);
+        if (!n_) return;
+        if (same) detail::hip(hipMemcpyAsync(p_, o.p_, n_ * sizeof(T), hipMemcpyDeviceToDevice, s_));
+        else detail::hip(hipMemcpyPeer(p_, dev_, o.p_, o.dev_, n_ * sizeof(T))); // synchronous: the source's stream is foreign
     }
     T* p_ = nullptr;
     size_t n_ = 0;
     hipStream_t s_ = nullptr;
+    int dev_ = -1;
 };
 
 // util/hostvector.cuh:17-31: host vector in pinned (page-locked) memory, so that the storage manager's
@@ -819,6 +849,11 @@ template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation
     inline int get_log_poly_modulus_degree() const noexcept { return n_power; }
     inline uint64_t get_plain_modulus() const noexcept { return plain_modulus_.value; }
     hegpu_context* handle() const { return h_; }
+    // The device this context's tables live on (generate() uploads them to the calling thread's current device); -1
+    // before generate().  Several GPUs in one process: one context per device, each generated and used by a thread
+    // that made that device current (hipSetDevice) -- buffers of the class layer are allocated on the calling thread's
+    // device (MemoryPool::instance()), the library calls themselves run on the context's device whatever the thread.
+    int device() const { return h_ ? hegpu_context_device(h_) : -1; }
 
     int n = 0, n_power = 0, Q_size = 0, P_size = 0, Q_prime_size = 0;
     int total_coeff_bit_count = 0;

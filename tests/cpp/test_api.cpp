@@ -4,6 +4,7 @@
 // oracle (test infrastructure).  Runs on the GPU box (pytest -m gpu wrapper).
 #define HEONGPU_WITH_ZLIB 1
 #include <heongpu/heongpu.hpp>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -956,6 +957,78 @@ static void storage_manager()
     EXPECT(decrypts_to(r2, b), "the staged operand is intact after the exception");
 }
 
+// One process, a thread per device (both threads on device 0 when there is only one): every thread makes its device
+// current, generates its own context there, works out of that device's memory pool; the evaluation key is generated once
+// and replicated by copy construction (a peer copy between devices).  Both threads must produce the same ciphertext.
+static void multi_device()
+{
+    constexpr auto S = Scheme::CKKS;
+    int ndev = 0;
+    detail::hip(hipGetDeviceCount(&ndev));
+    const int workers = 2;
+    std::vector<std::vector<Data64>> results(workers);
+    std::vector<int> ctx_dev(workers, -2), buf_dev(workers, -2);
+    // keys and inputs made on device 0
+    detail::hip(hipSetDevice(0));
+    auto make_ctx = [] {
+        HEContext<S> c = GenHEContext<S>();
+        c->set_poly_modulus_degree(8192);
+        c->set_coeff_modulus_bit_sizes({40, 30, 30, 30}, {40});
+        c->generate();
+        return c;
+    };
+    HEContext<S> ctx0 = make_ctx();
+    HEKeyGenerator<S> keygen(ctx0, 31);
+    Secretkey<S> sk(ctx0);
+    keygen.generate_secret_key(sk);
+    Publickey<S> pk(ctx0);
+    keygen.generate_public_key(pk, sk);
+    Relinkey<S> rk0(ctx0);
+    keygen.generate_relin_key(rk0, sk);
+    HEEncoder<S> enc0(ctx0);
+    HEEncryptor<S> encryptor(ctx0, pk, 32);
+    std::vector<double> m(4096);
+    for (size_t i = 0; i < m.size(); i++) m[i] = 0.001 * (double) (i % 97) - 0.04;
+    Plaintext<S> p(ctx0);
+    enc0.encode(p, m, 1073741824.0);
+    Ciphertext<S> c0(ctx0);
+    encryptor.encrypt(c0, p);
+    detail::hip(hipDeviceSynchronize());
+    std::vector<std::thread> th;
+    std::vector<std::string> errors(workers);
+    for (int w = 0; w < workers; w++)
+        th.emplace_back([&, w] {
+            try {
+                const int dev = w % ndev;
+                detail::hip(hipSetDevice(dev));
+                HEContext<S> ctx = make_ctx();          // tables on this thread's device
+                ctx_dev[w] = ctx->device();
+                Relinkey<S> rk(rk0);                    // replica on this device (peer copy when the devices differ)
+                rk.set_context(ctx);
+                Ciphertext<S> c(c0);                    // the input, copied to this device
+                buf_dev[w] = dev;
+                HEEncoder<S> enc(ctx);
+                HEArithmeticOperator<S> op(ctx, enc);
+                hipStream_t st;
+                detail::hip(hipStreamCreate(&st));
+                ExecutionOptions o;
+                o.set_stream(st);
+                Ciphertext<S> prod(ctx, o);
+                op.multiply(c, c, prod, o);
+                op.relinearize_inplace(prod, rk, o);
+                op.rescale_inplace(prod, o);
+                prod.get_data(results[w], st);
+                detail::hip(hipStreamSynchronize(st));
+                detail::hip(hipStreamDestroy(st));
+            } catch (const std::exception& e) { errors[w] = e.what(); }
+        });
+    for (auto& t : th) t.join();
+    detail::hip(hipSetDevice(0));
+    for (int w = 0; w < workers; w++) EXPECT(errors[w].empty(), ("device thread failed: " + errors[w]).c_str());
+    EXPECT(ctx_dev[0] == 0 && ctx_dev[1] == 1 % ndev, "every thread's context lives on that thread's device");
+    EXPECT(!results[0].empty() && results[0] == results[1], "both devices compute the same multiply + relinearize + rescale");
+}
+
 int main()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
@@ -975,6 +1048,7 @@ int main()
     ckks_encoder_flow();
     memory_pool();
     storage_manager();
+    multi_device();
     serializer_round_trip();
     serialize_all_objects();
     bfv_ntt_domain_and_shift();
