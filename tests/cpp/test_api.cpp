@@ -1013,12 +1013,14 @@ static void multi_device()
                 detail::hip(hipStreamCreate(&st));
                 ExecutionOptions o;
                 o.set_stream(st);
-                Ciphertext<S> prod(ctx, o);
-                op.multiply(c, c, prod, o);
-                op.relinearize_inplace(prod, rk, o);
-                op.rescale_inplace(prod, o);
-                prod.get_data(results[w], st);
-                detail::hip(hipStreamSynchronize(st));
+                {
+                    Ciphertext<S> prod(ctx, o); // must not outlive its stream
+                    op.multiply(c, c, prod, o);
+                    op.relinearize_inplace(prod, rk, o);
+                    op.rescale_inplace(prod, o);
+                    prod.get_data(results[w], st);
+                    detail::hip(hipStreamSynchronize(st));
+                }
                 detail::hip(hipStreamDestroy(st));
             } catch (const std::exception& e) { errors[w] = e.what(); }
         });
