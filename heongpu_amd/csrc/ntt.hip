@@ -52,13 +52,46 @@ __device__ __forceinline__ void fp_ct_bfly(double& x, double& y, ulonglong2 w, c
     y = x - t;
     x = x + t;
 }
-// LOGR CT stages + the centred reduction that ends a register round
+// Where the centred reductions of the FP64 forward transform go (round 3).  A stage takes |x| <= b q to at most
+// (1.25 b + 0.5) q (fpmod.cuh, q < 2^50), and everything stays exact while |x| < 2^53 = 8 * 2^50: from b = 1/2 that is
+// SIX stages (1.125, 1.91, 2.88, 4.10, 5.63, 7.54), from an un-reduced input (b <= 1.05: a canonical residue, or a digit
+// that is a residue of a prime at most 1/64 larger) five.  Round 2 reduced after every register round of four stages and
+// the input of a decomposing launch as well -- five times per 16 stages; three suffice.  The schedule is computed at
+// compile time from the bound: `before` bit s = reduce before local stage s, `at_end` = the hand-over bound would be
+// exceeded.  Contract between the passes: the column stages hand over centred residues (|x| <= q / 2) -- the row stages
+// of the fused key switch recompute their twiddle companions (growth 1.375 b + 0.5: five stages per reduction, not
+// six), so a looser hand-over would cost that kernel the reduction the column pass saved.  What the schedule buys:
+// the input of a decomposing launch is not reduced (its digit is a residue of a prime of the same size), and the one
+// reduction inside the column stages sits after the fifth stage instead of the fourth.
+struct FpSched { unsigned before; bool at_end; };
+#define FP_STAGE_GROW(b) (1.25 * (b) + 0.5)
+#define FP_BOUND_LIMIT 7.9
+#define FP_HANDOVER 0.51
+#define FP_UNREDUCED_IN 1.05
+constexpr FpSched fp_sched(int stages, double b_in, double b_out_max)
+{
+    unsigned m = 0;
+    double b = b_in;
+    for (int s = 0; s < stages; s++) {
+        if (FP_STAGE_GROW(b) > FP_BOUND_LIMIT) {
+            m |= 1u << s;
+            b = 0.5;
+        }
+        b = FP_STAGE_GROW(b);
+    }
+    return FpSched{m, b > b_out_max};
+}
+// LOGR CT stages; reductions where the schedule says (`before` bit s: before local stage s; at_end)
 template <int LOGR>
 __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], const ulonglong2* __restrict__ tw, u32 root0,
-                                            const FC& c)
+                                            const FC& c, unsigned before, bool at_end)
 {
 #pragma unroll
     for (int s = 0; s < LOGR; s++) {
+        if ((before >> s) & 1u) {
+#pragma unroll
+            for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
+        }
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
@@ -67,9 +100,20 @@ __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], const ulongl
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
+    if (at_end) {
 #pragma unroll
-    for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
+        for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
+    }
 }
+// the column stages of a transform with S1 of them (round A: S1 - 4, round B: 4) and the first four row stages
+template <int S1> struct FpColSched {
+    static constexpr FpSched s = fp_sched(S1, FP_UNREDUCED_IN, FP_HANDOVER);
+    static constexpr unsigned a_before = s.before & ((1u << (S1 - 4)) - 1u);
+    static constexpr unsigned b_before = (s.before >> (S1 - 4)) & 15u;
+    static constexpr bool b_at_end = s.at_end;
+};
+// (the row stages: four stages, a reduction, four stages, the canonical reduction -- from |x| <= q / 2 each round
+// stays below 4.11 q)
 // last four stages of the row pass (re-laid table), result canonical in [0,q)
 __device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglong2* __restrict__ tb, const FC& c)
 {
@@ -447,6 +491,9 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     }
     const u64 half_qP = (DECOMP && a.half_on) ? a.mods[a.half_src_mod].q : 0;
     const double half_hm = (DECOMP && a.half_on) ? fp_from_u64(a.half_mod[ps.mod]) : 0.0;
+    // plain decomposition of a digit whose prime is at most 1/64 above this modulus: no input reduction (FpSched)
+    const bool in_small = DECOMP && !WIDE && !a.half_on && a.mods[ps.digit].q <= md.q + (md.q >> 6);
+    typedef FpColSched<S1> CS;
     // SREG: `sreg` holds the thread's 16 source coefficients, the mod-down half already added: for a
     // source modulus of at most 52 bits as the bits of the converted double, for a wider one as u64
     // CNT source values -> reduced doubles.  The loads first, then (uniform conditions, one branch each around a
@@ -455,8 +502,13 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     auto load_all = [&](auto& y, auto addr, int si0) {
         constexpr int CNT = sizeof(y) / sizeof(y[0]);
         if constexpr (SREG && !WIDE) {
+            if (in_small) { // (uniform) the digit's own prime is at most 1/64 larger than this modulus: |y| <= 1.05 q
 #pragma unroll
-            for (int k = 0; k < CNT; k++) y[k] = fp_reduce(as_f64(sreg[si0 + k]), fc);
+                for (int k = 0; k < CNT; k++) y[k] = as_f64(sreg[si0 + k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < CNT; k++) y[k] = fp_reduce(as_f64(sreg[si0 + k]), fc);
+            }
         } else {
             u64 v[CNT];
 #pragma unroll
@@ -473,7 +525,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
 #pragma unroll
             for (int k = 0; k < CNT; k++) {
                 if constexpr (DECOMP && WIDE) y[k] = fp_mul(fp_from_u32((u32) (v[k] >> 32)), c32, c32i, fc) + fp_from_u32((u32) v[k]);
-                else if constexpr (DECOMP) y[k] = fp_reduce(fp_from_u64(v[k]), fc);
+                else if constexpr (DECOMP) y[k] = in_small ? fp_from_u64(v[k]) : fp_reduce(fp_from_u64(v[k]), fc);
                 else y[k] = fp_from_u64(v[k]);
             }
         }
@@ -497,7 +549,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
             const int c = L % CT, rb = L / CT;
             double y[RA];
             load_all(y, [&](int k) { return &src[(u64) (rb + 16 * k) * 256 + c]; }, g * RA);
-            fp_ct_radix<NSA>(y, tw, 1u, fc);
+            fp_ct_radix<NSA>(y, tw, 1u, fc, CS::a_before, false);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
         }
@@ -506,10 +558,10 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = as_f64(lds[col_phys((16 * r1 + k) * CT + col)]);
         if (SREG) __syncthreads();
-        fp_ct_radix<4>(x, twl, (u32) (RA + r1), fc);
+        fp_ct_radix<4>(x, twl, (u32) (RA + r1), fc, CS::b_before, CS::b_at_end);
     } else {
         load_all(x, [&](int k) { return &src[(u64) k * 256 + col]; }, 0);
-        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
+        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc, CS::b_before, CS::b_at_end);
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(u64) (16 * r1 + k) * 256 + col] = as_bits(x[k]);
@@ -664,7 +716,7 @@ __device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel&
     double x[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = as_f64(p[row * 256 + i0 + 16 * k]);
-    fp_ct_radix<4>(x, tw, (1u << s1) + crow, fc);
+    fp_ct_radix<4>(x, tw, (1u << s1) + crow, fc, 0u, true);
 #pragma unroll
     for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
     wave_lds_fence();
@@ -736,7 +788,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
                 double y[RA];
 #pragma unroll
                 for (int k = 0; k < RA; k++) y[k] = fp_from_u64(src[(u64) (rb + 16 * k) * 256 + c]);
-                fp_ct_radix<NSA>(y, tw, 1u, fc);
+                fp_ct_radix<NSA>(y, tw, 1u, fc, FpColSched<S1>::a_before, false);
 #pragma unroll
                 for (int k = 0; k < RA; k++) limb[single_pos<S1>(rb + 16 * k, g * CT + c)] = as_bits(y[k]);
             }
@@ -747,7 +799,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fp_from_u64(src[(u64) k * 256 + col]);
         }
-        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc);
+        fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc, FpColSched<S1>::b_before, FpColSched<S1>::b_at_end);
 #pragma unroll
         for (int k = 0; k < 16; k++) limb[single_pos<S1>(16 * r1 + k, g * CT + col)] = as_bits(x[k]);
     } else {
@@ -786,7 +838,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
         double x[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = as_f64(lds[row_phys(row * 256 + i0 + 16 * k)]);
-        fp_ct_radix<4>(x, tw, (1u << S1) + crow, fc);
+        fp_ct_radix<4>(x, tw, (1u << S1) + crow, fc, 0u, true);
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
         wave_lds_fence();
