@@ -492,7 +492,9 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     const u64 half_qP = (DECOMP && a.half_on) ? a.mods[a.half_src_mod].q : 0;
     const double half_hm = (DECOMP && a.half_on) ? fp_from_u64(a.half_mod[ps.mod]) : 0.0;
     // plain decomposition of a digit whose prime is at most 1/64 above this modulus: no input reduction (FpSched)
-    const bool in_small = DECOMP && !WIDE && !a.half_on && a.mods[ps.digit].q <= md.q + (md.q >> 6);
+    // (not at S1 = 7: the second form of the load loops costs ntt_fwd_col_multi<7> sixteen registers and with them its
+    // fourth wave per SIMD, which the integer limbs of the same kernel use -- tests/test_kernel_budgets.py)
+    const bool in_small = S1 != 7 && DECOMP && !WIDE && !a.half_on && a.mods[ps.digit].q <= md.q + (md.q >> 6);
     typedef FpColSched<S1> CS;
     // SREG: `sreg` holds the thread's 16 source coefficients, the mod-down half already added: for a
     // source modulus of at most 52 bits as the bits of the converted double, for a wider one as u64

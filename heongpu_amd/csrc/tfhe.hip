@@ -626,6 +626,212 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
+// ------------------------------------------------------------------ few gates: four wavefronts per transform
+// A call with fewer gates than CUs leaves k_tfhe_blind_rotate_fp at one wavefront per SIMD on as many CUs as
+// there are gates: every LDS exchange, key load and dependent FP64 chain of the 512 iterations is exposed.  Here a
+// gate is one workgroup of 16 wavefronts; a group of four (256 lanes, 4 coefficients each) owns digit polynomial
+// (y,z) for the forward transform and output (c,half) for the inverse one.  A transform is five radix-4 rounds:
+// the first (last, for the inverse) exchange crosses the wavefronts of the group (workgroup barrier), the other
+// three stay inside a wavefront, which owns positions [256a, 256a + 256) from then on.  Same tables, same key
+// layout, same bounds as the one-wavefront transforms; the key values of an iteration (16 per lane) are requested
+// before the decomposition and arrive under the forward transform.
+// MEASURED SLOWER (MI355X, 1..256 gates per call: 5.8 ms against 4.4 ms, tools/tfhe_shapes.py): sixteen wavefronts
+// in lockstep between four workgroup barriers per iteration do their LDS exchanges at the same time and their FP64
+// rounds at the same time, and four values per lane leave two independent butterflies per round.  Kept behind the
+// option "wide_max" (default 0 = never), bit-exact like the other form (tests/test_gpu_tfhe.py).
+#define TFW_THREADS 1024
+// stages s, s+1 on four values at local distances 2 and 1: root index (1 << s) + B, then (2 << s) + 2B + {0,1}
+__device__ __forceinline__ void f_ct4(double (&x)[4], ulonglong2 wa, ulonglong2 wb0, ulonglong2 wb1, const FC& c)
+{
+    f_ct(x[0], x[2], wa, c);
+    f_ct(x[1], x[3], wa, c);
+    f_ct(x[0], x[1], wb0, c);
+    f_ct(x[2], x[3], wb1, c);
+}
+__device__ __forceinline__ void f_gs4(double (&x)[4], ulonglong2 wa, ulonglong2 wb0, ulonglong2 wb1, const FC& c)
+{
+    f_gs(x[0], x[1], wb0, c);
+    f_gs(x[2], x[3], wb1, c);
+    f_gs(x[0], x[2], wa, c);
+    f_gs(x[1], x[3], wa, c);
+}
+
+// In: x[m] = element L + 256m of the group's polynomial, |x| <= p'.  Out: x[m] = slot 4L + m, centred.
+// `sc`: the group's exchange area.  Called by all 16 wavefronts together (one workgroup barrier inside).
+__device__ __forceinline__ void fwide_ntt1024(double (&x)[4], u64* sc, const ulonglong2* __restrict__ tw,
+                                              const ulonglong2* twl, const FC& c, int L)
+{
+    const int a = L >> 6, l = L & 63;
+    f_ct4(x, tw[1], tw[2], tw[3], c);
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(L + 256 * m)] = as_bits(x[m]);
+    __syncthreads();
+    int e0 = 256 * a + l; // stride 64
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 64 * m)]);
+    f_ct4(x, twl[4 + a], twl[8 + 2 * a], twl[9 + 2 * a], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 64 * m)] = as_bits(x[m]);
+    wave_fence();
+    e0 = 256 * a + 64 * (l >> 4) + (l & 15); // stride 16
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 16 * m)]);
+    int B = 4 * a + (l >> 4);
+    f_ct4(x, twl[16 + B], twl[32 + 2 * B], twl[33 + 2 * B], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 16 * m)] = as_bits(x[m]);
+    wave_fence();
+    e0 = 256 * a + 16 * (l >> 2) + (l & 3); // stride 4
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 4 * m)]);
+    B = 16 * a + (l >> 2);
+    f_ct4(x, twl[64 + B], twl[128 + 2 * B], twl[129 + 2 * B], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(4 * L + m)]);
+    f_ct4(x, twl[256 + L], twl[512 + 2 * L], twl[513 + 2 * L], c);
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = fp_reduce(x[m], c);
+    wave_fence();
+}
+
+// In: x[m] = slot 4L + m, |x| <= 2.2 p'.  Out: x[m] = coefficient L + 256m, centred, N^-1 applied (the bounds
+// of fwave_intt1024: six stages, one reduction, four stages).
+__device__ __forceinline__ void fwide_intt1024(double (&x)[4], u64* sc, const ulonglong2* __restrict__ itw,
+                                               const ulonglong2* itwl, ulonglong2 ninv, ulonglong2 w1ninv,
+                                               const FC& c, int L)
+{
+    const int a = L >> 6, l = L & 63;
+    f_gs4(x, itwl[256 + L], itwl[512 + 2 * L], itwl[513 + 2 * L], c);
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(4 * L + m)] = as_bits(x[m]);
+    wave_fence();
+    int e0 = 256 * a + 16 * (l >> 2) + (l & 3);
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 4 * m)]);
+    int B = 16 * a + (l >> 2);
+    f_gs4(x, itwl[64 + B], itwl[128 + 2 * B], itwl[129 + 2 * B], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+    e0 = 256 * a + 64 * (l >> 4) + (l & 15);
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 16 * m)]);
+    B = 4 * a + (l >> 4);
+    f_gs4(x, itwl[16 + B], itwl[32 + 2 * B], itwl[33 + 2 * B], c);
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = fp_reduce(x[m], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 16 * m)] = as_bits(x[m]);
+    wave_fence();
+    e0 = 256 * a + l;
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 64 * m)]);
+    f_gs4(x, itwl[4 + a], itwl[8 + 2 * a], itwl[9 + 2 * a], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[bi(e0 + 64 * m)] = as_bits(x[m]);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(L + 256 * m)]);
+    f_gs(x[0], x[1], itw[2], c);
+    f_gs(x[2], x[3], itw[3], c);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const double s = x[j] + x[j + 2], d = x[j] - x[j + 2];
+        x[j] = fp_mul(s, as_f64(ninv.x), as_f64(ninv.y), c);
+        x[j + 2] = fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), c);
+    }
+}
+
+__global__ __launch_bounds__(TFW_THREADS) void k_tfhe_blind_rotate_fp_wide(const int* __restrict__ in_a,
+                                                                          const int* __restrict__ in_b,
+                                                                          const u64* __restrict__ prepared,
+                                                                          int* __restrict__ out_a,
+                                                                          int* __restrict__ out_b, TfheDev p,
+                                                                          int encoded)
+{
+    if (prepared[0] != 1) return; // integer-layout key: k_tfhe_blind_rotate runs instead
+    const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
+    __shared__ int acc[2][TF_N];
+    __shared__ __attribute__((aligned(16))) u64 sc[4][TF_BUF];    // exchange areas of the four groups
+    __shared__ __attribute__((aligned(16))) double xs[4][TF_N];   // the transformed digits, slot order
+    __shared__ ulonglong2 twf[TF_N], twi[TF_N];
+    const int t = threadIdx.x, L = t & 255, gq = t >> 8;
+    const int y = gq >> 1, z = gq & 1;
+    twf[t] = p.ftw[t];
+    twi[t] = p.fitw[t];
+    const int g = blockIdx.x;
+    const int n = p.n;
+    const FC fc = make_fc(p.fprime);
+    {
+        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
+        const int j = t;
+        acc[0][j] = 0;
+        acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
+    }
+    __syncthreads();
+
+    const int shift = 32 - 10 * (z + 1);
+    const int cc = gq >> 1, sh = (gq & 1) ? 16 : 0;
+    // slot 4L + m of a key polynomial lies at [k = 4 (L & 3) + m][lane = L >> 2] of the prepared layout
+    const u64* bk0 = bk + (u64) gq * TF_N + (4 * (L & 3)) * 64 + (L >> 2);
+    for (int i = 0; i < n; i++) {
+        // kv[d][m]: key polynomial (iteration i, digit d, output gq), slots 4L + m
+        const u64* bkp = bk0 + (u64) i * 16 * TF_N;
+        double kv[4][4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) kv[d][m] = as_f64(bkp[(u64) (d * 4) * TF_N + m * 64]);
+        const int aN = modswitch(in_a[(u64) g * n + i], 10);
+        double x[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int j = L + 256 * m;
+            const int idx = (j - aN) & (2 * TF_N - 1);
+            const int v = acc[y][idx & (TF_N - 1)];
+            const int r = (idx & TF_N) ? -v : v;
+            const u32 diff = (u32) r - (u32) acc[y][j];
+            const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
+            x[m] = (double) d;
+        }
+        fwide_ntt1024(x, sc[gq], p.ftw, twf, fc, L);
+        *reinterpret_cast<double2*>(&xs[gq][4 * L]) = make_double2(x[0], x[1]);
+        *reinterpret_cast<double2*>(&xs[gq][4 * L + 2]) = make_double2(x[2], x[3]);
+        __syncthreads();
+        // output gq = sum over the four transformed digits (exact: |sum| <= 4 * 0.51 p' < 2^47)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const double2 u0 = *reinterpret_cast<const double2*>(&xs[d][4 * L]);
+            const double2 u1 = *reinterpret_cast<const double2*>(&xs[d][4 * L + 2]);
+            const double xo[4] = {u0.x, u0.y, u1.x, u1.y};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const double pr = fp_mul(kv[d][m], xo[m], xo[m] * fc.qi, fc);
+                x[m] = d ? x[m] + pr : pr;
+            }
+        }
+        fwide_intt1024(x, sc[gq], p.fitw, twi, p.fninv, p.fw1ninv, fc, L);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            atomicAdd(reinterpret_cast<u32*>(&acc[cc][L + 256 * m]), f_low32(x[m]) << sh);
+        __syncthreads();
+    }
+    {
+        const int j = t;
+        out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
+        if (t == 0) out_b[g] = acc[1][0];
+    }
+}
+
 // out = enc + m*(s1*in1 + s2*in2) on the 32-bit torus (bootstrapping.cu:378-660)
 __global__ __launch_bounds__(256) void k_tfhe_gate_pre(int* __restrict__ out_a, int* __restrict__ out_b,
                                                        const int* __restrict__ a1, const int* __restrict__ b1,
@@ -900,13 +1106,16 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
 }
 
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int g4_min, hipStream_t st)
+                             int* out_b, int encoded, int shape, int g4_min, int wide_max, hipStream_t st)
 {
     // both kernels cover all gates; the one whose key layout is absent exits at once
     // one gate per workgroup: measured faster than four gates sharing the key registers at every
     // batch size (64 k vs 53 k gates/s at 4096 gates; 7.4 ms for a batch of 8); the shared
     // variant stays selectable for experiments (context option "g4_min")
-    if (shape >= g4_min)
+    if (shape <= wide_max)
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp_wide, dim3(shape), dim3(TFW_THREADS), 0, st, in_a, in_b, bk_prepared,
+                           out_a, out_b, p, encoded);
+    else if (shape >= g4_min)
         hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<4>, dim3((shape + 3) / 4), dim3(TF_THREADS), 0, st, in_a, in_b,
                            bk_prepared, out_a, out_b, p, encoded, shape);
     else

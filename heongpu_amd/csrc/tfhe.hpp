@@ -45,7 +45,7 @@ hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase
 
 hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, hipStream_t st);
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int g4_min, hipStream_t st);
+                             int* out_b, int encoded, int shape, int g4_min, int wide_max, hipStream_t st);
 hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
                          int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st);
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,

@@ -39,9 +39,14 @@ def _dev32(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def test_blind_rotate_and_key_switch(hg, setup):
+@pytest.mark.parametrize("wide_max", [256, 0], ids=["sixteen-waves-per-gate", "four-waves-per-gate"])
+def test_blind_rotate_and_key_switch(hg, setup, wide_max):
+    """Both forms of the FP64 blind rotate (option "wide_max": a gate on 16 wavefronts, four per transform, for
+    calls of few gates -- measured slower, off by default; on 4 wavefronts, one per transform) and the integer one
+    (residues60 key)."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
+    t.set_option("wide_max", wide_max)
     shape = 6
     a = rng.integers(-2**31, 2**31, shape * 512, dtype=np.int64).astype(np.int32)
     b = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
@@ -54,6 +59,7 @@ def test_blind_rotate_and_key_switch(hg, setup):
     out_b = torch.empty(shape, dtype=torch.int32, device="cuda")
     t.bootstrapping(_dev32(a), _dev32(b), prepared, out_a, out_b, shape)
     torch.cuda.synchronize()
+    t.set_option("wide_max", 0)
     assert np.array_equal(out_b.cpu().numpy(), want_b)
     assert np.array_equal(out_a.cpu().numpy(), want_a)
     ks_want_a, ks_want_b = o.key_switching(want_a, want_b, ks_a, ks_b)
