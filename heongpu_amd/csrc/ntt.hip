@@ -977,17 +977,14 @@ __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
     return r;
 }
 
+// (bodies shared by the kernels below; `twbuf`: KS_TW_LDS_BYTES of LDS for the digit-invariant twiddles)
+#define KS_TW_LDS_BYTES ((15 * 256 + 15 * 16) * 8)
 template <bool SPLIT>
-__global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacArgs a)
+__device__ __forceinline__ void ks_row_mac_int_body(const KsMacArgs& a, const KsIdx& ki, const Mod& md, int midx,
+                                                    u64* lds, void* twbuf)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const KsIdx ki = ks_index<SPLIT>(a);
-    if (!ki.valid) return;
     const int item = ki.item, tile = ki.tile, slot = ki.slot;
-    const int midx = a.mod_order ? a.mod_order[slot] : slot;
-    const Mod md = a.mods[midx];
-    if (md.fp) return; // FP64 moduli are handled by ks_row_mac_fp
     const QC qc = make_qc(md.q);
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
@@ -1003,7 +1000,7 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
     const bool lazy = row_stages_lazy(md, a.lazy_q_max) && md.q <= ~0ull / (u64) a.digits;
     // digit-invariant twiddles of the first four stages, shared by the 16 lanes of a row (see
     // ks_row_mac_fp; the per-lane ones of the last four stages would need 61 KiB as pairs)
-    __shared__ ulonglong2 twa[15 * 16];
+    ulonglong2* twa = reinterpret_cast<ulonglong2*>(twbuf); // [15 * 16]
     if (i0 < 15) {
         const int s = (i0 >= 7) ? 3 : (i0 >= 3) ? 2 : (i0 >= 1) ? 1 : 0;
         twa[i0 * 16 + row] = tw[((((u32) 1 << s1) + crow) << s) + (i0 - ((1 << s) - 1))];
@@ -1045,6 +1042,19 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
     (void) n;
 }
 
+template <bool SPLIT>
+__global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    __shared__ ulonglong2 twa[15 * 16];
+    const KsIdx ki = ks_index<SPLIT>(a);
+    if (!ki.valid) return;
+    const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
+    const Mod md = a.mods[midx];
+    if (md.fp) return; // FP64 moduli are handled by ks_row_mac_fp
+    ks_row_mac_int_body<SPLIT>(a, ki, md, midx, lds, twa);
+}
+
 // FP64 moduli (Mod::fp): same fused row pass + inner product, but the inner
 // product is accumulated in FP64 as well: each digit*key product is reduced by
 // fp_mul (|t| <= 0.7 q for |digit| <= q/2), the running sums are re-centred
@@ -1052,16 +1062,11 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
 // Two double accumulators per coefficient instead of two 128-bit integers
 // halve the register footprint (3 waves per SIMD instead of 2).
 template <bool SPLIT>
-__global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
+__device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsIdx& ki, const Mod& md, int midx,
+                                                   u64* lds, void* twbuf)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     const int t = threadIdx.x;
-    const KsIdx ki = ks_index<SPLIT>(a);
-    if (!ki.valid) return;
     const int item = ki.item, tile = ki.tile, slot = ki.slot;
-    const int midx = a.mod_order ? a.mod_order[slot] : slot;
-    const Mod md = a.mods[midx];
-    if (!md.fp) return; // integer moduli are handled by ks_row_mac
     const FC fc = make_fc(md.q);
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
@@ -1081,7 +1086,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
     // a row ([k][row], written by lane i0 == k).  Only w is kept; its companion RN(w/q) is
     // recomputed as w * RN(1/q) when the twiddle is used (one multiply per twiddle; the quotient
     // estimate stays within 0.63 of the exact one, so |x| <= 4.1 q < 2^53 after four stages).
-    __shared__ double twl[15 * 256 + 15 * 16];
+    double* twl = reinterpret_cast<double*>(twbuf); // [15 * 256 + 15 * 16]
 #pragma unroll
     for (int k = 0; k < 15; k++) twl[k * 256 + t] = as_f64(tb[k * 16].x);
     if (i0 < 15) {
@@ -1193,6 +1198,35 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
     }
 }
 
+template <bool SPLIT>
+__global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    __shared__ double twl[15 * 256 + 15 * 16];
+    const KsIdx ki = ks_index<SPLIT>(a);
+    if (!ki.valid) return;
+    const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
+    const Mod md = a.mods[midx];
+    if (!md.fp) return; // integer moduli are handled by ks_row_mac
+    ks_row_mac_fp_body<SPLIT>(a, ki, md, midx, lds, twl);
+}
+
+// Split launches are small launches (fewer workgroups than the chip holds, or barely more): the integer and the
+// FP64 moduli of a chain in ONE grid instead of two half-empty ones one after the other -- at N = 2^16, one
+// ciphertext, four pieces the two kernels took 87 + 58 us (the two integer moduli of the chain alone 58: 128
+// workgroups on 256 CUs).  Both bodies run two waves per SIMD (250 / 234 registers), so nothing is lost by sharing.
+__global__ __launch_bounds__(NTT_THREADS, 2) void ks_row_mac_split(KsMacArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
+    __shared__ double twl[15 * 256 + 15 * 16];
+    const KsIdx ki = ks_index<true>(a);
+    if (!ki.valid) return;
+    const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
+    const Mod md = a.mods[midx];
+    if (md.fp) ks_row_mac_fp_body<true>(a, ki, md, midx, lds, twl);
+    else ks_row_mac_int_body<true>(a, ki, md, midx, lds, twl);
+}
+
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
 {
     if (a.digits > 64 || items <= 0) return hipErrorInvalidValue;
@@ -1203,8 +1237,7 @@ hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
     const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned) items * (a.splits > 1 ? (unsigned) a.splits : 1u);
     // both kernels cover the whole grid; each exits at once on the other's moduli
     if (a.splits > 1) {
-        hipLaunchKernelGGL(ks_row_mac_fp<true>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
-        hipLaunchKernelGGL(ks_row_mac<true>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        hipLaunchKernelGGL(ks_row_mac_split, dim3(grid), dim3(NTT_THREADS), 0, st, k);
     } else {
         hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
         hipLaunchKernelGGL(ks_row_mac<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);

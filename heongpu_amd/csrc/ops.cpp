@@ -41,15 +41,20 @@ static long fused_row_mac_need(const Context& c)
 // us per launch, unfused / fused / two pieces / four pieces): N = 2^16, Q = 16: B = 1 289 / 368 / 307 / 289, B = 2
 // 456 / 457 / 410 / 410; Q = 30: B = 1 766 / 810 / 718 / 687, B = 2 1217 / 1123 / 1044 / 1027; N = 2^15, Q = 15: B = 1
 // 154 / 251 / 195 / 171, B = 2 219 / 307 / 255 / 234; chains of integer-butterfly moduli: never ahead, and the order
-// of fused and unfused changes from box to box there.  So: two pieces, on FP64-path chains at N = 2^16, for launches
-// that reach the fused path's size that way.  Returns 0 (no split) or the number of pieces.
+// of fused and unfused changes from box to box there.  Round 3, with the integer and the FP64 moduli of a split
+// launch in one grid (ks_row_mac_split; before, two half-empty grids one after the other): unfused / fused / four
+// pieces, N = 2^16, Q = 16: B = 1 294 / 409 / 285, B = 2 467 / 476 / 409, B = 4 813 / 702 / 701; Q = 30: B = 1
+// 806 / 832 / 690, B = 2 1277 / 1138 / 1029, B = 4 2283 / 1864 / 1829; N = 2^15, Q = 15: B = 1 155 / 252 / 154, B = 2
+// 221 / 302 / 232, B = 4 370 / 394 / 347 (tools/relin_small.py).  So: four pieces, on FP64-path chains at N = 2^16,
+// for launches below two rounds of the fused path's size that reach one round that way.  Returns 0 (no split) or
+// the number of pieces.
 static int fused_digit_splits(const Context& c, int rc, int digits, int batch)
 {
     if (c.digit_split == 0) return 0;
     if (c.digit_split > 0) return digits >= 2 * c.digit_split ? c.digit_split : 0;
     if (c.fused_row_mac >= 0 || c.n_power < 16 || digits < 8) return 0;
     const long wgs = (long) batch * rc * (long) (c.n >> 12), need = fused_row_mac_need(c);
-    return (need == 768 && wgs < need && 2 * wgs >= need) ? 2 : 0;
+    return (need == 768 && wgs < 2 * need && 4 * wgs >= need) ? 4 : 0;
 }
 static bool use_fused_row_mac(const Context& c, int rc, int batch)
 {

@@ -52,8 +52,9 @@ def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi, batc
     """BASELINE.json config C4 / bench.py's workload: CKKS N=2^16, Q = {60, 50 x 15}, P = {60}, depth 0,
     batch 3 (two distinct pairs + a twin): multiply -> relinearize_inplace -> rotate by one slot, every
     limb compared with the oracle.  Both forms of the decomposing column pass (bench.py's batch of 64
-    takes the multi-modulus one, a batch of 3 would not on its own); with two ciphertexts the launch-size rules
-    pick the fused key switch in two pieces per unit (ops.cpp: fused_digit_splits), with one the unfused sequence."""
+    takes the multi-modulus one, a batch of 3 would not on its own); with one to five ciphertexts the launch-size
+    rules pick the fused key switch in four pieces per unit, integer and FP64 moduli in one grid (ops.cpp:
+    fused_digit_splits, ks_row_mac_split); the unfused sequence is forced by the switch sets below."""
     n = 65536
     with backend_switches(**({} if col_multi is None else dict(HEGPU_COL_MULTI=col_multi))):
         c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])

@@ -15,8 +15,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 BUDGETS = {
     "10ks_row_macILb0EE": (2, 0),          # integer row pass + inner product, main path
     "13ks_row_mac_fpILb0EE": (2, 0),       # FP64 row pass + inner product, main path
-    "10ks_row_macILb1EE": (2, 0),          # digit-split forms
-    "13ks_row_mac_fpILb1EE": (2, 0),
+    "16ks_row_mac_split": (2, 64),         # digit-split form, both kinds of moduli in one grid (the 56 bytes hold
+                                           # output addresses across the digit loop, not inside it)
     "17ntt_fwd_col_multiILi8EE": (3, 0),   # decomposing column pass, N = 2^16
     "17ntt_fwd_col_multiILi7EE": (4, 0),
     "11ntt_fwd_colILi8ELb0EE": (4, 0),     # plain passes
