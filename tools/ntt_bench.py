@@ -14,10 +14,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n-power", type=int, default=16)
 ap.add_argument("--polys", type=int, default=17 * 512)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--all-fp", action="store_true", help="a chain of 50-bit primes only (every limb on the FP64 butterflies)")
 args = ap.parse_args()
 n = 1 << args.n_power
-log_q = [60] + [50] * 15
-ctx = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, [60], sec=hg.SEC_NONE)
+log_q = [50] * 16 if args.all_fp else [60] + [50] * 15
+ctx = hg.Context.from_bit_sizes(hg.CKKS, n, log_q, [50 if args.all_fp else 60], sec=hg.SEC_NONE)
 ctx.upload()
 rc = 17
 g = torch.Generator(device="cuda").manual_seed(1)
