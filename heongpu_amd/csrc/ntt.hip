@@ -1239,8 +1239,8 @@ hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
     if (a.splits > 1) {
         hipLaunchKernelGGL(ks_row_mac_split, dim3(grid), dim3(NTT_THREADS), 0, st, k);
     } else {
-        hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
-        hipLaunchKernelGGL(ks_row_mac<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        if (!a.no_fp) hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        if (!a.no_int) hipLaunchKernelGGL(ks_row_mac<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
     }
     return hipGetLastError();
 }

@@ -201,6 +201,7 @@ struct KsMacArgs {
     // partial sums (canonical residues) IN PLACE of the first two digits of its range in `in` (those regions are
     // read by this workgroup alone; digits >= 2 * splits); rns_sum_partials adds them into `out` afterwards.
     int splits;             // 0 / 1: none
+    int no_fp, no_int;      // the plan has no FP64 / no integer-butterfly moduli: that kernel is not launched at all
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 

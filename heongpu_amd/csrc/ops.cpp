@@ -122,6 +122,8 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         k.lazy_q_max = a.lazy_q_max; k.n_power = c.n_power; k.digits = digits; k.rc = rc; k.key_limbs = c.Qp_size; k.skip_identity = skip_identity;
         k.ident = ident ? ident + (u64) b0 * ident_stride : nullptr; k.ident_item_stride = ident_stride;
         k.splits = splits;
+        k.no_fp = !a.plan_has_fp;
+        k.no_int = !a.plan_has_int;
         TRY(ks_row_mac_launch(k, nb, st));
         if (splits > 1)
             TRY(rns_sum_partials(ca.out, a.out_item_stride, k.out, acc_stride, c.plan_qp.mods, a.mod_order, c.n_power,
