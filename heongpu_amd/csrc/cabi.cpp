@@ -1179,6 +1179,7 @@ struct hegpu_tfhe_context {
     int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
     int g4_min = 0x7fffffff;   // option "g4_min": from this many gates four gates share a workgroup's key registers
+    int ks_batched = -1;       // option "ks_batched": key switching with eight gates per workgroup sharing the key rows (1 / 0 / from 8192 gates)
     int wide_max = 0;          // option "wide_max": up to this many gates per call a gate runs on 16 wavefronts (measured slower)
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
     double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
@@ -1239,6 +1240,7 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
             if (const char* e = getenv("HEGPU_TFHE_FP")) h->allow_fp = e[0] != '0';             // defaults only:
             if (const char* e = getenv("HEGPU_TFHE_G4_MIN")) h->g4_min = atoi(e);                // hegpu_tfhe_context_set_option
             if (const char* e = getenv("HEGPU_TFHE_WIDE_MAX")) h->wide_max = atoi(e);
+            if (const char* e = getenv("HEGPU_TFHE_KS_BATCHED")) h->ks_batched = atoi(e);
         }
         *out = h;
         return 0;
@@ -1254,6 +1256,9 @@ int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int
     } else if (!strcmp(name, "g4_min")) {
         if (value < 1) return fail(HEGPU_E_INVALID, "value out of range for option g4_min");
         ctx->g4_min = value;
+    } else if (!strcmp(name, "ks_batched")) {
+        if (value < -1 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
+        ctx->ks_batched = value;
     } else if (!strcmp(name, "wide_max")) {
         if (value < 0) return fail(HEGPU_E_INVALID, "value out of range for option wide_max");
         ctx->wide_max = value;
@@ -1382,7 +1387,7 @@ int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              hegpu_stream stream)
 {
     TFHE_NEED(ctx);
-    return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, (hipStream_t) stream),
+    return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, ctx->ks_batched, (hipStream_t) stream),
                    "hegpu_tfhe_key_switching");
 }
 

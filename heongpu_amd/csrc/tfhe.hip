@@ -916,6 +916,87 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
     }
 }
 
+// Many gates per call (C5: 8192): KS_GB gates per workgroup share the key rows.  One gate per workgroup reads
+// N k * len rows of 2 KiB per gate -- 16 MiB, 137 GB of L2 traffic for 8192 gates, a quarter of it rows of zero
+// digits that are masked away.  Here the 2^bb - 1 = 3 candidate rows of a digit position are loaded once and each of
+// the KS_GB gates subtracts the one its digit names (the digit is wave-uniform: a scalar mask per gate and row):
+// 6 KiB of key per position for 8 gates instead of 16.  Same sums on the 32-bit torus, so the same bits.  The b
+// column of the key: lane (gate, position) of the first wavefront keeps its own partial sum.  base_bit = 2 only.
+#define KS_GB 8
+__global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* __restrict__ in_a,
+                                                                    const int* __restrict__ in_b,
+                                                                    int* __restrict__ out_a, int* __restrict__ out_b,
+                                                                    const int* __restrict__ ks_a,
+                                                                    const int* __restrict__ ks_b, int len, int n, int Nk,
+                                                                    int shape)
+{
+    constexpr int bb = 2, mask = 3;
+    __shared__ u32 bsum[KS_GB];
+    const int t = threadIdx.x;
+    const int g0 = blockIdx.x * KS_GB;
+    const u32 precision_offset = 1u << (32 - (1 + bb * len));
+    const int t2 = (t + 256 < n) ? t + 256 : t;
+    const u32 m2 = (t + 256 < n) ? 0xffffffffu : 0u;
+    u32 acc0[KS_GB], acc1[KS_GB];
+#pragma unroll
+    for (int gg = 0; gg < KS_GB; gg++) acc0[gg] = acc1[gg] = 0;
+    if (t < KS_GB) bsum[t] = 0;
+    // (gate, position) of this lane for the b column
+    const int bg = (t >> 3) & (KS_GB - 1), bp = t & 7;
+    const int bgate = (g0 + bg < shape) ? g0 + bg : shape - 1;
+    const bool bon = t < 8 * KS_GB && bp < len;
+    u32 accb = 0;
+    const int* pa[KS_GB];
+#pragma unroll
+    for (int gg = 0; gg < KS_GB; gg++) pa[gg] = in_a + (u64) ((g0 + gg < shape) ? g0 + gg : shape - 1) * Nk;
+    for (int i = 0; i < Nk; i++) {
+        u32 a[KS_GB];
+#pragma unroll
+        for (int gg = 0; gg < KS_GB; gg++) a[gg] = (u32) pa[gg][i] + precision_offset;
+        if (bon) {
+            const u32 ab = (u32) in_a[(u64) bgate * Nk + i] + precision_offset;
+            const int d = (int) ((ab >> ((32 - (bp + 1) * bb) & 31)) & (u32) mask);
+            const u64 row = ((u64) i * len + bp) * mask + (d ? d - 1 : 0);
+            accb -= d ? (u32) ks_b[row] : 0u;
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 8; i2++) {
+            if (i2 < len) { // (uniform)
+                const int* kr = ks_a + ((u64) i * len + i2) * mask * n;
+                u32 r0[3], r1[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    r0[r] = (u32) kr[(u64) r * n + t];
+                    r1[r] = (u32) kr[(u64) r * n + t2] & m2;
+                }
+#pragma unroll
+                for (int gg = 0; gg < KS_GB; gg++) {
+                    const u32 d = (a[gg] >> ((32 - (i2 + 1) * bb) & 31)) & (u32) mask; // wave-uniform
+                    // two selects on scalar conditions, a scalar mask for the zero digit, one subtraction
+                    const u32 m = d ? 0xffffffffu : 0u;
+                    u32 s0 = (d == 2u) ? r0[1] : r0[0], s1 = (d == 2u) ? r1[1] : r1[0];
+                    s0 = (d == 3u) ? r0[2] : s0;
+                    s1 = (d == 3u) ? r1[2] : s1;
+                    acc0[gg] -= s0 & m;
+                    acc1[gg] -= s1 & m;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (bon) atomicAdd(&bsum[bg], accb);
+    __syncthreads();
+#pragma unroll
+    for (int gg = 0; gg < KS_GB; gg++) {
+        const int g = g0 + gg;
+        if (g < shape) {
+            out_a[(u64) g * n + t] = (int) acc0[gg];
+            if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1[gg];
+            if (t == 0) out_b[g] = (int) ((u32) in_b[g] + bsum[gg]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ front end: keys, encryption, decryption
 __global__ __launch_bounds__(256) void k_tfhe_gen_bits(int* __restrict__ out, int count, DrbgKey seed, u64 stream)
 {
@@ -1135,7 +1216,7 @@ hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, c
 }
 
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,
-                              const int* ks_a, const int* ks_b, int shape, hipStream_t st)
+                              const int* ks_a, const int* ks_b, int shape, int ks_batched, hipStream_t st)
 {
     if (p.n > 512 || p.ks_length > 8) return hipErrorInvalidValue;
     if (shape <= 0) return hipSuccess;
@@ -1150,6 +1231,12 @@ hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_tfhe_key_switching<true>, dim3(shape, pieces), dim3(256), 0, st, in_a, in_b, out_a, out_b,
                            ks_a, ks_b, p.ks_base_bit, p.ks_length, p.n, Nk, chunk);
+        return hipGetLastError();
+    }
+    // beyond four resident rounds of one-gate workgroups: KS_GB gates per workgroup share the key rows
+    if (ks_batched != 0 && p.ks_base_bit == 2 && p.n >= 256 && (ks_batched == 1 || shape >= 8192)) {
+        hipLaunchKernelGGL(k_tfhe_key_switching_batched, dim3((shape + KS_GB - 1) / KS_GB), dim3(256), 0, st, in_a, in_b,
+                           out_a, out_b, ks_a, ks_b, p.ks_length, p.n, Nk, shape);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tfhe_key_switching<false>, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,

@@ -71,6 +71,28 @@ def test_blind_rotate_and_key_switch(hg, setup, wide_max):
     assert np.array_equal(kb.cpu().numpy(), ks_want_b)
 
 
+@pytest.mark.parametrize("shape", [5, 8, 21])
+def test_key_switching_eight_gates_per_workgroup(hg, setup, shape):
+    """The batched form of the key switching (eight gates per workgroup share the three candidate rows of every digit
+    position; chosen from 8192 gates, forced here), with a last workgroup that is not full: every gate against the
+    oracle, stale output contents must not leak in."""
+    import torch
+    t, o, rng, bk, ks_a, ks_b = setup
+    ea = rng.integers(-2**31, 2**31, shape * 1024, dtype=np.int64).astype(np.int32)
+    eb = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
+    ea[:8] = [0, -1, 2**31 - 1, -2**31, 1 << 15, (1 << 15) - 1, 3 << 14, 1 << 14]  # digits at the rounding edges
+    t.set_option("ks_batched", 1)
+    ka = torch.full((shape * 512,), 7, dtype=torch.int32, device="cuda")
+    kb = torch.full((shape,), 7, dtype=torch.int32, device="cuda")
+    t.key_switching(_dev32(ea), _dev32(eb), ka, kb, _dev32(ks_a), _dev32(ks_b), shape)
+    torch.cuda.synchronize()
+    t.set_option("ks_batched", -1)
+    got_a, got_b = ka.cpu().numpy().reshape(shape, 512), kb.cpu().numpy()
+    for g in range(shape):
+        want_a, want_b = o.key_switching(ea[g * 1024:(g + 1) * 1024], eb[g:g + 1], ks_a, ks_b)
+        assert np.array_equal(got_a[g], want_a) and got_b[g] == want_b[0], g
+
+
 @pytest.mark.parametrize("shape", [1, 33, 1024, 1025])
 def test_key_switching_split_launches(hg, setup, shape):
     """Key switching alone on random extracted samples, on both sides of the launch-size rule of tfhe_key_switching:
