@@ -1179,7 +1179,7 @@ struct hegpu_tfhe_context {
     int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
     int g4_min = 0x7fffffff;   // option "g4_min": from this many gates four gates share a workgroup's key registers
-    int ks_batched = -1;       // option "ks_batched": key switching with eight gates per workgroup sharing the key rows (1 / 0 / from 8192 gates)
+    int ks_batched = -1;       // option "ks_batched": key switching with 8 / 12 / 16 gates per workgroup sharing the key rows (tfhe.hip)
     int wide_max = 0;          // option "wide_max": up to this many gates per call a gate runs on 16 wavefronts (measured slower)
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
     double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
@@ -1257,7 +1257,8 @@ int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int
         if (value < 1) return fail(HEGPU_E_INVALID, "value out of range for option g4_min");
         ctx->g4_min = value;
     } else if (!strcmp(name, "ks_batched")) {
-        if (value < -1 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
+        if (value < -1 || (value > 1 && value != 8 && value != 12 && value != 16))
+            return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
         ctx->ks_batched = value;
     } else if (!strcmp(name, "wide_max")) {
         if (value < 0) return fail(HEGPU_E_INVALID, "value out of range for option wide_max");

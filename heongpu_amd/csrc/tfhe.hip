@@ -921,8 +921,11 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
 // digits that are masked away.  Here the 2^bb - 1 = 3 candidate rows of a digit position are loaded once and each of
 // the KS_GB gates subtracts the one its digit names (the digit is wave-uniform: a scalar mask per gate and row):
 // 6 KiB of key per position for 8 gates instead of 16.  Same sums on the 32-bit torus, so the same bits.  The b
-// column of the key: lane (gate, position) of the first wavefront keeps its own partial sum.  base_bit = 2 only.
-#define KS_GB 8
+// column of the key: lane (gate, position) of the first wavefronts keeps its own partial sum.  base_bit = 2 only.
+// A workgroup is a chain of N k iterations of ~4.5 us whatever KS_GB is (4.6 ms), three are resident per CU (144
+// registers; capped at 128 the loads are no longer batched: 7.9 ms), so KS_GB is chosen to finish in ONE round of
+// 768 workgroups where 8, 12 or 16 gates per workgroup allow it (tools/tfhe_ks_shapes.py).
+template <int KS_GB>
 __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* __restrict__ in_a,
                                                                     const int* __restrict__ in_b,
                                                                     int* __restrict__ out_a, int* __restrict__ out_b,
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* _
     for (int gg = 0; gg < KS_GB; gg++) acc0[gg] = acc1[gg] = 0;
     if (t < KS_GB) bsum[t] = 0;
     // (gate, position) of this lane for the b column
-    const int bg = (t >> 3) & (KS_GB - 1), bp = t & 7;
+    const int bg = (t >> 3) < KS_GB ? (t >> 3) : 0, bp = t & 7;
     const int bgate = (g0 + bg < shape) ? g0 + bg : shape - 1;
     const bool bon = t < 8 * KS_GB && bp < len;
     u32 accb = 0;
@@ -1233,10 +1236,21 @@ hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b
                            ks_a, ks_b, p.ks_base_bit, p.ks_length, p.n, Nk, chunk);
         return hipGetLastError();
     }
-    // beyond four resident rounds of one-gate workgroups: KS_GB gates per workgroup share the key rows
-    if (ks_batched != 0 && p.ks_base_bit == 2 && p.n >= 256 && (ks_batched == 1 || shape >= 8192)) {
-        hipLaunchKernelGGL(k_tfhe_key_switching_batched, dim3((shape + KS_GB - 1) / KS_GB), dim3(256), 0, st, in_a, in_b,
-                           out_a, out_b, ks_a, ks_b, p.ks_length, p.n, Nk, shape);
+    // many gates: 8 / 12 / 16 gates per workgroup share the key rows (4.6 ms per round of 768 workgroups against
+    // 1.38 us per gate: ahead from ~3400 gates)
+    // (ks_batched: -1 by launch size, 0 never, 1 always, 8 / 12 / 16 always with that many gates per workgroup)
+    if (ks_batched != 0 && p.ks_base_bit == 2 && p.n >= 256 && (ks_batched >= 1 || shape >= 3584)) {
+        const int gb = (ks_batched >= 8) ? ks_batched : (shape <= 8 * 768) ? 8 : (shape <= 12 * 768) ? 12 : 16;
+        const dim3 grid((unsigned) ((shape + gb - 1) / gb));
+        if (gb == 8)
+            hipLaunchKernelGGL(k_tfhe_key_switching_batched<8>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
+                               ks_b, p.ks_length, p.n, Nk, shape);
+        else if (gb == 12)
+            hipLaunchKernelGGL(k_tfhe_key_switching_batched<12>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
+                               ks_b, p.ks_length, p.n, Nk, shape);
+        else
+            hipLaunchKernelGGL(k_tfhe_key_switching_batched<16>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
+                               ks_b, p.ks_length, p.n, Nk, shape);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tfhe_key_switching<false>, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,

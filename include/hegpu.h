@@ -459,7 +459,9 @@ void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
  * "g4_min": from this many gates per call four gates share one workgroup's key registers (default: never);
  * "wide_max": up to this many gates per call a gate is one workgroup of 16 wavefronts, four per transform
  * (default 0 = never: measured 5.8 ms against 4.4 ms for 1..256 gates).
- * "ks_batched" -1/0/1: key switching with eight gates per workgroup sharing the key rows (default: from 8192 gates).
+ * "ks_batched" -1/0/1/8/12/16: key switching with 8, 12 or 16 gates per workgroup sharing the key rows: by launch
+ * size (-1, default: from 3584 gates per call, the count that finishes in one round of workgroups), never, always,
+ * always with that many.
  * Defaults seeded once from HEGPU_TFHE_FP / _G4_MIN / _WIDE_MAX / _KS_BATCHED at creation. */
 int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int value);
 /* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems",

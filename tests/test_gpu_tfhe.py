@@ -71,17 +71,17 @@ def test_blind_rotate_and_key_switch(hg, setup, wide_max):
     assert np.array_equal(kb.cpu().numpy(), ks_want_b)
 
 
-@pytest.mark.parametrize("shape", [5, 8, 21])
-def test_key_switching_eight_gates_per_workgroup(hg, setup, shape):
-    """The batched form of the key switching (eight gates per workgroup share the three candidate rows of every digit
-    position; chosen from 8192 gates, forced here), with a last workgroup that is not full: every gate against the
-    oracle, stale output contents must not leak in."""
+@pytest.mark.parametrize("shape,per_wg", [(5, 8), (8, 8), (21, 8), (29, 12), (12, 12), (35, 16)])
+def test_key_switching_gates_sharing_key_rows(hg, setup, shape, per_wg):
+    """The batched form of the key switching (8 / 12 / 16 gates per workgroup share the three candidate rows of every
+    digit position; chosen from 3584 gates per call, forced here), with a last workgroup that is not full: every gate
+    against the oracle, stale output contents must not leak in."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
     ea = rng.integers(-2**31, 2**31, shape * 1024, dtype=np.int64).astype(np.int32)
     eb = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
     ea[:8] = [0, -1, 2**31 - 1, -2**31, 1 << 15, (1 << 15) - 1, 3 << 14, 1 << 14]  # digits at the rounding edges
-    t.set_option("ks_batched", 1)
+    t.set_option("ks_batched", per_wg)
     ka = torch.full((shape * 512,), 7, dtype=torch.int32, device="cuda")
     kb = torch.full((shape,), 7, dtype=torch.int32, device="cuda")
     t.key_switching(_dev32(ea), _dev32(eb), ka, kb, _dev32(ks_a), _dev32(ks_b), shape)
