@@ -32,6 +32,9 @@ TFHE_BUDGETS = {
     "22k_tfhe_blind_rotate_fpILi1EE": (2, 0),  # FP64 blind rotate: one wavefront per decomposed polynomial
     "27k_tfhe_blind_rotate_fp_wideE": (4, 0),  # few gates: 16 wavefronts per gate in one workgroup
     "19k_tfhe_blind_rotateE": (2, 0),          # integer blind rotate (keys beyond int32)
+    "28k_tfhe_key_switching_batchedILi8EE": (3, 0),   # many gates: three resident workgroups per CU is what the
+    "28k_tfhe_key_switching_batchedILi12EE": (3, 0),  # one-round choice of gates per workgroup counts on
+    "28k_tfhe_key_switching_batchedILi16EE": (3, 0),
     "20k_tfhe_key_switchingILb0EE": (4, 0),
     "20k_tfhe_key_switchingILb1EE": (4, 0),
 }
