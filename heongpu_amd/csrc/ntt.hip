@@ -765,7 +765,11 @@ __device__ __forceinline__ int single_pos(int row, int col)
     return (row >> 4) * 4096 + row_phys((row & 15) * 256 + col);
 }
 
-template <int S1, bool FP, bool LAZY>
+// DECOMP (NttArgs::decomp_mods, opted in by the caller with single_decomp_ok): the source limb is a digit -- a
+// residue of another prime of the plan, optionally through the mod-down "+ half" / "- half mod q" -- and is
+// converted as the two-pass column bodies do (fwd_col_body / fwd_col_body_fp): all 16 loads of a thread first, then
+// uniform conditions around whole loops.
+template <int S1, bool FP, bool LAZY, bool DECOMP = false>
 __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel& ps, const Mod& md, u64* limb)
 {
     constexpr int R = 1 << S1;
@@ -779,6 +783,53 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + g * CT;
     const int col = tt % CT, r1 = tt / CT;
+    // DECOMP: the thread's 16 source coefficients in load order (group gi, slot k at [gi * RA + k]; NSA == 0: row k)
+    u64 dv[DECOMP ? 16 : 1];
+    double dy[(DECOMP && FP) ? 16 : 1];
+    if constexpr (DECOMP) {
+        if constexpr (NSA > 0) {
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                const int L = tt + 256 * gi;
+                const int c = L % CT, rb = L / CT;
+#pragma unroll
+                for (int k = 0; k < RA; k++) dv[gi * RA + k] = src[(u64) (rb + 16 * k) * 256 + c];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dv[k] = src[(u64) k * 256 + col];
+        }
+        const u64 half_qP = a.half_on ? a.mods[a.half_src_mod].q : 0;
+        if constexpr (FP) {
+            if (a.half_on) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) dv[k] = add_mod(dv[k], a.half, half_qP);
+            }
+            if (a.mods[a.half_on ? a.half_src_mod : ps.digit].bit > 52) { // v = vh 2^32 + vl == vh (2^32 mod q) + vl
+                const double c32 = (double) reduce64(1ull << 32, md), c32i = c32 * fc.qi;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    dy[k] = fp_mul(fp_from_u32((u32) (dv[k] >> 32)), c32, c32i, fc) + fp_from_u32((u32) dv[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) dy[k] = fp_reduce(fp_from_u64(dv[k]), fc);
+            }
+            if (a.half_on) {
+                const double half_hm = fp_from_u64(a.half_mod[ps.mod]);
+#pragma unroll
+                for (int k = 0; k < 16; k++) dy[k] = fp_reduce(dy[k] - half_hm, fc);
+            }
+        } else {
+            if (a.half_on) {
+                const u64 half_hm = a.half_mod[ps.mod];
+#pragma unroll
+                for (int k = 0; k < 16; k++) dv[k] = sub_mod(reduce64(add_mod(dv[k], a.half, half_qP), md), half_hm, md.q);
+            } else if (!LAZY && a.mods[ps.digit].q > 8 * md.q) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) dv[k] = reduce64(dv[k], md);
+            }
+        }
+    }
     // ---- column stages 0 .. S1-1
     if constexpr (FP) {
         double x[16];
@@ -789,7 +840,10 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
                 const int c = L % CT, rb = L / CT;
                 double y[RA];
 #pragma unroll
-                for (int k = 0; k < RA; k++) y[k] = fp_from_u64(src[(u64) (rb + 16 * k) * 256 + c]);
+                for (int k = 0; k < RA; k++) {
+                    if constexpr (DECOMP) y[k] = dy[gi * RA + k];
+                    else y[k] = fp_from_u64(src[(u64) (rb + 16 * k) * 256 + c]);
+                }
                 fp_ct_radix<NSA>(y, tw, 1u, fc, FpColSched<S1>::a_before, false);
 #pragma unroll
                 for (int k = 0; k < RA; k++) limb[single_pos<S1>(rb + 16 * k, g * CT + c)] = as_bits(y[k]);
@@ -799,7 +853,10 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
             for (int k = 0; k < 16; k++) x[k] = as_f64(limb[single_pos<S1>(16 * r1 + k, g * CT + col)]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_from_u64(src[(u64) k * 256 + col]);
+            for (int k = 0; k < 16; k++) {
+                if constexpr (DECOMP) x[k] = dy[k];
+                else x[k] = fp_from_u64(src[(u64) k * 256 + col]);
+            }
         }
         fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc, FpColSched<S1>::b_before, FpColSched<S1>::b_at_end);
 #pragma unroll
@@ -813,7 +870,10 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
                 const int c = L % CT, rb = L / CT;
                 u64 y[RA];
 #pragma unroll
-                for (int k = 0; k < RA; k++) y[k] = src[(u64) (rb + 16 * k) * 256 + c];
+                for (int k = 0; k < RA; k++) {
+                    if constexpr (DECOMP) y[k] = dv[gi * RA + k];
+                    else y[k] = src[(u64) (rb + 16 * k) * 256 + c];
+                }
                 ct_radix<NSA, LAZY>(y, tw, 1u, qc);
 #pragma unroll
                 for (int k = 0; k < RA; k++) limb[single_pos<S1>(rb + 16 * k, g * CT + c)] = y[k];
@@ -823,7 +883,10 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
             for (int k = 0; k < 16; k++) x[k] = limb[single_pos<S1>(16 * r1 + k, g * CT + col)];
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = src[(u64) k * 256 + col];
+            for (int k = 0; k < 16; k++) {
+                if constexpr (DECOMP) x[k] = dv[k];
+                else x[k] = src[(u64) k * 256 + col];
+            }
         }
         ct_radix<4, LAZY>(x, tw, (u32) (RA + r1), qc);
 #pragma unroll
@@ -885,15 +948,16 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
 }
 
 // grid = batch polynomials, N / 16 threads, N * 8 bytes of dynamic LDS
-template <int S1>
+template <int S1, bool DECOMP = false>
 __global__ __launch_bounds__(16 << S1, 4) void ntt_fwd_single(NttArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u64 limb[];
     const PolySel ps = select_poly(a, blockIdx.x);
+    if (DECOMP && a.skip_identity && ps.mod == ps.digit) return;
     const Mod md = a.mods[ps.mod];
-    if (md.fp) fwd_single_body<S1, true, false>(a, ps, md, limb);
-    else if (fwd_stages_lazy(md, a.lazy_q_max)) fwd_single_body<S1, false, true>(a, ps, md, limb);
-    else fwd_single_body<S1, false, false>(a, ps, md, limb);
+    if (md.fp) fwd_single_body<S1, true, false, DECOMP>(a, ps, md, limb);
+    else if (fwd_stages_lazy(md, a.lazy_q_max)) fwd_single_body<S1, false, true, DECOMP>(a, ps, md, limb);
+    else fwd_single_body<S1, false, false, DECOMP>(a, ps, md, limb);
 }
 
 // ------------------------------------------------------------------ fused row pass + key-switch MAC
@@ -956,22 +1020,28 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
 // else is re-used, so they are placed on ONE XCD (workgroup b runs on XCD b % 8): group g goes to XCD
 // g % 8 and its ciphertexts run there back to back -- one L2 instead of eight fetches every key tile.
 struct KsIdx { int item, tile, slot; bool valid; int d0, d1; };
-template <bool SPLIT>
+// COMPACT (the integer kernel of an unsplit launch that knows its slots): groups run over KsMacArgs::int_slots only
+template <bool SPLIT, bool COMPACT = false>
 __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
 {
     const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
     // with digit splits (item, split) takes the place of the item: splits of one item sit next to each other
     const unsigned splits = SPLIT ? (unsigned) a.splits : 1u;
     const unsigned units = (unsigned) a.items * splits;
-    const unsigned gi = j / units, unit = j - gi * units;
+    const bool spread = COMPACT && a.int_spread;
+    const unsigned gi = spread ? b / units : j / units, unit = spread ? b - gi * units : j - gi * units;
     const unsigned item = SPLIT ? unit / splits : unit, sp = SPLIT ? unit - item * splits : 0u;
-    const unsigned g = gi * 8u + xcd;
+    const unsigned g = spread ? gi : gi * 8u + xcd;
     const unsigned tiles = 1u << (a.n_power - 12);
     KsIdx r;
     r.item = (int) item;
     r.slot = (int) (g >> (a.n_power - 12));
     r.tile = (int) (g & (tiles - 1));
-    r.valid = r.slot < a.rc;
+    if (COMPACT && a.int_slot_count > 0) {
+        r.valid = r.slot < a.int_slot_count;
+        r.slot = a.int_slots[r.valid ? r.slot : 0];
+    } else
+        r.valid = r.slot < a.rc;
     r.d0 = SPLIT ? (int) (sp * (unsigned) a.digits / splits) : 0;
     r.d1 = SPLIT ? (int) ((sp + 1) * (unsigned) a.digits / splits) : a.digits;
     return r;
@@ -1047,7 +1117,7 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     __shared__ ulonglong2 twa[15 * 16];
-    const KsIdx ki = ks_index<SPLIT>(a);
+    const KsIdx ki = ks_index<SPLIT, !SPLIT>(a);
     if (!ki.valid) return;
     const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
     const Mod md = a.mods[midx];
@@ -1240,7 +1310,18 @@ hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
         hipLaunchKernelGGL(ks_row_mac_split, dim3(grid), dim3(NTT_THREADS), 0, st, k);
     } else {
         if (!a.no_fp) hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
-        if (!a.no_int) hipLaunchKernelGGL(ks_row_mac<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        if (!a.no_int) {
+            unsigned igrid = grid;
+            if (a.int_slot_count > 0) { // compact grid over the integer slots; few groups: dealt over all XCDs
+                const unsigned igroups = ((1u << a.n_power) / 4096) * (unsigned) a.int_slot_count;
+                k.int_spread = igroups < 16;
+                igrid = (k.int_spread ? igroups : ((igroups + 7) / 8) * 8) * (unsigned) items;
+            } else {
+                k.int_slot_count = 0;
+                k.int_spread = 0;
+            }
+            hipLaunchKernelGGL(ks_row_mac<false>, dim3(igrid), dim3(NTT_THREADS), 0, st, k);
+        }
     }
     return hipGetLastError();
 }
@@ -1838,6 +1919,20 @@ static void launch_fwd(const NttArgs& a, int batch, hipStream_t st)
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
             (void) attr;
             hipLaunchKernelGGL((ntt_fwd_single<S1>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, a);
+            return;
+        }
+        // a decomposing launch whose caller allows it (no operand of the epilogue may alias the source limbs: every
+        // workgroup reads a whole source limb while others already store) and that is neither the multi-modulus
+        // column pass nor carrying a copy
+        if (a.decomp_mods && a.single_decomp_ok && !a.copy_src && !a.src_inv && !use_col_multi<S1>(a, batch) &&
+            use_single_pass(a, batch)) {
+            static const hipError_t attr_d = hipFuncSetAttribute((const void*) ntt_fwd_single<S1, true>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 << (S1 + 8));
+            (void) attr_d;
+            NttArgs c = a; // natural order: the targets of one source limb run back to back and share it in L2
+            c.group_span = 0;
+            c.mg_group_span = 0;
+            hipLaunchKernelGGL((ntt_fwd_single<S1, true>), dim3(batch), dim3(16 << S1), (size_t) 8 << (S1 + 8), st, c);
             return;
         }
     }

@@ -132,6 +132,9 @@ struct NttArgs {
     // subtraction (set from the plan: (2^64 - 1 - 2 max q) / (4 log2 N), see context.cpp build_plan)
     u64 lazy_q_max;
     int only_int;                  // set by the launcher: the per-polynomial kernel skips FP64 moduli
+    // Decomposing launch at N <= 2^14: the caller states that neither the output nor an operand of the epilogue
+    // overlaps the source limbs, so the launch may run as ONE pass (ntt_fwd_single<S1, true>) by the single-pass rule
+    int single_decomp_ok;
     // Decomposing launches whose FP64 targets go through ntt_fwd_col_multi: the target slots (index into the
     // decomp_mods moduli of a digit) that have INTEGER moduli, if the caller knows them -- the per-polynomial kernel
     // is then launched for exactly those (count > 0), or not at all (count < 0: none); 0 = unknown: it is launched
@@ -202,6 +205,14 @@ struct KsMacArgs {
     // read by this workgroup alone; digits >= 2 * splits); rns_sum_partials adds them into `out` afterwards.
     int splits;             // 0 / 1: none
     int no_fp, no_int;      // the plan has no FP64 / no integer-butterfly moduli: that kernel is not launched at all
+    // The limb slots with integer moduli, if the caller knows them (count > 0; as NttArgs::int_slots): the integer
+    // kernel then runs on a compact grid over those slots only.  The XCD-aware order puts all ciphertexts of a
+    // (slot, tile) group on one XCD; with two integer moduli and N / 4096 <= 4 tiles that is 2 to 4 of the 8 XCDs
+    // (N = 2^13, q0 and P of 60 bits: 671 us for 2 moduli next to 378 us for the 7 FP64 ones), so below 16 groups
+    // the workgroups of a group are dealt round-robin over the XCDs instead (set by ks_row_mac_launch: int_spread).
+    int int_slot_count;
+    int int_slots[8];
+    int int_spread;
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 

@@ -123,7 +123,9 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         k.ident = ident ? ident + (u64) b0 * ident_stride : nullptr; k.ident_item_stride = ident_stride;
         k.splits = splits;
         k.no_fp = !a.plan_has_fp;
-        k.no_int = !a.plan_has_int;
+        k.no_int = !a.plan_has_int || a.int_slot_count < 0;
+        k.int_slot_count = a.int_slot_count > 0 ? a.int_slot_count : 0;
+        for (int q = 0; q < 8; q++) k.int_slots[q] = a.int_slots[q];
         TRY(ks_row_mac_launch(k, nb, st));
         if (splits > 1)
             TRY(rns_sum_partials(ca.out, a.out_item_stride, k.out, acc_stride, c.plan_qp.mods, a.mod_order, c.n_power,
@@ -208,6 +210,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
         else TRY(ntt_launch(a, l * batch, true, st));
     }
     dgt.src_inv = fuse_inv ? 1 : 0;
+    dgt.single_decomp_ok = 1; // temp2 -> temp1, no epilogue
     a = dgt;
     // forward NTT of the digits + inner product with the key      (:956-988)
     const int which = ((phases & RELIN_PHASE_COLUMN) ? 1 : 0) | ((phases & RELIN_PHASE_ROW_MAC) ? 2 : 0);
@@ -252,6 +255,7 @@ static hipError_t ckks_keyswitch_core(const Context& c, const u64* src, u64 src_
         a.epi.limbs = l;
         a.epi.galois_inv = galois_elt ? (unsigned) inv_mod_2n((u64) galois_elt, 2 * c.n) : 0u;
         a.src_inv = fuse_inv_p ? 1 : 0;
+        a.single_decomp_ok = 1; // source: the P-limb slots of temp2; the epilogue reads its Q-limb slots and `add`, writes `outp`
         fill_int_slots(c, a, nullptr);
         return ntt_launch(a, 2 * l * batch, false, st);
     }

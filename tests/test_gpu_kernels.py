@@ -109,6 +109,10 @@ _SWITCHES = [
     dict(HEGPU_DIGIT_SPLIT=4, HEGPU_COL_MULTI=1),
     dict(HEGPU_FP_NTT=0),
     dict(HEGPU_FUSED_ROW_MAC=0, HEGPU_FUSED_MODDOWN=0, HEGPU_FP_NTT=0),
+    # decomposing launches as ONE pass (ntt_fwd_single<S1, true>): the digits of the unfused key switch and the
+    # mod-down transform with its epilogue, FP64 and integer moduli
+    dict(HEGPU_FUSED_ROW_MAC=0, HEGPU_SINGLE_PASS=1, HEGPU_COL_MULTI=0),
+    dict(HEGPU_FUSED_ROW_MAC=0, HEGPU_SINGLE_PASS=1, HEGPU_COL_MULTI=0, HEGPU_FP_NTT=0),
 ]
 
 
