@@ -1015,33 +1015,46 @@ __device__ __forceinline__ void ks_row_digit(u64 (&x)[16], const u64* __restrict
     wave_lds_fence();
 }
 
-// One-dimensional grid of 8 * ceil(groups / 8) * items workgroups, group = (tile, limb slot).  The
-// `items` workgroups of a group share the key tiles of that group (1 MiB at 16 digits) and nothing
-// else is re-used, so they are placed on ONE XCD (workgroup b runs on XCD b % 8): group g goes to XCD
-// g % 8 and its ciphertexts run there back to back -- one L2 instead of eight fetches every key tile.
+// One-dimensional grid, group = (limb slot, tile).  The `items` workgroups of a group share the key tiles of that
+// group (1 MiB at 16 digits) and nothing else is re-used, so a group should run on ONE XCD (workgroup b runs on XCD
+// b % 8) -- one L2 instead of eight fetches every key tile -- AND every XCD should get the same number of
+// workgroups.  Round 2 pinned group g to XCD g % 8, which is balanced for C4's 240 groups but not for the 4, 14 or 28
+// groups of N <= 2^14 (round 3: two integer moduli on 2 of 8 XCDs).  Now the workgroups, in group-major order, are cut
+// into eight equal contiguous chunks, one per XCD: a group straddles at most two XCDs, the load is even to within one
+// workgroup.  grid = 8 * ceil(T / 8), T = slots * tiles * units.
+// KIND: which limb slots the grid runs over -- 0 all (split launches, or the caller does not know the kinds: the
+// kernels exit on the other kind's moduli), 1 / 2 the integer / the FP64 ones of KsMacArgs::int_slots (ascending).
 struct KsIdx { int item, tile, slot; bool valid; int d0, d1; };
-// COMPACT (the integer kernel of an unsplit launch that knows its slots): groups run over KsMacArgs::int_slots only
-template <bool SPLIT, bool COMPACT = false>
+__host__ __device__ __forceinline__ unsigned ks_slots(const KsMacArgs& a, int kind)
+{
+    if (a.int_slot_count <= 0 || kind == 0) return (unsigned) a.rc;
+    return kind == 1 ? (unsigned) a.int_slot_count : (unsigned) (a.rc - a.int_slot_count);
+}
+template <bool SPLIT, int KIND = 0>
 __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
 {
     const unsigned b = blockIdx.x, xcd = b & 7u, j = b >> 3;
     // with digit splits (item, split) takes the place of the item: splits of one item sit next to each other
     const unsigned splits = SPLIT ? (unsigned) a.splits : 1u;
     const unsigned units = (unsigned) a.items * splits;
-    const bool spread = COMPACT && a.int_spread;
-    const unsigned gi = spread ? b / units : j / units, unit = spread ? b - gi * units : j - gi * units;
-    const unsigned item = SPLIT ? unit / splits : unit, sp = SPLIT ? unit - item * splits : 0u;
-    const unsigned g = spread ? gi : gi * 8u + xcd;
     const unsigned tiles = 1u << (a.n_power - 12);
+    const unsigned total = ks_slots(a, KIND) * tiles * units, chunk = (total + 7u) >> 3;
+    const unsigned lin = xcd * chunk + j;
+    const unsigned g = lin / units, unit = lin - g * units;
+    const unsigned item = SPLIT ? unit / splits : unit, sp = SPLIT ? unit - item * splits : 0u;
     KsIdx r;
+    r.valid = lin < total;
     r.item = (int) item;
-    r.slot = (int) (g >> (a.n_power - 12));
     r.tile = (int) (g & (tiles - 1));
-    if (COMPACT && a.int_slot_count > 0) {
-        r.valid = r.slot < a.int_slot_count;
-        r.slot = a.int_slots[r.valid ? r.slot : 0];
-    } else
-        r.valid = r.slot < a.rc;
+    int si = (int) (g >> (a.n_power - 12));
+    if (KIND == 1 && a.int_slot_count > 0) {
+        si = a.int_slots[r.valid ? si : 0];
+    } else if (KIND == 2 && a.int_slot_count > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) // the si-th slot that is not in the (ascending) list
+            if (q < a.int_slot_count && a.int_slots[q] <= si) si++;
+    }
+    r.slot = si;
     r.d0 = SPLIT ? (int) (sp * (unsigned) a.digits / splits) : 0;
     r.d1 = SPLIT ? (int) ((sp + 1) * (unsigned) a.digits / splits) : a.digits;
     return r;
@@ -1117,7 +1130,7 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     __shared__ ulonglong2 twa[15 * 16];
-    const KsIdx ki = ks_index<SPLIT, !SPLIT>(a);
+    const KsIdx ki = ks_index<SPLIT, SPLIT ? 0 : 1>(a);
     if (!ki.valid) return;
     const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
     const Mod md = a.mods[midx];
@@ -1273,7 +1286,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ks_row_mac_fp(KsMacArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[ROW_LDS_ELEMS];
     __shared__ double twl[15 * 256 + 15 * 16];
-    const KsIdx ki = ks_index<SPLIT>(a);
+    const KsIdx ki = ks_index<SPLIT, SPLIT ? 0 : 2>(a);
     if (!ki.valid) return;
     const int midx = a.mod_order ? a.mod_order[ki.slot] : ki.slot;
     const Mod md = a.mods[midx];
@@ -1303,25 +1316,17 @@ hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st)
     if (a.splits > 1 && a.digits < 2 * a.splits) return hipErrorInvalidValue;
     KsMacArgs k = a;
     k.items = items;
-    const unsigned groups = ((1u << a.n_power) / 4096) * (unsigned) a.rc;
-    const unsigned grid = ((groups + 7) / 8) * 8 * (unsigned) items * (a.splits > 1 ? (unsigned) a.splits : 1u);
-    // both kernels cover the whole grid; each exits at once on the other's moduli
+    if (k.int_slot_count < 0 || k.int_slot_count > 8) k.int_slot_count = 0;
+    const unsigned tiles = (1u << a.n_power) / 4096, units = (unsigned) items * (a.splits > 1 ? (unsigned) a.splits : 1u);
+    auto grid_of = [&](int kind) { return dim3(8u * ((ks_slots(k, kind) * tiles * units + 7u) / 8u)); };
     if (a.splits > 1) {
-        hipLaunchKernelGGL(ks_row_mac_split, dim3(grid), dim3(NTT_THREADS), 0, st, k);
+        hipLaunchKernelGGL(ks_row_mac_split, grid_of(0), dim3(NTT_THREADS), 0, st, k);
     } else {
-        if (!a.no_fp) hipLaunchKernelGGL(ks_row_mac_fp<false>, dim3(grid), dim3(NTT_THREADS), 0, st, k);
-        if (!a.no_int) {
-            unsigned igrid = grid;
-            if (a.int_slot_count > 0) { // compact grid over the integer slots; few groups: dealt over all XCDs
-                const unsigned igroups = ((1u << a.n_power) / 4096) * (unsigned) a.int_slot_count;
-                k.int_spread = igroups < 16;
-                igrid = (k.int_spread ? igroups : ((igroups + 7) / 8) * 8) * (unsigned) items;
-            } else {
-                k.int_slot_count = 0;
-                k.int_spread = 0;
-            }
-            hipLaunchKernelGGL(ks_row_mac<false>, dim3(igrid), dim3(NTT_THREADS), 0, st, k);
-        }
+        // each kernel over the slots of its kind where the caller named them, else over all (the other kind exits)
+        if (!a.no_fp && ks_slots(k, 2) > 0)
+            hipLaunchKernelGGL(ks_row_mac_fp<false>, grid_of(2), dim3(NTT_THREADS), 0, st, k);
+        if (!a.no_int && ks_slots(k, 1) > 0)
+            hipLaunchKernelGGL(ks_row_mac<false>, grid_of(1), dim3(NTT_THREADS), 0, st, k);
     }
     return hipGetLastError();
 }

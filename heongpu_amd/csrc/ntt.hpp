@@ -205,14 +205,10 @@ struct KsMacArgs {
     // read by this workgroup alone; digits >= 2 * splits); rns_sum_partials adds them into `out` afterwards.
     int splits;             // 0 / 1: none
     int no_fp, no_int;      // the plan has no FP64 / no integer-butterfly moduli: that kernel is not launched at all
-    // The limb slots with integer moduli, if the caller knows them (count > 0; as NttArgs::int_slots): the integer
-    // kernel then runs on a compact grid over those slots only.  The XCD-aware order puts all ciphertexts of a
-    // (slot, tile) group on one XCD; with two integer moduli and N / 4096 <= 4 tiles that is 2 to 4 of the 8 XCDs
-    // (N = 2^13, q0 and P of 60 bits: 671 us for 2 moduli next to 378 us for the 7 FP64 ones), so below 16 groups
-    // the workgroups of a group are dealt round-robin over the XCDs instead (set by ks_row_mac_launch: int_spread).
+    // The limb slots with integer moduli in ascending order, if the caller knows them (count > 0; as
+    // NttArgs::int_slots): each kernel then runs on a compact grid over the slots of its own kind.
     int int_slot_count;
     int int_slots[8];
-    int int_spread;
 };
 hipError_t ks_row_mac_launch(const KsMacArgs& a, int items, hipStream_t st);
 
