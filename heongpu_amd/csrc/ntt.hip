@@ -1042,11 +1042,14 @@ __device__ __forceinline__ KsIdx ks_index(const KsMacArgs& a)
     const unsigned lin = xcd * chunk + j;
     const unsigned g = lin / units, unit = lin - g * units;
     const unsigned item = SPLIT ? unit / splits : unit, sp = SPLIT ? unit - item * splits : 0u;
+    // groups in tile-major order: a chunk of the split kernel, whose integer slots cost about twice the FP64 ones,
+    // then holds every slot in proportion (C4, one ciphertext: two tiles x all 17 slots per XCD)
+    const unsigned nslots = ks_slots(a, KIND), gt = g / nslots;
     KsIdx r;
     r.valid = lin < total;
     r.item = (int) item;
-    r.tile = (int) (g & (tiles - 1));
-    int si = (int) (g >> (a.n_power - 12));
+    r.tile = (int) gt;
+    int si = (int) (g - gt * nslots);
     if (KIND == 1 && a.int_slot_count > 0) {
         si = a.int_slots[r.valid ? si : 0];
     } else if (KIND == 2 && a.int_slot_count > 0) {
