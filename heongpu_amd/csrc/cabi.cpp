@@ -473,8 +473,8 @@ int hegpu_base_conversion_DtoQtilde(hegpu_context* ctx, const uint64_t* in, uint
     if (depth < 0 || depth >= (int) c.m2_levels.size()) return fail(HEGPU_E_INVALID, "invalid depth");
     const Context::M2Level& L = c.m2_levels[depth];
     return hip_ret(rns_base_conversion_DtoQtilde((const u64*) in, in_stride, (u64*) out, out_stride, c.plan_qp.mods,
-                                                 c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
-                                                 c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
+                                                 c.d64("m2_matrix_mg") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
+                                                 c.d64("m2_negprod_mg") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
                                                  c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc,
                                                  c.Q_size - depth, depth, c.m2_width, batch, (hipStream_t) stream),
                    "hegpu_base_conversion_DtoQtilde");

@@ -177,7 +177,8 @@ void Context::build_host()
         // greedy digits of m primes (m = 2 for BFV, P_size for CKKS), per depth for CKKS
         m2_width = (scheme == SCHEME_BFV) ? 2 : P;
         const int levels = (scheme == SCHEME_BFV) ? 1 : Q;
-        vec Ij, Iloc, mi, matrix, prod;
+        vec Ij, Iloc, mi, matrix, prod, matrix_mg, negprod_mg;
+        auto R64 = [](u64 m) { return (u64) ((((unsigned __int128) 1) << 64) % m); };
         m2_levels.clear();
         for (int lvl = 0; lvl < levels; lvl++) {
             const int l = Q - lvl, rc = Qp - lvl;
@@ -200,6 +201,7 @@ void Context::build_host()
                         for (int j = 0; j < cnt; j++)
                             if (j != i) acc = mul_mod(acc, base[s0 + j] % base[k], base[k]);
                         matrix.push_back(acc);
+                        matrix_mg.push_back(mul_mod(acc, R64(base[k]), base[k]));
                     }
                 for (int i = 0; i < cnt; i++) {
                     u64 acc = 1;
@@ -211,6 +213,7 @@ void Context::build_host()
                     u64 acc = 1;
                     for (int j = 0; j < cnt; j++) acc = mul_mod(acc, base[s0 + j] % base[k], base[k]);
                     prod.push_back(acc);
+                    negprod_mg.push_back(mul_mod((base[k] - acc) % base[k], R64(base[k]), base[k]));
                 }
             }
             m2_levels.push_back(L);
@@ -246,6 +249,10 @@ void Context::build_host()
         host["m2_Mi_inv"] = mi;
         host["m2_matrix"] = matrix;
         host["m2_prod"] = prod;
+        // the same rows with the 2^64 of a Montgomery reduction multiplied in, and -prod likewise: the kernel forms
+        // out_k = sum_i y_i M_ik + r (q_k - prod_k) as ONE lazy 128-bit sum and reduces it once (rns.hip)
+        host["m2_matrix_mg"] = matrix_mg;
+        host["m2_negprod_mg"] = negprod_mg;
     }
 
     if (scheme == SCHEME_BFV) {
@@ -651,7 +658,9 @@ hipError_t Context::upload()
                                        "Qi_inverse",
                                        "m2_Mi_inv",
                                        "m2_matrix",
-                                       "m2_prod"};
+                                       "m2_prod",
+                                       "m2_matrix_mg",
+                                       "m2_negprod_mg"};
     for (const char* nm : u64_tables) {
         auto it = host.find(nm);
         if (it == host.end()) continue;

@@ -502,8 +502,8 @@ static hipError_t dtoq(const Context& c, int lvl, const u64* in, u64 in_stride, 
 {
     const Context::M2Level& L = c.m2_levels[lvl];
     return rns_base_conversion_DtoQtilde(in, in_stride, out, out_stride, c.plan_qp.mods,
-                                         c.d64("m2_matrix") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
-                                         c.d64("m2_prod") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
+                                         c.d64("m2_matrix_mg") + L.off_matrix, c.d64("m2_Mi_inv") + L.off_mi,
+                                         c.d64("m2_negprod_mg") + L.off_prod, c.d32("m2_I_j") + L.off_digits,
                                          c.d32("m2_I_location") + L.off_digits, c.n_power, L.d, L.rc, l, level,
                                          c.m2_width, batch, st);
 }
