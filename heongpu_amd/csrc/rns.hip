@@ -323,6 +323,20 @@ __device__ __forceinline__ void col_mad(ColSum& s, u64 a, u64 b)
     s.s10 += (u64) a1 * b0;
     s.s11 += (u64) a1 * b1;
 }
+// the same term in five instructions (col_mad_uniform with both operands in vector registers).  On its own it made
+// k_keyswitch_mac_keys slower -- the compiler stopped requesting the key values of a sum ahead of the multiplies (99
+// registers instead of 162) -- so that kernel requests them itself, one (key, part) ahead.
+__device__ __forceinline__ void col_mad_v(ColSum& s, u64 a, u64 b)
+{
+    asm("v_mad_u64_u32 %0, vcc, %5, %7, %0\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %6, %8, %3"
+        : "+v"(s.s00), "+v"(s.s01), "+v"(s.s10), "+v"(s.s11), "+v"(s.c00)
+        : "v"((u32) a), "v"((u32) (a >> 32)), "v"((u32) b), "v"((u32) (b >> 32))
+        : "vcc");
+}
 __device__ __forceinline__ void col_fold(const ColSum& s, u64& hi, u64& lo)
 {
     const u64 mid = s.s01 + s.s10;
@@ -389,23 +403,34 @@ __global__ __launch_bounds__(RNS_THREADS) void k_keyswitch_mac_keys(const u64* _
         fetch(item + E);
         // (run-time loops over key and part: unrolled, the compiler requests all 2 E x 16 key values from LDS up
         // front -- 256 registers, one wave per SIMD and scratch)
+        // the 16 key values of (key e, part) come out of LDS one (key, part) ahead of their products: part 0 in ka,
+        // part 1 in kb
+        auto keys_of = [&](u64 (&kv)[16], int ep) {
+            const u64* kp = kl + (size_t) (ep * digits) * TILE + coef;
+#pragma unroll
+            for (int i = 0; i < 16; i++) kv[i] = kp[(size_t) (i < digits ? i : 0) * TILE];
+        };
+        auto sum_out = [&](const u64 (&kv)[16], int e, int part) {
+            u64 hi = 0, lo = 0;
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 8) {
+                ColSum cs;
+                col_clear(cs);
+#pragma unroll
+                for (int ii = 0; ii < 8; ii++) col_mad_v(cs, d[i0 + ii], kv[i0 + ii]);
+                col_fold(cs, hi, lo);
+            }
+            out[out_key_stride * e + out_stride * item + ((u64) y << n_power) + c0 + coef + dig_off * part] =
+                reduce128(hi, lo, m);
+        };
+        u64 ka[16], kb[16];
+        keys_of(ka, 0);
 #pragma unroll 1
         for (int e = 0; e < E; e++) {
-#pragma unroll 1
-            for (int part = 0; part < 2; part++) {
-                const u64* kp = kl + (size_t) ((e * 2 + part) * digits) * TILE + coef;
-                u64 hi = 0, lo = 0;
-#pragma unroll
-                for (int i0 = 0; i0 < 16; i0 += 8) {
-                    ColSum cs;
-                    col_clear(cs);
-#pragma unroll
-                    for (int ii = 0; ii < 8; ii++) col_mad(cs, d[i0 + ii], kp[(size_t) (i0 + ii < digits ? i0 + ii : 0) * TILE]);
-                    col_fold(cs, hi, lo);
-                }
-                out[out_key_stride * e + out_stride * item + ((u64) y << n_power) + c0 + coef + dig_off * part] =
-                    reduce128(hi, lo, m);
-            }
+            keys_of(kb, 2 * e + 1);
+            sum_out(ka, e, 0);
+            keys_of(ka, (e + 1 < E) ? 2 * e + 2 : 0);
+            sum_out(kb, e, 1);
         }
     }
 }
