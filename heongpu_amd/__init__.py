@@ -10,9 +10,11 @@ from .api import (BFV, CKKS, SEC_NONE, SEC_128, SEC_192, SEC_256, TABLES_QP, TAB
                   E_NODEVICE, Context, HEError, Rng, TfheContext, OP_KEYGEN_SECRET, OP_KEYGEN_PUBLIC,
                   OP_KEYGEN_SWITCH, OP_CKKS_ENCRYPT, OP_BFV_ENCRYPT, OP_BFV_DECRYPT, OP_BFV_DECODE, OP_CKKS_ENCODE,
                   OP_CKKS_DECODE, OP_BFV_MULTIPLY_PLAIN, GATE_NAND, GATE_AND, GATE_AND_FIRST_NOT,
-                  GATE_NOR, GATE_OR, GATE_XNOR, GATE_XOR, GATE_NOT, steps_to_galois_elt, to_device, to_host, default_options, broadcast_key)
+                  GATE_NOR, GATE_OR, GATE_XNOR, GATE_XOR, GATE_NOT, steps_to_galois_elt, to_device, to_host, default_options, broadcast_key, broadcast_bytes, broadcast_path_name,
+                  BCAST_FLAT, BCAST_TREE, BCAST_STAGED, BCAST_SAME_DEVICE)
 
 _lib.load()
 
 __all__ = ["BFV", "CKKS", "SEC_NONE", "SEC_128", "SEC_192", "SEC_256", "TABLES_QP", "TABLES_Q_BSK", "Context", "HEError", "Rng",
-           "steps_to_galois_elt", "to_device", "to_host", "default_options", "broadcast_key"]
+           "steps_to_galois_elt", "to_device", "to_host", "default_options", "broadcast_key", "broadcast_bytes", "broadcast_path_name",
+           "BCAST_FLAT", "BCAST_TREE", "BCAST_STAGED", "BCAST_SAME_DEVICE"]

@@ -32,6 +32,9 @@ SIGNATURES = [
     ("hegpu_context_upload_device", c_int, [voidp, c_int]),
     ("hegpu_context_device", c_int, [voidp]),
     ("hegpu_broadcast_key", c_int, [ctypes.POINTER(voidp), c_int, ctypes.POINTER(voidp), c_size_t, ctypes.POINTER(voidp)]),
+    ("hegpu_broadcast_bytes", c_int, [ctypes.POINTER(c_int), c_int, ctypes.POINTER(voidp), c_size_t, ctypes.POINTER(voidp),
+                                      ctypes.POINTER(c_int)]),
+    ("hegpu_last_broadcast_path", c_int, []),
     ("hegpu_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),
     ("hegpu_context_get_option", c_int, [voidp, ctypes.c_char_p, ctypes.POINTER(c_int)]),
     ("hegpu_tfhe_context_set_option", c_int, [voidp, ctypes.c_char_p, c_int]),
@@ -118,6 +121,7 @@ SIGNATURES = [
     ("hegpu_tfhe_context_int", ctypes.c_long, [voidp, ctypes.c_char_p]),
     ("hegpu_tfhe_prime", u64, [voidp]),
     ("hegpu_tfhe_prepare_bootkey", c_int, [voidp, u64p, u64p, voidp]),
+    ("hegpu_tfhe_prepared_format", c_int, [voidp, u64p, c_int]),
     ("hegpu_tfhe_gate_precompute", c_int, [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_bootstrapping", c_int, [voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_key_switching", c_int, [voidp, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),

@@ -79,14 +79,44 @@ def default_options(**options):
         _default_options.update(old)
 
 
+BCAST_FLAT, BCAST_TREE, BCAST_STAGED, BCAST_SAME_DEVICE = 1, 2, 0x100, 0x200
+
+
+def broadcast_path_name(path):
+    """words for the value of hegpu_last_broadcast_path / *path_out (include/hegpu.h)"""
+    if not path:
+        return "none (one buffer)"
+    shape = {BCAST_FLAT: "flat fan-out from device 0 (every peer directly reachable: one hop)",
+             BCAST_TREE: "binomial tree in 32 MiB chunks (some peer not directly reachable from device 0)"}[path & 0xff]
+    if path & BCAST_STAGED:
+        shape += ", at least one edge WITHOUT peer access (staged through host memory by the runtime)"
+    if path & BCAST_SAME_DEVICE:
+        shape += ", all buffers on ONE device (functional run)"
+    return shape
+
+
 def broadcast_key(contexts, keys, elems, streams=None):
-    """hegpu_broadcast_key: keys[0] (a tensor on contexts[0]'s device) -> keys[i] on contexts[i]'s device."""
+    """hegpu_broadcast_key: keys[0] (a tensor on contexts[0]'s device) -> keys[i] on contexts[i]'s device.
+    Returns the path taken (BCAST_* flags)."""
     n = len(contexts)
     lib = _lib.load()
     hs = (ctypes.c_void_p * n)(*[c._h for c in contexts])
     ks = (ctypes.c_void_p * n)(*[_ptr(k) for k in keys])
     ss = (ctypes.c_void_p * n)(*[s for s in streams]) if streams is not None else None
     _check(lib.hegpu_broadcast_key(hs, n, ks, int(elems), ss))
+    return int(lib.hegpu_last_broadcast_path())
+
+
+def broadcast_bytes(devices, bufs, nbytes, streams=None):
+    """hegpu_broadcast_bytes: bufs[0] on devices[0] -> bufs[i] on devices[i] (tensors or addresses).  Returns the path."""
+    n = len(devices)
+    lib = _lib.load()
+    ds = (ctypes.c_int * n)(*[int(d) for d in devices])
+    bs = (ctypes.c_void_p * n)(*[_ptr(b) for b in bufs])
+    ss = (ctypes.c_void_p * n)(*[s for s in streams]) if streams is not None else None
+    path = ctypes.c_int(0)
+    _check(lib.hegpu_broadcast_bytes(ds, n, bs, int(nbytes), ss, ctypes.byref(path)))
+    return int(path.value)
 
 
 class Context:
@@ -607,6 +637,13 @@ class TfheContext:
     def prepared_is_fp64(prepared):
         """True when the prepared key uses the FP64 blind-rotate layout (real torus32 key)."""
         return int(prepared[0].item()) == 1
+
+    def prepared_format(self, prepared, refresh=False):
+        """1 = FP64 layout, 0 = integer layout, as this context will launch it (hegpu_tfhe_prepared_format)"""
+        f = self._lib.hegpu_tfhe_prepared_format(self._h, _ptr(prepared), 1 if refresh else 0)
+        if f < 0:
+            raise HEError(f, _lib.load().hegpu_last_error().decode())
+        return f
 
     def gate_precompute(self, gate, out_a, out_b, a1, b1, a2, b2, shape, stream=None):
         _check(self._lib.hegpu_tfhe_gate_precompute(self._h, gate, _ptr(out_a), _ptr(out_b), _ptr(a1), _ptr(b1),

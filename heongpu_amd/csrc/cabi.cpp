@@ -6,7 +6,12 @@
 #include "ops.hpp"
 #include <cmath>
 #include "tfhe.hpp"
+#include <algorithm>
 #include <cerrno>
+#include <climits>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include <cstring>
 #include <sys/random.h>
 #include <new>
@@ -33,9 +38,16 @@ static int fail(int code, const std::string& msg)
 struct DevGuard {
     int prev = -1;
     bool switched = false;
+    hipError_t err = hipSuccess; // a failed switch is reported by the entry point (NEED_CTX / TFHE_NEED), never ignored:
+                                 // the call would otherwise launch on the caller's device with another device's pointers
     explicit DevGuard(int dev)
     {
-        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        if (dev < 0) return;
+        if ((err = hipGetDevice(&prev)) != hipSuccess) return;
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
     }
     ~DevGuard()
     {
@@ -261,41 +273,132 @@ int hegpu_context_clone(const hegpu_context* src, hegpu_context** out)
     });
 }
 
-// Evaluation keys are the only data every GPU needs a copy of: binomial fan-out over the
-// device-to-device links, copy i -> i + 2^r in round r, each ordered on the destination's stream behind the
-// arrival of the source's copy.
+// Evaluation keys are the only data every GPU needs a copy of.  xGMI is point-to-point: on a fully
+// connected node every destination has its own link to the source, so the replication is ONE hop -- a flat fan-out,
+// every copy on its destination's stream, all links busy at once (272 MiB at ~50 GB/s per direction and link: ~5 ms).
+// Where some destination is not directly reachable from the source (hipDeviceCanAccessPeer) the copies form a binomial
+// tree (copy i -> i + 2^r in round r) cut into <= 32 MiB chunks, so that hop r + 1 of a chunk starts as soon as that
+// chunk has arrived, not when the whole buffer has.  Peer access is enabled for every edge that is used; an edge
+// without it is still copied (the runtime stages it through host memory) and reported (HEGPU_BCAST_STAGED).
+static thread_local int g_bcast_path = 0;
+int hegpu_last_broadcast_path(void) { return g_bcast_path; }
+
+static const size_t kBcastChunk = (size_t) 32 << 20;
+
+// 1: direct (same device, or peer access available and now enabled on `dst` for `src`), 0: not, <0: error in *e
+static int peer_edge(int src, int dst, hipError_t* e)
+{
+    if (src == dst) return 1;
+    int can = 0;
+    if ((*e = hipDeviceCanAccessPeer(&can, dst, src)) != hipSuccess) return -1;
+    if (!can) return 0;
+    DevGuard g(dst);
+    if (g.err != hipSuccess) {
+        *e = g.err;
+        return -1;
+    }
+    const hipError_t en = hipDeviceEnablePeerAccess(src, 0);
+    if (en != hipSuccess && en != hipErrorPeerAccessAlreadyEnabled) {
+        *e = en;
+        return -1;
+    }
+    (void) hipGetLastError(); // "already enabled" is not an error to leave behind
+    return 1;
+}
+
+int hegpu_broadcast_bytes(const int* devices, int n, void* const* bufs, size_t bytes, const hegpu_stream* streams,
+                          int* path_out)
+{
+    g_bcast_path = 0;
+    if (path_out) *path_out = 0;
+    if (!devices || !bufs || n < 1) return fail(HEGPU_E_INVALID, "null argument");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        (void) hipGetLastError();
+        return fail(HEGPU_E_NODEVICE, "no HIP device available: the HIP backend cannot run (no CPU fallback)");
+    }
+    for (int i = 0; i < n; i++) {
+        if (!bufs[i]) return fail(HEGPU_E_INVALID, "null buffer");
+        if (devices[i] < 0 || devices[i] >= cnt) return fail(HEGPU_E_INVALID, "no such device");
+    }
+    if (n == 1 || bytes == 0) return 0;
+    hipError_t e = hipSuccess;
+    // ---- shape: flat when every destination is directly reachable from the source
+    bool flat = true, same = true;
+    for (int j = 1; j < n && flat; j++) {
+        const int r = peer_edge(devices[0], devices[j], &e);
+        if (r < 0) return hip_ret(e, "hegpu_broadcast: peer access");
+        flat = r == 1;
+    }
+    for (int j = 1; j < n; j++) same = same && devices[j] == devices[0];
+    std::vector<int> parent(n, 0);
+    bool staged = false;
+    if (!flat) {
+        for (int span = 1; span < n; span <<= 1)
+            for (int i = 0; i < span && i + span < n; i++) parent[i + span] = i;
+        for (int j = 1; j < n; j++) {
+            const int r = peer_edge(devices[parent[j]], devices[j], &e);
+            if (r < 0) return hip_ret(e, "hegpu_broadcast: peer access");
+            staged = staged || r == 0;
+        }
+    }
+    // ---- copies: chunk c reaches node j on stream j, behind the event "chunk c complete at parent[j]"
+    const size_t nchunks = (bytes + kBcastChunk - 1) / kBcastChunk;
+    auto stream_of = [&](int i) { return streams ? (hipStream_t) streams[i] : (hipStream_t) nullptr; };
+    std::vector<hipEvent_t> events;
+    auto mark = [&](int i, hipEvent_t* ev) { // everything queued on stream i so far
+        DevGuard g(devices[i]);
+        if ((e = g.err) != hipSuccess) return;
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return;
+        events.push_back(*ev);
+        e = hipEventRecord(*ev, stream_of(i));
+    };
+    // arrived[j][c]; the source's one event covers all its chunks
+    std::vector<std::vector<hipEvent_t>> arrived(n, std::vector<hipEvent_t>(nchunks, nullptr));
+    hipEvent_t src_ready = nullptr;
+    mark(0, &src_ready);
+    for (size_t c = 0; c < nchunks; c++) arrived[0][c] = src_ready;
+    // chunk-major order: a chunk walks down the tree before the next one is queued, so every stream sees its copies in
+    // chunk order and a child never waits for more than the chunk it forwards
+    for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+        const size_t off = c * kBcastChunk, len = std::min(kBcastChunk, bytes - off);
+        for (int j = 1; j < n && e == hipSuccess; j++) { // parents precede children in index order
+            const int pj = parent[j];
+            DevGuard g(devices[j]);
+            if ((e = g.err) != hipSuccess) break;
+            if ((e = hipStreamWaitEvent(stream_of(j), arrived[pj][c], 0)) != hipSuccess) break;
+            if ((e = hipMemcpyPeerAsync((char*) bufs[j] + off, devices[j], (const char*) bufs[pj] + off, devices[pj], len,
+                                        stream_of(j))) != hipSuccess)
+                break;
+            bool has_child = false;
+            for (int k = j + 1; k < n; k++) has_child = has_child || parent[k] == j;
+            if (has_child) mark(j, &arrived[j][c]);
+        }
+    }
+    for (hipEvent_t ev : events) (void) hipEventDestroy(ev); // released by the runtime once the recorded work has completed
+    if (e != hipSuccess) return hip_ret(e, "hegpu_broadcast");
+    int path = flat ? HEGPU_BCAST_FLAT : HEGPU_BCAST_TREE;
+    if (staged) path |= HEGPU_BCAST_STAGED;
+    if (same) path |= HEGPU_BCAST_SAME_DEVICE;
+    g_bcast_path = path;
+    if (path_out) *path_out = path;
+    return 0;
+}
+
 int hegpu_broadcast_key(hegpu_context* const* ctxs, int n_ctx, uint64_t* const* keys, size_t elems,
                         const hegpu_stream* streams)
 {
+    g_bcast_path = 0;
     if (!ctxs || !keys || n_ctx < 1) return fail(HEGPU_E_INVALID, "null argument");
+    std::vector<int> devs(n_ctx);
+    std::vector<void*> bufs(n_ctx);
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i] || !keys[i]) return fail(HEGPU_E_INVALID, "null context or key pointer");
         if (!ctxs[i]->c.uploaded) return fail(HEGPU_E_LOGIC, "every context must be uploaded (hegpu_context_upload_device)");
+        devs[i] = ctxs[i]->c.device;
+        bufs[i] = keys[i];
     }
-    if (n_ctx == 1 || elems == 0) return 0;
-    std::vector<hipEvent_t> ready(n_ctx, nullptr);
-    auto stream_of = [&](int i) { return streams ? (hipStream_t) streams[i] : (hipStream_t) nullptr; };
-    hipError_t e = hipSuccess;
-    auto mark = [&](int i) { // keys[i] is complete once stream i reaches this point
-        DevGuard g(ctxs[i]->c.device);
-        if ((e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming)) != hipSuccess) return;
-        e = hipEventRecord(ready[i], stream_of(i));
-    };
-    mark(0);
-    for (int span = 1; span < n_ctx && e == hipSuccess; span <<= 1) {
-        for (int i = 0; i < span && i + span < n_ctx && e == hipSuccess; i++) {
-            const int j = i + span;
-            DevGuard g(ctxs[j]->c.device);
-            if ((e = hipStreamWaitEvent(stream_of(j), ready[i], 0)) != hipSuccess) break;
-            if ((e = hipMemcpyPeerAsync(keys[j], ctxs[j]->c.device, keys[i], ctxs[i]->c.device, elems * sizeof(u64),
-                                        stream_of(j))) != hipSuccess)
-                break;
-            mark(j);
-        }
-    }
-    for (hipEvent_t ev : ready)
-        if (ev) (void) hipEventDestroy(ev); // released by the runtime once the recorded work has completed
-    return hip_ret(e, "hegpu_broadcast_key");
+    return hegpu_broadcast_bytes(devs.data(), n_ctx, bufs.data(), elems * sizeof(u64), streams, nullptr);
 }
 
 long hegpu_context_int(const hegpu_context* ctx, const char* name)
@@ -352,7 +455,8 @@ int hegpu_steps_to_galois_elt(int steps, int coeff_count, int group_order)
         int r__ = hegpu_context_upload(ctx);                                               \
         if (r__) return r__;                                                               \
     }                                                                                      \
-    DevGuard dev_guard__((ctx)->c.device)
+    DevGuard dev_guard__((ctx)->c.device);                                                 \
+    if (dev_guard__.err != hipSuccess) return hip_ret(dev_guard__.err, "switching to the context's device")
 
 static const Mod* mods_of(const Context& c, int table_set)
 {
@@ -1178,9 +1282,13 @@ struct hegpu_tfhe_context {
     bool uploaded = false;
     int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
-    int g4_min = 0x7fffffff;   // option "g4_min": from this many gates four gates share a workgroup's key registers
+    int br_form = 3;           // option "br_form": 3 = three workgroups per CU (k_tfhe_blind_rotate_fp3), 2 = round 3's kernel
     int ks_batched = -1;       // option "ks_batched": key switching with 8 / 12 / 16 gates per workgroup sharing the key rows (tfhe.hip)
-    int wide_max = 0;          // option "wide_max": up to this many gates per call a gate runs on 16 wavefronts (measured slower)
+    // layout of every prepared boot key this context has met (header word 0: 1 = FP64, 0 = integer): filled by
+    // hegpu_tfhe_prepare_bootkey; a buffer that arrived by other means (a peer copy from another device's context) is
+    // looked up once by reading its header word (prepared_format)
+    std::mutex fmt_mu;
+    std::unordered_map<const void*, int> fmt;
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
     double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
 };
@@ -1237,12 +1345,15 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
             p.fprime = fq;
             p.fninv = fp_pair(fn, fq);
             p.fw1ninv = fp_pair(host::mul_mod(fi[1], fn, fq), fq);
-            if (const char* e = getenv("HEGPU_TFHE_FP")) h->allow_fp = e[0] != '0';             // defaults only:
-            if (const char* e = getenv("HEGPU_TFHE_G4_MIN")) h->g4_min = atoi(e);                // hegpu_tfhe_context_set_option
-            if (const char* e = getenv("HEGPU_TFHE_WIDE_MAX")) h->wide_max = atoi(e);
-            if (const char* e = getenv("HEGPU_TFHE_KS_BATCHED")) h->ks_batched = atoi(e);
         }
         *out = h;
+        // defaults only, through the setter's own validation (a value it refuses is ignored, not stored)
+        for (const char* nm : {"fp", "ks_batched", "br_form"}) {
+            std::string env = std::string("HEGPU_TFHE_") + nm;
+            for (char& ch : env) ch = (char) toupper((unsigned char) ch);
+            long v;
+            if (env_long(env.c_str(), &v) && v >= INT_MIN && v <= INT_MAX) (void) hegpu_tfhe_context_set_option(h, nm, (int) v);
+        }
         return 0;
     });
 }
@@ -1253,16 +1364,13 @@ int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int
     if (!strcmp(name, "fp")) {
         if (value < 0 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option fp");
         ctx->allow_fp = value != 0;
-    } else if (!strcmp(name, "g4_min")) {
-        if (value < 1) return fail(HEGPU_E_INVALID, "value out of range for option g4_min");
-        ctx->g4_min = value;
+    } else if (!strcmp(name, "br_form")) {
+        if (value < 2 || value > 6) return fail(HEGPU_E_INVALID, "value out of range for option br_form");
+        ctx->br_form = value;
     } else if (!strcmp(name, "ks_batched")) {
         if (value < -1 || (value > 1 && value != 8 && value != 12 && value != 16))
             return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
         ctx->ks_batched = value;
-    } else if (!strcmp(name, "wide_max")) {
-        if (value < 0) return fail(HEGPU_E_INVALID, "value out of range for option wide_max");
-        ctx->wide_max = value;
     } else {
         return fail(HEGPU_E_INVALID, std::string("unknown option: ") + name);
     }
@@ -1330,7 +1438,8 @@ static int tfhe_need(hegpu_tfhe_context* ctx)
 #define TFHE_NEED(ctx)        \
     int r = tfhe_need(ctx);   \
     if (r) return r;          \
-    DevGuard dev_guard__((ctx)->device)
+    DevGuard dev_guard__((ctx)->device); \
+    if (dev_guard__.err != hipSuccess) return hip_ret(dev_guard__.err, "switching to the TFHE context's device")
 
 // tfhe/operator.cu:317-323
 static int32_t encode_to_torus32(uint32_t mu, uint32_t m_size)
@@ -1346,9 +1455,48 @@ int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key
     TFHE_NEED(ctx);
     const TfheDev& p = ctx->p;
     const u64 polys = (u64) p.n * (p.k + 1) * p.bk_l * (p.k + 1);
-    return hip_ret(tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp,
-                                        (hipStream_t) stream),
-                   "hegpu_tfhe_prepare_bootkey");
+    int fmt = -1;
+    hipError_t e = tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp, &fmt,
+                                        (hipStream_t) stream);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
+        ctx->fmt[prepared] = fmt;
+    }
+    return hip_ret(e, "hegpu_tfhe_prepare_bootkey");
+}
+
+// Layout of a prepared key: from the context's record, else one synchronous read of the header word (first use of a
+// buffer this context did not prepare itself, e.g. the replica of another device's key), remembered from then on.
+static int prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int* fmt)
+{
+    if (!prepared) return fail(HEGPU_E_INVALID, "null prepared boot key");
+    {
+        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
+        auto it = ctx->fmt.find(prepared);
+        if (it != ctx->fmt.end()) {
+            *fmt = it->second;
+            return 0;
+        }
+    }
+    uint64_t w = ~0ULL;
+    hipError_t e = hipMemcpy(&w, prepared, sizeof(w), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_ret(e, "reading the prepared boot key's header");
+    if (w > 1) return fail(HEGPU_E_INVALID, "not a prepared boot key (header word is neither 0 nor 1)");
+    std::lock_guard<std::mutex> lk(ctx->fmt_mu);
+    ctx->fmt[prepared] = *fmt = (int) w;
+    return 0;
+}
+
+int hegpu_tfhe_prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int refresh)
+{
+    TFHE_NEED(ctx);
+    if (refresh) {
+        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
+        ctx->fmt.erase(prepared);
+    }
+    int fmt = -1;
+    if ((r = prepared_format(ctx, prepared, &fmt))) return -1;
+    return fmt;
 }
 
 int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a, int32_t* out_b,
@@ -1378,8 +1526,11 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              hegpu_stream stream)
 {
     TFHE_NEED(ctx);
+    if (shape <= 0) return 0;
+    int fmt = -1;
+    if ((r = prepared_format(ctx, prepared_boot_key, &fmt))) return r;
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
-                                     encode_to_torus32(1, 8), shape, ctx->g4_min, ctx->wide_max, (hipStream_t) stream),
+                                     encode_to_torus32(1, 8), shape, fmt, ctx->br_form, (hipStream_t) stream),
                    "hegpu_tfhe_bootstrapping");
 }
 

@@ -1,5 +1,8 @@
 // context.cpp -- see context.hpp.
 #include "context.hpp"
+#include <cerrno>
+#include <climits>
+#include <cstdlib>
 #include "host_params.hpp"
 #include <algorithm>
 #include <cmath>
@@ -380,6 +383,27 @@ void Context::build_host()
                 ff_npB.push_back(mul_mod(q - prod_B_q[k], r, q));
             }
             for (int i = 0; i < bsk - 1; i++) ff_mskm.push_back(mul_mod(m_msk[i], R(msk), msk));
+            // Contract of the lazy sums (rns.hip dot128 + acc128 -> redc128): every operand below 2^61 (prime widths are
+            // checked at creation, the internal primes are 61-bit) and the worst-case sum of a row below 2^128.  With the
+            // moduli at hand that is exact arithmetic, not an estimate: a base of 64 primes just below 2^61 plus the
+            // trailing term does NOT fit (65 * 2^122 > 2^128), shorter or narrower bases do.
+            auto fits = [](const vec& in_mods, size_t cnt, u64 out_mod, u64 extra_a, u64 extra_b) {
+                unsigned __int128 s = (unsigned __int128) extra_a * extra_b;
+                for (size_t j = 0; j < cnt; j++) {
+                    const unsigned __int128 t = (unsigned __int128) (in_mods[j] - 1) * (out_mod - 1);
+                    if (s + t < s) return false;
+                    s += t;
+                }
+                return true;
+            };
+            bool ok = true;
+            vec qv(primes.begin(), primes.begin() + Q);
+            for (int i = 0; i < bsk; i++) ok = ok && fits(qv, Q, B[i], B[i], B[i] - 1);     // fc rows, first ff rows
+            ok = ok && fits(B, bsk - 1, msk, 0, 0);                                          // the m_sk row
+            for (int k = 0; k < Q; k++) ok = ok && fits(B, bsk - 1, primes[k], msk, primes[k] - 1); // second ff rows
+            if (!ok)
+                throw std::invalid_argument("BFV base too long for its prime widths: a lazy 128-bit row sum of the BEHZ base "
+                                            "conversions would overflow (use fewer or narrower primes)");
             host["behz_fc_matrix"] = fc_m;
             host["behz_fc_c1"] = fc_c1;
             host["behz_ff_matrix"] = ff_m;
@@ -786,10 +810,27 @@ int Context::get_option(const char* name, int* value) const
     return 0;
 }
 
+// The one place the library reads the environment: a variable that is set to a whole decimal integer (optional sign,
+// nothing else -- "yes", "", "1x" are not numbers and are ignored, they do not mean 0).
+bool env_long(const char* name, long* out)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return false;
+    char* end = nullptr;
+    errno = 0;
+    const long v = strtol(e, &end, 10);
+    if (errno || end == e || *end) return false;
+    *out = v;
+    return true;
+}
+
 void Context::seed_options_from_env()
 {
-    for (const OptDesc& o : kOptions)
-        if (const char* e = getenv(o.env)) (void) set_option(o.name, atoi(e)); // out-of-range values are ignored
+    for (const OptDesc& o : kOptions) {
+        long v;
+        if (env_long(o.env, &v) && v >= INT_MIN && v <= INT_MAX)
+            (void) set_option(o.name, (int) v); // a value the setter refuses (out of range) is ignored
+    }
 }
 
 void Context::release_device()

@@ -17,6 +17,10 @@
 
 namespace hegpu {
 
+// context.cpp: the value of an environment variable that holds a whole decimal integer (false otherwise)
+bool env_long(const char* name, long* out);
+
+
 enum Scheme { SCHEME_BFV = 1, SCHEME_CKKS = 2 };
 
 struct NttPlan {

@@ -111,14 +111,19 @@ HG_HD u64 reduce128(u64 hi, u64 lo, const Mod& m)
     return (r >= m.q) ? r - m.q : r;
 }
 
-// (hi:lo) * 2^-64 mod q for hi < 2^63, odd q < 2^62: Montgomery reduction -- m = lo * q^-1 mod 2^64, then
-// (hi:lo - m q) / 2^64 = hi - mulhi(m, q) exactly (the low words cancel), a value in (-q, hi]; made positive and reduced.
+// (hi:lo) * 2^-64 mod q for ANY 128-bit (hi:lo), odd q < 2^62: Montgomery reduction -- m = lo * q^-1 mod 2^64, then
+// (hi:lo - m q) / 2^64 = hi - mulhi(m, q) exactly (the low words cancel), a value in (-q, hi]; made non-negative by one
+// conditional +q (the wrapped difference plus q is exact because the true value lies in (-q, 0)) and reduced.
 // 14 32-bit multiplies against the 18 of reduce128, and half its additions.  For sums whose constant factors carry
-// the compensating 2^64 (the BFV base-conversion tables).
+// the compensating 2^64 (the BFV base-conversion tables).  Round 3's form added q unconditionally and so needed
+// hi + q < 2^64 -- false for sums of ~56 or more 122-bit terms; the callers' remaining contract is that the
+// lazy sum itself fits 128 bits, which Context::build_host checks for every table it builds (lazy_sum_fits).
 HG_HD u64 redc128(u64 hi, u64 lo, const Mod& m)
 {
     const u64 k = lo * m.qinv;
-    const u64 r = hi - mulhi64(k, m.q) + m.q; // in (0, hi + q]
+    const u64 t = mulhi64(k, m.q); // < q
+    const u64 d = hi - t;
+    const u64 r = (hi < t) ? d + m.q : d; // in [0, hi]
     return reduce64(r, m);
 }
 

@@ -520,42 +520,39 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
 
 __global__ void k_tfhe_set_header(u64* hdr, u64 fmt) { hdr[0] = fmt; }
 
-// TF_G gates per workgroup, wavefront w = (y,z): digit polynomial z of accumulator
+// One gate per workgroup, wavefront w = (y,z): digit polynomial z of accumulator
 // y -> forward NTT -> staged in LDS; wavefront w then sums ITS output o = w (c = w >> 1, half = w & 1) over the
 // four transformed digits times the key polynomials BK_i[y'][z'][c][half] in registers, inverse-transforms it
 // and adds it into the accumulator (two 16-bit halves per coefficient: integer atomics on the LDS words).  The 64
-// key values a lane needs in iteration i are loaded once and reused for the
-// TF_G gates (the 64 MiB key stream is the other resource next to the ALU).
-template <int TF_G>
+// key values a lane needs in iteration i are requested before the decomposition and arrive under the forward
+// transform.  (Four gates per workgroup sharing the key registers, and a gate on sixteen wavefronts, were built in
+// rounds 2 / 3 and measured slower -- profiles/r3c_experiments/README.md section 4; they are in the history, not here.)
 __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tfhe_blind_rotate_fp(const int* __restrict__ in_a,
                                                                      const int* __restrict__ in_b,
                                                                      const u64* __restrict__ prepared,
                                                                      int* __restrict__ out_a, int* __restrict__ out_b,
-                                                                     TfheDev p, int encoded, int shape)
+                                                                     TfheDev p, int encoded)
 {
-    if (prepared[0] != 1) return; // integer-layout key: k_tfhe_blind_rotate runs instead
+    if (prepared[0] != 1) return; // not the FP64 layout (the host picks the kernel from the header: tfhe_blind_rotate)
     const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
-    __shared__ int acc[TF_G][2][TF_N];
+    __shared__ int acc[2][TF_N];
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
     // lane-dependent twiddles of both transforms (entries 16..1023; (w, companion) pairs, 2 x 16 KiB)
-    constexpr bool TW_LDS = (TF_G == 1); // the experimental multi-gate variant has no LDS left for them
-    __shared__ ulonglong2 twf[TW_LDS ? TF_N : 1], twi[TW_LDS ? TF_N : 1];
+    __shared__ ulonglong2 twf[TF_N], twi[TF_N];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int y = wv >> 1, z = wv & 1;
-    if (TW_LDS)
-        for (int j = t; j < TF_N; j += TF_THREADS) {
-            twf[j] = p.ftw[j];
-            twi[j] = p.fitw[j];
-        }
-    const int g0 = blockIdx.x * TF_G;
-    const int ng = (shape - g0 < TF_G) ? shape - g0 : TF_G;
+    for (int j = t; j < TF_N; j += TF_THREADS) {
+        twf[j] = p.ftw[j];
+        twi[j] = p.fitw[j];
+    }
+    const int g = blockIdx.x;
     const int n = p.n;
     const FC fc = make_fc(p.fprime);
-    for (int gi = 0; gi < ng; gi++) {
-        const int bN = 2 * TF_N - modswitch(in_b[g0 + gi], 10);
+    {
+        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
         for (int j = t; j < TF_N; j += TF_THREADS) {
-            acc[gi][0][j] = 0;
-            acc[gi][1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
+            acc[0][j] = 0;
+            acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
         }
     }
     __syncthreads();
@@ -563,9 +560,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int shift = 32 - 10 * (z + 1);
     const int cc = wv >> 1, sh = (wv & 1) ? 16 : 0;
     for (int i = 0; i < n; i++) {
-        // key polynomials of this wavefront: [(i,y,z)][o = 2c+half][k][lane].  The per-CU load
-        // pipeline (~20 GB/s of L2 hits) cannot stream 128 KiB per gate and iteration, so the
-        // 64 values a lane needs stay in registers for the TF_G gates of the workgroup.
+        // key polynomials of this wavefront: [(i,y,z)][o = 2c+half][k][lane].
         // kv[r] = key polynomial (digit wavefront (wv + r) & 3, output wv): every wavefront sums ITS output over
         // the four transformed digits (read from the other wavefronts' staging areas) in registers
         const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
@@ -575,261 +570,302 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 kv[r][k] = as_f64(bkp[(u64) (((wv + r) & 3) * 4) * TF_N + k * 64]);
-        for (int gi = 0; gi < ng; gi++) {
-            const int aN = modswitch(in_a[(u64) (g0 + gi) * n + i], 10);
-            double x[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int j = lane + 64 * k;
-                // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
-                // arithmetic and a select (branches per element would put every LDS read in its own basic block)
-                const int idx = (j - aN) & (2 * TF_N - 1);
-                const int v = acc[gi][y][idx & (TF_N - 1)];
-                const int r = (idx & TF_N) ? -v : v;
-                const u32 diff = (u32) r - (u32) acc[gi][y][j];
-                const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
-                x[k] = (double) d;
-            }
-            fwave_ntt1024(x, buf[wv], p.ftw, TW_LDS ? twf : p.ftw, fc, lane);
-            // The transformed digit goes to the own staging area (free after the transform); after the barrier
-            // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
-            // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
-            // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
-#pragma unroll
-            for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc);
-#pragma unroll
-            for (int r = 1; r < 4; r++) {
-                const u64* ob = &buf[(wv + r) & 3][lane];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const double xo = as_f64(ob[k * 64]);
-                    x[k] += fp_mul(kv[r][k], xo, xo * fc.qi, fc);
-                }
-            }
-            __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
-            fwave_intt1024(x, buf[wv], p.fitw, TW_LDS ? twi : p.fitw, p.fninv, p.fw1ninv, fc, lane);
-            // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                atomicAdd(reinterpret_cast<u32*>(&acc[gi][cc][lane + 64 * k]), f_low32(x[k]) << sh);
-            __syncthreads();
-        }
-    }
-    for (int gi = 0; gi < ng; gi++) {
-        const int g = g0 + gi;
-        for (int j = t; j < TF_N; j += TF_THREADS)
-            out_a[(u64) g * TF_N + j] = (j < 1) ? acc[gi][0][j] : (int) (0u - (u32) acc[gi][0][TF_N - j]);
-        if (t == 0) out_b[g] = acc[gi][1][0];
-    }
-}
-
-// ------------------------------------------------------------------ few gates: four wavefronts per transform
-// A call with fewer gates than CUs leaves k_tfhe_blind_rotate_fp at one wavefront per SIMD on as many CUs as
-// there are gates: every LDS exchange, key load and dependent FP64 chain of the 512 iterations is exposed.  Here a
-// gate is one workgroup of 16 wavefronts; a group of four (256 lanes, 4 coefficients each) owns digit polynomial
-// (y,z) for the forward transform and output (c,half) for the inverse one.  A transform is five radix-4 rounds:
-// the first (last, for the inverse) exchange crosses the wavefronts of the group (workgroup barrier), the other
-// three stay inside a wavefront, which owns positions [256a, 256a + 256) from then on.  Same tables, same key
-// layout, same bounds as the one-wavefront transforms; the key values of an iteration (16 per lane) are requested
-// before the decomposition and arrive under the forward transform.
-// MEASURED SLOWER (MI355X, 1..256 gates per call: 5.8 ms against 4.4 ms, tools/tfhe_shapes.py): sixteen wavefronts
-// in lockstep between four workgroup barriers per iteration do their LDS exchanges at the same time and their FP64
-// rounds at the same time, and four values per lane leave two independent butterflies per round.  Kept behind the
-// option "wide_max" (default 0 = never), bit-exact like the other form (tests/test_gpu_tfhe.py).
-#define TFW_THREADS 1024
-// stages s, s+1 on four values at local distances 2 and 1: root index (1 << s) + B, then (2 << s) + 2B + {0,1}
-__device__ __forceinline__ void f_ct4(double (&x)[4], ulonglong2 wa, ulonglong2 wb0, ulonglong2 wb1, const FC& c)
-{
-    f_ct(x[0], x[2], wa, c);
-    f_ct(x[1], x[3], wa, c);
-    f_ct(x[0], x[1], wb0, c);
-    f_ct(x[2], x[3], wb1, c);
-}
-__device__ __forceinline__ void f_gs4(double (&x)[4], ulonglong2 wa, ulonglong2 wb0, ulonglong2 wb1, const FC& c)
-{
-    f_gs(x[0], x[1], wb0, c);
-    f_gs(x[2], x[3], wb1, c);
-    f_gs(x[0], x[2], wa, c);
-    f_gs(x[1], x[3], wa, c);
-}
-
-// In: x[m] = element L + 256m of the group's polynomial, |x| <= p'.  Out: x[m] = slot 4L + m, centred.
-// `sc`: the group's exchange area.  Called by all 16 wavefronts together (one workgroup barrier inside).
-__device__ __forceinline__ void fwide_ntt1024(double (&x)[4], u64* sc, const ulonglong2* __restrict__ tw,
-                                              const ulonglong2* twl, const FC& c, int L)
-{
-    const int a = L >> 6, l = L & 63;
-    f_ct4(x, tw[1], tw[2], tw[3], c);
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(L + 256 * m)] = as_bits(x[m]);
-    __syncthreads();
-    int e0 = 256 * a + l; // stride 64
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 64 * m)]);
-    f_ct4(x, twl[4 + a], twl[8 + 2 * a], twl[9 + 2 * a], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 64 * m)] = as_bits(x[m]);
-    wave_fence();
-    e0 = 256 * a + 64 * (l >> 4) + (l & 15); // stride 16
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 16 * m)]);
-    int B = 4 * a + (l >> 4);
-    f_ct4(x, twl[16 + B], twl[32 + 2 * B], twl[33 + 2 * B], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 16 * m)] = as_bits(x[m]);
-    wave_fence();
-    e0 = 256 * a + 16 * (l >> 2) + (l & 3); // stride 4
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 4 * m)]);
-    B = 16 * a + (l >> 2);
-    f_ct4(x, twl[64 + B], twl[128 + 2 * B], twl[129 + 2 * B], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 4 * m)] = as_bits(x[m]);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(4 * L + m)]);
-    f_ct4(x, twl[256 + L], twl[512 + 2 * L], twl[513 + 2 * L], c);
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fp_reduce(x[m], c);
-    wave_fence();
-}
-
-// In: x[m] = slot 4L + m, |x| <= 2.2 p'.  Out: x[m] = coefficient L + 256m, centred, N^-1 applied (the bounds
-// of fwave_intt1024: six stages, one reduction, four stages).
-__device__ __forceinline__ void fwide_intt1024(double (&x)[4], u64* sc, const ulonglong2* __restrict__ itw,
-                                               const ulonglong2* itwl, ulonglong2 ninv, ulonglong2 w1ninv,
-                                               const FC& c, int L)
-{
-    const int a = L >> 6, l = L & 63;
-    f_gs4(x, itwl[256 + L], itwl[512 + 2 * L], itwl[513 + 2 * L], c);
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(4 * L + m)] = as_bits(x[m]);
-    wave_fence();
-    int e0 = 256 * a + 16 * (l >> 2) + (l & 3);
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 4 * m)]);
-    int B = 16 * a + (l >> 2);
-    f_gs4(x, itwl[64 + B], itwl[128 + 2 * B], itwl[129 + 2 * B], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 4 * m)] = as_bits(x[m]);
-    wave_fence();
-    e0 = 256 * a + 64 * (l >> 4) + (l & 15);
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 16 * m)]);
-    B = 4 * a + (l >> 4);
-    f_gs4(x, itwl[16 + B], itwl[32 + 2 * B], itwl[33 + 2 * B], c);
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = fp_reduce(x[m], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 16 * m)] = as_bits(x[m]);
-    wave_fence();
-    e0 = 256 * a + l;
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(e0 + 64 * m)]);
-    f_gs4(x, itwl[4 + a], itwl[8 + 2 * a], itwl[9 + 2 * a], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[bi(e0 + 64 * m)] = as_bits(x[m]);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = as_f64(sc[bi(L + 256 * m)]);
-    f_gs(x[0], x[1], itw[2], c);
-    f_gs(x[2], x[3], itw[3], c);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const double s = x[j] + x[j + 2], d = x[j] - x[j + 2];
-        x[j] = fp_mul(s, as_f64(ninv.x), as_f64(ninv.y), c);
-        x[j + 2] = fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), c);
-    }
-}
-
-__global__ __launch_bounds__(TFW_THREADS) void k_tfhe_blind_rotate_fp_wide(const int* __restrict__ in_a,
-                                                                          const int* __restrict__ in_b,
-                                                                          const u64* __restrict__ prepared,
-                                                                          int* __restrict__ out_a,
-                                                                          int* __restrict__ out_b, TfheDev p,
-                                                                          int encoded)
-{
-    if (prepared[0] != 1) return; // integer-layout key: k_tfhe_blind_rotate runs instead
-    const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
-    __shared__ int acc[2][TF_N];
-    __shared__ __attribute__((aligned(16))) u64 sc[4][TF_BUF];    // exchange areas of the four groups
-    __shared__ __attribute__((aligned(16))) double xs[4][TF_N];   // the transformed digits, slot order
-    __shared__ ulonglong2 twf[TF_N], twi[TF_N];
-    const int t = threadIdx.x, L = t & 255, gq = t >> 8;
-    const int y = gq >> 1, z = gq & 1;
-    twf[t] = p.ftw[t];
-    twi[t] = p.fitw[t];
-    const int g = blockIdx.x;
-    const int n = p.n;
-    const FC fc = make_fc(p.fprime);
-    {
-        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
-        const int j = t;
-        acc[0][j] = 0;
-        acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
-    }
-    __syncthreads();
-
-    const int shift = 32 - 10 * (z + 1);
-    const int cc = gq >> 1, sh = (gq & 1) ? 16 : 0;
-    // slot 4L + m of a key polynomial lies at [k = 4 (L & 3) + m][lane = L >> 2] of the prepared layout
-    const u64* bk0 = bk + (u64) gq * TF_N + (4 * (L & 3)) * 64 + (L >> 2);
-    for (int i = 0; i < n; i++) {
-        // kv[d][m]: key polynomial (iteration i, digit d, output gq), slots 4L + m
-        const u64* bkp = bk0 + (u64) i * 16 * TF_N;
-        double kv[4][4];
-#pragma unroll
-        for (int d = 0; d < 4; d++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) kv[d][m] = as_f64(bkp[(u64) (d * 4) * TF_N + m * 64]);
         const int aN = modswitch(in_a[(u64) g * n + i], 10);
-        double x[4];
+        double x[16];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int j = L + 256 * m;
+        for (int k = 0; k < 16; k++) {
+            const int j = lane + 64 * k;
+            // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
+            // arithmetic and a select (branches per element would put every LDS read in its own basic block)
             const int idx = (j - aN) & (2 * TF_N - 1);
             const int v = acc[y][idx & (TF_N - 1)];
             const int r = (idx & TF_N) ? -v : v;
             const u32 diff = (u32) r - (u32) acc[y][j];
             const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
-            x[m] = (double) d;
+            x[k] = (double) d;
         }
-        fwide_ntt1024(x, sc[gq], p.ftw, twf, fc, L);
-        *reinterpret_cast<double2*>(&xs[gq][4 * L]) = make_double2(x[0], x[1]);
-        *reinterpret_cast<double2*>(&xs[gq][4 * L + 2]) = make_double2(x[2], x[3]);
+        fwave_ntt1024(x, buf[wv], p.ftw, twf, fc, lane);
+        // The transformed digit goes to the own staging area (free after the transform); after the barrier
+        // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
+        // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
+        // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
+#pragma unroll
+        for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
         __syncthreads();
-        // output gq = sum over the four transformed digits (exact: |sum| <= 4 * 0.51 p' < 2^47)
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const double2 u0 = *reinterpret_cast<const double2*>(&xs[d][4 * L]);
-            const double2 u1 = *reinterpret_cast<const double2*>(&xs[d][4 * L + 2]);
-            const double xo[4] = {u0.x, u0.y, u1.x, u1.y};
+        for (int k = 0; k < 16; k++) x[k] = fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc);
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const double pr = fp_mul(kv[d][m], xo[m], xo[m] * fc.qi, fc);
-                x[m] = d ? x[m] + pr : pr;
+        for (int r = 1; r < 4; r++) {
+            const u64* ob = &buf[(wv + r) & 3][lane];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double xo = as_f64(ob[k * 64]);
+                x[k] += fp_mul(kv[r][k], xo, xo * fc.qi, fc);
             }
         }
-        fwide_intt1024(x, sc[gq], p.fitw, twi, p.fninv, p.fw1ninv, fc, L);
+        __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
+        fwave_intt1024(x, buf[wv], p.fitw, twi, p.fninv, p.fw1ninv, fc, lane);
+        // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
 #pragma unroll
-        for (int m = 0; m < 4; m++)
-            atomicAdd(reinterpret_cast<u32*>(&acc[cc][L + 256 * m]), f_low32(x[m]) << sh);
+        for (int k = 0; k < 16; k++)
+            atomicAdd(reinterpret_cast<u32*>(&acc[cc][lane + 64 * k]), f_low32(x[k]) << sh);
         __syncthreads();
     }
-    {
-        const int j = t;
+    for (int j = t; j < TF_N; j += TF_THREADS)
         out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
-        if (t == 0) out_b[g] = acc[1][0];
+    if (t == 0) out_b[g] = acc[1][0];
+}
+
+// ------------------------------------------------------------------ FP64 blind rotate, three workgroups per CU
+// Round 4.  Counters of the kernel above at 8192 gates (profiles/r4a_c5/): 2.37 GHz (not power-limited -- there is
+// no HBM stream next to the FP64 work), vector ALU 0.61 busy, waves waiting 45 % of their cycles, 1.9 waves per SIMD,
+// and SQ_LDS_BANK_CONFLICT = 18 % of the CU cycles.  Two causes, two changes:
+//  * the per-lane twiddles of stages 4..9 sat in LDS in table order ((w, w') pairs, 16 bytes): lane l reads
+//    tw[256 + 4l + g] (64-byte lane stride: 4-way conflict) and tw[512 + 8l + e] (128-byte stride: 8-way).  Here they
+//    are re-laid in the order of use -- [stage][slot][lane] -- so a wavefront reads 64 consecutive doubles.
+//  * 74 KiB of LDS and 254 registers allow two workgroups per CU (two waves per SIMD).  One table serves both
+//    directions (itw[2^L + o] = -tw[2^L + (2^L - 1 - o)]: the inverse reads the forward table mirrored and multiplies
+//    y - x instead of x - y), entries are the plain double w with the companion formed as w * RN(1/p') (one multiply per
+//    twiddle read; a representative may differ from the RN(w/p') one, the exact integer result cannot): 8 KiB instead
+//    of 32; the key values are requested two polynomials at a time (64 registers instead of 128): 50 KiB and <= 168
+//    registers = three workgroups per CU, the third wave of a SIMD filling the LDS-exchange and barrier waits.
+#define TF3_TW 1008 // 240 (stages 4..7: [s][bb][b]) + 256 (stage 8: [g][lane]) + 512 (stage 9: [e][lane])
+__device__ __forceinline__ int tf3_src(int e)
+{
+    if (e < 240) {
+        const int r = (e >> 4) + 1, b = e & 15; // r = (1 << s) + bb
+        const int s = 31 - __builtin_clz(r);
+        return ((16 + b) << s) + (r - (1 << s));
     }
+    if (e < 496) return 256 + 4 * ((e - 240) & 63) + ((e - 240) >> 6);
+    return 512 + 8 * ((e - 496) & 63) + ((e - 496) >> 6);
+}
+__device__ __forceinline__ void f_ct_l(double& x, double& y, double w, const FC& c)
+{
+    const double t = fp_mul(y, w, w * c.qi, c);
+    y = x - t;
+    x = x + t;
+}
+// inverse butterfly with the FORWARD twiddle of the mirrored position: (x - y) * (-w) = (y - x) * w
+__device__ __forceinline__ void f_gs_l(double& x, double& y, double w, const FC& c)
+{
+    const double s = x + y, d = y - x;
+    x = s;
+    y = fp_mul(d, w, w * c.qi, c);
+}
+// as fwave_ntt1024, lane-dependent twiddles from the re-laid LDS table
+__device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const ulonglong2* __restrict__ tw,
+                                                const double* twl, const FC& c, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const ulonglong2 w = tw[(1 << s) + b];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_ct(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(lane + 64 * k)] = as_bits(x[k]);
+    wave_fence();
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const double w = twl[16 * ((1 << s) - 1 + bb) + b];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_ct_l(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(16 * lane + k)]);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const double w8 = twl[240 + 64 * g + lane];
+        f_ct_l(x[4 * g + 0], x[4 * g + 2], w8, c);
+        f_ct_l(x[4 * g + 1], x[4 * g + 3], w8, c);
+        const double w9a = twl[496 + 64 * (2 * g) + lane], w9b = twl[496 + 64 * (2 * g + 1) + lane];
+        f_ct_l(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        f_ct_l(x[4 * g + 2], x[4 * g + 3], w9b, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], c);
+    wave_fence();
+}
+// as fwave_intt1024; the lane-dependent inverse twiddles are the forward table's mirrored entries with the sign moved
+// into the butterfly (f_gs_l)
+__device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, const ulonglong2* __restrict__ itw,
+                                                 const double* twl, ulonglong2 ninv, ulonglong2 w1ninv, const FC& c,
+                                                 int lane)
+{
+    const int rl = 63 - lane;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        // itw[512 + 8 lane + e] = -tw[512 + 8 (63 - lane) + (7 - e)], itw[256 + 4 lane + g] = -tw[256 + 4 (63 - lane) + (3 - g)]
+        const double w9a = twl[496 + 64 * (7 - 2 * g) + rl], w9b = twl[496 + 64 * (6 - 2 * g) + rl];
+        f_gs_l(x[4 * g + 0], x[4 * g + 1], w9a, c);
+        f_gs_l(x[4 * g + 2], x[4 * g + 3], w9b, c);
+        const double w8 = twl[240 + 64 * (3 - g) + rl];
+        f_gs_l(x[4 * g + 0], x[4 * g + 2], w8, c);
+        f_gs_l(x[4 * g + 1], x[4 * g + 3], w8, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[bi(16 * lane + k)] = as_bits(x[k]);
+    wave_fence();
+    const int b = lane >> 2, c0 = lane & 3;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            // itw[((16 + b) << s) + bb] = -tw[((16 + 15 - b) << s) + ((1 << s) - 1 - bb)]
+            const double w = twl[16 * ((1 << s) - 1 + ((1 << s) - 1 - bb)) + (15 - b)];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_gs_l(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = fp_reduce(x[m], c);
+    wave_fence();
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(lane + 64 * k)]);
+#pragma unroll
+    for (int s = 3; s >= 1; s--) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int bb = 0; bb < (1 << s); bb++) {
+            const ulonglong2 w = itw[(1 << s) + bb];
+#pragma unroll
+            for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const double s = x[j] + x[j + 8], d = x[j] - x[j + 8];
+        x[j] = fp_mul(s, as_f64(ninv.x), as_f64(ninv.y), c);
+        x[j + 8] = fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), c);
+    }
+    wave_fence();
+}
+
+template <int PF>
+__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_tfhe_blind_rotate_fp3(
+    const int* __restrict__ in_a, const int* __restrict__ in_b, const u64* __restrict__ prepared, int* __restrict__ out_a,
+    int* __restrict__ out_b, TfheDev p, int encoded)
+{
+    if (prepared[0] != 1) return; // not the FP64 layout (the host picks the kernel from the header: tfhe_blind_rotate)
+    const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
+    __shared__ int acc[2][TF_N];
+    __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
+    __shared__ double twl[TF3_TW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int y = wv >> 1, z = wv & 1;
+    for (int e = t; e < TF3_TW; e += TF_THREADS) twl[e] = as_f64(p.ftw[tf3_src(e)].x);
+    const int g = blockIdx.x;
+    const int n = p.n;
+    const FC fc = make_fc(p.fprime);
+    {
+        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
+        for (int j = t; j < TF_N; j += TF_THREADS) {
+            acc[0][j] = 0;
+            acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
+        }
+    }
+    __syncthreads();
+
+    const int shift = 32 - 10 * (z + 1);
+    const int cc = wv >> 1, sh = (wv & 1) ? 16 : 0;
+    for (int i = 0; i < n; i++) {
+        // key polynomial r = (digit wavefront (wv + r) & 3, output wv): [(i, digit)][o = wv][k][lane]
+        const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
+        double ka[16], kb[16];
+        if (PF != 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
+        }
+        const int aN = modswitch(in_a[(u64) g * n + i], 10);
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = lane + 64 * k;
+            const int idx = (j - aN) & (2 * TF_N - 1);
+            const int v = acc[y][idx & (TF_N - 1)];
+            const int r = (idx & TF_N) ? -v : v;
+            const u32 diff = (u32) r - (u32) acc[y][j];
+            const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
+            x[k] = (double) d;
+        }
+        fwave_ntt1024_l(x, buf[wv], p.ftw, twl, fc, lane);
+#pragma unroll
+        for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
+        if (PF == 2) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) kb[k] = as_f64(bkp[(u64) (((wv + 1) & 3) * 4) * TF_N + k * 64]);
+        }
+        __syncthreads();
+        if (PF == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = fp_mul(ka[k], x[k], x[k] * fc.qi, fc);
+        if (PF == 2) {
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                double (&kc)[16] = (r & 1) ? kb : ka;  // this round's key
+                double (&kn)[16] = (r & 1) ? ka : kb;  // next round's, requested now
+                if (r < 3) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) kn[k] = as_f64(bkp[(u64) (((wv + r + 1) & 3) * 4) * TF_N + k * 64]);
+                }
+                const u64* ob = &buf[(wv + r) & 3][lane];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double xo[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) xo[k] = as_f64(ob[(8 * h + k) * 64]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[8 * h + k] += fp_mul(kc[8 * h + k], xo[k], xo[k] * fc.qi, fc);
+                }
+            }
+        } else {
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + r) & 3) * 4) * TF_N + k * 64]);
+            const u64* ob = &buf[(wv + r) & 3][lane];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double xo = as_f64(ob[k * 64]);
+                x[k] += fp_mul(ka[k], xo, xo * fc.qi, fc);
+            }
+        }
+        }
+        __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
+        fwave_intt1024_l(x, buf[wv], p.fitw, twl, p.fninv, p.fw1ninv, fc, lane);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            atomicAdd(reinterpret_cast<u32*>(&acc[cc][lane + 64 * k]), f_low32(x[k]) << sh);
+        __syncthreads();
+    }
+    for (int j = t; j < TF_N; j += TF_THREADS)
+        out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
+    if (t == 0) out_b[g] = acc[1][0];
 }
 
 // out = enc + m*(s1*in1 + s2*in2) on the 32-bit torus (bootstrapping.cu:378-660)
@@ -1168,9 +1204,11 @@ hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase
 
 // Synchronous (one-time): tries the FP64 layout, falls back to the integer
 // layout when a key coefficient does not fit int32.
-hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, hipStream_t st)
+hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, int* fmt_out,
+                                hipStream_t st)
 {
     hipError_t e;
+    *fmt_out = 0;
     if (allow_fp) {
         if ((e = hipMemsetAsync(dst, 0, TFHE_PREP_HEADER * sizeof(u64), st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_tfhe_prepare_bootkey_fp, dim3((unsigned) polys), dim3(64), 0, st, src,
@@ -1180,6 +1218,7 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
         if (!bad) {
             hipLaunchKernelGGL(k_tfhe_set_header, dim3(1), dim3(1), 0, st, dst, (u64) 1);
+            *fmt_out = 1;
             return hipGetLastError();
         }
     }
@@ -1189,24 +1228,33 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
     return hipGetLastError();
 }
 
+// `fmt`: the layout of the prepared key, from its header word (1 = FP64, 0 = integer); the caller (cabi.cpp) knows it
+// from hegpu_tfhe_prepare_bootkey or reads the word once per buffer -- ONE kernel is launched (round 3 launched both and
+// let the one whose layout was absent exit: an empty grid of `shape` workgroups, ~5 us, on every call).
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int g4_min, int wide_max, hipStream_t st)
+                             int* out_b, int encoded, int shape, int fmt, int form, hipStream_t st)
 {
-    // both kernels cover all gates; the one whose key layout is absent exits at once
-    // one gate per workgroup: measured faster than four gates sharing the key registers at every
-    // batch size (64 k vs 53 k gates/s at 4096 gates; 7.4 ms for a batch of 8); the shared
-    // variant stays selectable for experiments (context option "g4_min")
-    if (shape <= wide_max)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp_wide, dim3(shape), dim3(TFW_THREADS), 0, st, in_a, in_b, bk_prepared,
+    if (shape <= 0) return hipSuccess;
+    if (fmt == 1 && form == 3)
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<1>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
                            out_a, out_b, p, encoded);
-    else if (shape >= g4_min)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<4>, dim3((shape + 3) / 4), dim3(TF_THREADS), 0, st, in_a, in_b,
-                           bk_prepared, out_a, out_b, p, encoded, shape);
+    else if (fmt == 1 && form == 4)
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<2>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
+                           out_a, out_b, p, encoded);
+    else if (fmt == 1 && form == 5) // knock-out: no key prefetch at all
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<0>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
+                           out_a, out_b, p, encoded);
+    else if (fmt == 1 && form == 6) // knock-out: the new kernel held at two workgroups per CU by 30 KiB of unused LDS
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<1>, dim3(shape), dim3(TF_THREADS), 30 << 10, st, in_a, in_b,
+                           bk_prepared, out_a, out_b, p, encoded);
+    else if (fmt == 1)
+        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
+                           out_b, p, encoded);
+    else if (fmt == 0)
+        hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
+                           out_b, p, encoded);
     else
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp<1>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
-                           out_a, out_b, p, encoded, shape);
-    hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
-                       out_b, p, encoded);
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

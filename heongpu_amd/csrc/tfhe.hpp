@@ -43,9 +43,12 @@ hipError_t tfhe_gen_bootkey(const TfheDev& p, u64* boot_key, const int* lwe_key,
 // phase[s] = b[s] - <a[s], key>
 hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase, int n, int shape, hipStream_t st);
 
-hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, hipStream_t st);
+// *fmt_out: the layout written (1 = FP64, 0 = integer)
+hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, int* fmt_out,
+                                hipStream_t st);
+// fmt: the prepared key's layout (its header word), known to the caller
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int g4_min, int wide_max, hipStream_t st);
+                             int* out_b, int encoded, int shape, int fmt, int form, hipStream_t st);
 hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
                          int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st);
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,

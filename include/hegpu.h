@@ -93,14 +93,25 @@ int hegpu_context_upload(hegpu_context* ctx);
  * context's device whatever the caller's current device is (the caller's is restored on return), so a consumer drives
  * device d from any thread -- one OpenMP thread per device as the reference drives one stream per thread in
  * example/basic/9_multi_stream_usage_way1.cpp:27-66 -- with buffers and streams that belong to device d.
- * hegpu_broadcast_key copies keys[0] (on the device of ctxs[0]) to keys[i] on the device of ctxs[i], i = 1..n-1, as a
- * binomial fan-out of peer copies over xGMI; the copy into keys[i] is ordered on streams[i] (NULL: the default
- * streams), the source must be complete on streams[0]'s timeline.  hegpu_context_device: -1 before upload. */
+ * hegpu_broadcast_key copies keys[0] (on the device of ctxs[0]) to keys[i] on the device of ctxs[i], i = 1..n-1;
+ * hegpu_broadcast_bytes is the same for any buffer (the TFHE boot and key-switch keys) with the devices given directly.
+ * The copy into buffer i is ordered on streams[i] (NULL: the default streams), the source must be complete on
+ * streams[0]'s timeline.  Path (hegpu_last_broadcast_path of the calling thread, or *path_out): peer access is
+ * queried per edge (hipDeviceCanAccessPeer) and enabled (hipDeviceEnablePeerAccess); when every destination is
+ * directly reachable from the source -- a fully connected xGMI node -- the copies are a FLAT fan-out, one hop, every
+ * link of the source busy at once; otherwise a binomial TREE in <= 32 MiB chunks (hop r + 1 of a chunk starts when that
+ * chunk has arrived).  HEGPU_BCAST_STAGED: at least one edge has no peer access and is staged through host memory by
+ * the runtime; HEGPU_BCAST_SAME_DEVICE: every buffer lies on one device (a functional run on a 1-GPU box).
+ * hegpu_context_device: -1 before upload. */
+enum { HEGPU_BCAST_FLAT = 1, HEGPU_BCAST_TREE = 2, HEGPU_BCAST_STAGED = 0x100, HEGPU_BCAST_SAME_DEVICE = 0x200 };
 int hegpu_context_clone(const hegpu_context* src, hegpu_context** out);
 int hegpu_context_upload_device(hegpu_context* ctx, int device);
 int hegpu_context_device(const hegpu_context* ctx);
 int hegpu_broadcast_key(hegpu_context* const* ctxs, int n_ctx, uint64_t* const* keys, size_t elems,
                         const hegpu_stream* streams);
+int hegpu_broadcast_bytes(const int* devices, int n, void* const* bufs, size_t bytes, const hegpu_stream* streams,
+                          int* path_out);
+int hegpu_last_broadcast_path(void);
 /* integer properties: "n_power","Q_size","P_size","Q_prime_size","bsk_modulus" */
 long hegpu_context_int(const hegpu_context* ctx, const char* name);
 /* copy the named HOST table (reference member name without trailing '_',
@@ -456,13 +467,11 @@ enum {
 int hegpu_tfhe_context_create(hegpu_tfhe_context** out);
 void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
 /* "fp" 0/1: re-encode a torus32 boot key for the FP64 blind rotate (1, read by hegpu_tfhe_prepare_bootkey);
- * "g4_min": from this many gates per call four gates share one workgroup's key registers (default: never);
- * "wide_max": up to this many gates per call a gate is one workgroup of 16 wavefronts, four per transform
- * (default 0 = never: measured 5.8 ms against 4.4 ms for 1..256 gates).
  * "ks_batched" -1/0/1/8/12/16: key switching with 8, 12 or 16 gates per workgroup sharing the key rows: by launch
  * size (-1, default: from 3584 gates per call, the count that finishes in one round of workgroups), never, always,
  * always with that many.
- * Defaults seeded once from HEGPU_TFHE_FP / _G4_MIN / _WIDE_MAX / _KS_BATCHED at creation. */
+ * Defaults seeded once, at creation, from HEGPU_TFHE_FP / HEGPU_TFHE_KS_BATCHED when these hold whole decimal integers
+ * the setter accepts (anything else is ignored). */
 int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int value);
 /* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems",
  * "prepared_bootkey_elems","kskey_a_elems","kskey_b_elems" */
@@ -474,6 +483,12 @@ uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx);
  * any other key keeps the reference's 60-bit prime (results are identical either way). */
 int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
                                hegpu_stream stream);
+/* Layout of a prepared boot key: 1 = FP64, 0 = integer (its header word), -1 on error.  The blind rotate launches the
+ * one kernel for that layout; the context remembers the layout of every buffer it prepared and looks any other buffer
+ * up ONCE with a synchronous 8-byte read on its first use (a replica on another device: hegpu_broadcast_bytes, then the
+ * destination's own TFHE context).  refresh != 0 forgets the remembered value first -- call it after overwriting a
+ * prepared buffer by other means than hegpu_tfhe_prepare_bootkey. */
+int hegpu_tfhe_prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int refresh);
 /* tfhe_{nand,and,and_first_not,nor,or,xnor,xor}_pre_comp_kernel / tfhe_not_comp_kernel
  * (src/lib/kernel/bootstrapping.cu:378-660); in2_* ignored for NOT */
 int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a, int32_t* out_b,

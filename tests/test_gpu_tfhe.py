@@ -39,14 +39,12 @@ def _dev32(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("wide_max", [256, 0], ids=["sixteen-waves-per-gate", "four-waves-per-gate"])
-def test_blind_rotate_and_key_switch(hg, setup, wide_max):
-    """Both forms of the FP64 blind rotate (option "wide_max": a gate on 16 wavefronts, four per transform, for
-    calls of few gates -- measured slower, off by default; on 4 wavefronts, one per transform) and the integer one
-    (residues60 key)."""
+@pytest.mark.parametrize("br_form", [3, 2, 4], ids=["three-workgroups-per-cu", "round3-kernel", "rolling-key-prefetch"])
+def test_blind_rotate_and_key_switch(hg, setup, br_form):
+    """The forms of the FP64 blind rotate (option "br_form") and the integer one (residues60 key)."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
-    t.set_option("wide_max", wide_max)
+    t.set_option("br_form", br_form)
     shape = 6
     a = rng.integers(-2**31, 2**31, shape * 512, dtype=np.int64).astype(np.int32)
     b = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
@@ -59,7 +57,7 @@ def test_blind_rotate_and_key_switch(hg, setup, wide_max):
     out_b = torch.empty(shape, dtype=torch.int32, device="cuda")
     t.bootstrapping(_dev32(a), _dev32(b), prepared, out_a, out_b, shape)
     torch.cuda.synchronize()
-    t.set_option("wide_max", 0)
+    t.set_option("br_form", 3)
     assert np.array_equal(out_b.cpu().numpy(), want_b)
     assert np.array_equal(out_a.cpu().numpy(), want_a)
     ks_want_a, ks_want_b = o.key_switching(want_a, want_b, ks_a, ks_b)
@@ -69,6 +67,45 @@ def test_blind_rotate_and_key_switch(hg, setup, wide_max):
     torch.cuda.synchronize()
     assert np.array_equal(ka.cpu().numpy(), ks_want_a)
     assert np.array_equal(kb.cpu().numpy(), ks_want_b)
+
+
+def test_prepared_key_that_arrived_by_copy(hg, setup):
+    """The blind rotate launches ONE kernel, chosen on the host from the prepared key's layout.  A buffer the context
+    did not prepare itself (a replica: here a device-to-device copy, on several GPUs the broadcast of the key) is looked
+    up once from its header word; overwriting it with a key of the other layout needs the refresh."""
+    import torch
+    t, o, rng, bk, ks_a, ks_b = setup
+    prepared = t.prepare_bootkey(hg.to_device(bk))
+    fmt = t.prepared_format(prepared)
+    assert fmt == (1 if t.prepared_is_fp64(prepared) else 0)
+    replica = prepared.clone()
+    shape = 2
+    a = rng.integers(-2**31, 2**31, shape * 512, dtype=np.int64).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
+    outs = []
+    for key in (prepared, replica):
+        out_a = torch.zeros(shape * 1024, dtype=torch.int32, device="cuda")
+        out_b = torch.zeros(shape, dtype=torch.int32, device="cuda")
+        t.bootstrapping(_dev32(a), _dev32(b), key, out_a, out_b, shape)
+        torch.cuda.synchronize()
+        outs.append((out_a.cpu().numpy(), out_b.cpu().numpy()))
+    want_a, want_b = o.bootstrapping(a, b, bk)
+    for got_a, got_b in outs:
+        assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b)
+    assert t.prepared_format(replica) == fmt
+    # a key of the other layout written over the replica: the remembered layout is stale until refreshed
+    other = rng.integers(0, o.prime, t.int("bootkey_elems"), dtype=np.uint64) if fmt == 1 else None
+    if other is not None:
+        replica.copy_(t.prepare_bootkey(hg.to_device(other)))
+        assert t.prepared_format(replica) == 1 and t.prepared_format(replica, refresh=True) == 0
+        out_a = torch.zeros(shape * 1024, dtype=torch.int32, device="cuda")
+        out_b = torch.zeros(shape, dtype=torch.int32, device="cuda")
+        t.bootstrapping(_dev32(a), _dev32(b), replica, out_a, out_b, shape)
+        torch.cuda.synchronize()
+        want_a, want_b = o.bootstrapping(a, b, other)
+        assert np.array_equal(out_a.cpu().numpy(), want_a) and np.array_equal(out_b.cpu().numpy(), want_b)
+    with pytest.raises(hg.HEError):
+        t.prepared_format(torch.full((256,), 7, dtype=torch.int64, device="cuda"))
 
 
 @pytest.mark.parametrize("shape,per_wg", [(5, 8), (8, 8), (21, 8), (29, 12), (12, 12), (35, 16)])
