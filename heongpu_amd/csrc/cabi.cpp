@@ -1282,7 +1282,6 @@ struct hegpu_tfhe_context {
     bool uploaded = false;
     int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
-    int br_form = 3;           // option "br_form": 3 = three workgroups per CU (k_tfhe_blind_rotate_fp3), 2 = round 3's kernel
     int ks_batched = -1;       // option "ks_batched": key switching with 8 / 12 / 16 gates per workgroup sharing the key rows (tfhe.hip)
     // layout of every prepared boot key this context has met (header word 0: 1 = FP64, 0 = integer): filled by
     // hegpu_tfhe_prepare_bootkey; a buffer that arrived by other means (a peer copy from another device's context) is
@@ -1348,7 +1347,7 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
         }
         *out = h;
         // defaults only, through the setter's own validation (a value it refuses is ignored, not stored)
-        for (const char* nm : {"fp", "ks_batched", "br_form"}) {
+        for (const char* nm : {"fp", "ks_batched"}) {
             std::string env = std::string("HEGPU_TFHE_") + nm;
             for (char& ch : env) ch = (char) toupper((unsigned char) ch);
             long v;
@@ -1364,9 +1363,6 @@ int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int
     if (!strcmp(name, "fp")) {
         if (value < 0 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option fp");
         ctx->allow_fp = value != 0;
-    } else if (!strcmp(name, "br_form")) {
-        if (value < 2 || value > 6) return fail(HEGPU_E_INVALID, "value out of range for option br_form");
-        ctx->br_form = value;
     } else if (!strcmp(name, "ks_batched")) {
         if (value < -1 || (value > 1 && value != 8 && value != 12 && value != 16))
             return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
@@ -1530,7 +1526,7 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
     int fmt = -1;
     if ((r = prepared_format(ctx, prepared_boot_key, &fmt))) return r;
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
-                                     encode_to_torus32(1, 8), shape, fmt, ctx->br_form, (hipStream_t) stream),
+                                     encode_to_torus32(1, 8), shape, fmt, (hipStream_t) stream),
                    "hegpu_tfhe_bootstrapping");
 }
 

@@ -409,67 +409,6 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
     wave_fence();
 }
 
-// Inverse 1024-point NTT mod p' by one wavefront.  In: x[k] = slot 16*lane + k,
-// |x| <= 2.2 p'.  Out: x[k] = coefficient lane + 64k as the centred residue
-// (exact integer when the true value is below p'/2 - 2^40 in magnitude), N^-1
-// applied.  The un-multiplied outputs double per stage: 2.2 p' -> 141 p' < 2^52
-// after six stages, one centred reduction, then 8 p' before the last stage.
-__device__ __forceinline__ void fwave_intt1024(double (&x)[16], u64* buf, const ulonglong2* __restrict__ itw,
-                                               const ulonglong2* itwl, ulonglong2 ninv, ulonglong2 w1ninv,
-                                               const FC& c, int lane)
-{
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const ulonglong2 w9a = itwl[512 + 8 * lane + 2 * g], w9b = itwl[512 + 8 * lane + 2 * g + 1];
-        f_gs(x[4 * g + 0], x[4 * g + 1], w9a, c);
-        f_gs(x[4 * g + 2], x[4 * g + 3], w9b, c);
-        const ulonglong2 w8 = itwl[256 + 4 * lane + g];
-        f_gs(x[4 * g + 0], x[4 * g + 2], w8, c);
-        f_gs(x[4 * g + 1], x[4 * g + 3], w8, c);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) buf[bi(16 * lane + k)] = as_bits(x[k]);
-    wave_fence();
-    const int b = lane >> 2, c0 = lane & 3;
-#pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
-#pragma unroll
-    for (int s = 3; s >= 0; s--) {
-        const int half = 8 >> s;
-#pragma unroll
-        for (int bb = 0; bb < (1 << s); bb++) {
-            const ulonglong2 w = itwl[((16 + b) << s) + bb];
-#pragma unroll
-            for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = fp_reduce(x[m], c);
-    wave_fence();
-#pragma unroll
-    for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
-    wave_fence();
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(lane + 64 * k)]);
-#pragma unroll
-    for (int s = 3; s >= 1; s--) {
-        const int half = 8 >> s;
-#pragma unroll
-        for (int bb = 0; bb < (1 << s); bb++) {
-            const ulonglong2 w = itw[(1 << s) + bb];
-#pragma unroll
-            for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const double s = x[j] + x[j + 8], d = x[j] - x[j + 8];
-        x[j] = fp_mul(s, as_f64(ninv.x), as_f64(ninv.y), c);
-        x[j + 8] = fp_mul(d, as_f64(w1ninv.x), as_f64(w1ninv.y), c);
-    }
-    wave_fence();
-}
-
 // low 32 bits (two's complement) of an integer-valued double, |v| < 2^51
 __device__ __forceinline__ u32 f_low32(double v) { return (u32) as_bits(v + 6755399441055744.0); }
 
@@ -519,102 +458,6 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
 }
 
 __global__ void k_tfhe_set_header(u64* hdr, u64 fmt) { hdr[0] = fmt; }
-
-// One gate per workgroup, wavefront w = (y,z): digit polynomial z of accumulator
-// y -> forward NTT -> staged in LDS; wavefront w then sums ITS output o = w (c = w >> 1, half = w & 1) over the
-// four transformed digits times the key polynomials BK_i[y'][z'][c][half] in registers, inverse-transforms it
-// and adds it into the accumulator (two 16-bit halves per coefficient: integer atomics on the LDS words).  The 64
-// key values a lane needs in iteration i are requested before the decomposition and arrive under the forward
-// transform.  (Four gates per workgroup sharing the key registers, and a gate on sixteen wavefronts, were built in
-// rounds 2 / 3 and measured slower -- profiles/r3c_experiments/README.md section 4; they are in the history, not here.)
-__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tfhe_blind_rotate_fp(const int* __restrict__ in_a,
-                                                                     const int* __restrict__ in_b,
-                                                                     const u64* __restrict__ prepared,
-                                                                     int* __restrict__ out_a, int* __restrict__ out_b,
-                                                                     TfheDev p, int encoded)
-{
-    if (prepared[0] != 1) return; // not the FP64 layout (the host picks the kernel from the header: tfhe_blind_rotate)
-    const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
-    __shared__ int acc[2][TF_N];
-    __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
-    // lane-dependent twiddles of both transforms (entries 16..1023; (w, companion) pairs, 2 x 16 KiB)
-    __shared__ ulonglong2 twf[TF_N], twi[TF_N];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int y = wv >> 1, z = wv & 1;
-    for (int j = t; j < TF_N; j += TF_THREADS) {
-        twf[j] = p.ftw[j];
-        twi[j] = p.fitw[j];
-    }
-    const int g = blockIdx.x;
-    const int n = p.n;
-    const FC fc = make_fc(p.fprime);
-    {
-        const int bN = 2 * TF_N - modswitch(in_b[g], 10);
-        for (int j = t; j < TF_N; j += TF_THREADS) {
-            acc[0][j] = 0;
-            acc[1][j] = (bN < TF_N) ? ((j < bN) ? -encoded : encoded) : ((j < bN - TF_N) ? encoded : -encoded);
-        }
-    }
-    __syncthreads();
-
-    const int shift = 32 - 10 * (z + 1);
-    const int cc = wv >> 1, sh = (wv & 1) ? 16 : 0;
-    for (int i = 0; i < n; i++) {
-        // key polynomials of this wavefront: [(i,y,z)][o = 2c+half][k][lane].
-        // kv[r] = key polynomial (digit wavefront (wv + r) & 3, output wv): every wavefront sums ITS output over
-        // the four transformed digits (read from the other wavefronts' staging areas) in registers
-        const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
-        double kv[4][16];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                kv[r][k] = as_f64(bkp[(u64) (((wv + r) & 3) * 4) * TF_N + k * 64]);
-        const int aN = modswitch(in_a[(u64) g * n + i], 10);
-        double x[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int j = lane + 64 * k;
-            // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
-            // arithmetic and a select (branches per element would put every LDS read in its own basic block)
-            const int idx = (j - aN) & (2 * TF_N - 1);
-            const int v = acc[y][idx & (TF_N - 1)];
-            const int r = (idx & TF_N) ? -v : v;
-            const u32 diff = (u32) r - (u32) acc[y][j];
-            const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
-            x[k] = (double) d;
-        }
-        fwave_ntt1024(x, buf[wv], p.ftw, twf, fc, lane);
-        // The transformed digit goes to the own staging area (free after the transform); after the barrier
-        // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
-        // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
-        // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
-#pragma unroll
-        for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = fp_mul(kv[0][k], x[k], x[k] * fc.qi, fc);
-#pragma unroll
-        for (int r = 1; r < 4; r++) {
-            const u64* ob = &buf[(wv + r) & 3][lane];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const double xo = as_f64(ob[k * 64]);
-                x[k] += fp_mul(kv[r][k], xo, xo * fc.qi, fc);
-            }
-        }
-        __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
-        fwave_intt1024(x, buf[wv], p.fitw, twi, p.fninv, p.fw1ninv, fc, lane);
-        // output o = wv: polynomial c = wv >> 1, half wv & 1 (bootstrapping.cu:1294-1311)
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            atomicAdd(reinterpret_cast<u32*>(&acc[cc][lane + 64 * k]), f_low32(x[k]) << sh);
-        __syncthreads();
-    }
-    for (int j = t; j < TF_N; j += TF_THREADS)
-        out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
-    if (t == 0) out_b[g] = acc[1][0];
-}
 
 // ------------------------------------------------------------------ FP64 blind rotate, three workgroups per CU
 // Round 4.  Counters of the kernel above at 8192 gates (profiles/r4a_c5/): 2.37 GHz (not power-limited -- there is
@@ -763,8 +606,7 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
     wave_fence();
 }
 
-template <int PF>
-__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_tfhe_blind_rotate_fp3(
+__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_tfhe_blind_rotate_fp(
     const int* __restrict__ in_a, const int* __restrict__ in_b, const u64* __restrict__ prepared, int* __restrict__ out_a,
     int* __restrict__ out_b, TfheDev p, int encoded)
 {
@@ -793,16 +635,20 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     for (int i = 0; i < n; i++) {
         // key polynomial r = (digit wavefront (wv + r) & 3, output wv): [(i, digit)][o = wv][k][lane]
         const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
-        double ka[16], kb[16];
-        if (PF != 0) {
+        // the first key polynomial is requested ahead of the decomposition and arrives under the forward transform;
+        // the other three are loaded where they are used -- with three waves per SIMD their latency is covered by
+        // the other workgroups (measured: no prefetch at all is as fast at 8192 gates, a rolling two-polynomial
+        // prefetch needs 168 + 21 spilled registers and is slower: profiles/r4_c5/README.md)
+        double ka[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
-        }
+        for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
         const int aN = modswitch(in_a[(u64) g * n + i], 10);
         double x[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int j = lane + 64 * k;
+            // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
+            // arithmetic and a select (branches per element would put every LDS read in its own basic block)
             const int idx = (j - aN) & (2 * TF_N - 1);
             const int v = acc[y][idx & (TF_N - 1)];
             const int r = (idx & TF_N) ? -v : v;
@@ -811,39 +657,15 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
             x[k] = (double) d;
         }
         fwave_ntt1024_l(x, buf[wv], p.ftw, twl, fc, lane);
+        // The transformed digit goes to the own staging area (free after the transform); after the barrier
+        // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
+        // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
+        // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
 #pragma unroll
         for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
-        if (PF == 2) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) kb[k] = as_f64(bkp[(u64) (((wv + 1) & 3) * 4) * TF_N + k * 64]);
-        }
         __syncthreads();
-        if (PF == 0) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
-        }
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = fp_mul(ka[k], x[k], x[k] * fc.qi, fc);
-        if (PF == 2) {
-#pragma unroll
-            for (int r = 1; r < 4; r++) {
-                double (&kc)[16] = (r & 1) ? kb : ka;  // this round's key
-                double (&kn)[16] = (r & 1) ? ka : kb;  // next round's, requested now
-                if (r < 3) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) kn[k] = as_f64(bkp[(u64) (((wv + r + 1) & 3) * 4) * TF_N + k * 64]);
-                }
-                const u64* ob = &buf[(wv + r) & 3][lane];
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    double xo[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) xo[k] = as_f64(ob[(8 * h + k) * 64]);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) x[8 * h + k] += fp_mul(kc[8 * h + k], xo[k], xo[k] * fc.qi, fc);
-                }
-            }
-        } else {
 #pragma unroll
         for (int r = 1; r < 4; r++) {
 #pragma unroll
@@ -854,7 +676,6 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
                 const double xo = as_f64(ob[k * 64]);
                 x[k] += fp_mul(ka[k], xo, xo * fc.qi, fc);
             }
-        }
         }
         __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
         fwave_intt1024_l(x, buf[wv], p.fitw, twl, p.fninv, p.fw1ninv, fc, lane);
@@ -1232,22 +1053,10 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
 // from hegpu_tfhe_prepare_bootkey or reads the word once per buffer -- ONE kernel is launched (round 3 launched both and
 // let the one whose layout was absent exit: an empty grid of `shape` workgroups, ~5 us, on every call).
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int fmt, int form, hipStream_t st)
+                             int* out_b, int encoded, int shape, int fmt, hipStream_t st)
 {
     if (shape <= 0) return hipSuccess;
-    if (fmt == 1 && form == 3)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<1>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
-                           out_a, out_b, p, encoded);
-    else if (fmt == 1 && form == 4)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<2>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
-                           out_a, out_b, p, encoded);
-    else if (fmt == 1 && form == 5) // knock-out: no key prefetch at all
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<0>, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared,
-                           out_a, out_b, p, encoded);
-    else if (fmt == 1 && form == 6) // knock-out: the new kernel held at two workgroups per CU by 30 KiB of unused LDS
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp3<1>, dim3(shape), dim3(TF_THREADS), 30 << 10, st, in_a, in_b,
-                           bk_prepared, out_a, out_b, p, encoded);
-    else if (fmt == 1)
+    if (fmt == 1)
         hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
                            out_b, p, encoded);
     else if (fmt == 0)

@@ -48,7 +48,7 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
                                 hipStream_t st);
 // fmt: the prepared key's layout (its header word), known to the caller
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int fmt, int form, hipStream_t st);
+                             int* out_b, int encoded, int shape, int fmt, hipStream_t st);
 hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
                          int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st);
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,

@@ -39,12 +39,10 @@ def _dev32(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("br_form", [3, 2, 4], ids=["three-workgroups-per-cu", "round3-kernel", "rolling-key-prefetch"])
-def test_blind_rotate_and_key_switch(hg, setup, br_form):
-    """The forms of the FP64 blind rotate (option "br_form") and the integer one (residues60 key)."""
+def test_blind_rotate_and_key_switch(hg, setup):
+    """The FP64 blind rotate (torus32 key) and the integer one (residues60 key)."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
-    t.set_option("br_form", br_form)
     shape = 6
     a = rng.integers(-2**31, 2**31, shape * 512, dtype=np.int64).astype(np.int32)
     b = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
@@ -57,7 +55,6 @@ def test_blind_rotate_and_key_switch(hg, setup, br_form):
     out_b = torch.empty(shape, dtype=torch.int32, device="cuda")
     t.bootstrapping(_dev32(a), _dev32(b), prepared, out_a, out_b, shape)
     torch.cuda.synchronize()
-    t.set_option("br_form", 3)
     assert np.array_equal(out_b.cpu().numpy(), want_b)
     assert np.array_equal(out_a.cpu().numpy(), want_a)
     ks_want_a, ks_want_b = o.key_switching(want_a, want_b, ks_a, ks_b)

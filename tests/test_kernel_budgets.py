@@ -29,8 +29,8 @@ BUDGETS = {
 
 
 TFHE_BUDGETS = {
-    "22k_tfhe_blind_rotate_fpILi1EE": (2, 0),  # FP64 blind rotate: one wavefront per decomposed polynomial
-    "27k_tfhe_blind_rotate_fp_wideE": (4, 0),  # few gates: 16 wavefronts per gate in one workgroup
+    "22k_tfhe_blind_rotate_fpE": (3, 0),       # FP64 blind rotate: three workgroups per CU (<= 168 registers AND
+                                               # <= 53 KiB of LDS, checked below) -- round 4's 77.8 -> 90 k gates/s
     "19k_tfhe_blind_rotateE": (2, 0),          # integer blind rotate (keys beyond int32)
     "28k_tfhe_key_switching_batchedILi8EE": (3, 0),   # many gates: three resident workgroups per CU is what the
     "28k_tfhe_key_switching_batchedILi12EE": (3, 0),  # one-round choice of gates per workgroup counts on
@@ -70,3 +70,5 @@ def test_hot_kernels_keep_their_register_budgets(tmp_path, source, budgets):
         u = usage[hits[0]]
         assert u.get("Occupancy", 0) >= min_waves, (hits[0], u)
         assert u.get("ScratchSize", 0) <= max_scratch, (hits[0], u)
+        if key == "22k_tfhe_blind_rotate_fpE":
+            assert u.get("LDS Size", 1 << 30) * 3 <= 160 * 1024, (hits[0], u)
