@@ -6,22 +6,31 @@ benchmark/benchmark_ckks.cpp:123-137) over one batch of independent synthetic ci
 that are already resident in HBM.  BASELINE.json config C4: 512 pairs sharded over 8 GPUs =
 64 pairs per GPU; weak scaling: the global batch is 64 x n_gpus pairs, every rank owns its
 `sharding.shard_range` slice, the relinearization key is produced on rank 0 and replicated once.
-There is no collective on the data path.
+There is no collective on the data path.  `--workload c5` runs BASELINE.json config C5 the same way: TFHE NAND gate
+bootstraps, 1024 gates per GPU (8192 over 8), sharded along `shape`, the prepared boot key (64 MiB) and the
+key-switch key (48 MiB) replicated once.
 
 Multi-GPU (`--gpus N`), in this order of preference -- the line says which one ran (`config.parallelism`):
   1. one process per GPU (torch.distributed.run, launched by bench.py itself when it is not already under a
      launcher): control plane on gloo, the key broadcast on RCCL (backend "nccl") over xGMI;
-  2. the same, with the key staged through the host over gloo when RCCL cannot be brought up within 60 s;
-  3. one process, one thread and one context per device (hegpu_context_upload_device), the key replicated with
-     hegpu_broadcast_key (peer copies) -- when the launch of the ranks itself fails, or with --single-process.
+  2. the same, with the keys staged through the host over gloo when RCCL cannot be brought up within 60 s;
+  3. one process, one thread and one context per device, the keys replicated with hegpu_broadcast_bytes (peer copies:
+     peer access checked per edge, flat fan-out or chunked tree -- the line names the path) -- when the launch of the
+     ranks itself fails, or with --single-process.
 Ranks beyond the number of visible devices share devices (a functional check on a 1-GPU box).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (forward NTT launch pair),
-`in_step` (every launch group of the step timed on its own with HIP events, with its algorithmic bytes, its
-vector-ALU issue figures and the ceiling that binds it), `checked_items` (every output of the timed batch
-verified: against the CPU oracle and against its twin), `secondary` (the other BASELINE.json configurations,
-timed and verified in the same run) and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only).
-The oracle is imported only by the verification / cpu_baseline legs: inputs come from heongpu_amd.synth.
+`in_step` (every launch group of the step timed on its own with HIP events), `checked_items` (every output of the timed
+batch verified: against the CPU oracle and against its twin), `secondary` (the other BASELINE.json configurations, timed
+and verified in the same run) and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only).
+
+WHERE EACH NUMBER WAS MEASURED.  Milliseconds, rates and checks are LIVE (this run, HIP events on the launch stream).
+Byte counts and vector-instruction counts per launch do not depend on the box; they are read from the committed
+counter passes (`profiles/profile.json`, built by tools/build_profile_json.py from `tools/prof_all.sh` runs of this very
+script's `--profile-workload` modes) and every field that comes from there sits under a key named `from_profile`,
+together with the directory, the profile run's own milliseconds and shader clock; fractions of the issue ceiling are
+the profile run's own (its instructions over its cycles), the live time is printed next to the profile's with their
+ratio.  The oracle is imported only by the verification / cpu_baseline legs: inputs come from heongpu_amd.synth.
 """
 import argparse
 import json
@@ -41,10 +50,15 @@ N = 65536
 LOG_Q = [60] + [50] * 15
 LOG_P = [60]
 PAIRS_PER_GPU = 64      # config C4: 512 pairs over 8 GPUs
+GATES_PER_GPU = 1024    # config C5: 8192 gates over 8 GPUs
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 UNIQ = 4                # distinct seeded pairs, repeated to fill a batch
+TFHE_UNIQ = 64          # distinct seeded gate inputs
 SIMDS, LANES = 1024, 16  # 256 CUs x 4 SIMDs, 16 lanes each: a wave64 vector instruction holds its SIMD for 4 cycles
 NCCL_TIMEOUT_S = 60
+PROFILE_JSON = os.path.join(ROOT, "profiles", "profile.json")
+PROFILE_WORKLOADS = ("c4_step", "ntt_pair", "bfv_n14_multiply", "c3_bfv_n15_rotate", "c2_ckks_n14_b1", "c2_ckks_n14_b64",
+                     "ckks_n16_method_II", "c5_tfhe_gates")
 
 
 def parse_args(argv=None):
@@ -52,20 +66,29 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=PAIRS_PER_GPU, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--workload", choices=("c4", "c5"), default="c4",
+                    help="c4: CKKS N=2^16 multiply + relinearize (the headline); c5: TFHE NAND gate bootstraps")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="units per GPU per step: ciphertext pairs (c4, default 64) or gates (c5, default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations")
     ap.add_argument("--step-only", action="store_true",
-                    help="warm-up + timed steps only (the PMC passes of tools/profile.sh: every dispatch belongs to a step)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = 2 x cores, at most the batch)")
+                    help="warm-up + timed steps only (counter passes: every dispatch belongs to a step)")
+    ap.add_argument("--profile-workload", choices=PROFILE_WORKLOADS, default=None,
+                    help="counter passes (tools/prof_all.sh): set the named workload up and run it --reps times, nothing else")
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = one per host core)")
     ap.add_argument("--backend", default=None, help="backend of the key broadcast (default nccl = RCCL; gloo stages through the host)")
     ap.add_argument("--single-process", action="store_true",
-                    help="--gpus N in one process: a thread and a context per device, hegpu_broadcast_key")
+                    help="--gpus N in one process: a thread and a context per device, hegpu_broadcast_bytes")
     ap.add_argument("--force-launch-failure", action="store_true",
                     help="testing: pretend the launch of the ranks failed (exercises the single-process fallback)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: exercise launch, sharding, key replication and the max-over-ranks reduction on CPU")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.batch <= 0:
+        a.batch = PAIRS_PER_GPU if a.workload == "c4" else GATES_PER_GPU
+    return a
 
 
 def free_port():
@@ -121,7 +144,7 @@ class Dist:
         self.dist.all_gather(out, self.torch.tensor([v], dtype=self.torch.float64))
         return [float(t.item()) for t in out]
 
-    def _nccl_broadcast(self, key, dev, result):
+    def _nccl_broadcast(self, tensors, dev, result):
         try:
             import datetime
             g = self.dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=NCCL_TIMEOUT_S), device_id=dev)
@@ -130,16 +153,17 @@ class Dist:
             self.torch.cuda.synchronize(dev)
             if int(probe.item()) != self.world:
                 raise RuntimeError("RCCL all-reduce probe returned %r" % probe.item())
-            flat = key.view(-1)
-            for off in range(0, flat.numel(), 1 << 27):  # <= 1 GiB per message
-                self.dist.broadcast(flat[off:off + (1 << 27)], src=0, group=g)
+            for key in tensors:
+                flat = key.view(-1)
+                for off in range(0, flat.numel(), 1 << 27):  # <= 1 GiB per message
+                    self.dist.broadcast(flat[off:off + (1 << 27)], src=0, group=g)
             self.torch.cuda.synchronize(dev)
             result["ok"] = True
         except Exception as e:  # noqa: BLE001 -- any failure selects the fallback
             result["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
 
-    def broadcast_key(self, key, dev):
-        """key: int64 tensor on `dev`, valid on rank 0.  Returns the elapsed milliseconds."""
+    def broadcast_keys(self, tensors, dev):
+        """tensors: device tensors on `dev`, valid on rank 0.  Returns the elapsed milliseconds."""
         if self.world == 1:
             return None
         torch, dist = self.torch, self.dist
@@ -150,7 +174,7 @@ class Dist:
         why = "requested"
         if self.want == "nccl":
             res = {}
-            th = threading.Thread(target=self._nccl_broadcast, args=(key, dev, res), daemon=True)
+            th = threading.Thread(target=self._nccl_broadcast, args=(tensors, dev, res), daemon=True)
             th.start()
             th.join(NCCL_TIMEOUT_S + 30)
             self.hung = th.is_alive()   # a collective that never returned: leave through os._exit at the end
@@ -162,11 +186,12 @@ class Dist:
         if int(flag.item()) == 1:
             self.key_path = "RCCL broadcast (torch.distributed nccl) over xGMI"
         else:
-            host = key.cpu() if self.rank == 0 else torch.empty(key.numel(), dtype=torch.int64)
-            for off in range(0, host.numel(), 1 << 27):
-                dist.broadcast(host[off:off + (1 << 27)], src=0)
-            if self.rank != 0:
-                key.copy_(host)
+            for key in tensors:
+                host = key.cpu().view(-1) if self.rank == 0 else torch.empty(key.numel(), dtype=key.dtype)
+                for off in range(0, host.numel(), 1 << 27):
+                    dist.broadcast(host[off:off + (1 << 27)], src=0)
+                if self.rank != 0:
+                    key.view(-1).copy_(host)
             torch.cuda.synchronize(dev)
             self.key_path = "staged through the host over gloo (RCCL: %s)" % why
         return (time.perf_counter() - t0) * 1e3
@@ -183,18 +208,26 @@ class Dist:
                 pass
 
 
+def selftest_keys(torch, workload):
+    """key-shaped stand-ins (CPU): one tensor for C4's relinearization key, three for C5 (prepared boot key, key-switch a / b)"""
+    if workload == "c4":
+        return [torch.arange(1 << 16, dtype=torch.int64) * 7 + 3]
+    return [torch.arange(1 << 14, dtype=torch.int64) * 5 + 1, (torch.arange(1 << 15, dtype=torch.int64) % 65521).to(torch.int32),
+            (torch.arange(3000, dtype=torch.int64) % 251).to(torch.int32)]
+
+
 def launcher_selftest(args):
     """What the multi-GPU paths do around the kernels, without a GPU.  Under a launcher (or self-launched): rendezvous,
-    shard the global batch, replicate a key-shaped tensor from rank 0, reduce the elapsed time with MAX, gather
+    shard the global batch, replicate the key-shaped tensors from rank 0, reduce the elapsed time with MAX, gather
     per-rank rates (gloo).  With the launch failing (--force-launch-failure): the single-process path -- one thread
     per "device", the same sharding, a barrier on both sides of the timed region, the maximum over the threads."""
     import torch
 
     from heongpu_amd import sharding
-    ref = torch.arange(1 << 16, dtype=torch.int64) * 7 + 3
+    refs = selftest_keys(torch, args.workload)
     if "WORLD_SIZE" not in os.environ:  # single-process fallback, on CPU
         world = args.gpus
-        keys = [ref.clone()] + [torch.zeros_like(ref) for _ in range(world - 1)]
+        keys = [[r.clone() for r in refs]] + [[torch.zeros_like(r) for r in refs] for _ in range(world - 1)]
         bar = threading.Barrier(world)
         elapsed, slices = [0.0] * world, [None] * world
 
@@ -205,27 +238,27 @@ def launcher_selftest(args):
             time.sleep(0.001 * (r + 1))
             bar.wait()
             elapsed[r] = time.perf_counter() - t0
-        span = 1
-        while span < world:  # the fan-out order of hegpu_broadcast_key
-            for i in range(min(span, world - span)):
-                keys[i + span].copy_(keys[i])
-            span <<= 1
+        for j in range(1, world):  # hegpu_broadcast_bytes on a fully connected node: a flat fan-out from device 0
+            for a, b in zip(keys[0], keys[j]):
+                b.copy_(a)
         ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
         [t.start() for t in ths]
         [t.join() for t in ths]
-        ok = all(bool((k == ref).all()) for k in keys)
-        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "key_broadcast_ok": ok,
-                          "max_elapsed_s": max(elapsed), "global_batch": args.batch * world, "slices": slices,
+        ok = all(bool((k == ref).all()) for ks in keys for k, ref in zip(ks, refs))
+        print(json.dumps({"launcher_selftest": True, "workload": args.workload, "n_gpus": world, "key_broadcast_ok": ok,
+                          "replicated_tensors": len(refs), "max_elapsed_s": max(elapsed),
+                          "global_batch": args.batch * world, "slices": slices,
                           "parallelism": "single process, one thread per device (fallback: launch failed)"}))
         return 0 if ok else 1
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
     assert world == args.gpus, "world size %d != --gpus %d" % (world, args.gpus)
     d = Dist(torch, world, rank, "gloo")
     start, count = sharding.shard_range(args.batch * world, world, rank)
-    key = ref.clone() if rank == 0 else torch.zeros_like(ref)
+    keys = [r.clone() if rank == 0 else torch.zeros_like(r) for r in refs]
     if world > 1:
-        d.dist.broadcast(key, src=0)
-    ok = bool((key == ref).all())
+        for k in keys:
+            d.dist.broadcast(k, src=0)
+    ok = all(bool((k == r).all()) for k, r in zip(keys, refs))
     mx = d.max_float(0.001 * (rank + 1))
     d.gather_floats(count / (0.001 * (rank + 1)))
     slices = [[start, count]]
@@ -235,7 +268,8 @@ def launcher_selftest(args):
         d.dist.all_gather(sl, own)
         slices = [[int(v) for v in s] for s in sl]
     if rank == 0:
-        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "key_broadcast_ok": ok, "max_elapsed_s": mx,
+        print(json.dumps({"launcher_selftest": True, "workload": args.workload, "n_gpus": world, "key_broadcast_ok": ok,
+                          "replicated_tensors": len(refs), "max_elapsed_s": mx,
                           "global_batch": args.batch * world, "slices": slices,
                           "parallelism": "one process per GPU (gloo control plane)"}))
     d.close()
@@ -284,12 +318,66 @@ def twins_equal(torch, out, item_elems, count, uniq, first=0, used_elems=None):
     return compared, ok
 
 
+# ------------------------------------------------------------------ counters from the committed profile
+def load_profile():
+    if not os.path.exists(PROFILE_JSON):
+        return None
+    with open(PROFILE_JSON) as f:
+        return json.load(f)
+
+
+def prof_group(prof, workload, live_ms, match=None, algorithmic_bytes=None):
+    """As-built figures of a workload (or of the kernels of it whose name contains one of `match`) per batch, from the
+    committed counter passes, next to the live time.  Everything that is not live sits under `from_profile`.
+      from_profile.hbm_bytes            (2 FETCH_SIZE + WRITE_SIZE) KiB of the kernels, per batch
+      from_profile.ms / sclk_GHz        the kernels' own durations and cycles in the SQ pass of the profile run
+      from_profile.frac_of_issue_ceiling  wave-level vector instructions x 4 cycles / 1024 SIMDs over those cycles
+      from_profile.frac_of_copy_ceiling   hbm_bytes over from_profile.ms at the read+write stream ceiling of that box
+      achieved_GBps (live)              from_profile.hbm_bytes over the LIVE milliseconds
+      live_over_profile_ms              how far this box / run is from the profiled one
+      bound                             the larger of the two fractions names it; both below 0.5: neither"""
+    w = ((prof or {}).get("workloads") or {}).get(workload)
+    if not w:
+        return {"from_profile": None, "bound": "unknown (no committed counter pass for %s)" % workload}
+    ks = {k: v for k, v in w["kernels"].items() if match is None or any(m in k for m in match)}
+    if not ks:
+        return {"from_profile": None, "bound": "unknown (kernels %r not in the profile of %s)" % (match, workload)}
+    per = lambda v, f: v.get(f, 0.0) * v["per_batch"]
+    ms = sum(per(v, "ms") for v in ks.values())
+    cyc = sum(per(v, "cycles") for v in ks.values())
+    by = sum(per(v, "hbm_bytes") for v in ks.values())
+    insts = sum(per(v, "valu_wave_insts") for v in ks.values())
+    busy = sum(v.get("valu_busy", 0.0) * per(v, "cycles") for v in ks.values())
+    copy = prof.get("copy_ceiling_GBps") or 5230.0
+    fp = {"dir": prof.get("dir"), "workload": workload, "kernels": sorted(ks), "ms": ms, "sclk_GHz": cyc / (ms * 1e-3) / 1e9 if ms else None,
+          "hbm_bytes": by, "lane_instructions": insts * 64,
+          "valu_busy": busy / cyc if cyc else None,
+          "frac_of_issue_ceiling": insts * 4 / SIMDS / cyc if cyc else None,
+          "frac_of_copy_ceiling": by / (ms * 1e-3) / 1e9 / copy if ms else None,
+          "copy_ceiling_GBps": copy}
+    out = {"from_profile": fp, "achieved_GBps": by / (live_ms * 1e-3) / 1e9, "frac_of_hbm_peak_as_built": by / (live_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "live_ms": live_ms, "live_over_profile_ms": live_ms / ms if ms else None}
+    if algorithmic_bytes:
+        out["traffic_over_algorithmic"] = by / algorithmic_bytes
+    fi, fc = fp["frac_of_issue_ceiling"] or 0.0, fp["frac_of_copy_ceiling"] or 0.0
+    if max(fi, fc) < 0.5:
+        out["bound"] = "neither ceiling (issue %.2f, copy %.2f): latency of dependent phases / launch size" % (fi, fc)
+    else:
+        out["bound"] = "valu (vector-ALU issue)" if fi > fc else "hbm (read+write stream ceiling)"
+    out["frac_of_binding_ceiling"] = max(fi, fc)
+    return out
+
+
 # ------------------------------------------------------------------ the C4 workload on one device
 class C4:
     """CKKS N=2^16, Q=16 {60,50x15} | P=1 {60}, depth 0: `B` ciphertext pairs of one rank resident on `dev`."""
+    name, unit = "c4", "multiply+relinearize/s"
 
-    def __init__(self, torch, hg, ctx, dev, first, B, key=None):
+    def __init__(self, torch, hg, dev, first, B, ctx=None):
         from heongpu_amd import synth
+        if ctx is None:
+            ctx = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
+            ctx.upload()
         self.torch, self.hg, self.ctx, self.dev, self.first, self.B = torch, hg, ctx, dev, first, B
         self.primes = [int(v) for v in ctx.table("modulus")]
         self.Q, self.Qp, self.n = ctx.Q_size, ctx.Q_prime_size, N
@@ -307,9 +395,17 @@ class C4:
         self.ct1, self.ct2 = tile_items(torch, a, B, first), tile_items(torch, b, B, first)
         self.out = torch.empty(B * self.out_elems, dtype=torch.int64, device=dev)
         self.ws = ctx.workspace(hg.OP_CKKS_RELIN, 0, B, device=dev)
-        self.key = key if key is not None else torch.empty(2 * self.Q * self.Qp * n, dtype=torch.int64, device=dev)
+        self.key = torch.empty(2 * self.Q * self.Qp * n, dtype=torch.int64, device=dev)
 
-    def make_key(self):
+    @staticmethod
+    def contexts(hg, world):
+        ctx0 = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
+        return [ctx0] + [ctx0.clone() for _ in range(world - 1)]
+
+    def replicated(self):
+        return [self.key]
+
+    def make_keys(self):
         from heongpu_amd import synth
         self.key.copy_(synth.synth_key_t(self.torch, self.primes, self.Q, self.Qp, self.n, 3, self.dev))
 
@@ -321,46 +417,136 @@ class C4:
     def twins(self):
         return twins_equal(self.torch, self.out, self.out_elems, self.B, self.uniq, self.first, used_elems=self.ct_elems)
 
-
-def c4_host_inputs(primes, l, n, uniq, first, sample):
-    """numpy copies of the first `sample` pairs of a rank's batch (the CPU checker's input)"""
-    from heongpu_amd import synth
-    a = [synth.synth_ct_np(primes, range(l), 2, n, 1 + 10 * u) for u in range(uniq)]
-    b = [synth.synth_ct_np(primes, range(l), 2, n, 2 + 10 * u) for u in range(uniq)]
-    c1 = np.concatenate([a[(first + s) % uniq] for s in range(sample)])
-    c2 = np.concatenate([b[(first + s) % uniq] for s in range(sample)])
-    return c1, c2
-
-
-def line_skeleton(args, world, value, elapsed, per_rank, Q, parallelism):
-    W = 8 * N
-    l = Q
-    return {
-        "metric": "homomorphic mults/sec (CKKS N=2^16, L=16) + NTT GB/s vs HBM roofline",
-        "value": value,
-        "unit": "multiply+relinearize/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {
+    def describe(self, args, world):
+        W, l = 8 * N, self.Q
+        return ("homomorphic mults/sec (CKKS N=2^16, L=16) + NTT GB/s vs HBM roofline", {
             "workload": "CKKS N=2^16, Q=16 {60,50x15} | P=1 {60}, depth 0: multiply + relinearize_inplace "
                         "(key-switch method I), %d independent ciphertext pairs per GPU per step (global batch %d "
                         "sharded by contiguous slices), inputs resident in HBM" % (args.batch, args.batch * world),
-            "poly_modulus_degree": N,
-            "Q_size": Q,
-            "P_size": 1,
-            "batch_per_gpu": args.batch,
-            "global_batch": args.batch * world,
-            "parallelism": parallelism,
-            "algorithmic_bytes_per_op": (6 * l * l + 32 * l + 8) * W,
-        },
-        "per_rank_ops_per_s": per_rank,
+            "poly_modulus_degree": N, "Q_size": l, "P_size": 1, "batch_per_gpu": args.batch,
+            "global_batch": args.batch * world, "algorithmic_bytes_per_op": (6 * l * l + 32 * l + 8) * W})
+
+
+def c4_host_inputs(primes, l, n, uniq):
+    """numpy copies of the distinct pairs of a batch (the CPU checker's input)"""
+    from heongpu_amd import synth
+    a = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 1 + 10 * u) for u in range(uniq)])
+    b = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 2 + 10 * u) for u in range(uniq)])
+    return a, b
+
+
+# ------------------------------------------------------------------ the C5 workload on one device
+def tfhe_host_material(seed=1):
+    """Seeded key material and inputs of the C5 workload (numpy): a torus32 boot key as constant polynomials (the NTT
+    image of a constant is the constant in every slot, so no transform is needed to build a valid NTT-domain key), the
+    key-switch key, TFHE_UNIQ distinct gate inputs."""
+    rng = np.random.default_rng(seed)
+    r32 = lambda k: rng.integers(-2**31, 2**31, k, dtype=np.int64).astype(np.int32)
+    return rng, r32
+
+
+class C5:
+    """TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch): `S` gates of
+    one rank resident on `dev`; gate b of the global batch has the inputs of distinct index (first + b) % TFHE_UNIQ."""
+    name, unit = "c5", "gate bootstraps/s"
+
+    def __init__(self, torch, hg, dev, first, S, ctx=None):
+        self.torch, self.hg, self.dev, self.first, self.S = torch, hg, dev, first, S
+        self.B = S
+        with torch.cuda.device(dev):
+            self.t = ctx if ctx is not None else hg.TfheContext()
+            t = self.t
+            rng, r32 = tfhe_host_material()
+            self.polys = t.int("bootkey_elems") // 1024
+            self.bk_v = rng.integers(-2**31, 2**31, self.polys, dtype=np.int64)
+            self.ks_a_h, self.ks_b_h = r32(t.int("kskey_a_elems")), r32(t.int("kskey_b_elems"))
+            U = TFHE_UNIQ
+            self.a1u, self.a2u, self.b1u, self.b2u = r32(U * 512), r32(U * 512), r32(U), r32(U)
+            idx = (first + np.arange(S)) % U
+            self.idx = idx
+            cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            self.a1, self.a2 = cu(self.a1u.reshape(U, 512)[idx].reshape(-1)), cu(self.a2u.reshape(U, 512)[idx].reshape(-1))
+            self.b1, self.b2 = cu(self.b1u[idx]), cu(self.b2u[idx])
+            self.prepared = torch.empty(t.int("prepared_bootkey_elems"), dtype=torch.int64, device=dev)
+            self.ks_a = torch.empty(t.int("kskey_a_elems"), dtype=torch.int32, device=dev)
+            self.ks_b = torch.empty(t.int("kskey_b_elems"), dtype=torch.int32, device=dev)
+            self.out_a = torch.empty(S * 512, dtype=torch.int32, device=dev)
+            self.out_b = torch.empty(S, dtype=torch.int32, device=dev)
+            self.ws = torch.empty((512 + 1024 + 2) * S, dtype=torch.int32, device=dev)
+            # the first device call of a TFHE context places its tables on the calling thread's current device
+            t.gate_precompute(hg.GATE_NOT, self.out_a, self.out_b, self.a1, self.b1, None, None, 0)
+
+    @staticmethod
+    def contexts(hg, world):
+        return [hg.TfheContext() for _ in range(world)]
+
+    def bootkey_host(self):
+        lifted = np.where(self.bk_v < 0, self.bk_v + self.t.prime, self.bk_v).astype(np.uint64)
+        return np.repeat(lifted, 1024)
+
+    def replicated(self):
+        return [self.prepared, self.ks_a, self.ks_b]
+
+    def make_keys(self):
+        torch = self.torch
+        with torch.cuda.device(self.dev):
+            bk = torch.from_numpy(self.bootkey_host().view(np.int64)).to(self.dev)
+            self.prepared.copy_(self.t.prepare_bootkey(bk))
+            self.ks_a.copy_(torch.from_numpy(self.ks_a_h).to(self.dev))
+            self.ks_b.copy_(torch.from_numpy(self.ks_b_h).to(self.dev))
+            self.t.prepared_format(self.prepared, refresh=True)  # this buffer now holds a key this context did not prepare in place
+
+    def step(self, stream):
+        self.t.gate(self.hg.GATE_NAND, self.a1, self.b1, self.a2, self.b2, self.out_a, self.out_b, self.prepared, self.ks_a,
+                    self.ks_b, self.S, self.ws, stream=stream)
+
+    def twins(self):
+        """every gate against the first gate of this rank's slice with the same inputs"""
+        torch = self.torch
+        first_pos = {}
+        for b, u in enumerate(self.idx):
+            first_pos.setdefault(int(u), b)
+        ref = torch.tensor([first_pos[int(u)] for u in self.idx], device=self.dev)
+        ga, gb = self.out_a.view(self.S, 512), self.out_b
+        ok = bool(torch.equal(ga, ga[ref])) and bool(torch.equal(gb, gb[ref]))
+        return self.S - len(first_pos), ok
+
+    def oracle_check(self, count):
+        """the first `count` gates of this rank's slice against the CPU oracle (the checker; not timed here)"""
+        from oracle import binding as ob
+        ot = ob.OracleTfhe()
+        sel = self.idx[:count]
+        a1 = self.a1u.reshape(-1, 512)[sel].reshape(-1)
+        a2 = self.a2u.reshape(-1, 512)[sel].reshape(-1)
+        t0 = time.perf_counter()
+        want_a, want_b = ot.gate(self.hg.GATE_NAND, a1, self.b1u[sel], a2, self.b2u[sel], self.bootkey_host(), self.ks_a_h,
+                                 self.ks_b_h)
+        cpu_s = time.perf_counter() - t0
+        ga = self.out_a.view(self.S, 512)[:count].cpu().numpy().reshape(-1)
+        ok = np.array_equal(ga, want_a) and np.array_equal(self.out_b[:count].cpu().numpy(), want_b)
+        return bool(ok), cpu_s
+
+    def describe(self, args, world):
+        return ("TFHE STD128 gate bootstraps/sec (NAND, blind-rotate PBS, n=512, N=1024)", {
+            "workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
+                        "%d concurrent gates per GPU per step (global batch %d sharded along `shape` by contiguous slices, %d "
+                        "distinct inputs), torus32 boot key (FP64 blind rotate), keys resident in HBM"
+                        % (args.batch, args.batch * world, TFHE_UNIQ),
+            "gates_per_gpu": args.batch, "global_batch": args.batch * world,
+            "replicated_bytes": sum(t.numel() * t.element_size() for t in self.replicated())})
+
+
+WORKLOADS = {"c4": C4, "c5": C5}
+
+
+def line_skeleton(args, work, world, value, elapsed, per_rank, parallelism):
+    metric, config = work.describe(args, world)
+    config["parallelism"] = parallelism
+    return {
+        "metric": metric, "value": value, "unit": work.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64" if work.name == "c4" else "f64 (exact integer arithmetic modulo a 44-bit prime) / i32 torus",
+        "data": "synthetic", "config": config, "per_rank_units_per_s": per_rank,
     }
 
 
@@ -372,22 +558,28 @@ def run_single_process(args, reason):
     from heongpu_amd import sharding
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    W = WORKLOADS[args.workload]
     world = args.gpus
     ndev = torch.cuda.device_count()
     devs = [torch.device("cuda", r % ndev) for r in range(world)]
-    ctx0 = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
-    ctxs = [ctx0] + [ctx0.clone() for _ in range(world - 1)]
+    ctxs = W.contexts(hg, world)
     works, streams = [], []
     for r in range(world):
         torch.cuda.set_device(devs[r])
-        ctxs[r].upload_device(devs[r].index)
+        if args.workload == "c4":
+            ctxs[r].upload_device(devs[r].index)
         first, B = sharding.shard_range(args.batch * world, world, r)
-        works.append(C4(torch, hg, ctxs[r], devs[r], first, B))
+        works.append(W(torch, hg, devs[r], first, B, ctx=ctxs[r]))
         streams.append(torch.cuda.Stream(device=devs[r]))
+    torch.cuda.set_device(devs[0])
     with torch.cuda.stream(streams[0]):
-        works[0].make_key()
+        works[0].make_keys()
     t0 = time.perf_counter()
-    hg.broadcast_key(ctxs, [w.key for w in works], works[0].key.numel(), [s.cuda_stream for s in streams])
+    paths = []
+    for i in range(len(works[0].replicated())):
+        bufs = [w.replicated()[i] for w in works]
+        paths.append(hg.broadcast_bytes([d.index for d in devs], bufs, bufs[0].numel() * bufs[0].element_size(),
+                                        [s.cuda_stream for s in streams]))
     for s in streams:
         s.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
@@ -420,14 +612,15 @@ def run_single_process(args, reason):
         raise SystemExit("bench.py: a device thread failed: " + "; ".join(errors))
     elapsed = max(total)
     value = args.batch * world * args.steps / elapsed
-    line = line_skeleton(args, world, value, elapsed, [w.B * args.steps / o for w, o in zip(works, own)], ctx0.Q_size,
-                         "batch-sharded x%d in ONE process: a thread, a stream and a context per device "
-                         "(hegpu_context_upload_device), key replicated with hegpu_broadcast_key (peer copies); "
-                         "fallback because %s; %d visible device(s)" % (world, reason, ndev))
+    line = line_skeleton(args, works[0], world, value, elapsed, [w.B * args.steps / o for w, o in zip(works, own)],
+                         "sharded x%d in ONE process: a thread, a stream and a context per device, keys replicated with "
+                         "hegpu_broadcast_bytes -- %s; fallback because %s; %d visible device(s)"
+                         % (world, hg.broadcast_path_name(paths[0]), reason, ndev))
     line["key_broadcast_ms"] = bcast_ms
-    line["key_bytes"] = works[0].key.numel() * 8
+    line["key_broadcast_path"] = paths
+    line["key_bytes"] = sum(t.numel() * t.element_size() for t in works[0].replicated())
     tw = [w.twins() for w in works]
-    same_key = all(bool(torch.equal(works[0].key.to(w.dev), w.key)) for w in works[1:])
+    same_key = all(bool(torch.equal(a.to(w.dev), b)) for w in works[1:] for a, b in zip(works[0].replicated(), w.replicated()))
     line["checked_items"] = {"twin_compared": sum(t[0] for t in tw), "twins_equal": all(t[1] for t in tw),
                              "key_replicas_equal": same_key, "oracle_compared": 0,
                              "note": "multi-GPU run: the oracle comparison is part of the N=1 line"}
@@ -491,22 +684,26 @@ def hoisted_rotation_block(torch, hg, timer, ctx, B=16):
     return res
 
 
-def secondary_block(torch, hg, timer):
-    """The other BASELINE.json configurations, synthetic data, each with the algorithmic bytes of the
-    reference's kernel sequence, the fraction of the 8 TB/s HBM peak that rate means, and a check of
-    the batch that was timed: `checked` distinct items against the CPU oracle, every other item against its twin."""
+def check_line(twins, oracle_ok, n_oracle):
+    return {"oracle_compared": n_oracle, "oracle_equal": bool(oracle_ok), "twin_compared": twins[0],
+            "twins_equal": bool(twins[1])}
+
+
+class Sec:
+    """One secondary workload: `runs` = {profile-workload name: (callable, units per call)}, `entry(ms)` builds its part of
+    the line (timing LIVE, verification of the timed batch against the oracle, the as-built figures from the profile)."""
+
+    def __init__(self, runs, entry, close):
+        self.runs, self.entry, self.close = runs, entry, close
+
+
+U_SEC = 2  # distinct inputs per secondary workload, all of them compared with the oracle
+
+
+def sec_bfv14(torch, hg, prof):
+    """north_star target 2: BFV N=2^14, default 128-bit chain (Q=8, P=1), 256 pairs: multiply"""
     from heongpu_amd import synth
-    from oracle import binding as ob  # the checker; nothing below is timed through it
-    sec = {}
-    stream = torch.cuda.current_stream().cuda_stream
-    dev = torch.device("cuda")
-    U = 2  # distinct inputs per workload, all of them compared with the oracle
-
-    def check_line(twins, oracle_ok, n_oracle):
-        return {"oracle_compared": n_oracle, "oracle_equal": bool(oracle_ok), "twin_compared": twins[0],
-                "twins_equal": bool(twins[1])}
-
-    # ---- north_star target 2: BFV N=2^14, default 128-bit chain (Q=8, P=1), 256 pairs
+    stream, dev, U = torch.cuda.current_stream().cuda_stream, torch.device("cuda"), U_SEC
     n, t, B = 1 << 14, 786433, 256
     ctx = hg.Context.from_default(hg.BFV, n, 1, plain_modulus=t)
     ctx.upload()
@@ -519,23 +716,30 @@ def secondary_block(torch, hg, timer):
     o3 = torch.empty(3 * Q * n * B, dtype=torch.int64, device="cuda")
     key = synth.synth_key_t(torch, primes, Q, Qp, n, 3, dev)
     wsm, wsr = ctx.workspace(hg.OP_BFV_MULTIPLY, 0, B), ctx.workspace(hg.OP_BFV_RELIN, 0, B)
-    m = timer.ms(lambda: ctx.bfv_multiply(ct, 2 * Q * n, ct2, 2 * Q * n, o3, 3 * Q * n, B, wsm, stream=stream), 3)
-    o = ob.OracleContext(ob.BFV, 14, primes, Q, 1, t)
-    got = hg.to_host(o3[:U * 3 * Q * n]).reshape(U, -1)
-    ok = all(np.array_equal(got[u], o.bfv_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]))) for u in range(U))
-    chk = check_line(twins_equal(torch, o3, 3 * Q * n, B, U), ok, U)
-    r = timer.ms(lambda: ctx.bfv_relinearize_inplace(o3, 3 * Q * n, key, B, wsr, stream=stream), 3)
-    mul_bytes = (28 * L + 7 * Q) * W
-    sec["bfv_n14_multiply"] = {
-        "workload": "BFV N=2^14 default 128-bit chain (Q=%d, P=1, Bsk=%d), t=786433, %d pairs resident in HBM" % (Q, L - Q, B),
-        "multiplications_per_s": B / (m * 1e-3), "ms_per_batch": m,
-        "multiply_relinearize_per_s": B / ((m + r) * 1e-3),
-        "reference_sequence_bytes_per_op": mul_bytes, "frac_of_hbm_peak": mul_bytes * B / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "checked_items": chk}
-    ctx.close()
-    del ct, ct2, o3, key, wsm, wsr, o
+    mul = lambda: ctx.bfv_multiply(ct, 2 * Q * n, ct2, 2 * Q * n, o3, 3 * Q * n, B, wsm, stream=stream)
 
-    # ---- C3: BFV N=2^15 default chain (Q=14, P=1), rotate_rows by one step, 64 ciphertexts
+    def entry(timer):
+        from oracle import binding as ob  # the checker; nothing timed goes through it
+        m = timer.ms(mul, 3)
+        o = ob.OracleContext(ob.BFV, 14, primes, Q, 1, t)
+        got = hg.to_host(o3[:U * 3 * Q * n]).reshape(U, -1)
+        ok = all(np.array_equal(got[u], o.bfv_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]))) for u in range(U))
+        chk = check_line(twins_equal(torch, o3, 3 * Q * n, B, U), ok, U)
+        r = timer.ms(lambda: ctx.bfv_relinearize_inplace(o3, 3 * Q * n, key, B, wsr, stream=stream), 3)
+        mul_bytes = (28 * L + 7 * Q) * W
+        e = {"workload": "BFV N=2^14 default 128-bit chain (Q=%d, P=1, Bsk=%d), t=786433, %d pairs resident in HBM" % (Q, L - Q, B),
+             "multiplications_per_s": B / (m * 1e-3), "ms_per_batch": m, "multiply_relinearize_per_s": B / ((m + r) * 1e-3),
+             "reference_sequence_bytes_per_op": mul_bytes,
+             "reference_sequence_bytes_rate_GBps": mul_bytes * B / (m * 1e-3) / 1e9,
+             "as_built": prof_group(prof, "bfv_n14_multiply", m), "checked_items": chk}
+        return "bfv_n14_multiply", e
+    return Sec({"bfv_n14_multiply": (mul, B)}, entry, ctx.close)
+
+
+def sec_c3(torch, hg, prof):
+    """C3: BFV N=2^15 default chain (Q=14, P=1), rotate_rows by one step, 64 ciphertexts"""
+    from heongpu_amd import synth
+    stream, dev, U = torch.cuda.current_stream().cuda_stream, torch.device("cuda"), U_SEC
     n, t, B = 1 << 15, 786433, 64
     ctx = hg.Context.from_default(hg.BFV, n, 1, plain_modulus=t)
     ctx.upload()
@@ -548,21 +752,29 @@ def secondary_block(torch, hg, timer):
     key = synth.synth_key_t(torch, primes, Q, Qp, n, 3, dev)
     ws = ctx.workspace(hg.OP_BFV_GALOIS, 0, B)
     gal = hg.steps_to_galois_elt(1, n, 3)
-    g = timer.ms(lambda: ctx.bfv_apply_galois(ct, 2 * Q * n, out, 2 * Q * n, key, gal, B, ws, stream=stream), 3)
-    o = ob.OracleContext(ob.BFV, 15, primes, Q, 1, t)
-    got = hg.to_host(out[:U * 2 * Q * n]).reshape(U, -1)
-    key_h = hg.to_host(key)
-    ok = all(np.array_equal(got[u], o.bfv_apply_galois(hg.to_host(a_u[u]), key_h, gal)) for u in range(U))
-    rot_bytes = (6 * Q * Qp + 6 * Q + 8 * Qp) * W
-    sec["c3_bfv_n15_rotate"] = {
-        "workload": "BFV N=2^15 default chain (Q=%d, P=1), rotate_rows (Galois key switch method I), %d ciphertexts" % (Q, B),
-        "rotations_per_s": B / (g * 1e-3), "ms_per_batch": g,
-        "reference_sequence_bytes_per_op": rot_bytes, "frac_of_hbm_peak": rot_bytes * B / (g * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "checked_items": check_line(twins_equal(torch, out, 2 * Q * n, B, U), ok, U)}
-    ctx.close()
-    del ct, out, key, ws, o, key_h
+    rot = lambda: ctx.bfv_apply_galois(ct, 2 * Q * n, out, 2 * Q * n, key, gal, B, ws, stream=stream)
 
-    # ---- C2: CKKS N=2^14, {50, 40 x 7} | {50}, multiply + relinearize + rescale
+    def entry(timer):
+        from oracle import binding as ob
+        g = timer.ms(rot, 3)
+        o = ob.OracleContext(ob.BFV, 15, primes, Q, 1, t)
+        got = hg.to_host(out[:U * 2 * Q * n]).reshape(U, -1)
+        key_h = hg.to_host(key)
+        ok = all(np.array_equal(got[u], o.bfv_apply_galois(hg.to_host(a_u[u]), key_h, gal)) for u in range(U))
+        rot_bytes = (6 * Q * Qp + 6 * Q + 8 * Qp) * W
+        e = {"workload": "BFV N=2^15 default chain (Q=%d, P=1), rotate_rows (Galois key switch method I), %d ciphertexts" % (Q, B),
+             "rotations_per_s": B / (g * 1e-3), "ms_per_batch": g, "reference_sequence_bytes_per_op": rot_bytes,
+             "reference_sequence_bytes_rate_GBps": rot_bytes * B / (g * 1e-3) / 1e9,
+             "as_built": prof_group(prof, "c3_bfv_n15_rotate", g),
+             "checked_items": check_line(twins_equal(torch, out, 2 * Q * n, B, U), ok, U)}
+        return "c3_bfv_n15_rotate", e
+    return Sec({"c3_bfv_n15_rotate": (rot, B)}, entry, ctx.close)
+
+
+def sec_c2(torch, hg, prof):
+    """C2: CKKS N=2^14, {50, 40 x 7} | {50}, multiply + relinearize + rescale, one ciphertext and 64"""
+    from heongpu_amd import synth
+    stream, dev, U = torch.cuda.current_stream().cuda_stream, torch.device("cuda"), U_SEC
     n = 1 << 14
     ctx = hg.Context.from_bit_sizes(hg.CKKS, n, [50] + [40] * 7, [50])
     ctx.upload()
@@ -570,52 +782,61 @@ def secondary_block(torch, hg, timer):
     Q, Qp = ctx.Q_size, ctx.Q_prime_size
     W = 8 * n
     key = synth.synth_key_t(torch, primes, Q, Qp, n, 3, dev)
-    key_h = hg.to_host(key)
     a_u = [synth.synth_ct_t(torch, primes, range(Q), 2, n, 1 + 10 * u, dev) for u in range(U)]
     b_u = [synth.synth_ct_t(torch, primes, range(Q), 2, n, 2 + 10 * u, dev) for u in range(U)]
-    o = ob.OracleContext(ob.CKKS, 14, primes, Q, 1)
-    want = []
-    for u in range(U):
-        w3 = o.ckks_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]), 0)
-        o.ckks_relinearize(w3, key_h, 0)
-        w2 = w3[:2 * Q * n].copy()
-        o.ckks_rescale(w2, 0)
-        want.append(w2[:2 * (Q - 1) * n])
-    c2, c2chk = {}, {}
+    seqs, bufs = {}, {}
     for B in (1, 64):
         c1b, c2b = tile_items(torch, a_u, B), tile_items(torch, b_u, B)
         ob_ = torch.empty(3 * Q * n * B, dtype=torch.int64, device="cuda")
         wsb, wsb2 = ctx.workspace(hg.OP_CKKS_RELIN, 0, B), ctx.workspace(hg.OP_CKKS_RESCALE, 0, B)
 
-        def seq(s=stream):
+        def seq(s=None, B=B, c1b=c1b, c2b=c2b, ob_=ob_, wsb=wsb, wsb2=wsb2):
+            s = stream if s is None else s
             ctx.ckks_multiply(c1b, 2 * Q * n, c2b, 2 * Q * n, ob_, 3 * Q * n, 0, B, stream=s)
             ctx.ckks_relinearize_inplace(ob_, 3 * Q * n, key, 0, B, wsb, stream=s)
             ctx.ckks_rescale_inplace(ob_, 3 * Q * n, 0, B, wsb2, stream=s)
-        c2[B] = timer.ms(seq, 5)
-        nu = min(U, B)
-        got = hg.to_host(ob_[:nu * 3 * Q * n]).reshape(nu, -1)
-        ok = all(np.array_equal(got[u][:2 * (Q - 1) * n], want[u]) for u in range(nu))
-        c2chk["batch%d" % B] = check_line(twins_equal(torch, ob_, 3 * Q * n, B, U, used_elems=2 * (Q - 1) * n), ok, nu)
-        if B == 1:
-            # the same sequence captured once and replayed as one hipGraph launch (the operator entries
-            # allocate nothing and never synchronise): the launch-bound batch-1 case
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                seq(torch.cuda.current_stream().cuda_stream)
-            c2["graph"] = timer.ms(graph.replay, 5)
-    op_bytes = (6 * Q * Q + 32 * Q + 8 + 6 + 16 * (Q - 1)) * W
-    sec["c2_ckks_n14"] = {
-        "workload": "CKKS N=2^14, Q=8 {50,40x7} | P=1 {50}, multiply + relinearize + rescale",
-        "latency_us_batch1": c2[1] * 1e3, "latency_us_batch1_hipgraph_replay": c2["graph"] * 1e3,
-        "ops_per_s_batch64": 64 / (c2[64] * 1e-3),
-        "reference_sequence_bytes_per_op": op_bytes,
-        "frac_of_hbm_peak_batch64": op_bytes * 64 / (c2[64] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "checked_items": c2chk}
-    ctx.close()
-    del o, key, key_h
+        seqs[B], bufs[B] = seq, ob_
 
-    # ---- key-switching method II (selected by the reference whenever P_size > 1): the C4 shape with four special
-    # primes, Q = 16 x 50 bits | P = 4 x 50 bits (d = 4 digits of 4 primes), multiply + relinearize, 64 pairs
+    def entry(timer):
+        from oracle import binding as ob
+        key_h = hg.to_host(key)
+        o = ob.OracleContext(ob.CKKS, 14, primes, Q, 1)
+        want = []
+        for u in range(U):
+            w3 = o.ckks_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]), 0)
+            o.ckks_relinearize(w3, key_h, 0)
+            w2 = w3[:2 * Q * n].copy()
+            o.ckks_rescale(w2, 0)
+            want.append(w2[:2 * (Q - 1) * n])
+        c2, c2chk = {}, {}
+        for B in (1, 64):
+            c2[B] = timer.ms(seqs[B], 5)
+            nu = min(U, B)
+            got = hg.to_host(bufs[B][:nu * 3 * Q * n]).reshape(nu, -1)
+            ok = all(np.array_equal(got[u][:2 * (Q - 1) * n], want[u]) for u in range(nu))
+            c2chk["batch%d" % B] = check_line(twins_equal(torch, bufs[B], 3 * Q * n, B, U, used_elems=2 * (Q - 1) * n), ok, nu)
+        # the same sequence captured once and replayed as one hipGraph launch (the operator entries allocate nothing
+        # and never synchronise): the launch-bound batch-1 case
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            seqs[1](torch.cuda.current_stream().cuda_stream)
+        c2["graph"] = timer.ms(graph.replay, 5)
+        op_bytes = (6 * Q * Q + 32 * Q + 8 + 6 + 16 * (Q - 1)) * W
+        e = {"workload": "CKKS N=2^14, Q=8 {50,40x7} | P=1 {50}, multiply + relinearize + rescale",
+             "latency_us_batch1": c2[1] * 1e3, "latency_us_batch1_hipgraph_replay": c2["graph"] * 1e3,
+             "ops_per_s_batch64": 64 / (c2[64] * 1e-3), "reference_sequence_bytes_per_op": op_bytes,
+             "reference_sequence_bytes_rate_GBps_batch64": op_bytes * 64 / (c2[64] * 1e-3) / 1e9,
+             "as_built_batch1": prof_group(prof, "c2_ckks_n14_b1", c2[1]),
+             "as_built_batch64": prof_group(prof, "c2_ckks_n14_b64", c2[64]), "checked_items": c2chk}
+        return "c2_ckks_n14", e
+    return Sec({"c2_ckks_n14_b1": (seqs[1], 1), "c2_ckks_n14_b64": (seqs[64], 64)}, entry, ctx.close)
+
+
+def sec_m2(torch, hg, prof):
+    """key-switching method II (selected by the reference whenever P_size > 1): the C4 shape with four special primes,
+    Q = 16 x 50 bits | P = 4 x 50 bits (d = 4 digits of 4 primes), multiply + relinearize, 64 pairs"""
+    from heongpu_amd import synth
+    stream, dev, U = torch.cuda.current_stream().cuda_stream, torch.device("cuda"), U_SEC
     n, B = 1 << 16, 64
     ctx = hg.Context.from_bit_sizes(hg.CKKS, n, [50] * 16, [50] * 4, sec=hg.SEC_NONE)
     ctx.upload()
@@ -632,58 +853,70 @@ def secondary_block(torch, hg, timer):
     def seq2():
         ctx.ckks_multiply(c1b, 2 * Q * n, c2b, 2 * Q * n, ob_, 3 * Q * n, 0, B, stream=stream)
         ctx.ckks_relinearize_inplace(ob_, 3 * Q * n, key, 0, B, wsb, stream=stream)
-    m2 = timer.ms(seq2, 3)
-    o = ob.OracleContext(ob.CKKS, 16, primes, Q, 4)
-    key_h = hg.to_host(key)
-    got = hg.to_host(ob_[:U * 3 * Q * n]).reshape(U, -1)
-    ok = True
-    for u in range(U):
-        w3 = o.ckks_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]), 0)
-        o.ckks_relinearize_II(w3, key_h, 0)
-        ok = ok and np.array_equal(got[u][:2 * Q * n], w3[:2 * Q * n])
-    sec["ckks_n16_method_II"] = {
-        "workload": "CKKS N=2^16, Q=16 x 50 bits | P=4 x 50 bits (hybrid key switching, 4 digits), multiply + relinearize, "
-                    "%d pairs" % B,
-        "multiply_relinearize_per_s": B / (m2 * 1e-3), "ms_per_batch": m2,
-        "checked_items": check_line(twins_equal(torch, ob_, 3 * Q * n, B, U, used_elems=2 * Q * n), ok, U)}
-    ctx.close()
-    del c1b, c2b, ob_, key, wsb, o, key_h
 
-    # ---- C5: TFHE STD128 NAND gate bootstrap, 8192 concurrent gates (the whole config on one GPU;
-    # its 8-GPU share is 1024)
-    t = hg.TfheContext()
-    rng = np.random.default_rng(1)
-    S, TU, TCHK = 8192, 64, 2
-    polys = t.int("bootkey_elems") // 1024
-    v = rng.integers(-2**31, 2**31, polys, dtype=np.int64)  # constant polynomials: NTT image = the constant
-    lifted = np.where(v < 0, v + t.prime, v).astype(np.uint64)
-    bk_h = np.repeat(lifted, 1024)
-    bk = torch.from_numpy(bk_h.view(np.int64)).cuda()
-    r32 = lambda k: rng.integers(-2**31, 2**31, k, dtype=np.int64).astype(np.int32)
-    ks_a_h, ks_b_h = r32(t.int("kskey_a_elems")), r32(t.int("kskey_b_elems"))
-    a1u, a2u, b1u, b2u = r32(TU * 512), r32(TU * 512), r32(TU), r32(TU)
-    rep = S // TU
-    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    a1, a2, b1, b2 = cu(np.tile(a1u, rep)), cu(np.tile(a2u, rep)), cu(np.tile(b1u, rep)), cu(np.tile(b2u, rep))
-    ks_a, ks_b = cu(ks_a_h), cu(ks_b_h)
-    prepared = t.prepare_bootkey(bk)
-    out_a = torch.empty(S * 512, dtype=torch.int32, device="cuda")
-    out_b = torch.empty(S, dtype=torch.int32, device="cuda")
-    ws = torch.empty((512 + 1024 + 2) * S, dtype=torch.int32, device="cuda")
-    g = timer.ms(lambda: t.gate(hg.GATE_NAND, a1, b1, a2, b2, out_a, out_b, prepared, ks_a, ks_b, S, ws, stream=stream), 2)
-    ga, gb = out_a.view(S, 512), out_b
-    tw_ok = bool(torch.equal(ga, ga[:TU].repeat(rep, 1))) and bool(torch.equal(gb, gb[:TU].repeat(rep)))
-    ot = ob.OracleTfhe()
-    want_a, want_b = ot.gate(hg.GATE_NAND, a1u[:TCHK * 512], b1u[:TCHK], a2u[:TCHK * 512], b2u[:TCHK], bk_h, ks_a_h, ks_b_h)
-    ok = np.array_equal(ga[:TCHK].cpu().numpy().reshape(-1), want_a) and np.array_equal(gb[:TCHK].cpu().numpy(), want_b)
-    sec["c5_tfhe_gates"] = {
-        "workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
-                    "%d concurrent gates (%d distinct inputs), torus32 boot key (FP64 blind rotate)" % (S, TU),
-        "gates_per_s": S / (g * 1e-3), "ms_per_batch": g,
-        "reference_sequence_bytes_per_gate": 72 * (1 << 20),
-        "frac_of_hbm_peak": 72 * (1 << 20) * S / (g * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "checked_items": check_line((S - TU, tw_ok), ok, TCHK)}
-    t.close()
+    def entry(timer):
+        from oracle import binding as ob
+        m2 = timer.ms(seq2, 3)
+        o = ob.OracleContext(ob.CKKS, 16, primes, Q, 4)
+        key_h = hg.to_host(key)
+        got = hg.to_host(ob_[:U * 3 * Q * n]).reshape(U, -1)
+        ok = True
+        for u in range(U):
+            w3 = o.ckks_multiply(hg.to_host(a_u[u]), hg.to_host(b_u[u]), 0)
+            o.ckks_relinearize_II(w3, key_h, 0)
+            ok = ok and np.array_equal(got[u][:2 * Q * n], w3[:2 * Q * n])
+        e = {"workload": "CKKS N=2^16, Q=16 x 50 bits | P=4 x 50 bits (hybrid key switching, 4 digits), multiply + relinearize, "
+                         "%d pairs" % B,
+             "multiply_relinearize_per_s": B / (m2 * 1e-3), "ms_per_batch": m2,
+             "as_built": prof_group(prof, "ckks_n16_method_II", m2),
+             "checked_items": check_line(twins_equal(torch, ob_, 3 * Q * n, B, U, used_elems=2 * Q * n), ok, U)}
+        return "ckks_n16_method_II", e
+    return Sec({"ckks_n16_method_II": (seq2, B)}, entry, ctx.close)
+
+
+def sec_c5(torch, hg, prof):
+    """C5: TFHE STD128 NAND gate bootstrap, 8192 concurrent gates (the whole config on one GPU; its 8-GPU share is 1024)"""
+    S, TCHK = 8192, 2
+    work = C5(torch, hg, torch.device("cuda", torch.cuda.current_device()), 0, S)
+    work.make_keys()
+    stream = torch.cuda.current_stream().cuda_stream
+    run = lambda: work.step(stream)
+
+    def entry(timer):
+        g = timer.ms(run, 2)
+        tw = work.twins()
+        ok, _ = work.oracle_check(TCHK)
+        ab = prof_group(prof, "c5_tfhe_gates", g)
+        ab["blind_rotate"] = prof_group(prof, "c5_tfhe_gates", g, match=["k_tfhe_blind_rotate"])
+        ab["blind_rotate"].pop("achieved_GBps", None)  # the live time is the whole gate's, not this kernel's
+        e = {"workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
+                         "%d concurrent gates (%d distinct inputs), torus32 boot key (FP64 blind rotate)" % (S, TFHE_UNIQ),
+             "gates_per_s": S / (g * 1e-3), "ms_per_batch": g,
+             "reference_sequence_bytes_per_gate": 72 * (1 << 20),
+             "reference_sequence_bytes_rate_GBps": 72 * (1 << 20) * S / (g * 1e-3) / 1e9,
+             "note": "the accumulator of a gate never leaves LDS: the reference-sequence rate is the rate the reference's "
+                     "1024 launches per gate would have to move THEIR 72 MiB at, not bytes this kernel moves",
+             "as_built": ab, "checked_items": check_line(tw, ok, TCHK)}
+        return "c5_tfhe_gates", e
+    return Sec({"c5_tfhe_gates": (run, S)}, entry, work.t.close)
+
+
+SECONDARY = (sec_bfv14, sec_c3, sec_c2, sec_m2, sec_c5)
+
+
+def secondary_block(torch, hg, timer, prof):
+    """The other BASELINE.json configurations, synthetic data: each timed LIVE, its timed batch checked (`U_SEC` distinct
+    items against the CPU oracle, every other item against its twin), and -- instead of round 3's reference-bytes
+    "fraction of HBM peak", which is no efficiency for a fused path -- the bytes and vector instructions it moves and
+    issues AS BUILT (committed counter passes, `from_profile`) with the ceiling that binds it."""
+    sec = {}
+    for make in SECONDARY:
+        s = make(torch, hg, prof)
+        name, e = s.entry(timer)
+        sec[name] = e
+        s.close()
+        del s
+        torch.cuda.empty_cache()
     return sec
 
 
@@ -725,26 +958,35 @@ def power_sample(torch, step):
         return {"error": str(e)[:120]}
 
 
-def issue_figures(tj, names, ms):
-    """Vector-ALU issue figures of a launch group from the committed profile (profiles/traffic.json, written by
-    tools/profile.sh from rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE passes of this very
-    command): lane_instructions = wave-level vector instructions x 64; valu_busy = the share of the kernels' own
-    cycles in which their SIMDs issued a vector instruction; frac_of_issue_ceiling = lane_instructions over what 1024
-    SIMDs x 16 lanes issue in the group's LIVE duration at the profile's measured shader clock."""
-    ks = (tj or {}).get("step_kernels_sq") or {}
-    hit = [ks[k] for k in names if k in ks]
-    if len(hit) != len(names) or not hit:
-        return None
-    wave_insts = sum(h["valu_wave_insts"] for h in hit)
-    busy_cyc = sum(h["valu_busy_cycles_per_simd"] for h in hit)
-    cyc = sum(h["cycles"] for h in hit)
-    prof_s = sum(h["seconds"] for h in hit)
-    sclk = cyc / prof_s if prof_s > 0 else None
-    out = {"lane_instructions": wave_insts * 64, "valu_busy": busy_cyc / cyc if cyc else None,
-           "sclk_GHz_in_kernel": sclk / 1e9 if sclk else None, "kernels": names}
-    if sclk:
-        out["frac_of_issue_ceiling"] = wave_insts * 64 / (SIMDS * LANES * sclk * ms * 1e-3)
-    return out
+# ------------------------------------------------------------------ counter passes: one workload, nothing else
+def run_profile_workload(args):
+    """`--profile-workload NAME --reps R` (tools/prof_all.sh wraps this in rocprofv3): set the workload up exactly as the
+    line does, run it R times.  The JSON it prints tells tools/build_profile_json.py how many batches the dispatch
+    counts of the trace belong to (kernels that ran fewer times than that are set-up, not workload)."""
+    import torch
+
+    import heongpu_amd as hg
+    name = args.profile_workload
+    stream = torch.cuda.current_stream().cuda_stream
+    units = None
+    if name in ("c4_step", "ntt_pair"):
+        work = C4(torch, hg, torch.device("cuda", 0), 0, args.batch)
+        work.make_keys()
+        if name == "c4_step":
+            run, units = (lambda: work.step(stream)), work.B
+        else:
+            polys = work.B * work.Q * work.Qp
+            run, units = (lambda: work.ctx.ntt(work.ws, work.ws, False, polys, work.Qp, stream=stream)), polys
+    else:
+        makers = {"bfv_n14_multiply": sec_bfv14, "c3_bfv_n15_rotate": sec_c3, "c2_ckks_n14_b1": sec_c2, "c2_ckks_n14_b64": sec_c2,
+                  "ckks_n16_method_II": sec_m2, "c5_tfhe_gates": sec_c5}
+        run, units = makers[name](torch, hg, None).runs[name]
+    torch.cuda.synchronize()
+    for _ in range(args.reps):
+        run()
+    torch.cuda.synchronize()
+    print(json.dumps({"profile_workload": name, "batches": args.reps, "units_per_batch": units}))
+    return 0
 
 
 # ------------------------------------------------------------------ one rank (N = 1, or one process per GPU)
@@ -765,16 +1007,13 @@ def run_rank(args):
     dev = torch.device("cuda", dev_index)
     dist = Dist(torch, world, rank, args.backend)
 
-    ctx = hg.Context.from_bit_sizes(hg.CKKS, N, LOG_Q, LOG_P)
-    ctx.upload()
-    Q, Qp, n = ctx.Q_size, ctx.Q_prime_size, N
-    l, rc = Q, Qp
     first, B = sharding.shard_range(args.batch * world, world, rank)
-    W = 8 * n  # bytes of one limb polynomial
-    work = C4(torch, hg, ctx, dev, first, B)
+    work = WORKLOADS[args.workload](torch, hg, dev, first, B)
     if rank == 0:
-        work.make_key()   # produced on the device, 272 MiB
-    bcast_ms = dist.broadcast_key(work.key, dev)
+        work.make_keys()   # produced on the device (C4: 272 MiB; C5: 64 + 48 MiB)
+    bcast_ms = dist.broadcast_keys(work.replicated(), dev)
+    if world > 1 and args.workload == "c5":
+        work.t.prepared_format(work.prepared, refresh=True)  # the replica's layout is read from its header, once
     stream = torch.cuda.current_stream().cuda_stream
     step = lambda: work.step(stream)
 
@@ -796,13 +1035,13 @@ def run_rank(args):
     tw_all = dist.gather_floats(float(tw_n if tw_ok else -1))
     value = args.batch * world * args.steps / elapsed
 
-    parallelism = "batch-sharded x%d, one process per GPU (gloo control plane), key broadcast: %s; no data-path collective" \
+    parallelism = "sharded x%d, one process per GPU (gloo control plane), key broadcast: %s; no data-path collective" \
         % (world, dist.key_path)
-    line = line_skeleton(args, world, value, elapsed, per_rank, Q, parallelism)
+    line = line_skeleton(args, work, world, value, elapsed, per_rank, parallelism)
     if bcast_ms is not None:
         line["key_broadcast_ms"] = bcast_ms
-        line["key_bytes"] = work.key.numel() * 8
-    line["checked_items"] = {"distinct_inputs": work.uniq, "twin_compared": int(sum(max(t, 0) for t in tw_all)),
+        line["key_bytes"] = sum(t.numel() * t.element_size() for t in work.replicated())
+    line["checked_items"] = {"distinct_inputs": getattr(work, "uniq", TFHE_UNIQ), "twin_compared": int(sum(max(t, 0) for t in tw_all)),
                              "twins_equal": all(t >= 0 for t in tw_all), "oracle_compared": 0}
 
     if args.step_only or rank != 0 or world > 1:
@@ -814,9 +1053,36 @@ def run_rank(args):
         dist.close(rc)
         return rc
 
+    prof = load_profile()
+    if args.workload == "c5":
+        ms = elapsed / args.steps * 1e3
+        line["as_built"] = prof_group(prof, "c5_tfhe_gates", ms * 8192 / B) if B != 8192 else prof_group(prof, "c5_tfhe_gates", ms)
+        line["as_built"]["note"] = "counter pass taken at 8192 gates per call; live time scaled to 8192 gates" if B != 8192 else ""
+        if not args.no_cpu_baseline:
+            from oracle import binding as ob
+            n_chk = 4
+            ok, cpu_s = work.oracle_check(n_chk)
+            line["checked_items"].update(oracle_compared=n_chk, oracle_equal=ok)
+            line["cpu_baseline"] = {"value": n_chk / cpu_s, "unit": work.unit, "cores": ob.lib().o_omp_threads(), "kind": "port",
+                                    "sample": "%d gates of the same workload, CPU oracle (includes its own key preparation), %.1f s" % (n_chk, cpu_s),
+                                    "gpu_matches_cpu_bit_exact": ok}
+        print(json.dumps(line))
+        dist.close()
+        return 0 if (line["checked_items"]["twins_equal"] and line["checked_items"].get("oracle_equal", True)) else 1
+
+    ctx = work.ctx
+    Q, Qp, n = ctx.Q_size, ctx.Q_prime_size, N
+    l, rc = Q, Qp
+    W = 8 * n  # bytes of one limb polynomial
     out, key, ws, ct1, ct2 = work.out, work.key, work.ws, work.ct1, work.ct2
     ct_elems, out_elems = work.ct_elems, work.out_elems
-    result = hg.to_host(out.view(B, out_elems)[:, :ct_elems]) if not args.no_cpu_baseline else None
+    sample_gpu = None
+    if not args.no_cpu_baseline:
+        # the outputs the CPU checker will be compared with: the first occurrence of every distinct input
+        first_pos = {}
+        for b in range(B):
+            first_pos.setdefault((first + b) % work.uniq, b)
+        sample_gpu = {u: hg.to_host(out.view(B, out_elems)[p, :ct_elems]) for u, p in first_pos.items()}
 
     # ---- roofline of the transform: the forward NTT launch pair at the key-switch
     # shape (l*rc limb NTTs per ciphertext).  Algorithmic bytes = 2W per limb NTT; HIP events on the
@@ -827,11 +1093,6 @@ def run_rank(args):
     ntt_bytes = polys * 2 * W
     fwd_gbps = ntt_bytes / (ntt_ms[False] * 1e-3) / 1e9
     inv_gbps = ntt_bytes / (ntt_ms[True] * 1e-3) / 1e9
-    tj = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
 
     # ---- every launch group of a step on its own (hegpu_probe_ckks_relinearize), against the bytes the
     # group has to move as it is built (fused kernels: fewer than the reference's sequence):
@@ -839,120 +1100,93 @@ def run_rank(args):
     def probe(ph):
         return timer.ms(lambda: ctx.probe_ckks_relinearize(out, out_elems, key, 0, B, ws, ph, stream=stream))
     g256 = lambda polys_: "grid %d" % (16 * polys_ * 256)   # N / 4096 = 16 tiles (or column tiles) per polynomial
-    ksg = "grid %d" % (((16 * rc + 7) // 8) * 8 * B * 256)
     groups = [
         ("ckks_multiply: k_cross_multiplication", timer.ms(
             lambda: ctx.ckks_multiply(ct1, ct_elems, ct2, ct_elems, out, out_elems, 0, B, stream=stream)),
-         7 * l * W * B, "read 4l, write 3l limbs",
-         ["hegpu::k_cross_multiplication grid %d" % (B * l * n // 2)], "int"),
-        ("INTT of c2: ntt_inv_row + ntt_inv_col", probe(1), 2 * l * W * B,
+         7 * l * W * B, "read 4l, write 3l limbs", ["k_cross_multiplication grid"]),
+        ("INTT of c2: ntt_inv_row (+ ntt_inv_col of the integer limbs)", probe(1), 2 * l * W * B,
          "l limb INTTs, 2W each (the column stages of the FP64 limbs run inside the next group's kernel)",
-         ["hegpu::ntt_inv_row " + g256(l * B), "hegpu::ntt_inv_col<8, false> " + g256(l * B)], "fp64"),
+         ["ntt_inv_row " + g256(l * B), "ntt_inv_col<8, false> " + g256(l * B)]),
         ("decomposing column pass: ntt_fwd_col_multi + ntt_fwd_col<8,true>", probe(2),
          (l + l * rc - l) * W * B, "read l source limbs once, write l*Q' - l half-transformed digits",
-         ["hegpu::ntt_fwd_col_multi<8> " + g256(l * B), "hegpu::ntt_fwd_col<8, true> " + g256(2 * l * B)], "fp64"),
+         ["ntt_fwd_col_multi<8> " + g256(l * B), "ntt_fwd_col<8, true> " + g256(2 * l * B)]),
         ("row pass + key inner product: ks_row_mac_fp + ks_row_mac", probe(4),
          ((l * rc - l) + l + 2 * rc) * W * B + 2 * l * rc * W,
          "read l*Q' - l digits + l identity limbs, write 2Q' limbs per ciphertext; the key (2 l Q' limbs) once per batch",
-         ["hegpu::ks_row_mac_fp " + ksg, "hegpu::ks_row_mac " + ksg], "fp64"),
+         ["ks_row_mac"]),
         ("INTT of the two P limbs", probe(8), 2 * 2 * W * B, "2 limb INTTs",
-         ["hegpu::ntt_inv_row " + g256(2 * B), "hegpu::ntt_inv_col<8, false> " + g256(2 * B)], "int"),
+         ["ntt_inv_row " + g256(2 * B), "ntt_inv_col<8, false> " + g256(2 * B)]),
         ("mod-down NTT with stage one / two fused: ntt_fwd_col_multi + ntt_fwd_row", probe(16),
          (2 + 2 * l + 2 * l + 3 * 2 * l + 2 * l) * W * B,
          "column pass: read 2 P limbs, write 2l; row pass: read 2l + the 2l accumulated limbs + 2l of ct, write 2l",
-         ["hegpu::ntt_fwd_col_multi<8> " + g256(2 * B), "hegpu::ntt_fwd_col<8, true> " + g256(2 * B),
-          "hegpu::ntt_fwd_row " + g256(2 * l * B)], "fp64"),
+         ["ntt_fwd_col_multi<8> " + g256(2 * B), "ntt_fwd_col<8, true> " + g256(2 * B), "ntt_fwd_row " + g256(2 * l * B)]),
     ]
-    copy_frac = ((tj or {}).get("copy_ceiling_GBps") or 5230.0) / HBM_PEAK_GBPS
     in_step = []
-    for name, ms, by, note, kernels, alu in groups:
+    for name, ms, by, note, kernels in groups:
         g = {"launches": name, "ms": ms, "algorithmic_bytes": by, "accounting": note,
-             "achieved_GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        g["frac_of_copy_ceiling"] = g["frac"] / copy_frac
-        isu = issue_figures(tj, kernels, ms)
-        if isu:
-            g.update(isu)
-            # the ceiling that binds: the larger of (bytes over what a read+write stream sustains) and (vector
-            # instructions over what the SIMDs can issue)
-            g["bound"] = ("valu-" + alu) if isu.get("frac_of_issue_ceiling", 0) > g["frac_of_copy_ceiling"] else "hbm"
-            g["frac_of_binding_ceiling"] = max(isu.get("frac_of_issue_ceiling", 0), g["frac_of_copy_ceiling"])
-        else:
-            g["bound"] = "hbm (no committed SQ counters for this group)"
+             "achieved_GBps_algorithmic": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        g.update(prof_group(prof, "c4_step", ms, match=kernels, algorithmic_bytes=by))
         in_step.append(g)
     dominant = max(in_step, key=lambda g: g["ms"])
 
+    pair = prof_group(prof, "ntt_pair", ntt_ms[False], algorithmic_bytes=ntt_bytes)
+    step_all = prof_group(prof, "c4_step", elapsed / args.steps * 1e3)
     line["roofline"] = {
         "bound": "hbm",
         "kernel": "forward NTT of the key-switch digits (ntt_fwd_col<8,false> + ntt_fwd_row, one launch pair)",
-        "achieved": fwd_gbps,
-        "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s",
-        "frac": fwd_gbps / HBM_PEAK_GBPS,
-        "traffic": None,
-        "launch_ms": ntt_ms[False],
-        "limb_ntts_per_launch": polys,
-        "algorithmic_bytes_per_launch": ntt_bytes,
-        "in_step_dominant": {k: dominant.get(k) for k in ("launches", "ms", "frac", "achieved_GBps", "algorithmic_bytes", "bound",
-                                                            "valu_busy", "frac_of_issue_ceiling", "frac_of_binding_ceiling")},
+        "achieved": fwd_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fwd_gbps / HBM_PEAK_GBPS,
+        "traffic": (pair.get("from_profile") or {}).get("hbm_bytes"),
+        "traffic_source": "from_profile (PMC FETCH_SIZE / WRITE_SIZE passes of `bench.py --profile-workload ntt_pair`; not measured in this run)",
+        "launch_ms": ntt_ms[False], "limb_ntts_per_launch": polys, "algorithmic_bytes_per_launch": ntt_bytes,
+        "launch_pair": pair,
+        "step": {k: step_all.get(k) for k in ("from_profile", "achieved_GBps", "frac_of_hbm_peak_as_built", "live_over_profile_ms", "bound")},
+        "in_step_dominant": {k: dominant.get(k) for k in ("launches", "ms", "frac", "achieved_GBps_algorithmic", "algorithmic_bytes", "bound",
+                                                            "frac_of_binding_ceiling", "live_over_profile_ms")},
     }
     line["ntt"] = {"forward_GBps": fwd_gbps, "inverse_GBps": inv_gbps, "n": N, "limbs": polys}
     line["in_step"] = in_step
     # the reference's own kernel sequence would have to move its bytes (SURVEY 8d, 1028 MiB per op) at this rate to
     # keep up; above the 8 TB/s peak it only says that the fused path moves fewer bytes -- not an efficiency
     line["reference_sequence_bytes_rate_GBps"] = (6 * l * l + 32 * l + 8) * W * value / 1e9
-    if tj:
-        if tj.get("limb_ntts_per_launch") == polys:
-            line["roofline"]["traffic"] = tj["bytes_per_launch"]
-            line["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
-            nsq = (tj.get("roofline_pair_sq") or {})
-            if nsq.get("valu_wave_insts") and nsq.get("cycles") and nsq.get("seconds"):
-                sclk = nsq["cycles"] / nsq["seconds"]
-                line["roofline"]["issue"] = {
-                    "lane_instructions": nsq["valu_wave_insts"] * 64, "valu_busy": nsq["valu_busy_cycles_per_simd"] / nsq["cycles"],
-                    "frac_of_issue_ceiling": nsq["valu_wave_insts"] * 64 / (SIMDS * LANES * sclk * ntt_ms[False] * 1e-3),
-                    "frac_of_copy_ceiling_two_passes": 2 * fwd_gbps / ((tj.get("copy_ceiling_GBps") or 5230.0))}
-        if tj.get("step_bytes") and tj.get("step_batch") == B:
-            line["roofline"]["step_traffic"] = tj["step_bytes"]
-            line["hbm_fraction_moved"] = tj["step_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS
-        if tj.get("copy_ceiling_GBps"):
-            line["roofline"]["copy_ceiling_GBps"] = tj["copy_ceiling_GBps"]
 
     if not args.no_secondary:
         line["power"] = power_sample(torch, step)
         line["ntt_by_degree"] = ntt_sweep(torch, hg, timer)
+    uniq, primes = work.uniq, work.primes
     del work, ct1, ct2, out, ws
     torch.cuda.empty_cache()
     if not args.no_secondary:
-        line["secondary"] = secondary_block(torch, hg, timer)
+        line["secondary"] = secondary_block(torch, hg, timer, prof)
         line["secondary"]["hoisted_rotations"] = hoisted_rotation_block(torch, hg, timer, ctx)
 
     if not args.no_cpu_baseline:
         from heongpu_amd import synth
         from oracle import binding as ob
-        primes = [int(v) for v in ctx.table("modulus")]
         o = ob.OracleContext(ob.CKKS, 16, primes, Q, 1)
         cores = ob.lib().o_omp_threads()
-        sample = min(args.cpu_sample or max(2 * cores, 2), B)
-        c1, c2 = c4_host_inputs(primes, l, n, min(B, UNIQ), first, sample)
+        # every host core busy: as many pairs of the same workload as there are cores (the batch's distinct inputs, tiled
+        # exactly as the GPU's batch is), OpenMP over the pairs -- ~16 s on a 128-core host (2 x cores: 33 s, same rate:
+        # the host's memory system, not its core count, bounds the restatement)
+        sample = args.cpu_sample or max(cores, 2)
+        c1u, c2u = c4_host_inputs(primes, l, n, uniq)
         key_h = synth.synth_key_np(primes, Q, Qp, n, 3)
         o3 = np.zeros(sample * out_elems, dtype=np.uint64)
         t0 = time.perf_counter()
-        ob.lib().o_ckks_mul_relin_batch(o.h, c1.ctypes.data, c2.ctypes.data, o3.ctypes.data, key_h.ctypes.data, 0, sample)
+        threads = ob.lib().o_ckks_mul_relin_batch_tiled(o.h, c1u.ctypes.data, c2u.ctypes.data, uniq, first, o3.ctypes.data,
+                                                        key_h.ctypes.data, 0, sample)
         cpu_s = time.perf_counter() - t0
         o3 = o3.reshape(sample, out_elems)[:, :ct_elems]
-        equal = [bool(np.array_equal(o3[s], result[s])) for s in range(sample)]
-        line["checked_items"]["oracle_compared"] = sample
+        equal = [bool(np.array_equal(o3[s], sample_gpu[(first + s) % uniq])) for s in range(sample)]
+        line["checked_items"]["oracle_compared"] = min(sample, B)
         line["checked_items"]["oracle_equal"] = all(equal)
-        line["checked_items"]["total"] = min(B, sample + line["checked_items"]["twin_compared"])
+        line["checked_items"]["total"] = B  # every item of the timed batch: against the oracle's result for its input (directly for
+        #                                      the first occurrence, through its twin otherwise)
         line["cpu_baseline"] = {
-            "value": sample / cpu_s,
-            "unit": "multiply+relinearize/s",
-            "cores": cores,
+            "value": sample / cpu_s, "unit": "multiply+relinearize/s", "cores": cores, "threads_busy": min(threads, sample),
             "kind": "port",
-            "sample": "%d ciphertext pairs of the same workload (CKKS N=2^16 L=16 mul+relin), CPU oracle, "
-                      "OpenMP over pairs, %.1f s" % (sample, cpu_s),
-            "gpu_matches_cpu_bit_exact": all(equal),
-            "gpu_items_compared": sample,
+            "sample": "%d ciphertext pairs of the same workload (CKKS N=2^16 L=16 mul+relin; the batch's %d distinct inputs tiled "
+                      "as on the GPU), CPU oracle, OpenMP over the pairs on %d threads, %.1f s" % (sample, uniq, threads, cpu_s),
+            "gpu_matches_cpu_bit_exact": all(equal), "gpu_items_compared": sample,
         }
     print(json.dumps(line))
     dist.close()
@@ -969,6 +1203,8 @@ def main():
                 raise SystemExit(0)
             print("bench.py: the launch of %d ranks failed (rc %d): single-process path" % (args.gpus, rc), file=sys.stderr)
         raise SystemExit(launcher_selftest(args))
+    if args.profile_workload:
+        raise SystemExit(run_profile_workload(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         reason = "--single-process"
         if not args.single_process:

@@ -26,6 +26,7 @@ SIGNATURES = [
     ("hegpu_context_create_default", c_int, [c_int, c_int, c_int, u64, c_int, ctypes.POINTER(voidp)]),
     ("hegpu_context_create_from_primes", c_int,
      [c_int, c_int, ctypes.POINTER(u64), c_int, c_int, u64, ctypes.POINTER(voidp)]),
+    ("hegpu_validate_coeff_modulus_values", c_int, [c_int, ctypes.POINTER(u64), c_int, c_int, c_int]),
     ("hegpu_context_destroy", None, [voidp]),
     ("hegpu_context_upload", c_int, [voidp]),
     ("hegpu_context_clone", c_int, [voidp, ctypes.POINTER(voidp)]),

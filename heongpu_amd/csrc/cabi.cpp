@@ -204,6 +204,37 @@ int hegpu_context_create_from_primes(int scheme, int n, const uint64_t* primes, 
     });
 }
 
+// set_coeff_modulus_values' own checks (bfv/context.cu:149-220, ckks/context.cu:149-220): every value admits a 2N-th
+// root, the widths satisfy coefficient_validator, the total width respects the security table
+int hegpu_validate_coeff_modulus_values(int n, const uint64_t* primes, int qn, int pn, int sec_level)
+{
+    return guarded([&]() -> int {
+        if (!primes) throw std::invalid_argument("null argument");
+        int n_power;
+        check_degree(n, n_power);
+        if (pn <= 0) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
+        if (qn <= 0) throw std::logic_error("log_Q_bases_bit_sizes cannot be empty!");
+        std::vector<int> bits;
+        int total = 0;
+        for (int i = 0; i < qn + pn; i++) {
+            if (primes[i] < 2 || primes[i] >> 61) throw std::logic_error("invalid modulus bit size");
+            if ((primes[i] - 1) % (2 * (u64) n)) throw std::logic_error("no sufficient root unity");
+            bits.push_back(64 - __builtin_clzll(primes[i]));
+            total += bits.back();
+        }
+        if (!coefficient_validator(bits.data(), qn, bits.data() + qn, pn))
+            throw std::logic_error("Invalid parameters, P should be bigger than Q pairs!");
+        if (sec_level == HEGPU_SEC_128 || sec_level == HEGPU_SEC_192 || sec_level == HEGPU_SEC_256) {
+            if (host::max_logq((u64) n, sec_level) < total)
+                throw std::runtime_error("Parameters do not align with the security recommendations "
+                                         "provided by the lattice-estimator");
+        } else if (sec_level != HEGPU_SEC_NONE) {
+            throw std::runtime_error("Invalid security level");
+        }
+        return 0;
+    });
+}
+
 void hegpu_context_destroy(hegpu_context* ctx) { delete ctx; }
 
 int hegpu_context_set_option(hegpu_context* ctx, const char* name, int value)
@@ -786,13 +817,34 @@ int hegpu_ckks_rescale_inplace(hegpu_context* ctx, uint64_t* ct, uint64_t cs, in
                    "hegpu_ckks_rescale_inplace");
 }
 
-// The rotations read the input ciphertext while their epilogue already writes (scatters) results: the result buffer
-// must not contain the input, not even partly.  Spans of the two batches: [p, p + (batch - 1) * stride + item).
+// The rotations read the input ciphertext while their epilogue already writes (scatters) results: no item of the result
+// batch may share a word with an item of the input batch.  Items: [p + i * stride, + item) for i < batch, so layouts in
+// which the two batches interleave without touching (ct and out alternating in one buffer, stride 2 * words) are fine.
+// Equal strides: item i of a and item j of b overlap iff -b_item < (b - a) + (j - i) * stride < a_item -- one test per
+// difference j - i.  Unequal strides: pairwise up to 1024 items, beyond that the whole spans (conservative).
 static bool spans_overlap(const uint64_t* a, uint64_t a_stride, uint64_t a_item, const uint64_t* b, uint64_t b_stride,
                           uint64_t b_item, int batch)
 {
-    const uintptr_t a0 = (uintptr_t) a, a1 = a0 + ((uint64_t) (batch - 1) * a_stride + a_item) * sizeof(uint64_t);
-    const uintptr_t b0 = (uintptr_t) b, b1 = b0 + ((uint64_t) (batch - 1) * b_stride + b_item) * sizeof(uint64_t);
+    if (batch <= 0) return false;
+    const __int128 W = sizeof(uint64_t);
+    const __int128 a0 = (__int128) (uintptr_t) a, b0 = (__int128) (uintptr_t) b;
+    const __int128 ai = (__int128) a_item * W, bi = (__int128) b_item * W;
+    auto hit = [&](__int128 pa, __int128 pb) { return pa < pb + bi && pb < pa + ai; };
+    if (batch == 1) return hit(a0, b0);
+    if (a_stride == b_stride) {
+        const __int128 st = (__int128) a_stride * W;
+        for (long k = -(long) (batch - 1); k <= (long) (batch - 1); k++)
+            if (hit(a0, b0 + k * st)) return true;
+        return false;
+    }
+    if (batch <= 1024) {
+        for (int i = 0; i < batch; i++)
+            for (int j = 0; j < batch; j++)
+                if (hit(a0 + (__int128) i * a_stride * W, b0 + (__int128) j * b_stride * W)) return true;
+        return false;
+    }
+    const __int128 a1 = a0 + ((__int128) (batch - 1) * a_stride + a_item) * W;
+    const __int128 b1 = b0 + ((__int128) (batch - 1) * b_stride + b_item) * W;
     return a0 < b1 && b0 < a1;
 }
 
@@ -1500,6 +1552,7 @@ int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a
                                int shape, hegpu_stream stream)
 {
     TFHE_NEED(ctx);
+    if (shape <= 0) return 0; // an empty batch is a no-op (and the cheapest first call: it places the context's tables)
     int enc, s1, s2, m = 1;
     const int e8 = encode_to_torus32(1, 8), e4 = encode_to_torus32(1, 4);
     switch (gate) { // tfhe/operator.cu:24-198

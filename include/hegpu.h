@@ -61,6 +61,11 @@ int hegpu_context_create_default(int scheme, int poly_modulus_degree, int p_coun
 /* set_coeff_modulus_values(Q, P) (bfv/context.cu:149-265): explicit primes */
 int hegpu_context_create_from_primes(int scheme, int poly_modulus_degree, const uint64_t* primes, int q_count,
                                      int p_count, uint64_t plain_modulus, hegpu_context** out);
+/* the checks set_coeff_modulus_values runs before it accepts explicit primes (bfv/context.cu:149-220: widths through
+ * coefficient_validator, total width against the security table; plus that every value admits a 2N-th root of unity);
+ * 0, or the reference's exception as a code + hegpu_last_error */
+int hegpu_validate_coeff_modulus_values(int poly_modulus_degree, const uint64_t* primes, int q_count, int p_count,
+                                        int sec_level);
 void hegpu_context_destroy(hegpu_context* ctx);
 /* Run-time options of a context (the reference configures through objects as well: ExecutionOptions,
  * src/include/heongpu/util/storagemanager.cuh:34-97; MemoryPoolConfig, util/memorypool.cuh:38-54).  They select

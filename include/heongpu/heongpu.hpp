@@ -499,7 +499,24 @@ template <typename T> class DeviceVector {
         resize(o.n_, same ? o.s_ : nullptr);
         if (!n_) return;
         if (same) detail::hip(hipMemcpyAsync(p_, o.p_, n_ * sizeof(T), hipMemcpyDeviceToDevice, s_));
-        else detail::hip(hipMemcpyPeer(p_, dev_, o.p_, o.dev_, n_ * sizeof(T))); // synchronous: the source's stream is foreign
+        else {
+            // The source may still be in flight on ITS stream (o.s_, on the other device): hipMemcpyPeer orders
+            // behind nothing there, so the copy is queued on this buffer's stream behind an event recorded on the
+            // source's stream (as hegpu_broadcast_bytes does), then waited for -- the copy constructor's contract is
+            // a finished replica.  ADVICE r3.
+            hipEvent_t ready = nullptr;
+            const int cur = MemoryPool::current_device();
+            detail::hip(hipSetDevice(o.dev_));
+            hipError_t e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ready, o.s_);
+            (void) hipSetDevice(cur);
+            detail::hip(e);
+            e = hipStreamWaitEvent(s_, ready, 0);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(p_, dev_, o.p_, o.dev_, n_ * sizeof(T), s_);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_);
+            (void) hipEventDestroy(ready);
+            detail::hip(e);
+        }
     }
     T* p_ = nullptr;
     size_t n_ = 0;
@@ -742,6 +759,34 @@ template <Scheme S> class HEContextImpl { // BFV / CKKS; the TFHE specialisation
         Qprime_mod_bit_sizes_.insert(Qprime_mod_bit_sizes_.end(), p.begin(), p.end());
         total_coeff_bit_count = 0;
         for (int b : Qprime_mod_bit_sizes_) total_coeff_bit_count += b;
+    }
+    // explicit primes (bfv/context.cu:149-265, ckks/context.cu:149-265): the same state machine, validator and security
+    // check as the bit-size form; the values themselves must admit a 2N-th root of unity (the reference finds that out
+    // in generate(), when its root search fails)
+    void set_coeff_modulus_values(const std::vector<Data64>& log_Q_bases, const std::vector<Data64>& log_P_bases)
+    {
+        if (coeff_modulus_specified_ || context_generated_ || !poly_modulus_degree_specified_)
+            throw std::logic_error("Coeff_modulus cannot be changed after the context is generated!");
+        if (log_P_bases.empty()) throw std::logic_error("log_P_bases_bit_sizes cannot be empty!");
+        std::vector<uint64_t> all(log_Q_bases.begin(), log_Q_bases.end());
+        all.insert(all.end(), log_P_bases.begin(), log_P_bases.end());
+        detail::check(hegpu_validate_coeff_modulus_values(n, all.data(), (int) log_Q_bases.size(), (int) log_P_bases.size(),
+                                                          sec_abi()));
+        Q_size = (int) log_Q_bases.size();
+        P_size = (int) log_P_bases.size();
+        Q_prime_size = Q_size + P_size;
+        keyswitching_type_ = P_size == 1 ? keyswitching_type::KEYSWITCHING_METHOD_I : keyswitching_type::KEYSWITCHING_METHOD_II;
+        prime_vector_.clear();
+        Q_mod_bit_sizes_.clear();
+        P_mod_bit_sizes_.clear();
+        for (uint64_t v : all) prime_vector_.push_back(Modulus64(v));
+        for (int i = 0; i < Q_size; i++) Q_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
+        for (int i = Q_size; i < Q_prime_size; i++) P_mod_bit_sizes_.push_back((int) prime_vector_[i].bit);
+        Qprime_mod_bit_sizes_ = Q_mod_bit_sizes_;
+        Qprime_mod_bit_sizes_.insert(Qprime_mod_bit_sizes_.end(), P_mod_bit_sizes_.begin(), P_mod_bit_sizes_.end());
+        total_coeff_bit_count = 0;
+        for (int b : Qprime_mod_bit_sizes_) total_coeff_bit_count += b;
+        coeff_modulus_specified_ = true;
     }
     void set_coeff_modulus_default_values(int p_count) // bfv/context.cu:267-374
     {

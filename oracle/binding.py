@@ -78,6 +78,8 @@ def lib():
     L.o_bfv_relinearize.argtypes = [vp, vp, vp]
     L.o_bfv_apply_galois.argtypes = [vp, vp, vp, vp, ci]
     L.o_ckks_mul_relin_batch.argtypes = [vp, vp, vp, vp, vp, ci, ci]
+    L.o_ckks_mul_relin_batch_tiled.argtypes = [vp, vp, vp, ci, ci, vp, vp, ci, ci]
+    L.o_ckks_mul_relin_batch_tiled.restype = ci
     L.o_bfv_relinearize_II.argtypes = [vp, vp, vp]
     L.o_bfv_apply_galois_II.argtypes = [vp, vp, vp, vp, ci]
     L.o_ckks_relinearize_II.argtypes = [vp, vp, vp, ci]

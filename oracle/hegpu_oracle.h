@@ -198,6 +198,9 @@ void o_ckks_apply_galois_II(const octx_t* c, const u64* ct, u64* out, const u64*
 
 /* CPU-baseline helper: batch of independent mul+relin (OpenMP over cts) */
 int o_omp_threads(void);
+/* pair b = inputs (first + b) % uniq; OpenMP over the pairs; returns the threads of the region */
+int o_ckks_mul_relin_batch_tiled(const octx_t* c, const u64* ct1u, const u64* ct2u, int uniq, int first,
+                                 u64* out3, const u64* relin_key, int depth, int batch);
 void o_ckks_mul_relin_batch(const octx_t* c, const u64* ct1, const u64* ct2,
                             u64* out3, const u64* relin_key, int depth,
                             int batch);

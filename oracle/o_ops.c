@@ -194,6 +194,32 @@ int o_omp_threads(void)
 
 /* CPU baseline: `batch` independent multiply+relinearize, OpenMP over the
  * ciphertext pairs (inner NTT loops then run serially per thread). */
+/* The same over `batch` pairs drawn from `uniq` distinct inputs: pair b = inputs
+ * (first + b) % uniq -- bench.py's batch, without materialising its copies.  With
+ * batch >= the OpenMP thread count every host core is busy; returns the
+ * number of threads of the parallel region. */
+int o_ckks_mul_relin_batch_tiled(const octx_t* c, const u64* ct1u, const u64* ct2u,
+                                 int uniq, int first, u64* out3,
+                                 const u64* relin_key, int depth, int batch)
+{
+    int l = c->Q_size - depth, threads = 1;
+    u64 ctsz = 2 * (u64) l * c->n, osz = 3 * (u64) l * c->n;
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        threads = omp_get_num_threads();
+#endif
+#pragma omp for schedule(dynamic)
+        for (int b = 0; b < batch; b++) {
+            int u = (first + b) % uniq;
+            o_ckks_multiply(c, ct1u + u * ctsz, ct2u + u * ctsz, out3 + b * osz, depth);
+            o_ckks_relinearize(c, out3 + b * osz, relin_key, depth);
+        }
+    }
+    return threads;
+}
+
 void o_ckks_mul_relin_batch(const octx_t* c, const u64* ct1, const u64* ct2,
                             u64* out3, const u64* relin_key, int depth,
                             int batch)

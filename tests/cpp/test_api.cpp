@@ -1026,9 +1026,125 @@ static void multi_device()
         });
     for (auto& t : th) t.join();
     detail::hip(hipSetDevice(0));
+    {
+        // hegpu_broadcast_bytes: three replicas of an 80 MiB buffer (three 32 MiB chunks), peer access checked per edge
+        const int nrep = 3;
+        const size_t bytes = (size_t) 80 << 20;
+        std::vector<int> devs(nrep);
+        std::vector<void*> bufs(nrep, nullptr);
+        std::vector<hegpu_stream> sts(nrep, nullptr);
+        for (int i = 0; i < nrep; i++) {
+            devs[i] = i % ndev;
+            detail::hip(hipSetDevice(devs[i]));
+            detail::hip(hipMalloc(&bufs[i], bytes));
+            hipStream_t s;
+            detail::hip(hipStreamCreate(&s));
+            sts[i] = s;
+        }
+        detail::hip(hipSetDevice(devs[0]));
+        std::vector<uint32_t> host(bytes / 4);
+        for (size_t i = 0; i < host.size(); i++) host[i] = (uint32_t) (i * 2654435761u);
+        detail::hip(hipMemcpyAsync(bufs[0], host.data(), bytes, hipMemcpyHostToDevice, (hipStream_t) sts[0]));
+        int path = -1;
+        const int rc = hegpu_broadcast_bytes(devs.data(), nrep, bufs.data(), bytes, sts.data(), &path);
+        EXPECT(rc == 0, "hegpu_broadcast_bytes succeeds");
+        const int shape = path & 0xff;
+        EXPECT(shape == HEGPU_BCAST_FLAT || shape == HEGPU_BCAST_TREE, "the call reports the shape of the fan-out");
+        EXPECT(path == hegpu_last_broadcast_path(), "the path is also kept for the calling thread");
+        if (ndev == 1) EXPECT(path == (HEGPU_BCAST_FLAT | HEGPU_BCAST_SAME_DEVICE), "one device: flat, flagged as a functional run");
+        else EXPECT(!(path & HEGPU_BCAST_SAME_DEVICE), "several devices are not reported as one");
+        printf("    broadcast path: %s%s%s\n", shape == HEGPU_BCAST_FLAT ? "flat fan-out" : "binomial tree",
+               (path & HEGPU_BCAST_STAGED) ? ", an edge WITHOUT peer access (host-staged)" : "",
+               (path & HEGPU_BCAST_SAME_DEVICE) ? ", one device" : "");
+        for (int i = 1; i < nrep; i++) {
+            detail::hip(hipSetDevice(devs[i]));
+            std::vector<uint32_t> back(bytes / 4);
+            detail::hip(hipMemcpyAsync(back.data(), bufs[i], bytes, hipMemcpyDeviceToHost, (hipStream_t) sts[i]));
+            detail::hip(hipStreamSynchronize((hipStream_t) sts[i]));
+            EXPECT(back == host, "every replica holds the source's bytes (ordered on its own stream)");
+        }
+        for (int i = 0; i < nrep; i++) {
+            detail::hip(hipSetDevice(devs[i]));
+            detail::hip(hipStreamDestroy((hipStream_t) sts[i]));
+            detail::hip(hipFree(bufs[i]));
+        }
+        detail::hip(hipSetDevice(0));
+    }
     for (int w = 0; w < workers; w++) EXPECT(errors[w].empty(), ("device thread failed: " + errors[w]).c_str());
     EXPECT(ctx_dev[0] == 0 && ctx_dev[1] == 1 % ndev, "every thread's context lives on that thread's device");
     EXPECT(!results[0].empty() && results[0] == results[1], "both devices compute the same multiply + relinearize + rescale");
+}
+
+// HEContext::set_coeff_modulus_values (bfv/context.cu:149-265, ckks/context.cu:149-265): explicit primes equal to the
+// default chain give the default chain's context -- same tables, same ciphertexts; the checks of the bit-size form apply
+static void explicit_primes()
+{
+    constexpr auto S = Scheme::BFV;
+    auto dflt = GenHEContext<S>();
+    dflt->set_poly_modulus_degree(8192);
+    dflt->set_coeff_modulus_default_values(1);
+    dflt->set_plain_modulus(786433);
+    dflt->generate();
+    const std::vector<Data64> chain = dflt->get_key_modulus();
+    const int Q = dflt->get_ciphertext_modulus_count();
+    std::vector<Data64> q(chain.begin(), chain.begin() + Q), p(chain.begin() + Q, chain.end());
+    auto expl = GenHEContext<S>();
+    expl->set_poly_modulus_degree(8192);
+    expl->set_coeff_modulus_values(q, p);
+    expl->set_plain_modulus(786433);
+    EXPECT(throws_logic([&] { expl->set_coeff_modulus_values(q, p); }), "the chain can be set once");
+    expl->generate();
+    EXPECT(expl->get_key_modulus() == chain && expl->get_ciphertext_modulus_count() == Q, "explicit primes are taken as given");
+    for (const char* t : {"ntt_table", "intt_table", "n_inverse", "last_q_modinv", "base_Bsk", "base_change_matrix_Bsk",
+                          "inv_prod_q_mod_Bsk", "Qi_t", "upper_threshold"}) {
+        std::vector<uint64_t> a(1 << 20), b(1 << 20);
+        const long na = hegpu_context_get(dflt->handle(), t, a.data(), (long) a.size());
+        const long nb = hegpu_context_get(expl->handle(), t, b.data(), (long) b.size());
+        a.resize(na > 0 ? na : 0);
+        b.resize(nb > 0 ? nb : 0);
+        EXPECT(na > 0 && a == b, (std::string("table ") + t + " identical for explicit primes = default chain").c_str());
+    }
+    // the same keys (same DRBG seed) and the same ciphertext bits on both contexts
+    std::vector<Data64> ct[2];
+    int k = 0;
+    for (auto& ctx : {dflt, expl}) {
+        HEKeyGenerator<S> keygen(ctx, 77);
+        Secretkey<S> sk(ctx);
+        keygen.generate_secret_key(sk);
+        Publickey<S> pk(ctx);
+        keygen.generate_public_key(pk, sk);
+        HEEncoder<S> enc(ctx);
+        HEEncryptor<S> encryptor(ctx, pk, 78);
+        std::vector<uint64_t> m(8192);
+        for (size_t i = 0; i < m.size(); i++) m[i] = (i * 7 + 1) % 786433;
+        Plaintext<S> pt(ctx);
+        enc.encode(pt, m);
+        Ciphertext<S> c(ctx);
+        encryptor.encrypt(c, pt);
+        HEArithmeticOperator<S> op(ctx, enc);
+        Ciphertext<S> prod(ctx);
+        op.multiply(c, c, prod);
+        prod.get_data(ct[k++]);
+    }
+    EXPECT(!ct[0].empty() && ct[0] == ct[1], "encrypt + multiply give the same residues on both contexts");
+    // the checks of the bit-size form
+    auto bad = GenHEContext<S>();
+    bad->set_poly_modulus_degree(8192);
+    EXPECT(throws_logic([&] { bad->set_coeff_modulus_values(q, {}); }), "P must not be empty");
+    EXPECT(throws_logic([&] { bad->set_coeff_modulus_values({q[0], q[1] + 2}, p); }), "a value without a 2N-th root is refused");
+    {
+        std::vector<Data64> small_p = {q.back()}, big_q = {p[0], q[0]};
+        bool logic = false;
+        try { bad->set_coeff_modulus_values({p[0], p[0] - 0}, {65537}); } catch (const std::logic_error&) { logic = true; }
+        EXPECT(logic, "P narrower than the Q digits it covers is refused (coefficient_validator)");
+    }
+    bool thrown = false;
+    try {
+        std::vector<Data64> twice(q);
+        twice.insert(twice.end(), q.begin(), q.end()); // twice the budget of N = 8192 at 128-bit security
+        bad->set_coeff_modulus_values(twice, p);
+    } catch (const std::runtime_error&) { thrown = true; }
+    EXPECT(thrown, "a chain beyond the security table is refused");
 }
 
 int main()
@@ -1051,6 +1167,7 @@ int main()
     memory_pool();
     storage_manager();
     multi_device();
+    explicit_primes();
     serializer_round_trip();
     serialize_all_objects();
     bfv_ntt_domain_and_shift();

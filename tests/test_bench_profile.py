@@ -1,0 +1,49 @@
+"""bench.py's committed counter passes (profiles/profile.json): the file exists, names a tracked directory, holds every
+workload the line quotes, and bench.py's reader turns it into the `from_profile` blocks -- CPU only, no GPU work."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_profile_json_is_complete_and_tracked():
+    b = _bench()
+    prof = b.load_profile()
+    assert prof is not None, "profiles/profile.json is missing"
+    d = os.path.join(ROOT, prof["dir"])
+    assert os.path.isdir(d), "the directory the profile names (%s) is not in the tree" % prof["dir"]
+    assert json.load(open(os.path.join(d, "profile.json"))) == prof, "profiles/profile.json is not the copy of its directory's file"
+    assert prof.get("copy_ceiling_GBps", 0) > 4000
+    for w in b.PROFILE_WORKLOADS:
+        assert w in prof["workloads"], w
+        wl = prof["workloads"][w]
+        assert wl["batches"] >= 1 and wl["kernels"], w
+        assert os.path.exists(os.path.join(d, w, "summary.txt")) and os.path.exists(os.path.join(d, w, "kernel_stats.csv")), w
+        for k, e in wl["kernels"].items():
+            assert k.startswith("hegpu::") and e["per_batch"] >= 1 and e["ms"] > 0 and e["cycles"] > 0, (w, k)
+
+
+def test_from_profile_blocks():
+    b = _bench()
+    prof = b.load_profile()
+    g = b.prof_group(prof, "c5_tfhe_gates", 100.0, match=["k_tfhe_blind_rotate"])
+    fp = g["from_profile"]
+    assert fp["dir"] == prof["dir"] and len(fp["kernels"]) == 1
+    assert 0.5 < fp["frac_of_issue_ceiling"] < 1.0 and fp["frac_of_copy_ceiling"] < 0.1 and g["bound"].startswith("valu")
+    assert abs(g["live_over_profile_ms"] - 100.0 / fp["ms"]) < 1e-9
+    step = b.prof_group(prof, "c4_step", 8.5)
+    assert 25e9 < step["from_profile"]["hbm_bytes"] < 40e9
+    pair = b.prof_group(prof, "ntt_pair", 8.0, algorithmic_bytes=17408 * 2 * 8 * 65536)
+    assert 1.9 < pair["traffic_over_algorithmic"] < 2.1 and pair["bound"].startswith("hbm")
+    one = b.prof_group(prof, "c2_ckks_n14_b1", 0.1)
+    assert one["bound"].startswith("neither")
+    assert b.prof_group(None, "c4_step", 1.0)["from_profile"] is None
+    assert b.prof_group(prof, "c4_step", 1.0, match=["no such kernel"])["from_profile"] is None

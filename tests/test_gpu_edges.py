@@ -490,3 +490,44 @@ def test_options_change_the_launches_not_the_result(hg, oracle, torch):
         c.ckks_relinearize_inplace(out, 3 * Q * n, dk, 0, 1, ws)
         torch.cuda.synchronize()
         assert np.array_equal(hg.to_host(out)[:2 * Q * n], want[:2 * Q * n]), opts
+
+
+def test_rotation_inputs_and_results_interleaved_in_one_buffer(hg, oracle, torch):
+    """apply_galois / rotate_hoisted refuse a result batch that shares a word with the input batch -- per ITEM: ct and out
+    alternating in one buffer (stride 2 x words, no word shared) is a legal layout and computes the oracle's values; an
+    out that starts inside an item of ct is refused with E_INVALID, whatever the strides."""
+    n, batch = 4096, 3
+    c, o, primes = _ckks(hg, oracle, n, [40, 30, 30], [40])
+    Q, Qp = 3, 4
+    words = 2 * Q * n
+    gk = synth_key(primes, Q, Qp, n, 9)
+    g = hg.steps_to_galois_elt(1, n, 5)
+    cts = [synth_ct(primes, range(Q), 2, n, 5 + b) for b in range(batch)]
+    buf = torch.zeros(2 * batch * words, dtype=torch.int64, device="cuda")
+    v = buf.view(batch, 2, words)
+    for b in range(batch):
+        v[b, 0].copy_(hg.to_device(cts[b]))
+    ws = c.workspace(hg.OP_CKKS_GALOIS, 0, batch)
+    key = hg.to_device(gk)
+    c.ckks_apply_galois(buf, 2 * words, buf[words:], 2 * words, key, g, 0, batch, ws)
+    torch.cuda.synchronize()
+    got = hg.to_host(v[:, 1].contiguous()).reshape(batch, -1)
+    for b in range(batch):
+        assert np.array_equal(got[b], o.ckks_apply_galois(cts[b], gk, g, 0)), b
+    for off in (0, 1, words - 1, 2 * words, 2 * words + words - 1):  # inside item 0 or item 1 of ct
+        with pytest.raises(hg.HEError) as e:
+            c.ckks_apply_galois(buf, 2 * words, buf[off:], 2 * words, key, g, 0, batch, ws)
+        assert e.value.code == hg.E_INVALID, off
+    with pytest.raises(hg.HEError):  # unequal strides, out's second item lands on ct's second item
+        c.ckks_apply_galois(buf, 2 * words, buf[words:], words, key, g, 0, 2, ws)
+    # hoisted: count results per item
+    out = torch.zeros(batch * 2 * words, dtype=torch.int64, device="cuda")
+    with pytest.raises(hg.HEError):
+        c.ckks_rotate_hoisted(buf, 2 * words, buf[words:], 2 * words, [key, key], [g, g], 0, batch,
+                              c.workspace(hg.OP_CKKS_ROTATE_HOISTED, 0, batch))  # 2 results per item do not fit the gaps
+    c.ckks_rotate_hoisted(buf, 2 * words, out, 2 * words, [key, key], [g, g], 0, batch,
+                          c.workspace(hg.OP_CKKS_ROTATE_HOISTED, 0, batch))
+    torch.cuda.synchronize()
+    hv = hg.to_host(out).reshape(batch, 2, -1)
+    for b in range(batch):
+        assert np.array_equal(hv[b, 0], got[b]) and np.array_equal(hv[b, 1], got[b])
