@@ -1132,9 +1132,6 @@ hipError_t rns_fast_convertion(const u64* in1, u64 s1, const u64* in2, u64 s2, u
     return hipGetLastError();
 }
 
-#ifndef FF_UNROLL_MAX
-#define FF_UNROLL_MAX 0
-#endif
 // SPLIT: as in k_fast_convertion; the rows of the first conversion computed by the four wavefronts meet in LDS
 // ([row][coefficient], one barrier) before every wavefront runs its quarter of the second one.
 template <int MAXB, bool SPLIT>
@@ -1176,24 +1173,9 @@ __global__ __launch_bounds__(RNS_THREADS) void k_fast_floor(const u64* __restric
 #pragma unroll
         for (int k = 0; k < MAXB; k++) temp3[k] = (k < ob - 1) ? meet[k * 64 + lane] : 0;
         reg_Bsk_last = meet[(ob - 1) * 64 + lane];
-    } else if constexpr (MAXB <= FF_UNROLL_MAX) {
-        // MAXB + 1 unrolled iterations on a clamped row index cover ob <= MAXB + 1 (the surplus ones
-        // recompute the m_sk row): static register indices, no selects
-#pragma unroll
-        for (int i = 0; i <= MAXB; i++) {
-            const int ii = i < ob - 1 ? i : ob - 1;
-            const bool last = i >= ob - 1;
-            const Mod mo = b.obase[ii];
-            u64 hi, lo;
-            dot128(reg_q, b.ff_matrix + ii * ib, ib, hi, lo);
-            acc128(hi, lo, pB[(u64) ii << n_power], b.ff_tc[ii]);
-            const u64 v = redc128(hi, lo, mo); // (x_Bsk t - sum) * q^-1 [* (B/b_i)^-1]
-            if (i < MAXB) temp3[i] = last ? 0 : v;
-            reg_Bsk_last = last ? v : reg_Bsk_last;
-        }
     } else {
-        // large bases: a run-time loop keeps code size and register pressure down; the row's slot of
-        // temp3 is picked with wave-uniform selects
+        // a run-time loop over the rows keeps code size and register pressure down; the row's slot of temp3 is picked
+        // with wave-uniform selects (a fully unrolled form for small bases was measured slower in round 3 and is gone)
 #pragma unroll
         for (int i = 0; i < MAXB; i++) temp3[i] = 0;
 #pragma unroll 1

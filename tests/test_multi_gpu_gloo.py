@@ -146,3 +146,82 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "world size" in (r.stdout + r.stderr)
+
+
+def _tfhe_material():
+    from oracle import binding as ob
+    ot = ob.OracleTfhe()
+    rng = np.random.default_rng(5)
+    polys = 512 * 2 * 2 * 2
+    v = rng.integers(-2**31, 2**31, polys, dtype=np.int64)  # constant polynomials: the NTT image of a constant is the constant
+    bk = np.repeat(np.where(v < 0, v + ot.prime, v).astype(np.uint64), 1024)
+    r32 = lambda k: rng.integers(-2**31, 2**31, k, dtype=np.int64).astype(np.int32)
+    ks_a, ks_b = r32(1024 * 8 * 3 * 512), r32(1024 * 8 * 3)
+    total = 3
+    return ot, bk, ks_a, ks_b, r32(total * 512), r32(total), r32(total * 512), r32(total), total
+
+
+def _worker_c5(rank, world, port, q):
+    """config C5's split: gates sharded along `shape`, the boot key and the key-switch key replicated from rank 0"""
+    import torch
+    import torch.distributed as dist
+
+    from heongpu_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sharding.init_distributed("gloo")
+    ot, bk, ks_a, ks_b, a1, b1, a2, b2, total = _tfhe_material()
+    keys = [torch.from_numpy(bk.view(np.int64).copy()), torch.from_numpy(ks_a.copy()), torch.from_numpy(ks_b.copy())]
+    if rank != 0:  # only rank 0 owns the keys before the broadcast
+        for k in keys:
+            k.zero_()
+    for k in keys:
+        sharding.broadcast_eval_key(k, src=0, chunk_elems=1 << 20)
+    start, count = sharding.shard_range(total, world, rank)
+    sl = slice(start, start + count)
+    out_a, out_b = ot.gate(0, a1[start * 512:(start + count) * 512], b1[sl], a2[start * 512:(start + count) * 512], b2[sl],
+                           keys[0].numpy().view(np.uint64), keys[1].numpy(), keys[2].numpy())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (start, count, out_a.tobytes(), out_b.tobytes()))
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_tfhe_gates_match_single_process(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c5, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ot, bk, ks_a, ks_b, a1, b1, a2, b2, total = _tfhe_material()
+    want_a, want_b = ot.gate(0, a1, b1, a2, b2, bk, ks_a, ks_b)
+    covered = 0
+    for start, count, ba, bb in gathered:
+        assert ba == want_a[start * 512:(start + count) * 512].tobytes(), (start, count)
+        assert bb == want_b[start:start + count].tobytes(), (start, count)
+        covered += count
+    assert covered == total and [g[0] for g in gathered] == [0, 2] and [g[1] for g in gathered] == [2, 1]
+
+
+def test_bench_c5_selftest_shards_gates_and_replicates_three_keys():
+    """`bench.py --workload c5 --gpus 2`: 1024 gates per GPU, contiguous slices, the prepared boot key and both parts of
+    the key-switch key replicated (gloo ranks, then the single-process fall-back)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for extra, where in (([], "one process per GPU"), (["--force-launch-failure"], "single process")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5",
+                            "--launcher-selftest"] + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["workload"] == "c5" and line["key_broadcast_ok"] and line["replicated_tensors"] == 3
+        assert line["slices"] == [[0, 1024], [1024, 1024]] and line["global_batch"] == 2048 and where in line["parallelism"]
