@@ -167,3 +167,15 @@ def test_options_are_an_interface_not_the_environment(hg):
         if f.endswith((".hip", ".cpp", ".hpp", ".cuh")):
             n = len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read()))
             assert n == allowed.get(f, 0), (f, n)
+
+
+def test_behz_base_beyond_the_lazy_sums_is_refused():
+    """A BFV base whose worst-case row sum of the BEHZ base conversions does not fit 128 bits is refused when the
+    context is created (exact arithmetic on the moduli at hand: 63 primes of 61 bits + their 64 base primes do not
+    fit, 58 primes of 60 bits do) -- not computed wrongly later (ADVICE r3 on redc128)."""
+    import heongpu_amd as hg
+    with pytest.raises(hg.HEError) as e:
+        hg.Context.from_bit_sizes(hg.BFV, 4096, [61] * 63, [61], plain_modulus=65537, sec=hg.SEC_NONE)
+    assert e.value.code == hg.E_INVALID and "lazy 128-bit row sum" in str(e.value)
+    c = hg.Context.from_bit_sizes(hg.BFV, 4096, [60] * 58, [60], plain_modulus=65537, sec=hg.SEC_NONE)
+    assert len(c.table("q_Bsk_merge_modulus")) == 58 + 59

@@ -749,11 +749,15 @@ def test_bench_line_proves_its_own_work():
 
 
 @pytest.mark.parametrize("split", [0, 1], ids=["one_thread_per_coefficient", "rows_over_four_wavefronts"])
-def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split):
+@pytest.mark.parametrize("Q,bits", [(42, 30), (58, 60)], ids=["42x30bit", "58x60bit"])
+def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split, Q, bits):
     """BEHZ with Q + |Bsk| beyond 40 moduli (the reference allows MAX_BSK_SIZE = 64, defines.h:26):
-    BFV N=2^12, 42 primes of 30 bits + one special prime, multiply + relinearize against the oracle."""
-    n, t, Q = 4096, 65537, 42
-    c = hg.Context.from_bit_sizes(hg.BFV, n, [30] * Q, [31], plain_modulus=t, sec=hg.SEC_NONE)
+    BFV N=2^12, 42 primes of 30 bits + one special prime, multiply against the oracle; and 58 primes of 60 bits with 59
+    base primes of 61 bits -- lazy row sums of 59 terms of up to 121 bits whose high word passes 2^63 (the
+    Montgomery reduction of round 3 assumed hi < 2^63; redc128 takes any 128-bit sum now, and the context refuses a base
+    whose worst-case sum would not fit 128 bits: tests/test_cabi.py)."""
+    n, t = 4096, 65537
+    c = hg.Context.from_bit_sizes(hg.BFV, n, [bits] * Q, [bits + 1 if bits < 60 else 60], plain_modulus=t, sec=hg.SEC_NONE)
     primes = [int(x) for x in c.table("modulus")]
     o = oracle.OracleContext(oracle.BFV, 12, primes, Q, 1, t)
     c.upload()
@@ -761,6 +765,7 @@ def test_bfv_multiply_with_more_than_40_base_primes(hg, oracle, torch, split):
     assert L - Q > 40, (L, Q)
     ct1 = synth_ct(primes, range(Q), 2, n, 1)
     ct2 = synth_ct(primes, range(Q), 2, n, 2)
+    ct1[:4] = [primes[0] - 1, 0, primes[0] - 1, 1]  # extreme residues among the random ones
     out = torch.empty(3 * Q * n, dtype=torch.int64, device="cuda")
     c.set_option("behz_split", split)
     c.bfv_multiply(hg.to_device(ct1), 2 * Q * n, hg.to_device(ct2), 2 * Q * n, out, 3 * Q * n, 1,
