@@ -1334,6 +1334,7 @@ struct hegpu_tfhe_context {
     bool uploaded = false;
     int device = -1;           // the device the tables live on (the calling thread's current device at first use)
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
+    int ks_pieces = -1;        // option "ks_pieces": workgroups per gate (group) of the key switching, -1 by launch size
     int ks_batched = -1;       // option "ks_batched": key switching with 8 / 12 / 16 gates per workgroup sharing the key rows (tfhe.hip)
     // layout of every prepared boot key this context has met (header word 0: 1 = FP64, 0 = integer): filled by
     // hegpu_tfhe_prepare_bootkey; a buffer that arrived by other means (a peer copy from another device's context) is
@@ -1399,7 +1400,7 @@ int hegpu_tfhe_context_create(hegpu_tfhe_context** out)
         }
         *out = h;
         // defaults only, through the setter's own validation (a value it refuses is ignored, not stored)
-        for (const char* nm : {"fp", "ks_batched"}) {
+        for (const char* nm : {"fp", "ks_batched", "ks_pieces"}) {
             std::string env = std::string("HEGPU_TFHE_") + nm;
             for (char& ch : env) ch = (char) toupper((unsigned char) ch);
             long v;
@@ -1415,6 +1416,9 @@ int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int
     if (!strcmp(name, "fp")) {
         if (value < 0 || value > 1) return fail(HEGPU_E_INVALID, "value out of range for option fp");
         ctx->allow_fp = value != 0;
+    } else if (!strcmp(name, "ks_pieces")) {
+        if (value < -1 || value == 0 || value > 64) return fail(HEGPU_E_INVALID, "value out of range for option ks_pieces");
+        ctx->ks_pieces = value;
     } else if (!strcmp(name, "ks_batched")) {
         if (value < -1 || (value > 1 && value != 8 && value != 12 && value != 16))
             return fail(HEGPU_E_INVALID, "value out of range for option ks_batched");
@@ -1588,7 +1592,7 @@ int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              hegpu_stream stream)
 {
     TFHE_NEED(ctx);
-    return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, ctx->ks_batched, (hipStream_t) stream),
+    return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, ctx->ks_batched, ctx->ks_pieces, (hipStream_t) stream),
                    "hegpu_tfhe_key_switching");
 }
 

@@ -25,6 +25,8 @@
 namespace hegpu {
 
 #define TF_N 1024
+// from this many gates per call the key switching runs several gates per workgroup (sweep: profiles/r4_c5/ks_shapes.txt)
+#define TFHE_KS_BATCH_MIN 48
 #define TF_THREADS 256
 
 __device__ __forceinline__ u64 tcsub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
@@ -541,8 +543,12 @@ __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const
         f_ct_l(x[4 * g + 0], x[4 * g + 1], w9a, c);
         f_ct_l(x[4 * g + 2], x[4 * g + 3], w9b, c);
     }
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], c);
+    // No reduction at the end: the outputs (|x| < 7 p' < 2^47, integers) are the "twiddle" side of the external
+    // product's fp_mul, whose result bound does not depend on that operand's magnitude -- with the companion
+    // x * RN(1/p') (relative error <= 2^-52) and a key value |y| <= p'/2 < 2^43: |k - y x / p'| <= 1/2 + 2^46 * 2^-52
+    // + 2^-7, so |y x - k p'| <= 0.53 p'; h = RN(y x) < 2^90 and h - k p' is an integer below 2^45, so the FMA that
+    // forms it is exact, as is the sum with l = y x - h (an integer below 2^38).  Four such terms: 2.13 p', inside the
+    // 2.2 p' the inverse transform takes.  (16 x 3 instructions less per transform.)
     wave_fence();
 }
 // as fwave_intt1024; the lane-dependent inverse twiddles are the forward table's mirrored entries with the sign moved
@@ -659,8 +665,8 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         fwave_ntt1024_l(x, buf[wv], p.ftw, twl, fc, lane);
         // The transformed digit goes to the own staging area (free after the transform); after the barrier
         // every wavefront reads the other three and forms its output sum_w X_w * BK[w][own] in registers
-        // (plain LDS reads -- no atomics, no read-back).  x is the "twiddle" of the products: companion
-        // RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.7 p' < 2^47.
+        // (plain LDS reads -- no atomics, no read-back).  x (un-reduced, below 7 p') is the "twiddle" of the products:
+        // companion RN(x/p') ~ x * RN(1/p'), one multiply per product.  |sum| <= 4 * 0.53 p' (fwave_ntt1024_l).
 #pragma unroll
         for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
         __syncthreads();
@@ -782,17 +788,27 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching(const int* __restric
 // A workgroup is a chain of N k iterations of ~4.5 us whatever KS_GB is (4.6 ms), three are resident per CU (144
 // registers; capped at 128 the loads are no longer batched: 7.9 ms), so KS_GB is chosen to finish in ONE round of
 // 768 workgroups where 8, 12 or 16 gates per workgroup allow it (tools/tfhe_ks_shapes.py).
-template <int KS_GB>
+// SPLIT: as in k_tfhe_key_switching -- gridDim.y workgroups share a group of gates, `chunk` input coefficients each,
+// partial sums added into the zeroed output with integer atomics (a call of 1024 gates, C5's share per GPU: 128 groups
+// of 8 x 6 pieces fill the chip, where 1024 one-gate workgroups took 1.65 ms).
+template <int KS_GB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* __restrict__ in_a,
                                                                     const int* __restrict__ in_b,
                                                                     int* __restrict__ out_a, int* __restrict__ out_b,
                                                                     const int* __restrict__ ks_a,
                                                                     const int* __restrict__ ks_b, int len, int n, int Nk,
-                                                                    int shape)
+                                                                    int shape, int chunk)
 {
     constexpr int bb = 2, mask = 3;
     __shared__ u32 bsum[KS_GB];
+    // The candidate rows of a digit position as an indexable register file (round 4): slot [digit][thread] holds the
+    // thread's own two key values of row digit - 1 (slot 0: zeros), written by the thread that reads them (LDS operations
+    // of a wave are ordered: no barrier), so a gate's row is ONE ds_read_b64 at a wave-uniform offset and two
+    // subtractions.  Round 3 picked it with six selects on scalar conditions and two masks per gate and position:
+    // 768 vector instructions per iteration and thread, vector ALU 0.55 busy, 6.9 ms per 8192 gates; now 3.98 ms.
+    __shared__ __attribute__((aligned(16))) u64 cand[2][4][256];
     const int t = threadIdx.x;
+    cand[0][0][t] = cand[1][0][t] = 0;
     const int g0 = blockIdx.x * KS_GB;
     const u32 precision_offset = 1u << (32 - (1 + bb * len));
     const int t2 = (t + 256 < n) ? t + 256 : t;
@@ -809,7 +825,9 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* _
     const int* pa[KS_GB];
 #pragma unroll
     for (int gg = 0; gg < KS_GB; gg++) pa[gg] = in_a + (u64) ((g0 + gg < shape) ? g0 + gg : shape - 1) * Nk;
-    for (int i = 0; i < Nk; i++) {
+    const int i_begin = SPLIT ? (int) blockIdx.y * chunk : 0;
+    const int i_end = SPLIT ? ((i_begin + chunk < Nk) ? i_begin + chunk : Nk) : Nk;
+    for (int i = i_begin; i < i_end; i++) {
         u32 a[KS_GB];
 #pragma unroll
         for (int gg = 0; gg < KS_GB; gg++) a[gg] = (u32) pa[gg][i] + precision_offset;
@@ -830,15 +848,13 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* _
                     r1[r] = (u32) kr[(u64) r * n + t2] & m2;
                 }
 #pragma unroll
+                for (int r = 0; r < 3; r++) cand[i2 & 1][1 + r][t] = (u64) r0[r] | ((u64) r1[r] << 32);
+#pragma unroll
                 for (int gg = 0; gg < KS_GB; gg++) {
                     const u32 d = (a[gg] >> ((32 - (i2 + 1) * bb) & 31)) & (u32) mask; // wave-uniform
-                    // two selects on scalar conditions, a scalar mask for the zero digit, one subtraction
-                    const u32 m = d ? 0xffffffffu : 0u;
-                    u32 s0 = (d == 2u) ? r0[1] : r0[0], s1 = (d == 2u) ? r1[1] : r1[0];
-                    s0 = (d == 3u) ? r0[2] : s0;
-                    s1 = (d == 3u) ? r1[2] : s1;
-                    acc0[gg] -= s0 & m;
-                    acc1[gg] -= s1 & m;
+                    const u64 v = cand[i2 & 1][d][t];
+                    acc0[gg] -= (u32) v;
+                    acc1[gg] -= (u32) (v >> 32);
                 }
             }
         }
@@ -850,9 +866,15 @@ __global__ __launch_bounds__(256) void k_tfhe_key_switching_batched(const int* _
     for (int gg = 0; gg < KS_GB; gg++) {
         const int g = g0 + gg;
         if (g < shape) {
-            out_a[(u64) g * n + t] = (int) acc0[gg];
-            if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1[gg];
-            if (t == 0) out_b[g] = (int) ((u32) in_b[g] + bsum[gg]);
+            if (SPLIT) {
+                atomicAdd(reinterpret_cast<u32*>(&out_a[(u64) g * n + t]), acc0[gg]);
+                if (t + 256 < n) atomicAdd(reinterpret_cast<u32*>(&out_a[(u64) g * n + t + 256]), acc1[gg]);
+                if (t == 0) atomicAdd(reinterpret_cast<u32*>(&out_b[g]), (i_begin == 0 ? (u32) in_b[g] : 0u) + bsum[gg]);
+            } else {
+                out_a[(u64) g * n + t] = (int) acc0[gg];
+                if (t + 256 < n) out_a[(u64) g * n + t + 256] = (int) acc1[gg];
+                if (t == 0) out_b[g] = (int) ((u32) in_b[g] + bsum[gg]);
+            }
         }
     }
 }
@@ -1076,38 +1098,64 @@ hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, c
 }
 
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,
-                              const int* ks_a, const int* ks_b, int shape, int ks_batched, hipStream_t st)
+                              const int* ks_a, const int* ks_b, int shape, int ks_batched, int ks_pieces, hipStream_t st)
 {
     if (p.n > 512 || p.ks_length > 8) return hipErrorInvalidValue;
     if (shape <= 0) return hipSuccess;
     const int Nk = p.N * p.k;
-    // fewer gates than resident workgroups (eight per CU): cut the coefficient loop, at least 16 coefficients a piece
+    // ks_batched: -1 by launch size, 0 never, 1 always, 8 / 12 / 16 always with that many gates per workgroup;
+    // ks_pieces: -1 by launch size, otherwise the number of workgroups the coefficient loop of a gate (group) is cut into
+    const bool can_batch = p.ks_base_bit == 2 && p.n >= 256;
+    const bool batch = can_batch && ks_batched != 0 && (ks_batched >= 1 || shape >= TFHE_KS_BATCH_MIN);
+    if (batch) {
+        // KS_GB gates per workgroup share the key rows.  A workgroup is a chain of iterations over the input coefficients
+        // (~4 us each: the loads of an iteration depend on nothing, but its 24 row loads are all there is to overlap),
+        // so throughput comes from MANY short chains: 16 gates per workgroup and the coefficient loop cut so that the launch
+        // has ~8192 workgroups (sweep: profiles/r4_c5/ks_sweep2.txt -- 8192 gates: 1 piece 4.2 ms, 16 pieces 3.06 ms;
+        // 1024 gates: 4.2 / 0.43 ms; more gates per workgroup or fewer pieces lose everywhere)
+        const int gb = (ks_batched >= 8) ? ks_batched : 16;
+        const int groups = (shape + gb - 1) / gb;
+        int pieces = ks_pieces >= 1 ? ks_pieces : 8192 / groups;
+        if (pieces < 1) pieces = 1;
+        if (pieces > 64) pieces = 64;
+        while (pieces > 1 && Nk / pieces < 16) pieces--;
+        const int chunk = (Nk + pieces - 1) / pieces;
+        pieces = (Nk + chunk - 1) / chunk;
+        const dim3 grid((unsigned) groups, (unsigned) pieces);
+        if (pieces > 1) {
+            hipError_t e = hipMemsetAsync(out_a, 0, (size_t) shape * p.n * sizeof(int), st);
+            if (e == hipSuccess) e = hipMemsetAsync(out_b, 0, (size_t) shape * sizeof(int), st);
+            if (e != hipSuccess) return e;
+        }
+#define KS_LAUNCH(GB)                                                                                                      \
+    do {                                                                                                                   \
+        if (pieces > 1)                                                                                                    \
+            hipLaunchKernelGGL((k_tfhe_key_switching_batched<GB, true>), grid, dim3(256), 0, st, in_a, in_b, out_a, out_b,  \
+                               ks_a, ks_b, p.ks_length, p.n, Nk, shape, chunk);                                           \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_tfhe_key_switching_batched<GB, false>), grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, \
+                               ks_a, ks_b, p.ks_length, p.n, Nk, shape, chunk);                                           \
+    } while (0)
+        if (gb == 8) KS_LAUNCH(8);
+        else if (gb == 12) KS_LAUNCH(12);
+        else KS_LAUNCH(16);
+#undef KS_LAUNCH
+        return hipGetLastError();
+    }
+    // one gate per workgroup; fewer gates than resident workgroups (eight per CU): cut the coefficient loop, at least 16
+    // coefficients a piece
     int pieces = 1;
-    while (pieces < 64 && (long) shape * pieces * 2 <= 2048 && Nk / (pieces * 2) >= 16) pieces *= 2;
+    if (ks_pieces >= 1) pieces = ks_pieces > 64 ? 64 : ks_pieces;
+    else
+        while (pieces < 64 && (long) shape * pieces * 2 <= 2048 && Nk / (pieces * 2) >= 16) pieces *= 2;
     if (pieces > 1) {
         const int chunk = (Nk + pieces - 1) / pieces;
+        pieces = (Nk + chunk - 1) / chunk;
         hipError_t e = hipMemsetAsync(out_a, 0, (size_t) shape * p.n * sizeof(int), st);
         if (e == hipSuccess) e = hipMemsetAsync(out_b, 0, (size_t) shape * sizeof(int), st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_tfhe_key_switching<true>, dim3(shape, pieces), dim3(256), 0, st, in_a, in_b, out_a, out_b,
-                           ks_a, ks_b, p.ks_base_bit, p.ks_length, p.n, Nk, chunk);
-        return hipGetLastError();
-    }
-    // many gates: 8 / 12 / 16 gates per workgroup share the key rows (4.6 ms per round of 768 workgroups against
-    // 1.38 us per gate: ahead from ~3400 gates)
-    // (ks_batched: -1 by launch size, 0 never, 1 always, 8 / 12 / 16 always with that many gates per workgroup)
-    if (ks_batched != 0 && p.ks_base_bit == 2 && p.n >= 256 && (ks_batched >= 1 || shape >= 3584)) {
-        const int gb = (ks_batched >= 8) ? ks_batched : (shape <= 8 * 768) ? 8 : (shape <= 12 * 768) ? 12 : 16;
-        const dim3 grid((unsigned) ((shape + gb - 1) / gb));
-        if (gb == 8)
-            hipLaunchKernelGGL(k_tfhe_key_switching_batched<8>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
-                               ks_b, p.ks_length, p.n, Nk, shape);
-        else if (gb == 12)
-            hipLaunchKernelGGL(k_tfhe_key_switching_batched<12>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
-                               ks_b, p.ks_length, p.n, Nk, shape);
-        else
-            hipLaunchKernelGGL(k_tfhe_key_switching_batched<16>, grid, dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
-                               ks_b, p.ks_length, p.n, Nk, shape);
+        hipLaunchKernelGGL(k_tfhe_key_switching<true>, dim3(shape, pieces), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a,
+                           ks_b, p.ks_base_bit, p.ks_length, p.n, Nk, chunk);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tfhe_key_switching<false>, dim3(shape), dim3(256), 0, st, in_a, in_b, out_a, out_b, ks_a, ks_b,

@@ -52,6 +52,6 @@ hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b,
 hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
                          int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st);
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,
-                              const int* ks_a, const int* ks_b, int shape, int ks_batched, hipStream_t st);
+                              const int* ks_a, const int* ks_b, int shape, int ks_batched, int ks_pieces, hipStream_t st);
 
 } // namespace hegpu

@@ -472,11 +472,12 @@ enum {
 int hegpu_tfhe_context_create(hegpu_tfhe_context** out);
 void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx);
 /* "fp" 0/1: re-encode a torus32 boot key for the FP64 blind rotate (1, read by hegpu_tfhe_prepare_bootkey);
- * "ks_batched" -1/0/1/8/12/16: key switching with 8, 12 or 16 gates per workgroup sharing the key rows: by launch
- * size (-1, default: from 3584 gates per call, the count that finishes in one round of workgroups), never, always,
- * always with that many.
- * Defaults seeded once, at creation, from HEGPU_TFHE_FP / HEGPU_TFHE_KS_BATCHED when these hold whole decimal integers
- * the setter accepts (anything else is ignored). */
+ * "ks_batched" -1/0/1/8/12/16: key switching with that many gates per workgroup sharing the key rows: by launch
+ * size (-1, default: 16 per workgroup from 48 gates per call), never, always (16), always with that many;
+ * "ks_pieces" -1 / 1..64: workgroups the input-coefficient loop of a gate (or group of gates) is cut into (partial sums
+ * added with integer atomics: the same bits), -1 = by launch size.
+ * Defaults seeded once, at creation, from HEGPU_TFHE_FP / HEGPU_TFHE_KS_BATCHED / HEGPU_TFHE_KS_PIECES when these hold
+ * whole decimal integers the setter accepts (anything else is ignored). */
 int hegpu_tfhe_context_set_option(hegpu_tfhe_context* ctx, const char* name, int value);
 /* "n","N","k","bk_l","bk_bg_bit","ks_base_bit","ks_length","offset","bootkey_elems",
  * "prepared_bootkey_elems","kskey_a_elems","kskey_b_elems" */

@@ -105,34 +105,41 @@ def test_prepared_key_that_arrived_by_copy(hg, setup):
         t.prepared_format(torch.full((256,), 7, dtype=torch.int64, device="cuda"))
 
 
-@pytest.mark.parametrize("shape,per_wg", [(5, 8), (8, 8), (21, 8), (29, 12), (12, 12), (35, 16)])
-def test_key_switching_gates_sharing_key_rows(hg, setup, shape, per_wg):
-    """The batched form of the key switching (8 / 12 / 16 gates per workgroup share the three candidate rows of every
-    digit position; chosen from 3584 gates per call, forced here), with a last workgroup that is not full: every gate
-    against the oracle, stale output contents must not leak in."""
+@pytest.mark.parametrize("shape,per_wg,pieces", [(5, 8, 1), (8, 8, 3), (21, 8, -1), (29, 12, 1), (12, 12, 7), (35, 16, 1),
+                                                  (35, 16, 64), (50, 16, 2), (40, 16, -1)])
+def test_key_switching_gates_sharing_key_rows(hg, setup, shape, per_wg, pieces):
+    """The batched form of the key switching (8, 12 or 16 gates per workgroup share the three candidate rows of every
+    digit position, picked through LDS at a wave-uniform offset; 16 per workgroup from 48 gates per call, forced here),
+    the coefficient loop in one piece, cut by launch size (-1) or into a forced number of pieces that add their partial
+    sums atomically; with a last workgroup that is not full: every gate against the oracle, stale output contents must
+    not leak in."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
     ea = rng.integers(-2**31, 2**31, shape * 1024, dtype=np.int64).astype(np.int32)
     eb = rng.integers(-2**31, 2**31, shape, dtype=np.int64).astype(np.int32)
     ea[:8] = [0, -1, 2**31 - 1, -2**31, 1 << 15, (1 << 15) - 1, 3 << 14, 1 << 14]  # digits at the rounding edges
     t.set_option("ks_batched", per_wg)
+    if pieces != -1:
+        t.set_option("ks_pieces", pieces)
     ka = torch.full((shape * 512,), 7, dtype=torch.int32, device="cuda")
     kb = torch.full((shape,), 7, dtype=torch.int32, device="cuda")
     t.key_switching(_dev32(ea), _dev32(eb), ka, kb, _dev32(ks_a), _dev32(ks_b), shape)
     torch.cuda.synchronize()
     t.set_option("ks_batched", -1)
+    t.set_option("ks_pieces", -1)
     got_a, got_b = ka.cpu().numpy().reshape(shape, 512), kb.cpu().numpy()
     for g in range(shape):
         want_a, want_b = o.key_switching(ea[g * 1024:(g + 1) * 1024], eb[g:g + 1], ks_a, ks_b)
         assert np.array_equal(got_a[g], want_a) and got_b[g] == want_b[0], g
 
 
-@pytest.mark.parametrize("shape", [1, 33, 1024, 1025])
+@pytest.mark.parametrize("shape", [1, 33, 47, 48, 1024, 1025])
 def test_key_switching_split_launches(hg, setup, shape):
-    """Key switching alone on random extracted samples, on both sides of the launch-size rule of tfhe_key_switching:
-    up to 1024 gates the coefficient loop of a gate is cut into several workgroups that add their partial sums with
-    integer atomics (64 pieces at 1 gate, 32 at 33, 2 at 1024), from 1025 on one workgroup per gate.  Bit-exact
-    against the oracle either way (sums on the 32-bit torus do not depend on the order)."""
+    """Key switching alone on random extracted samples, on both sides of the launch-size rules of tfhe_key_switching:
+    below 48 gates one gate per workgroup with the coefficient loop cut into up to 64 workgroups that add their partial
+    sums with integer atomics; from 48 gates 16 gates per workgroup and the loop cut so that the launch has ~8192
+    workgroups (64 pieces at 48 gates, 64 at 1024, 63 at 1025).  Bit-exact against the oracle either way (sums on the
+    32-bit torus do not depend on the order)."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
     ea = rng.integers(-2**31, 2**31, shape * 1024, dtype=np.int64).astype(np.int32)

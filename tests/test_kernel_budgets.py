@@ -32,9 +32,8 @@ TFHE_BUDGETS = {
     "22k_tfhe_blind_rotate_fpE": (3, 0),       # FP64 blind rotate: three workgroups per CU (<= 168 registers AND
                                                # <= 53 KiB of LDS, checked below) -- round 4's 77.8 -> 90 k gates/s
     "19k_tfhe_blind_rotateE": (2, 0),          # integer blind rotate (keys beyond int32)
-    "28k_tfhe_key_switching_batchedILi8EE": (3, 0),   # many gates: three resident workgroups per CU is what the
-    "28k_tfhe_key_switching_batchedILi12EE": (3, 0),  # one-round choice of gates per workgroup counts on
-    "28k_tfhe_key_switching_batchedILi16EE": (3, 0),
+    "28k_tfhe_key_switching_batchedILi16ELb0EE": (3, 0),  # from 48 gates per call: 16 gates per workgroup, three
+    "28k_tfhe_key_switching_batchedILi16ELb1EE": (3, 0),  # workgroups per CU (one piece / several pieces)
     "20k_tfhe_key_switchingILb0EE": (4, 0),
     "20k_tfhe_key_switchingILb1EE": (4, 0),
 }
