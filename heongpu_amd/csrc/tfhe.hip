@@ -415,7 +415,7 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
 __device__ __forceinline__ u32 f_low32(double v) { return (u32) as_bits(v + 6755399441055744.0); }
 
 // Boot key conversion: one wavefront per polynomial.  src: reference layout,
-// NTT domain mod q (slot order); dst: [poly][half][k][lane] doubles = forward
+// NTT domain mod q (slot order); dst: [poly][half][k / 2][lane][k & 1] doubles = forward
 // NTT mod p' of the lo / hi halves of the int32 coefficients, centred.  Sets
 // *bad when a coefficient does not fit int32.
 __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __restrict__ src, u64* __restrict__ dst,
@@ -451,11 +451,12 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
     if (oob) atomicOr(bad, 1);
     fwave_ntt1024(lo, buf, p.ftw, p.ftw, fc, lane);
     fwave_ntt1024(hi, buf, p.ftw, p.ftw, fc, lane);
+    // [k / 2][lane][k & 1]: a lane's slots 16 lane + k, two per 16-byte load, 64 lanes contiguous (1 KiB per load)
     u64* d = dst + pi * 2 * TF_N;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        d[k * 64 + lane] = as_bits(lo[k]);
-        d[TF_N + k * 64 + lane] = as_bits(hi[k]);
+        d[(k >> 1) * 128 + lane * 2 + (k & 1)] = as_bits(lo[k]);
+        d[TF_N + (k >> 1) * 128 + lane * 2 + (k & 1)] = as_bits(hi[k]);
     }
 }
 
@@ -639,15 +640,19 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int shift = 32 - 10 * (z + 1);
     const int cc = wv >> 1, sh = (wv & 1) ? 16 : 0;
     for (int i = 0; i < n; i++) {
-        // key polynomial r = (digit wavefront (wv + r) & 3, output wv): [(i, digit)][o = wv][k][lane]
-        const u64* bkp = bk + ((u64) i * 16 + wv) * TF_N + lane;
+        // key polynomial r = (digit wavefront (wv + r) & 3, output wv): [(i, digit)][o = wv][k / 2][lane][k & 1]
+        const ulonglong2* bkp = reinterpret_cast<const ulonglong2*>(bk + ((u64) i * 16 + wv) * TF_N) + lane;
         // the first key polynomial is requested ahead of the decomposition and arrives under the forward transform;
         // the other three are loaded where they are used -- with three waves per SIMD their latency is covered by
         // the other workgroups (measured: no prefetch at all is as fast at 8192 gates, a rolling two-polynomial
         // prefetch needs 168 + 21 spilled registers and is slower: profiles/r4_c5/README.md)
         double ka[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + 0) & 3) * 4) * TF_N + k * 64]);
+        for (int k = 0; k < 8; k++) {
+            const ulonglong2 v = bkp[(u64) (((wv + 0) & 3) * 4) * (TF_N / 2) + k * 64];
+            ka[2 * k] = as_f64(v.x);
+            ka[2 * k + 1] = as_f64(v.y);
+        }
         const int aN = modswitch(in_a[(u64) g * n + i], 10);
         double x[16];
 #pragma unroll
@@ -675,7 +680,11 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
         for (int r = 1; r < 4; r++) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) ka[k] = as_f64(bkp[(u64) (((wv + r) & 3) * 4) * TF_N + k * 64]);
+            for (int k = 0; k < 8; k++) {
+                const ulonglong2 v = bkp[(u64) (((wv + r) & 3) * 4) * (TF_N / 2) + k * 64];
+                ka[2 * k] = as_f64(v.x);
+                ka[2 * k + 1] = as_f64(v.y);
+            }
             const u64* ob = &buf[(wv + r) & 3][lane];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
