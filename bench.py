@@ -83,6 +83,17 @@ def parse_args(argv=None):
                     help="--gpus N in one process: a thread and a context per device, hegpu_broadcast_bytes")
     ap.add_argument("--force-launch-failure", action="store_true",
                     help="testing: pretend the launch of the ranks failed (exercises the single-process fallback)")
+    ap.add_argument("--allow-shared-devices", action="store_true",
+                    help="let --gpus N run with fewer visible devices than ranks (functional check on a 1-GPU box): the line then "
+                         "reports n_gpus = distinct devices and ranks = N")
+    ap.add_argument("--preflight", action="store_true",
+                    help="no timing: print the device count, the peer-access matrix, the RCCL version and which of the three "
+                         "multi-GPU tiers --gpus N would take on this node")
+    ap.add_argument("--detail", default=None,
+                    help="where the full detail of the run goes (default gpurun_out/bench_detail.json); stdout carries only the "
+                         "compact contract line")
+    ap.add_argument("--compact-from", default=None,
+                    help="no GPU work: read a detail file and print the compact contract line built from it")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: exercise launch, sharding, key replication and the max-over-ranks reduction on CPU")
     a = ap.parse_args(argv)
@@ -539,15 +550,203 @@ class C5:
 WORKLOADS = {"c4": C4, "c5": C5}
 
 
-def line_skeleton(args, work, world, value, elapsed, per_rank, parallelism):
+def line_skeleton(args, work, world, value, elapsed, per_rank, parallelism, distinct_devices):
+    """`n_gpus` is the number of DISTINCT devices the ranks ran on; `ranks` the number of ranks (they differ only under
+    --allow-shared-devices, where the line is a functional check and not an N-GPU point)"""
     metric, config = work.describe(args, world)
     config["parallelism"] = parallelism
     return {
-        "metric": metric, "value": value, "unit": work.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric, "value": value, "unit": work.unit, "n_gpus": distinct_devices, "ranks": world,
+        "distinct_devices": distinct_devices, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64" if work.name == "c4" else "f64 (exact integer arithmetic modulo a 44-bit prime) / i32 torus",
         "data": "synthetic", "config": config, "per_rank_units_per_s": per_rank,
     }
+
+
+# ------------------------------------------------------------------ what goes to stdout: one compact contract line
+COMPACT_LIMIT = 4096   # bytes; the driver keeps the last 8 KB of stdout and parses its last line (VERDICT r4: a 21 KB line was lost)
+DETAIL_DEFAULT = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the compact line is for reading and for the driver's checks, the detail file
+    keeps every digit)"""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float("%.*g" % (sig, v))
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+# per secondary workload: (key of the one rate that goes into the compact line, where its as-built block lives)
+SECONDARY_RATE = {"bfv_n14_multiply": ("multiplications_per_s", "as_built"), "c3_bfv_n15_rotate": ("rotations_per_s", "as_built"),
+                  "c2_ckks_n14": ("ops_per_s_batch64", "as_built_batch64"), "ckks_n16_method_II": ("multiply_relinearize_per_s", "as_built"),
+                  "c5_tfhe_gates": ("gates_per_s", "as_built")}
+
+
+def _all_true(chk, key):
+    """checked_items blocks are flat or one level deep (per batch size): every `key` in there is true"""
+    if not isinstance(chk, dict):
+        return None
+    if key in chk:
+        return bool(chk[key])
+    vals = [v[key] for v in chk.values() if isinstance(v, dict) and key in v]
+    return all(vals) if vals else None
+
+
+def compact_line(d, detail_path=None):
+    """The contract line (task statement + VERDICT r4 item 1) from the full detail of a run: the headline, `roofline`,
+    `cpu_baseline`, `checked_items` and ONE rate + binding ceiling + verification flags per secondary workload.  Kernel
+    lists, replayed counters and per-group accounting stay in the detail file and in profiles/profile.json."""
+    c = {k: _r(d[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data") if k in d}
+    for k in ("ranks", "distinct_devices", "key_broadcast_ms", "key_bytes"):
+        if k in d:
+            c[k] = _r(d[k])
+    cfg = d.get("config") or {}
+    c["config"] = {k: (_clip(v, 260) if k in ("workload", "parallelism") else v) for k, v in cfg.items()}
+    if "per_rank_units_per_s" in d and len(d["per_rank_units_per_s"]) > 1:
+        c["per_rank_units_per_s"] = [_r(v, 4) for v in d["per_rank_units_per_s"]]
+    rf = d.get("roofline")
+    if rf:
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes_per_launch"))
+        r["traffic_source"] = _clip(rf.get("traffic_source"), 90)
+        pair = rf.get("launch_pair") or {}
+        r["traffic_over_algorithmic"] = _r(pair.get("traffic_over_algorithmic"))
+        r["frac_of_copy_ceiling"] = _r(((pair.get("from_profile") or {}).get("frac_of_copy_ceiling")))
+        st = rf.get("step") or {}
+        r["step"] = _pick(st, ("achieved_GBps", "frac_of_hbm_peak_as_built", "bound"))
+        r["in_step_dominant"] = _pick(rf.get("in_step_dominant") or {}, ("launches", "ms", "bound", "frac_of_binding_ceiling"))
+        r["profile_dir"] = ((pair.get("from_profile") or st.get("from_profile") or {}).get("dir"))
+        c["roofline"] = r
+    if "as_built" in d:  # the C5 headline
+        ab = d["as_built"]
+        c["as_built"] = _pick(ab, ("bound", "frac_of_binding_ceiling", "achieved_GBps", "live_over_profile_ms"))
+    if "ntt" in d:
+        c["ntt"] = _pick(d["ntt"], ("forward_GBps", "inverse_GBps", "n", "limbs"))
+    if "ntt_by_degree" in d:
+        c["ntt_forward_frac_by_degree"] = {k: _r(v.get("forward_frac"), 3) for k, v in d["ntt_by_degree"].items()}
+    if d.get("power"):
+        c["power"] = _pick(d["power"], ("package_w", "package_limit_w", "sclk_mhz"))
+    if "checked_items" in d:
+        c["checked_items"] = {k: v for k, v in d["checked_items"].items() if k != "note"}
+    sec = {}
+    for name, e in (d.get("secondary") or {}).items():
+        if name == "hoisted_rotations":
+            k8 = (e.get("by_k") or {}).get("8") or {}
+            sec[name] = {"hoisted_rotations_per_s_k8": _r(k8.get("hoisted_rotations_per_s")),
+                         "separate_rotations_per_s_k8": _r(k8.get("separate_rotations_per_s")),
+                         "hoisted_equals_separate": all(v.get("hoisted_equals_separate") for v in (e.get("by_k") or {}).values())}
+            continue
+        rate_key, ab_key = SECONDARY_RATE.get(name, (None, "as_built"))
+        ab = e.get(ab_key) or {}
+        s = {rate_key: _r(e.get(rate_key))} if rate_key else {}
+        if name == "c2_ckks_n14":
+            s["latency_us_batch1"] = _r(e.get("latency_us_batch1"))
+        s["bound"] = _clip(ab.get("bound"), 48)
+        s["frac_of_binding_ceiling"] = _r(ab.get("frac_of_binding_ceiling"), 3)
+        s["oracle_equal"] = _all_true(e.get("checked_items"), "oracle_equal")
+        s["twins_equal"] = _all_true(e.get("checked_items"), "twins_equal")
+        sec[name] = s
+    if sec:
+        c["secondary"] = sec
+    cb = d.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "threads_busy", "kind", "gpu_matches_cpu_bit_exact", "gpu_items_compared"))
+        c["cpu_baseline"]["sample"] = _clip(cb.get("sample"), 200)
+    if detail_path:
+        c["detail"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+    text = json.dumps(c)
+    if len(text) > COMPACT_LIMIT:  # never again a line the driver cannot hold: drop what is optional, keep the contract
+        for k in ("secondary", "ntt_forward_frac_by_degree", "power", "ntt", "per_rank_units_per_s"):
+            c.pop(k, None)
+            text = json.dumps(c)
+            if len(text) <= COMPACT_LIMIT:
+                break
+    return text
+
+
+def emit(line, args):
+    """Full detail to a file (merged back from the GPU box under gpurun_out/), the compact contract line -- and nothing
+    else -- as the LAST line of stdout."""
+    path = args.detail or DETAIL_DEFAULT
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+    except OSError as e:   # a read-only tree must not cost the line
+        print("bench.py: could not write the detail file %s: %s" % (path, e), file=sys.stderr)
+        path = None
+    sys.stdout.flush()
+    print(compact_line(line, path), flush=True)
+
+
+# ------------------------------------------------------------------ which path a command line takes (pure; CPU-testable)
+def plan_run(gpus, env, device_count, single_process=False, allow_shared=False):
+    """What `bench.py --gpus N` does given the launcher's environment and the visible devices -- no side effects.
+      mode: "rank" (this process is one rank: plain N=1, or under torch.distributed.run), "self_launch" (start N ranks),
+            "single_process" (one thread per device), "refuse" (with `why`)
+      full_line: the rank-0 process also runs the roofline / secondary / cpu_baseline legs (N=1 only -- with or without a launcher)
+      distinct_devices / n_gpus: ranks beyond the visible devices share devices; the line reports the DISTINCT devices as
+      n_gpus and the rank count as `ranks`, and only with --allow-shared-devices."""
+    under = "WORLD_SIZE" in env
+    world = int(env.get("WORLD_SIZE", "1")) if under else (1 if gpus == 1 else gpus)
+    rank = int(env.get("RANK", "0")) if under else 0
+    local = int(env.get("LOCAL_RANK", "0")) if under else 0
+    p = {"mode": "rank", "world": world, "rank": rank, "under_launcher": under, "why": None}
+    if under and world != gpus:
+        return dict(p, mode="refuse", why="world size %d (WORLD_SIZE) does not match --gpus %d" % (world, gpus))
+    if device_count is not None:
+        if device_count < 1:
+            return dict(p, mode="refuse", why="bench.py needs a HIP device (there is no CPU fallback)")
+        distinct = min(gpus, device_count)
+        if distinct < gpus and not allow_shared:
+            return dict(p, mode="refuse", why="--gpus %d but %d visible device(s): ranks would share devices and the line would not be a "
+                                              "%d-GPU point; pass --allow-shared-devices for a functional check" % (gpus, device_count, gpus))
+        p.update(distinct_devices=distinct, n_gpus=distinct, ranks=gpus, dev_index=local % device_count)
+    if not under and gpus > 1:
+        p["mode"] = "single_process" if single_process else "self_launch"
+    p["full_line"] = (world == 1 and rank == 0)
+    return p
+
+
+def preflight(args):
+    """`--preflight`: what a multi-GPU run would find on this node, without timing anything."""
+    import torch
+    rep = {"preflight": True, "gpus_requested": args.gpus, "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    rep["visible_devices"] = ndev
+    rep["device_names"] = [torch.cuda.get_device_name(i) for i in range(ndev)]
+    rep["peer_access"] = [[(i == j) or bool(torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)]
+    try:
+        rep["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        rep["rccl_version"] = "unavailable (%s)" % str(e)[:80]
+    import torch.distributed as dist
+    rep["torch_distributed_backends"] = {"nccl": bool(dist.is_nccl_available()), "gloo": bool(dist.is_gloo_available())}
+    plan = plan_run(args.gpus, {}, ndev, args.single_process, args.allow_shared_devices)
+    rep["plan"] = plan
+    if plan["mode"] == "refuse":
+        rep["tier"] = "none: " + plan["why"]
+    elif args.gpus == 1:
+        rep["tier"] = "one rank, no replication"
+    elif plan["mode"] == "single_process":
+        all_peer = all(all(r) for r in rep["peer_access"])
+        rep["tier"] = "3: one process, a thread per device, hegpu_broadcast_bytes (%s)" % ("flat peer fan-out" if all_peer else "chunked tree / staged edges")
+    else:
+        rep["tier"] = ("1: one process per GPU, RCCL broadcast of the keys over xGMI (falls to tier 2, gloo host staging, if the RCCL "
+                       "probe all-reduce does not answer within %d s; to tier 3 if the launch itself fails)" % NCCL_TIMEOUT_S)
+        if plan.get("distinct_devices", args.gpus) < args.gpus:
+            rep["tier"] += "; ranks share devices: RCCL refuses two ranks on one device (ncclInvalidUsage) -> tier 2"
+    print(json.dumps(rep))
+    return 0
 
 
 # ------------------------------------------------------------------ one process, N devices (fallback 3)
@@ -561,6 +760,9 @@ def run_single_process(args, reason):
     W = WORKLOADS[args.workload]
     world = args.gpus
     ndev = torch.cuda.device_count()
+    plan = plan_run(args.gpus, {}, ndev, True, args.allow_shared_devices)
+    if plan["mode"] == "refuse":
+        raise SystemExit("bench.py: " + plan["why"])
     devs = [torch.device("cuda", r % ndev) for r in range(world)]
     ctxs = W.contexts(hg, world)
     works, streams = [], []
@@ -615,7 +817,7 @@ def run_single_process(args, reason):
     line = line_skeleton(args, works[0], world, value, elapsed, [w.B * args.steps / o for w, o in zip(works, own)],
                          "sharded x%d in ONE process: a thread, a stream and a context per device, keys replicated with "
                          "hegpu_broadcast_bytes -- %s; fallback because %s; %d visible device(s)"
-                         % (world, hg.broadcast_path_name(paths[0]), reason, ndev))
+                         % (world, hg.broadcast_path_name(paths[0]), reason, ndev), plan["distinct_devices"])
     line["key_broadcast_ms"] = bcast_ms
     line["key_broadcast_path"] = paths
     line["key_bytes"] = sum(t.numel() * t.element_size() for t in works[0].replicated())
@@ -624,7 +826,7 @@ def run_single_process(args, reason):
     line["checked_items"] = {"twin_compared": sum(t[0] for t in tw), "twins_equal": all(t[1] for t in tw),
                              "key_replicas_equal": same_key, "oracle_compared": 0,
                              "note": "multi-GPU run: the oracle comparison is part of the N=1 line"}
-    print(json.dumps(line))
+    emit(line, args)
     return 0 if (all(t[1] for t in tw) and same_key) else 1
 
 
@@ -998,11 +1200,12 @@ def run_rank(args):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: world size %d (WORLD_SIZE) does not match --gpus %d" % (world, args.gpus))
-    # one process per GPU; on a box with fewer devices than ranks (a functional check on one GPU) ranks share devices
-    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    plan = plan_run(args.gpus, os.environ, torch.cuda.device_count(), False, args.allow_shared_devices)
+    if plan["mode"] == "refuse":
+        raise SystemExit("bench.py: " + plan["why"])
+    world, rank = plan["world"], plan["rank"]
+    # one process per GPU; with --allow-shared-devices on a box with fewer devices than ranks, ranks share devices
+    dev_index = plan["dev_index"]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = Dist(torch, world, rank, args.backend)
@@ -1037,18 +1240,21 @@ def run_rank(args):
 
     parallelism = "sharded x%d, one process per GPU (gloo control plane), key broadcast: %s; no data-path collective" \
         % (world, dist.key_path)
-    line = line_skeleton(args, work, world, value, elapsed, per_rank, parallelism)
+    if plan["distinct_devices"] < world:
+        parallelism += "; %d ranks SHARE %d device(s) (--allow-shared-devices: functional check, not an N-GPU point)" \
+            % (world, plan["distinct_devices"])
+    line = line_skeleton(args, work, world, value, elapsed, per_rank, parallelism, plan["distinct_devices"])
     if bcast_ms is not None:
         line["key_broadcast_ms"] = bcast_ms
         line["key_bytes"] = sum(t.numel() * t.element_size() for t in work.replicated())
     line["checked_items"] = {"distinct_inputs": getattr(work, "uniq", TFHE_UNIQ), "twin_compared": int(sum(max(t, 0) for t in tw_all)),
                              "twins_equal": all(t >= 0 for t in tw_all), "oracle_compared": 0}
 
-    if args.step_only or rank != 0 or world > 1:
+    if args.step_only or not plan["full_line"]:
         if rank == 0:
             if world > 1:
                 line["checked_items"]["note"] = "multi-GPU run: the oracle comparison is part of the N=1 line"
-            print(json.dumps(line))
+            emit(line, args)
         rc = 0 if line["checked_items"]["twins_equal"] else 1
         dist.close(rc)
         return rc
@@ -1066,7 +1272,7 @@ def run_rank(args):
             line["cpu_baseline"] = {"value": n_chk / cpu_s, "unit": work.unit, "cores": ob.lib().o_omp_threads(), "kind": "port",
                                     "sample": "%d gates of the same workload, CPU oracle (includes its own key preparation), %.1f s" % (n_chk, cpu_s),
                                     "gpu_matches_cpu_bit_exact": ok}
-        print(json.dumps(line))
+        emit(line, args)
         dist.close()
         return 0 if (line["checked_items"]["twins_equal"] and line["checked_items"].get("oracle_equal", True)) else 1
 
@@ -1188,7 +1394,7 @@ def run_rank(args):
                       "as on the GPU), CPU oracle, OpenMP over the pairs on %d threads, %.1f s" % (sample, uniq, threads, cpu_s),
             "gpu_matches_cpu_bit_exact": all(equal), "gpu_items_compared": sample,
         }
-    print(json.dumps(line))
+    emit(line, args)
     dist.close()
     ok = line["checked_items"]["twins_equal"] and line["checked_items"].get("oracle_equal", True)
     return 0 if ok else 1
@@ -1203,9 +1409,20 @@ def main():
                 raise SystemExit(0)
             print("bench.py: the launch of %d ranks failed (rc %d): single-process path" % (args.gpus, rc), file=sys.stderr)
         raise SystemExit(launcher_selftest(args))
+    if args.compact_from:
+        with open(args.compact_from) as f:
+            print(compact_line(json.load(f), args.compact_from))
+        raise SystemExit(0)
+    if args.preflight:
+        raise SystemExit(preflight(args))
     if args.profile_workload:
         raise SystemExit(run_profile_workload(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        plan = plan_run(args.gpus, {}, torch.cuda.device_count() if torch.cuda.is_available() else 0, args.single_process,
+                        args.allow_shared_devices)
+        if plan["mode"] == "refuse":   # before any rank starts: fewer devices than ranks is not an N-GPU point
+            raise SystemExit("bench.py: " + plan["why"])
         reason = "--single-process"
         if not args.single_process:
             rc = self_launch(args)

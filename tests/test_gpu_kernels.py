@@ -738,10 +738,17 @@ def test_bench_line_proves_its_own_work():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-secondary"],
-                       capture_output=True, text=True, timeout=900)
+    detail = os.path.join(root, "gpurun_out", "bench_detail_test.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-secondary",
+                        "--detail", detail], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # as the driver reads it: the last 8000 characters of stdout, the last line that starts with `{`
+    text = [ln for ln in r.stdout[-8000:].splitlines() if ln.startswith("{")][-1]
+    assert len(text) < 4096 and r.stdout.rstrip().endswith(text), len(text)
+    line = json.loads(text)
+    full = json.load(open(detail))
+    assert full["value"] == pytest.approx(line["value"], rel=1e-4) and "in_step" in full and "in_step" not in line
+    assert line["distinct_devices"] == 1 and line["ranks"] == 1
     assert line["cpu_baseline"]["gpu_matches_cpu_bit_exact"] and line["cpu_baseline"]["kind"] == "port"
     chk = line["checked_items"]
     assert chk["oracle_equal"] and chk["twins_equal"] and chk["total"] == 64 and chk["oracle_compared"] >= 2
