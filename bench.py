@@ -447,18 +447,16 @@ def c4_host_inputs(primes, l, n, uniq):
 
 
 # ------------------------------------------------------------------ the C5 workload on one device
-def tfhe_host_material(seed=1):
-    """Seeded key material and inputs of the C5 workload (numpy): a torus32 boot key as constant polynomials (the NTT
-    image of a constant is the constant in every slot, so no transform is needed to build a valid NTT-domain key), the
-    key-switch key, TFHE_UNIQ distinct gate inputs."""
-    rng = np.random.default_rng(seed)
-    r32 = lambda k: rng.integers(-2**31, 2**31, k, dtype=np.int64).astype(np.int32)
-    return rng, r32
+TFHE_SEED = 2025   # DRBG seed of the C5 key material and inputs (the secret key is re-derived from it on every rank)
 
 
 class C5:
     """TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch): `S` gates of
-    one rank resident on `dev`; gate b of the global batch has the inputs of distinct index (first + b) % TFHE_UNIQ."""
+    one rank resident on `dev`; gate b of the global batch has the inputs of distinct index (first + b) % TFHE_UNIQ.
+    REAL key material from the backend's own key generator (hegpu_tfhe_generate_secret_key / _bootstrapping_key, seeded
+    DRBG): a torus32 boot key with random polynomials in every slot (round 4's constant polynomials could not
+    have shown a slot-order bug of the prepared layout), inputs are real encryptions of TFHE_UNIQ random bit pairs, so every
+    output of the timed batch is also DECRYPTED and compared with NAND of its input bits."""
     name, unit = "c5", "gate bootstraps/s"
 
     def __init__(self, torch, hg, dev, first, S, ctx=None):
@@ -467,45 +465,57 @@ class C5:
         with torch.cuda.device(dev):
             self.t = ctx if ctx is not None else hg.TfheContext()
             t = self.t
-            rng, r32 = tfhe_host_material()
-            self.polys = t.int("bootkey_elems") // 1024
-            self.bk_v = rng.integers(-2**31, 2**31, self.polys, dtype=np.int64)
-            self.ks_a_h, self.ks_b_h = r32(t.int("kskey_a_elems")), r32(t.int("kskey_b_elems"))
             U = TFHE_UNIQ
-            self.a1u, self.a2u, self.b1u, self.b2u = r32(U * 512), r32(U * 512), r32(U), r32(U)
+            # the same secret key on every rank (deterministic from the seed: the first two DRBG streams); the boot key and
+            # the key-switch key -- the big, random part -- are made on rank 0 only and replicated
+            self.rng = hg.Rng(TFHE_SEED)
+            self.lwe, self.tlwe = t.generate_secret_key(self.rng)
+            bits = np.random.default_rng(TFHE_SEED)
+            self.x_u, self.y_u = bits.integers(0, 2, U), bits.integers(0, 2, U)
+            mu = 1 << 29
+            enc = lambda v: torch.from_numpy(np.where(v == 1, mu, -mu).astype(np.int32)).to(dev)
+            in_rng = hg.Rng(TFHE_SEED + 1)   # inputs: their own streams, identical on every rank
+            a1u, b1u = t.encrypt(in_rng, self.lwe, enc(self.x_u))
+            a2u, b2u = t.encrypt(in_rng, self.lwe, enc(self.y_u))
+            self.a1u, self.a2u = a1u.cpu().numpy(), a2u.cpu().numpy()
+            self.b1u, self.b2u = b1u.cpu().numpy(), b2u.cpu().numpy()
             idx = (first + np.arange(S)) % U
             self.idx = idx
-            cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            self.a1, self.a2 = cu(self.a1u.reshape(U, 512)[idx].reshape(-1)), cu(self.a2u.reshape(U, 512)[idx].reshape(-1))
-            self.b1, self.b2 = cu(self.b1u[idx]), cu(self.b2u[idx])
+            it = torch.from_numpy(idx).to(dev)
+            self.a1, self.a2 = a1u.view(U, 512)[it].reshape(-1).contiguous(), a2u.view(U, 512)[it].reshape(-1).contiguous()
+            self.b1, self.b2 = b1u[it].contiguous(), b2u[it].contiguous()
             self.prepared = torch.empty(t.int("prepared_bootkey_elems"), dtype=torch.int64, device=dev)
             self.ks_a = torch.empty(t.int("kskey_a_elems"), dtype=torch.int32, device=dev)
             self.ks_b = torch.empty(t.int("kskey_b_elems"), dtype=torch.int32, device=dev)
             self.out_a = torch.empty(S * 512, dtype=torch.int32, device=dev)
             self.out_b = torch.empty(S, dtype=torch.int32, device=dev)
             self.ws = torch.empty((512 + 1024 + 2) * S, dtype=torch.int32, device=dev)
-            # the first device call of a TFHE context places its tables on the calling thread's current device
-            t.gate_precompute(hg.GATE_NOT, self.out_a, self.out_b, self.a1, self.b1, None, None, 0)
+            self.bk_host = None   # reference-layout boot key on the host (rank 0, for the CPU checker)
 
     @staticmethod
     def contexts(hg, world):
         return [hg.TfheContext() for _ in range(world)]
 
-    def bootkey_host(self):
-        lifted = np.where(self.bk_v < 0, self.bk_v + self.t.prime, self.bk_v).astype(np.uint64)
-        return np.repeat(lifted, 1024)
-
     def replicated(self):
         return [self.prepared, self.ks_a, self.ks_b]
 
     def make_keys(self):
+        torch, t = self.torch, self.t
+        with torch.cuda.device(self.dev):
+            bk, ks_a, ks_b = t.generate_bootstrapping_key(self.rng, self.lwe, self.tlwe)
+            self.prepared.copy_(t.prepare_bootkey(bk))
+            self.ks_a.copy_(ks_a)
+            self.ks_b.copy_(ks_b)
+            self.bk_host = bk.cpu().numpy().view(np.uint64)
+            self.ks_a_h, self.ks_b_h = ks_a.cpu().numpy(), ks_b.cpu().numpy()
+
+    def decrypt_check(self):
+        """every gate of the timed batch decrypted with the secret key: NAND of its two input bits?"""
         torch = self.torch
         with torch.cuda.device(self.dev):
-            bk = torch.from_numpy(self.bootkey_host().view(np.int64)).to(self.dev)
-            self.prepared.copy_(self.t.prepare_bootkey(bk))
-            self.ks_a.copy_(torch.from_numpy(self.ks_a_h).to(self.dev))
-            self.ks_b.copy_(torch.from_numpy(self.ks_b_h).to(self.dev))
-            self.t.prepared_format(self.prepared, refresh=True)  # this buffer now holds a key this context did not prepare in place
+            got = (self.t.decrypt_phase(self.lwe, self.out_a, self.out_b).cpu().numpy() > 0).astype(np.int64)
+        want = 1 - (self.x_u[self.idx] & self.y_u[self.idx])
+        return int(self.S), bool(np.array_equal(got, want))
 
     def step(self, stream):
         self.t.gate(self.hg.GATE_NAND, self.a1, self.b1, self.a2, self.b2, self.out_a, self.out_b, self.prepared, self.ks_a,
@@ -530,7 +540,7 @@ class C5:
         a1 = self.a1u.reshape(-1, 512)[sel].reshape(-1)
         a2 = self.a2u.reshape(-1, 512)[sel].reshape(-1)
         t0 = time.perf_counter()
-        want_a, want_b = ot.gate(self.hg.GATE_NAND, a1, self.b1u[sel], a2, self.b2u[sel], self.bootkey_host(), self.ks_a_h,
+        want_a, want_b = ot.gate(self.hg.GATE_NAND, a1, self.b1u[sel], a2, self.b2u[sel], self.bk_host, self.ks_a_h,
                                  self.ks_b_h)
         cpu_s = time.perf_counter() - t0
         ga = self.out_a.view(self.S, 512)[:count].cpu().numpy().reshape(-1)
@@ -541,7 +551,7 @@ class C5:
         return ("TFHE STD128 gate bootstraps/sec (NAND, blind-rotate PBS, n=512, N=1024)", {
             "workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
                         "%d concurrent gates per GPU per step (global batch %d sharded along `shape` by contiguous slices, %d "
-                        "distinct inputs), torus32 boot key (FP64 blind rotate), keys resident in HBM"
+                        "distinct encrypted bit pairs), generated torus32 boot key (FP64 blind rotate), keys resident in HBM"
                         % (args.batch, args.batch * world, TFHE_UNIQ),
             "gates_per_gpu": args.batch, "global_batch": args.batch * world,
             "replicated_bytes": sum(t.numel() * t.element_size() for t in self.replicated())})
@@ -654,6 +664,8 @@ def compact_line(d, detail_path=None):
         s["frac_of_binding_ceiling"] = _r(ab.get("frac_of_binding_ceiling"), 3)
         s["oracle_equal"] = _all_true(e.get("checked_items"), "oracle_equal")
         s["twins_equal"] = _all_true(e.get("checked_items"), "twins_equal")
+        if _all_true(e.get("checked_items"), "decrypt_equal") is not None:
+            s["decrypt_equal"] = _all_true(e.get("checked_items"), "decrypt_equal")
         sec[name] = s
     if sec:
         c["secondary"] = sec
@@ -826,8 +838,13 @@ def run_single_process(args, reason):
     line["checked_items"] = {"twin_compared": sum(t[0] for t in tw), "twins_equal": all(t[1] for t in tw),
                              "key_replicas_equal": same_key, "oracle_compared": 0,
                              "note": "multi-GPU run: the oracle comparison is part of the N=1 line"}
+    dec_ok = True
+    if hasattr(works[0], "decrypt_check"):
+        dec = [w.decrypt_check() for w in works]
+        dec_ok = all(d[1] for d in dec)
+        line["checked_items"].update(decrypt_compared=sum(d[0] for d in dec), decrypt_equal=dec_ok)
     emit(line, args)
-    return 0 if (all(t[1] for t in tw) and same_key) else 1
+    return 0 if (all(t[1] for t in tw) and same_key and dec_ok) else 1
 
 
 # ------------------------------------------------------------------ secondary workloads (N=1 only)
@@ -1088,17 +1105,18 @@ def sec_c5(torch, hg, prof):
         g = timer.ms(run, 2)
         tw = work.twins()
         ok, _ = work.oracle_check(TCHK)
+        dn, dok = work.decrypt_check()
         ab = prof_group(prof, "c5_tfhe_gates", g)
         ab["blind_rotate"] = prof_group(prof, "c5_tfhe_gates", g, match=["k_tfhe_blind_rotate"])
         ab["blind_rotate"].pop("achieved_GBps", None)  # the live time is the whole gate's, not this kernel's
         e = {"workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
-                         "%d concurrent gates (%d distinct inputs), torus32 boot key (FP64 blind rotate)" % (S, TFHE_UNIQ),
+                         "%d concurrent gates (%d distinct encrypted bit pairs), generated torus32 boot key (FP64 blind rotate)" % (S, TFHE_UNIQ),
              "gates_per_s": S / (g * 1e-3), "ms_per_batch": g,
              "reference_sequence_bytes_per_gate": 72 * (1 << 20),
              "reference_sequence_bytes_rate_GBps": 72 * (1 << 20) * S / (g * 1e-3) / 1e9,
              "note": "the accumulator of a gate never leaves LDS: the reference-sequence rate is the rate the reference's "
                      "1024 launches per gate would have to move THEIR 72 MiB at, not bytes this kernel moves",
-             "as_built": ab, "checked_items": check_line(tw, ok, TCHK)}
+             "as_built": ab, "checked_items": dict(check_line(tw, ok, TCHK), decrypt_compared=dn, decrypt_equal=dok)}
         return "c5_tfhe_gates", e
     return Sec({"c5_tfhe_gates": (run, S)}, entry, work.t.close)
 
@@ -1215,8 +1233,6 @@ def run_rank(args):
     if rank == 0:
         work.make_keys()   # produced on the device (C4: 272 MiB; C5: 64 + 48 MiB)
     bcast_ms = dist.broadcast_keys(work.replicated(), dev)
-    if world > 1 and args.workload == "c5":
-        work.t.prepared_format(work.prepared, refresh=True)  # the replica's layout is read from its header, once
     stream = torch.cuda.current_stream().cuda_stream
     step = lambda: work.step(stream)
 
@@ -1236,6 +1252,10 @@ def run_rank(args):
     per_rank = dist.gather_floats(B * args.steps / own_elapsed)
     tw_n, tw_ok = work.twins()
     tw_all = dist.gather_floats(float(tw_n if tw_ok else -1))
+    dec_all = None
+    if hasattr(work, "decrypt_check"):   # C5: every output decrypted with the secret key, on every rank
+        dn, dok = work.decrypt_check()
+        dec_all = dist.gather_floats(float(dn if dok else -1))
     value = args.batch * world * args.steps / elapsed
 
     parallelism = "sharded x%d, one process per GPU (gloo control plane), key broadcast: %s; no data-path collective" \
@@ -1249,13 +1269,15 @@ def run_rank(args):
         line["key_bytes"] = sum(t.numel() * t.element_size() for t in work.replicated())
     line["checked_items"] = {"distinct_inputs": getattr(work, "uniq", TFHE_UNIQ), "twin_compared": int(sum(max(t, 0) for t in tw_all)),
                              "twins_equal": all(t >= 0 for t in tw_all), "oracle_compared": 0}
+    if dec_all is not None:
+        line["checked_items"].update(decrypt_compared=int(sum(max(t, 0) for t in dec_all)), decrypt_equal=all(t >= 0 for t in dec_all))
 
     if args.step_only or not plan["full_line"]:
         if rank == 0:
             if world > 1:
                 line["checked_items"]["note"] = "multi-GPU run: the oracle comparison is part of the N=1 line"
             emit(line, args)
-        rc = 0 if line["checked_items"]["twins_equal"] else 1
+        rc = 0 if (line["checked_items"]["twins_equal"] and line["checked_items"].get("decrypt_equal", True)) else 1
         dist.close(rc)
         return rc
 
@@ -1274,7 +1296,8 @@ def run_rank(args):
                                     "gpu_matches_cpu_bit_exact": ok}
         emit(line, args)
         dist.close()
-        return 0 if (line["checked_items"]["twins_equal"] and line["checked_items"].get("oracle_equal", True)) else 1
+        chk = line["checked_items"]
+        return 0 if (chk["twins_equal"] and chk.get("oracle_equal", True) and chk.get("decrypt_equal", True)) else 1
 
     ctx = work.ctx
     Q, Qp, n = ctx.Q_size, ctx.Q_prime_size, N

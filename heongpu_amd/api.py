@@ -639,9 +639,10 @@ class TfheContext:
         return int(prepared[0].item()) == 1
 
     def prepared_format(self, prepared, refresh=False):
-        """1 = FP64 layout, 0 = integer layout, as this context will launch it (hegpu_tfhe_prepared_format)"""
+        """1 = FP64 layout, 0 = integer layout: the buffer's header word, read after the device has drained
+        (hegpu_tfhe_prepared_format; a query -- the blind rotate reads the word itself, on the device)"""
         f = self._lib.hegpu_tfhe_prepared_format(self._h, _ptr(prepared), 1 if refresh else 0)
-        if f < 0:
+        if f not in (0, 1):
             raise HEError(f, _lib.load().hegpu_last_error().decode())
         return f
 

@@ -831,6 +831,11 @@ static bool spans_overlap(const uint64_t* a, uint64_t a_stride, uint64_t a_item,
     const __int128 ai = (__int128) a_item * W, bi = (__int128) b_item * W;
     auto hit = [&](__int128 pa, __int128 pb) { return pa < pb + bi && pb < pa + ai; };
     if (batch == 1) return hit(a0, b0);
+    {   // the whole spans first: disjoint buffers (the common case) need no per-item test
+        const __int128 a1 = a0 + ((__int128) (batch - 1) * a_stride + a_item) * W;
+        const __int128 b1 = b0 + ((__int128) (batch - 1) * b_stride + b_item) * W;
+        if (!(a0 < b1 && b0 < a1)) return false;
+    }
     if (a_stride == b_stride) {
         const __int128 st = (__int128) a_stride * W;
         for (long k = -(long) (batch - 1); k <= (long) (batch - 1); k++)
@@ -843,9 +848,7 @@ static bool spans_overlap(const uint64_t* a, uint64_t a_stride, uint64_t a_item,
                 if (hit(a0 + (__int128) i * a_stride * W, b0 + (__int128) j * b_stride * W)) return true;
         return false;
     }
-    const __int128 a1 = a0 + ((__int128) (batch - 1) * a_stride + a_item) * W;
-    const __int128 b1 = b0 + ((__int128) (batch - 1) * b_stride + b_item) * W;
-    return a0 < b1 && b0 < a1;
+    return true; // beyond 1024 items with unequal strides: intersecting spans count as overlap (conservative)
 }
 
 int hegpu_ckks_apply_galois(hegpu_context* ctx, const uint64_t* ct, uint64_t cs, uint64_t* out, uint64_t so,
@@ -1336,11 +1339,10 @@ struct hegpu_tfhe_context {
     bool allow_fp = true;      // option "fp" = 0 keeps the integer blind rotate (read by hegpu_tfhe_prepare_bootkey)
     int ks_pieces = -1;        // option "ks_pieces": workgroups per gate (group) of the key switching, -1 by launch size
     int ks_batched = -1;       // option "ks_batched": key switching with 8 / 12 / 16 gates per workgroup sharing the key rows (tfhe.hip)
-    // layout of every prepared boot key this context has met (header word 0: 1 = FP64, 0 = integer): filled by
-    // hegpu_tfhe_prepare_bootkey; a buffer that arrived by other means (a peer copy from another device's context) is
-    // looked up once by reading its header word (prepared_format)
-    std::mutex fmt_mu;
-    std::unordered_map<const void*, int> fmt;
+    // The layout of a prepared boot key is its header word, read by the blind-rotate kernels themselves in stream order
+    // (tfhe.hip: tfhe_blind_rotate) -- nothing about a buffer is remembered on the host.  A buffer whose header is
+    // neither layout makes the kernel set this pinned word; the next entry of the context reports it (TFHE_NEED).
+    int* bad_key = nullptr;
     // tfhe/context.cu:39-42: ks_stdev = 2^-15 sqrt(2/pi), bk_stdev = 9e-9 sqrt(2/pi)
     double ks_stdev = (1.0 / 32768.0) * 0.7978845608028654, bk_stdev = 9e-9 * 0.7978845608028654;
 };
@@ -1436,6 +1438,7 @@ void hegpu_tfhe_context_destroy(hegpu_tfhe_context* ctx)
     if (ctx->ditw) (void) hipFree(ctx->ditw);
     if (ctx->dftw) (void) hipFree(ctx->dftw);
     if (ctx->dfitw) (void) hipFree(ctx->dfitw);
+    if (ctx->bad_key) (void) hipHostFree(ctx->bad_key);
     delete ctx;
 }
 
@@ -1464,7 +1467,12 @@ uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx) { return ctx ? ctx->p.m
 static int tfhe_need(hegpu_tfhe_context* ctx)
 {
     if (!ctx) return fail(HEGPU_E_INVALID, "null context");
-    if (ctx->uploaded) return 0;
+    if (ctx->uploaded) {
+        if (ctx->bad_key && __atomic_exchange_n(ctx->bad_key, 0, __ATOMIC_ACQ_REL))
+            return fail(HEGPU_E_INVALID, "an earlier bootstrapping call of this context was handed a buffer that is not a "
+                                         "prepared boot key (header word neither 0 nor 1): its outputs were not written");
+        return 0;
+    }
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
         (void) hipGetLastError();
@@ -1483,6 +1491,9 @@ static int tfhe_need(hegpu_tfhe_context* ctx)
     ctx->p.itw = ctx->ditw;
     ctx->p.ftw = ctx->dftw;
     ctx->p.fitw = ctx->dfitw;
+    if ((e = hipHostMalloc((void**) &ctx->bad_key, sizeof(int), hipHostMallocMapped)) != hipSuccess) return hip_ret(e, "tfhe upload");
+    *ctx->bad_key = 0;
+    ctx->p.bad_key = ctx->bad_key;
     (void) hipGetDevice(&ctx->device);
     ctx->uploaded = true;
     return 0;
@@ -1508,47 +1519,38 @@ int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key
     const TfheDev& p = ctx->p;
     const u64 polys = (u64) p.n * (p.k + 1) * p.bk_l * (p.k + 1);
     int fmt = -1;
-    hipError_t e = tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp, &fmt,
-                                        (hipStream_t) stream);
-    if (e == hipSuccess) {
-        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
-        ctx->fmt[prepared] = fmt;
-    }
-    return hip_ret(e, "hegpu_tfhe_prepare_bootkey");
+    return hip_ret(tfhe_prepare_bootkey(p, (const u64*) boot_key, (u64*) prepared, polys, ctx->allow_fp, &fmt,
+                                        (hipStream_t) stream),
+                   "hegpu_tfhe_prepare_bootkey");
 }
 
-// Layout of a prepared key: from the context's record, else one synchronous read of the header word (first use of a
-// buffer this context did not prepare itself, e.g. the replica of another device's key), remembered from then on.
-static int prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int* fmt)
-{
-    if (!prepared) return fail(HEGPU_E_INVALID, "null prepared boot key");
-    {
-        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
-        auto it = ctx->fmt.find(prepared);
-        if (it != ctx->fmt.end()) {
-            *fmt = it->second;
-            return 0;
-        }
-    }
-    uint64_t w = ~0ULL;
-    hipError_t e = hipMemcpy(&w, prepared, sizeof(w), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_ret(e, "reading the prepared boot key's header");
-    if (w > 1) return fail(HEGPU_E_INVALID, "not a prepared boot key (header word is neither 0 nor 1)");
-    std::lock_guard<std::mutex> lk(ctx->fmt_mu);
-    ctx->fmt[prepared] = *fmt = (int) w;
-    return 0;
-}
-
+// A query, not part of any launch path: the header word of a prepared key, read after the device has drained (so that it
+// is ordered behind whatever stream wrote the buffer).  Every failure is -1 (error codes leaked out as "formats").
 int hegpu_tfhe_prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int refresh)
 {
-    TFHE_NEED(ctx);
-    if (refresh) {
-        std::lock_guard<std::mutex> lk(ctx->fmt_mu);
-        ctx->fmt.erase(prepared);
+    (void) refresh; // nothing is remembered any more (kept for the ABI)
+    if (tfhe_need(ctx)) return -1;
+    DevGuard dev_guard__(ctx->device);
+    if (dev_guard__.err != hipSuccess) {
+        (void) hip_ret(dev_guard__.err, "switching to the TFHE context's device");
+        return -1;
     }
-    int fmt = -1;
-    if ((r = prepared_format(ctx, prepared, &fmt))) return -1;
-    return fmt;
+    if (!prepared) {
+        (void) fail(HEGPU_E_INVALID, "null prepared boot key");
+        return -1;
+    }
+    uint64_t w = ~0ULL;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(&w, prepared, sizeof(w), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void) hip_ret(e, "reading the prepared boot key's header");
+        return -1;
+    }
+    if (w > 1) {
+        (void) fail(HEGPU_E_INVALID, "not a prepared boot key (header word is neither 0 nor 1)");
+        return -1;
+    }
+    return (int) w;
 }
 
 int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a, int32_t* out_b,
@@ -1580,10 +1582,9 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
 {
     TFHE_NEED(ctx);
     if (shape <= 0) return 0;
-    int fmt = -1;
-    if ((r = prepared_format(ctx, prepared_boot_key, &fmt))) return r;
+    if (!prepared_boot_key) return fail(HEGPU_E_INVALID, "null prepared boot key");
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
-                                     encode_to_torus32(1, 8), shape, fmt, (hipStream_t) stream),
+                                     encode_to_torus32(1, 8), shape, (hipStream_t) stream),
                    "hegpu_tfhe_bootstrapping");
 }
 
@@ -1592,6 +1593,14 @@ int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                              hegpu_stream stream)
 {
     TFHE_NEED(ctx);
+    // the split forms zero the outputs before any input is read (tfhe.hip): in and out must be distinct buffers
+    if (shape > 0 && in_a && in_b && out_a && out_b) {
+        const char *ia = (const char*) in_a, *ib = (const char*) in_b, *oa = (const char*) out_a, *ob = (const char*) out_b;
+        const size_t ia_n = (size_t) shape * ctx->p.k * ctx->p.N * 4, ib_n = (size_t) shape * 4, oa_n = (size_t) shape * ctx->p.n * 4;
+        auto hit = [](const char* a, size_t an, const char* b, size_t bn) { return a < b + bn && b < a + an; };
+        if (hit(ia, ia_n, oa, oa_n) || hit(ia, ia_n, ob, ib_n) || hit(ib, ib_n, oa, oa_n) || hit(ib, ib_n, ob, ib_n))
+            return fail(HEGPU_E_INVALID, "hegpu_tfhe_key_switching: the output sample overlaps the input sample");
+    }
     return hip_ret(tfhe_key_switching(ctx->p, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, ctx->ks_batched, ctx->ks_pieces, (hipStream_t) stream),
                    "hegpu_tfhe_key_switching");
 }

@@ -221,7 +221,10 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                   const u64* __restrict__ bk, int* __restrict__ out_a,
                                                                   int* __restrict__ out_b, TfheDev p, int encoded)
 {
-    if (bk[0] != 0) return; // FP64-layout key: k_tfhe_blind_rotate_fp runs instead
+    if (bk[0] != 0) { // FP64-layout key: k_tfhe_blind_rotate_fp of the same call runs instead
+        if (bk[0] != 1 && blockIdx.x == 0 && threadIdx.x == 0 && p.bad_key) *p.bad_key = 1; // neither layout: say so
+        return;
+    }
     bk += TFHE_PREP_HEADER;
     __shared__ int acc[2][TF_N];
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int* __restrict__ in_a, const int* __restrict__ in_b, const u64* __restrict__ prepared, int* __restrict__ out_a,
     int* __restrict__ out_b, TfheDev p, int encoded)
 {
-    if (prepared[0] != 1) return; // not the FP64 layout (the host picks the kernel from the header: tfhe_blind_rotate)
+    if (prepared[0] != 1) return; // not the FP64 layout: the integer kernel of the same call takes it (or flags it)
     const u64* __restrict__ bk = prepared + TFHE_PREP_HEADER;
     __shared__ int acc[2][TF_N];
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
@@ -1080,21 +1083,19 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
     return hipGetLastError();
 }
 
-// `fmt`: the layout of the prepared key, from its header word (1 = FP64, 0 = integer); the caller (cabi.cpp) knows it
-// from hegpu_tfhe_prepare_bootkey or reads the word once per buffer -- ONE kernel is launched (round 3 launched both and
-// let the one whose layout was absent exit: an empty grid of `shape` workgroups, ~5 us, on every call).
+// The layout of the prepared key is its header word (1 = FP64, 0 = integer), read by the kernels themselves in stream
+// order: BOTH are launched and the one whose layout is absent exits at once (an empty grid of `shape` workgroups, ~5 us).
+// Round 4 picked the kernel on the host from a per-pointer cache filled by a synchronous read -- not ordered behind the
+// caller's stream, stale after the buffer was overwritten or its address reused, and a mismatch was a silent return
+// (ADVICE r4, medium).  A header that is neither layout sets the context's pinned flag; its next entry reports it.
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int fmt, hipStream_t st)
+                             int* out_b, int encoded, int shape, hipStream_t st)
 {
     if (shape <= 0) return hipSuccess;
-    if (fmt == 1)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
-                           out_b, p, encoded);
-    else if (fmt == 0)
-        hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a,
-                           out_b, p, encoded);
-    else
-        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a, out_b,
+                       p, encoded);
+    hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a, out_b, p,
+                       encoded);
     return hipGetLastError();
 }
 

@@ -20,6 +20,9 @@ struct TfheDev {
     const ulonglong2* ftw;
     const ulonglong2* fitw;
     ulonglong2 fninv, fw1ninv;
+    // pinned host word the blind rotate sets when it is handed a buffer whose header is neither layout: the context
+    // reports it at its next entry (cabi.cpp) -- a mismatch is never a silent return
+    int* bad_key;
 };
 
 // Prepared boot key: TFHE_PREP_HEADER u64 of header (word 0: 1 = FP64 layout,
@@ -46,9 +49,10 @@ hipError_t tfhe_lwe_phase(const int* a, const int* b, const int* key, int* phase
 // *fmt_out: the layout written (1 = FP64, 0 = integer)
 hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 polys, bool allow_fp, int* fmt_out,
                                 hipStream_t st);
-// fmt: the prepared key's layout (its header word), known to the caller
+// The layout is read ON THE DEVICE from the prepared key's header word, in stream order: both kernels are launched and
+// the one whose layout is absent exits (an empty grid, ~5 us); a header that is neither sets *p.bad_key.
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
-                             int* out_b, int encoded, int shape, int fmt, hipStream_t st);
+                             int* out_b, int encoded, int shape, hipStream_t st);
 hipError_t tfhe_gate_pre(int* out_a, int* out_b, const int* a1, const int* b1, const int* a2, const int* b2,
                          int encoded, int s1, int s2, int m, int n, int shape, hipStream_t st);
 hipError_t tfhe_key_switching(const TfheDev& p, const int* in_a, const int* in_b, int* out_a, int* out_b,

@@ -489,11 +489,12 @@ uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx);
  * any other key keeps the reference's 60-bit prime (results are identical either way). */
 int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key, uint64_t* prepared,
                                hegpu_stream stream);
-/* Layout of a prepared boot key: 1 = FP64, 0 = integer (its header word), -1 on error.  The blind rotate launches the
- * one kernel for that layout; the context remembers the layout of every buffer it prepared and looks any other buffer
- * up ONCE with a synchronous 8-byte read on its first use (a replica on another device: hegpu_broadcast_bytes, then the
- * destination's own TFHE context).  refresh != 0 forgets the remembered value first -- call it after overwriting a
- * prepared buffer by other means than hegpu_tfhe_prepare_bootkey. */
+/* Layout of a prepared boot key: 1 = FP64, 0 = integer (its header word), -1 on ANY error.  A query only: the blind
+ * rotate reads the header word on the device, in the order of the call's stream, so a buffer may be filled, copied
+ * (hegpu_broadcast_bytes) or overwritten on that stream right before a gate call without any host synchronisation.
+ * This call drains the device, then reads the word.  `refresh` is ignored (nothing is remembered since round 5).
+ * A bootstrapping call that is handed a buffer whose header is neither layout writes no outputs; the NEXT call on the
+ * context returns HEGPU_E_INVALID saying so (asynchronous error, like the runtime's own). */
 int hegpu_tfhe_prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int refresh);
 /* tfhe_{nand,and,and_first_not,nor,or,xnor,xor}_pre_comp_kernel / tfhe_not_comp_kernel
  * (src/lib/kernel/bootstrapping.cu:378-660); in2_* ignored for NOT */
@@ -505,7 +506,8 @@ int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a
 int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
                              const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
                              hegpu_stream stream);
-/* HELogicOperator<TFHE>::key_switching (tfhe/operator.cu:272-294) */
+/* HELogicOperator<TFHE>::key_switching (tfhe/operator.cu:272-294).  The output sample must not overlap the input
+ * sample (HEGPU_E_INVALID): the forms that cut a gate's coefficient loop over several workgroups clear the outputs first. */
 int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
                              int32_t* out_b, const int32_t* ks_key_a, const int32_t* ks_key_b, int shape,
                              hegpu_stream stream);

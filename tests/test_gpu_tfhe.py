@@ -67,9 +67,12 @@ def test_blind_rotate_and_key_switch(hg, setup):
 
 
 def test_prepared_key_that_arrived_by_copy(hg, setup):
-    """The blind rotate launches ONE kernel, chosen on the host from the prepared key's layout.  A buffer the context
-    did not prepare itself (a replica: here a device-to-device copy, on several GPUs the broadcast of the key) is looked
-    up once from its header word; overwriting it with a key of the other layout needs the refresh."""
+    """The blind rotate reads the prepared key's layout from its header word ON THE DEVICE, in stream order (both kernels
+    launched, the one whose layout is absent exits): a buffer the context did not prepare itself (a replica: here a
+    device-to-device copy, on several GPUs the broadcast of the key), and a buffer OVERWRITTEN with a key of the other
+    layout on a non-blocking stream right before the call, with no host synchronisation and no refresh (the
+    round-4 host-side cache went stale in exactly that case).  A buffer that is no prepared key writes nothing and the
+    context's next entry says so."""
     import torch
     t, o, rng, bk, ks_a, ks_b = setup
     prepared = t.prepare_bootkey(hg.to_device(bk))
@@ -90,19 +93,51 @@ def test_prepared_key_that_arrived_by_copy(hg, setup):
     for got_a, got_b in outs:
         assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b)
     assert t.prepared_format(replica) == fmt
-    # a key of the other layout written over the replica: the remembered layout is stale until refreshed
-    other = rng.integers(0, o.prime, t.int("bootkey_elems"), dtype=np.uint64) if fmt == 1 else None
-    if other is not None:
-        replica.copy_(t.prepare_bootkey(hg.to_device(other)))
-        assert t.prepared_format(replica) == 1 and t.prepared_format(replica, refresh=True) == 0
+    # a key of the other layout written over the replica on a side stream, the gate call queued right behind it
+    if fmt == 1:
+        other = rng.integers(0, o.prime, t.int("bootkey_elems"), dtype=np.uint64)
+        other_prepared = t.prepare_bootkey(hg.to_device(other))
+        da, db = _dev32(a), _dev32(b)
         out_a = torch.zeros(shape * 1024, dtype=torch.int32, device="cuda")
         out_b = torch.zeros(shape, dtype=torch.int32, device="cuda")
-        t.bootstrapping(_dev32(a), _dev32(b), replica, out_a, out_b, shape)
         torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            replica.copy_(other_prepared, non_blocking=True)
+            t.bootstrapping(da, db, replica, out_a, out_b, shape, stream=side.cuda_stream)
+        side.synchronize()
+        assert t.prepared_format(replica) == 0 and t.prepared_format(replica, refresh=True) == 0
         want_a, want_b = o.bootstrapping(a, b, other)
         assert np.array_equal(out_a.cpu().numpy(), want_a) and np.array_equal(out_b.cpu().numpy(), want_b)
+    junk = torch.full((t.int("prepared_bootkey_elems"),), 7, dtype=torch.int64, device="cuda")
     with pytest.raises(hg.HEError):
-        t.prepared_format(torch.full((256,), 7, dtype=torch.int64, device="cuda"))
+        t.prepared_format(junk)
+    out_a = torch.full((shape * 1024,), -5, dtype=torch.int32, device="cuda")
+    out_b = torch.full((shape,), -5, dtype=torch.int32, device="cuda")
+    t.bootstrapping(_dev32(a), _dev32(b), junk, out_a, out_b, shape)   # queued; the kernels find no layout of theirs
+    torch.cuda.synchronize()
+    assert bool((out_a == -5).all())
+    with pytest.raises(hg.HEError, match="not a prepared boot key"):     # reported by the context's next entry ...
+        t.bootstrapping(_dev32(a), _dev32(b), prepared, out_a, out_b, shape)
+    t.bootstrapping(_dev32(a), _dev32(b), prepared, out_a, out_b, shape)  # ... once
+    torch.cuda.synchronize()
+    want_a, want_b = o.bootstrapping(a, b, bk)
+    assert np.array_equal(out_a.cpu().numpy(), want_a) and np.array_equal(out_b.cpu().numpy(), want_b)
+
+
+def test_key_switching_refuses_aliased_samples(hg, setup):
+    """the split forms of the key switching clear the outputs before the inputs are read -- an output that
+    overlaps the input is refused instead of silently producing a wrong b."""
+    import torch
+    t, o, rng, bk, ks_a, ks_b = setup
+    shape = 64
+    ea = torch.zeros(shape * 1024, dtype=torch.int32, device="cuda")
+    eb = torch.zeros(shape, dtype=torch.int32, device="cuda")
+    ka = torch.zeros(shape * 512, dtype=torch.int32, device="cuda")
+    with pytest.raises(hg.HEError, match="overlaps"):
+        t.key_switching(ea, eb, ka, eb, _dev32(ks_a), _dev32(ks_b), shape)
+    with pytest.raises(hg.HEError, match="overlaps"):
+        t.key_switching(ea, eb, ea, torch.zeros_like(eb), _dev32(ks_a), _dev32(ks_b), shape)
 
 
 @pytest.mark.parametrize("shape,per_wg,pieces", [(5, 8, 1), (8, 8, 3), (21, 8, -1), (29, 12, 1), (12, 12, 7), (35, 16, 1),
