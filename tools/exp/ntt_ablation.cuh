@@ -23,8 +23,10 @@ __device__ __forceinline__ void gst(u64* p, u64 v)
 }
 #if NTT_EXP_MODE == 1 || NTT_EXP_MODE == 3
 #define NTT_ABLATE_BFLY(x, y, w) do { x ^= (w).x; y ^= (w).y; return; } while (0)
+#define NTT_ABLATE_FPBFLY(x, y, w) do { x += __longlong_as_double((long long) (w).x); y -= __longlong_as_double((long long) (w).y); return; } while (0)
 #else
 #define NTT_ABLATE_BFLY(x, y, w)
+#define NTT_ABLATE_FPBFLY(x, y, w)
 #endif
 #if NTT_EXP_MODE == 3
 #define NTT_ABLATE_TW(load, root0, s) make_ulonglong2(root0, s)

@@ -19,12 +19,14 @@ int main(int argc, char** argv)
     int polys = argc > 2 ? atoi(argv[2]) : 17 * 512;
     int reps = argc > 3 ? atoi(argv[3]) : 10;
     int chunk = argc > 4 ? atoi(argv[4]) : 0; // polys per launch pair (0 = all)
+    int single = argc > 5 ? atoi(argv[5]) : 0; // NttArgs::single_pass
+    int all_fp = argc > 6 ? atoi(argv[6]) : 0; // every modulus below 2^50
     const int mods = 17;
     const u64 n = 1ull << n_power;
     std::vector<Mod> hm(mods);
     std::vector<ulonglong2> htw(mods * n), hn(mods);
     u64 q = (1ull << 60) - (1ull << 18) + 1; // not prime; timing only
-    for (int k = 0; k < mods; k++) { hm[k] = make_mod((k == 0 || k == mods - 1) ? q - 2 * k * (1 << 17) : (1ull << 50) - (1ull << 18) * (k + 3) + 1); hn[k] = make_ulonglong2(12345, shoup_companion(12345, hm[k].q)); }
+    for (int k = 0; k < mods; k++) { hm[k] = make_mod(((k == 0 || k == mods - 1) && !all_fp) ? q - 2 * k * (1 << 17) : (1ull << 50) - (1ull << 18) * (k + 3) + 1); hn[k] = make_ulonglong2(12345, shoup_companion(12345, hm[k].q)); }
     for (u64 i = 0; i < mods * n; i++) { u64 w = (i * 0x9E3779B97F4A7C15ull) % q; htw[i] = make_ulonglong2(w, shoup_companion(w, q)); }
     NttArgs a{};
     CK(hipMalloc((void**) &a.mods, mods * sizeof(Mod)));
@@ -47,7 +49,7 @@ int main(int argc, char** argv)
     std::vector<u64> h(n * 64);
     for (u64 i = 0; i < h.size(); i++) h[i] = (i * 0xBF58476D1CE4E5B9ull) % q;
     for (int p = 0; p < polys; p += 64) CK(hipMemcpy(in + p * n, h.data(), (size_t) std::min(64, polys - p) * n * 8, hipMemcpyHostToDevice));
-    a.in = in; a.out = out; a.n_power = n_power; a.mod_count = mods;
+    a.in = in; a.out = out; a.n_power = n_power; a.mod_count = mods; a.single_pass = single; a.lazy_q_max = 1ull << 57;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int inverse = 0; inverse < 2; inverse++) {
         CK(ntt_launch(a, polys, inverse, 0));

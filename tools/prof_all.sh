@@ -67,29 +67,55 @@ for name in ("fetch", "write", "sq1", "sq2", "sq3"):
                 e.setdefault("cycles_" + name, v / 8 / n); e.setdefault("seconds_" + name, a["_s"] / n)
             else:
                 e[c] = v / n
+SHORT_MS = 0.1
 for key, e in res.items():
     if "FETCH_SIZE" in e:
         e["hbm_bytes"] = (2 * e["FETCH_SIZE"] + e.get("WRITE_SIZE", 0.0)) * 1024
+    if "SQ_BUSY_CYCLES" in e and e.get("cycles_sq2"):
+        # SQ_BUSY_CYCLES sums the busy cycles of the 32 shader engines' SQs; per engine it is the kernel's own span on that
+        # engine (no launch window around it, unlike GRBM_GUI_ACTIVE): the clock it implies over the dispatch's duration
+        e["sq_busy_over_gui"] = e["SQ_BUSY_CYCLES"] / e["cycles_sq2"]
+        e["GHz_sq_busy"] = e["SQ_BUSY_CYCLES"] / 32 / e["seconds_sq2"] / 1e9
+# Cycles of a dispatch.  GRBM_GUI_ACTIVE / 8 is the counter window, which for a dispatch of a few microseconds is several
+# times wider than the dispatch ("clocks" of 2.6 - 6.9 GHz).  Dispatches of >= 0.1 ms keep it (window
+# error < 3 %); shorter ones take SQ_BUSY_CYCLES / 32 engines scaled to this pass's duration when the launch is big enough to
+# keep every engine busy (>= 1024 waves), else duration x the median clock of the workload's other short kernels.
+short_clk = sorted(e["GHz_sq_busy"] for e in res.values()
+                   if "GHz_sq_busy" in e and e.get("seconds_sq1", 1) * 1e3 < SHORT_MS and e.get("SQ_WAVES", 0) >= 1024)
+long_clk = sorted(e["cycles_sq1"] / e["seconds_sq1"] / 1e9 for e in res.values()
+                  if e.get("cycles_sq1") and e.get("seconds_sq1", 0) * 1e3 >= SHORT_MS)
+ref_clk = (short_clk[len(short_clk) // 2] if short_clk else (long_clk[len(long_clk) // 2] if long_clk else 2.0))
+for key, e in res.items():
     if "SQ_INSTS_VALU" in e and e.get("cycles_sq1"):
         e["ms"] = e["seconds_sq1"] * 1e3
-        e["GHz"] = e["cycles_sq1"] / e["seconds_sq1"] / 1e9
-        e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / e["cycles_sq1"]
+        e["GHz_gui_window"] = e["cycles_sq1"] / e["seconds_sq1"] / 1e9
+        if e["ms"] >= SHORT_MS:
+            e["cycles"], e["cycles_source"] = e["cycles_sq1"], "GRBM_GUI_ACTIVE / 8"
+        elif "GHz_sq_busy" in e and e.get("SQ_WAVES", 0) >= 1024:
+            e["cycles"], e["cycles_source"] = e["GHz_sq_busy"] * 1e9 * e["seconds_sq1"], "SQ_BUSY_CYCLES / 32 (own pass), scaled to this pass's duration"
+        else:
+            e["cycles"], e["cycles_source"] = ref_clk * 1e9 * e["seconds_sq1"], "duration x %.2f GHz (median of the workload's short kernels)" % ref_clk
+        e["GHz"] = e["cycles"] / e["seconds_sq1"] / 1e9
+        e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / e["cycles"]
         e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / max(e["SQ_WAVES"], 1)
         # issue ceiling: one wave64 VALU instruction per SIMD per 4 cycles
-        e["frac_of_issue_ceiling"] = e["SQ_INSTS_VALU"] * 4 / 1024 / e["cycles_sq1"]
+        e["frac_of_issue_ceiling"] = e["SQ_INSTS_VALU"] * 4 / 1024 / e["cycles"]
         if "hbm_bytes" in e: e["hbm_GBps"] = e["hbm_bytes"] / e["seconds_sq1"] / 1e9
     if "SQ_WAVE_CYCLES" in e and e.get("cycles_sq2"):
         # SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count in units of 4 cycles per wave (guide); the ratio is unit-free
         e["wait_any_frac_of_wave_cycles"] = e["SQ_WAIT_INST_ANY"] / max(e["SQ_WAVE_CYCLES"], 1)
-        e["waves_resident_per_simd"] = e["SQ_WAVE_CYCLES"] * 4 / 1024 / e["cycles_sq2"]
+        c2 = e["cycles_sq2"] if e["seconds_sq2"] * 1e3 >= SHORT_MS else e.get("GHz", ref_clk) * 1e9 * e["seconds_sq2"]
+        e["waves_resident_per_simd"] = e["SQ_WAVE_CYCLES"] * 4 / 1024 / c2
     if "SQ_ACTIVE_INST_LDS" in e and e.get("cycles_sq3"):
-        e["lds_busy"] = e["SQ_ACTIVE_INST_LDS"] * 4 / 1024 / e["cycles_sq3"]
+        c3 = e["cycles_sq3"] if e["seconds_sq3"] * 1e3 >= SHORT_MS else e.get("GHz", ref_clk) * 1e9 * e["seconds_sq3"]
+        e["lds_busy"] = e["SQ_ACTIVE_INST_LDS"] * 4 / 1024 / c3
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
 with open(f"{out}/summary.txt", "w") as f:
     f.write("command: $*\n")
     for key, e in sorted(res.items(), key=lambda kv: -kv[1].get("ms", 0) * kv[1].get("dispatches", 1)):
         f.write("%s  x%d\n" % (key, e.get("dispatches", 0)))
-        for c in ("ms", "GHz", "hbm_bytes", "hbm_GBps", "valu_busy", "frac_of_issue_ceiling", "valu_insts_per_wave", "SQ_WAVES",
+        if "cycles_source" in e: f.write("    %-30s %s\n" % ("cycles from", e["cycles_source"]))
+        for c in ("ms", "GHz", "GHz_gui_window", "GHz_sq_busy", "hbm_bytes", "hbm_GBps", "valu_busy", "frac_of_issue_ceiling", "valu_insts_per_wave", "SQ_WAVES",
                   "waves_resident_per_simd", "wait_any_frac_of_wave_cycles", "lds_busy", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT"):
             if c in e: f.write("    %-30s %16.4f\n" % (c, e[c]))
 print(open(f"{out}/summary.txt").read()[:6000])
