@@ -751,7 +751,7 @@ namespace {
 struct OptDesc { const char* name; const char* env; int lo, hi; };
 const OptDesc kOptions[] = {
     {"fused_row_mac", "HEGPU_FUSED_ROW_MAC", -1, 1}, {"fused_moddown", "HEGPU_FUSED_MODDOWN", 0, 1},
-    {"col_multi", "HEGPU_COL_MULTI", -1, 1},         {"single_pass", "HEGPU_SINGLE_PASS", -1, 2},
+    {"col_multi", "HEGPU_COL_MULTI", -1, 1},         {"single_pass", "HEGPU_SINGLE_PASS", -1, 1},
     {"ntt_galois", "HEGPU_NTT_GALOIS", 0, 1},        {"galois_scatter", "HEGPU_GALOIS_SCATTER", 0, 1},
     {"fuse_inverse", "HEGPU_FUSE_INVERSE", 0, 1},    {"copy_along", "HEGPU_COPY_ALONG", 0, 1},
     {"digit_split", "HEGPU_DIGIT_SPLIT", -1, 4},     {"fp_ntt", "HEGPU_FP_NTT", 0, 1},

@@ -126,8 +126,6 @@ struct NttArgs {
     // N <= 2^14: one LDS-resident pass per transform.  1 always, 0 never (the two passes), otherwise by launch
     // size: one workgroup per limb needs a launch that fills the chip; a small one finishes sooner as two passes
     // of four times as many workgroups (C2, one ciphertext: inverse of 8 limbs 19.6 us against 6.0 + 5.5 us).
-    // 2: as 1, and N = 2^14 launches take the persistent prefetching form (ntt_fwd_single_pf) whatever their size; by
-    // launch size it is taken from two limbs per compute unit.
     int single_pass;
     int plan_has_fp, plan_has_int; // the plan holds FP64 (< 2^50) / integer-butterfly moduli
     // Integer butterflies: a modulus up to this bound runs ALL log2 N forward stages without a conditional

@@ -75,9 +75,7 @@ void hegpu_context_destroy(hegpu_context* ctx);
  *                            reference's kernel sequence (NTT of all digits, then keyswitch_multiply_accumulate)
  *   "fused_moddown"  0/1     mod-down stages as load transform / epilogue of the transform between them (1)
  *   "col_multi"      -1/0/1  decomposing column pass: one workgroup per source tile walking the target moduli
- *   "single_pass"    -1/0/1/2  N <= 2^14: one LDS-resident pass per transform instead of two (1: one workgroup per limb;
- *                            2: also the persistent form at N = 2^14 that keeps the next limb on its way, which -1 picks
- *                            for launches of two or more limbs per compute unit)
+ *   "single_pass"    -1/0/1  N <= 2^14: one LDS-resident pass per transform instead of two
  *   "ntt_galois"     0/1     CKKS rotations without leaving the NTT domain (1) / in the reference's order
  *   "galois_scatter" 0/1     the NTT-domain automorphism as the mod-down epilogue's store (1) / a kernel of its own
  *   "fuse_inverse"   0/1     the inverse transform feeding a decomposition ends inside it (1)

@@ -950,29 +950,7 @@ def test_method_II_and_hoisting_at_other_degrees(hg, oracle, torch, sw, n_power,
         assert np.array_equal(go[b], o.ckks_apply_galois_II(ct1[b], keys[0], elts[0], depth)), "method II rotate"
 
 
-@pytest.mark.parametrize("single", [-1, 2], ids=["by_launch_size", "forced"])
-@pytest.mark.parametrize("inplace", [False, True], ids=["out_of_place", "in_place"])
-def test_ntt_n14_persistent_prefetching_form(hg, oracle, torch, single, inplace):
-    """N = 2^14, forward: the persistent single pass that keeps the next limb on its way (ntt_fwd_single_pf, round 5) --
-    550 limbs over 256 workgroups, so every workgroup runs its loop two or three times and meets FP64 (30 / 45 / 50
-    bits), lazy integer (55) and full-range integer (60) moduli in turn; and forced onto a launch of 20 limbs (one
-    limb per workgroup, no loop)."""
-    n = 1 << 14
-    with backend_switches(HEGPU_SINGLE_PASS=single):
-        c, o, primes = _ckks(hg, oracle, n, [60, 30, 45, 50, 55], [60], sec=hg.SEC_NONE)
-    Qp = 6
-    for batch in ((550, 20) if single == 2 else (550,)):
-        x = np.concatenate([oracle.fill_poly(11 + i, i % Qp, n, primes[i % Qp]) for i in range(batch)])
-        x[:4] = [0, primes[0] - 1, 1, primes[0] // 2]
-        want = o.ntt(x.copy(), batch, Qp)
-        d = hg.to_device(x)
-        out = d if inplace else torch.empty_like(d)
-        c.ntt(d, out, False, batch, Qp)
-        torch.cuda.synchronize()
-        assert np.array_equal(hg.to_host(out), want), batch
-
-
-@pytest.mark.parametrize("single", [1, 0, 2], ids=["single_pass", "two_pass", "single_pass_prefetching"])
+@pytest.mark.parametrize("single", [1, 0], ids=["single_pass", "two_pass"])
 @pytest.mark.parametrize("n_power", [12, 13, 14])
 def test_ntt_small_degrees_both_forms(hg, oracle, torch, n_power, single):
     """N <= 2^14: the LDS-resident single pass (ntt_fwd_single) and the two passes give the oracle's transform,
