@@ -1145,8 +1145,8 @@ __global__ __launch_bounds__(NTT_THREADS, SPLIT ? 2 : 1) void ks_row_mac(KsMacAr
 
 // FP64 moduli (Mod::fp): same fused row pass + inner product, but the inner
 // product is accumulated in FP64 as well: each digit*key product is reduced by
-// fp_mul (|t| <= 0.7 q for |digit| <= q/2), the running sums are re-centred
-// every fourth digit (|acc| < 3.5 q < 2^53) and made canonical once at the end.
+// fp_mul (|t| <= 2.46 q for the un-reduced digit, |digit| <= 5.22 q: bound at the product), the running sums are
+// re-centred after every third digit (|acc| <= 7.88 q < 2^53) and made canonical once at the end.
 // Two double accumulators per coefficient instead of two 128-bit integers
 // halve the register footprint (3 waves per SIMD instead of 2).
 template <bool SPLIT>
@@ -1188,6 +1188,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     double a0[16], a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a0[k] = a1[k] = 0.0;
+    int since = 0; // digits accumulated since the sums were last re-centred
     for (int i = ki.d0; i < ki.d1; i++) {
         double x[16];
         const u64* p = pin + dig_off * i;
@@ -1248,8 +1249,8 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
                     for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
+            // (round 5) NO centred reduction here: x goes into the product as the "twiddle" operand, whose magnitude only
+            // enters the quotient error -- see the bound at the product below
             wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -1262,13 +1263,22 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            // x plays the role of the "twiddle": companion RN(x/q) ~ x*qi (|x| <= q/2 keeps
-            // the quotient error below 1), the key (canonical, < q < 2^50) is the operand
+            // x plays the role of the "twiddle" (companion RN(x/q) ~ x * qi), the key (canonical, y < q < 2^50) is the
+            // operand.  Round 5: x arrives UN-reduced from the last four stages, |x| <= 5.22 q (0.5 q after the reduction
+            // in the middle, then b -> 1.375 b + 0.5 four times: the stages recompute their companions).  Exactness of
+            // fp_mul(y, x, xi): xi = RN(x RN(1/q)) and the rounded product y xi are within |y x / q| * 1.5 * 2^-52 <=
+            // 5.22 * 2^50 * 1.5 * 2^-52 = 1.96 of y x / q, so |k - y x / q| <= 2.46; k < 2^53 is an exact integer, h - k q
+            // = (y x - k q) - l with |l| <= ulp(h) / 2 <= 2^49 is an integer below 2.46 q + 2^49 < 2^52 -- the FMA that
+            // forms it and the sum with l are exact, t = y x - k q EXACTLY with |t| <= 2.46 q.  What the larger operand
+            // costs is the accumulators' headroom: 0.5 q + 3 * 2.46 q = 7.88 q < 8 q <= 2^53, so they are re-centred after
+            // every THIRD digit (round 4: x reduced to q / 2 first -- 48 instructions per digit and thread -- |t| <= 0.75 q,
+            // re-centred every fourth: 24; now 0 + 32).
             const double xi = x[k] * fc.qi;
             a0[k] += fp_mul(fp_from_u64(kv0[k]), x[k], xi, fc);
             a1[k] += fp_mul(fp_from_u64(kv1[k]), x[k], xi, fc);
         }
-        if ((i & 3) == 3) {
+        if (++since == 3) {
+            since = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 a0[k] = fp_reduce(a0[k], fc);
