@@ -516,36 +516,48 @@ __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const
             for (int j = 0; j < half; j++) f_ct(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
+    // Round 5: the lane-dependent twiddles are REQUESTED AHEAD of the exchange they follow (they depend on nothing but the
+    // lane) and pinned there with scheduling fences.  Left to itself the compiler issued each twiddle read right in front
+    // of its butterflies -- ds_read, s_waitcnt lgkmcnt(0), butterflies, fifteen times per round: one exposed LDS round trip
+    // per twiddle (profiles/r5d_c5/README.md).
+    const int b = lane >> 2, c0 = lane & 3;
+    double wa[15];
+#pragma unroll
+    for (int e = 0; e < 15; e++) wa[e] = twl[16 * e + b];
 #pragma unroll
     for (int k = 0; k < 16; k++) buf[bi(lane + 64 * k)] = as_bits(x[k]);
     wave_fence();
-    const int b = lane >> 2, c0 = lane & 3;
 #pragma unroll
     for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
-            const double w = twl[16 * ((1 << s) - 1 + bb) + b];
+            const double w = wa[(1 << s) - 1 + bb];
 #pragma unroll
             for (int j = 0; j < half; j++) f_ct_l(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
         }
     }
+    double w8[4], w9[8];
+#pragma unroll
+    for (int g = 0; g < 4; g++) w8[g] = twl[240 + 64 * g + lane];
+#pragma unroll
+    for (int e = 0; e < 8; e++) w9[e] = twl[496 + 64 * e + lane];
     wave_fence();
 #pragma unroll
     for (int m = 0; m < 16; m++) buf[bi(64 * b + c0 + 4 * m)] = as_bits(x[m]);
     wave_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = as_f64(buf[bi(16 * lane + k)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const double w8 = twl[240 + 64 * g + lane];
-        f_ct_l(x[4 * g + 0], x[4 * g + 2], w8, c);
-        f_ct_l(x[4 * g + 1], x[4 * g + 3], w8, c);
-        const double w9a = twl[496 + 64 * (2 * g) + lane], w9b = twl[496 + 64 * (2 * g + 1) + lane];
-        f_ct_l(x[4 * g + 0], x[4 * g + 1], w9a, c);
-        f_ct_l(x[4 * g + 2], x[4 * g + 3], w9b, c);
+        f_ct_l(x[4 * g + 0], x[4 * g + 2], w8[g], c);
+        f_ct_l(x[4 * g + 1], x[4 * g + 3], w8[g], c);
+        f_ct_l(x[4 * g + 0], x[4 * g + 1], w9[2 * g], c);
+        f_ct_l(x[4 * g + 2], x[4 * g + 3], w9[2 * g + 1], c);
     }
     // No reduction at the end: the outputs (|x| < 7 p' < 2^47, integers) are the "twiddle" side of the external
     // product's fp_mul, whose result bound does not depend on that operand's magnitude -- with the companion
@@ -562,29 +574,38 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
                                                  int lane)
 {
     const int rl = 63 - lane;
+    // itw[512 + 8 lane + e] = -tw[512 + 8 (63 - lane) + (7 - e)], itw[256 + 4 lane + g] = -tw[256 + 4 (63 - lane) + (3 - g)]
+    // (twiddles requested ahead of their butterflies, as in fwave_ntt1024_l)
+    double w8[4], w9[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) w9[e] = twl[496 + 64 * e + rl];
+#pragma unroll
+    for (int g = 0; g < 4; g++) w8[g] = twl[240 + 64 * g + rl];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        // itw[512 + 8 lane + e] = -tw[512 + 8 (63 - lane) + (7 - e)], itw[256 + 4 lane + g] = -tw[256 + 4 (63 - lane) + (3 - g)]
-        const double w9a = twl[496 + 64 * (7 - 2 * g) + rl], w9b = twl[496 + 64 * (6 - 2 * g) + rl];
-        f_gs_l(x[4 * g + 0], x[4 * g + 1], w9a, c);
-        f_gs_l(x[4 * g + 2], x[4 * g + 3], w9b, c);
-        const double w8 = twl[240 + 64 * (3 - g) + rl];
-        f_gs_l(x[4 * g + 0], x[4 * g + 2], w8, c);
-        f_gs_l(x[4 * g + 1], x[4 * g + 3], w8, c);
+        f_gs_l(x[4 * g + 0], x[4 * g + 1], w9[7 - 2 * g], c);
+        f_gs_l(x[4 * g + 2], x[4 * g + 3], w9[6 - 2 * g], c);
+        f_gs_l(x[4 * g + 0], x[4 * g + 2], w8[3 - g], c);
+        f_gs_l(x[4 * g + 1], x[4 * g + 3], w8[3 - g], c);
     }
+    const int b = lane >> 2, c0 = lane & 3;
+    double wa[15];
+#pragma unroll
+    for (int e = 0; e < 15; e++) wa[e] = twl[16 * e + (15 - b)];
 #pragma unroll
     for (int k = 0; k < 16; k++) buf[bi(16 * lane + k)] = as_bits(x[k]);
     wave_fence();
-    const int b = lane >> 2, c0 = lane & 3;
 #pragma unroll
     for (int m = 0; m < 16; m++) x[m] = as_f64(buf[bi(64 * b + c0 + 4 * m)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 3; s >= 0; s--) {
         const int half = 8 >> s;
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
             // itw[((16 + b) << s) + bb] = -tw[((16 + 15 - b) << s) + ((1 << s) - 1 - bb)]
-            const double w = twl[16 * ((1 << s) - 1 + ((1 << s) - 1 - bb)) + (15 - b)];
+            const double w = wa[(1 << s) - 1 + ((1 << s) - 1 - bb)];
 #pragma unroll
             for (int j = 0; j < half; j++) f_gs_l(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
         }
@@ -658,17 +679,25 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         const int aN = modswitch(in_a[(u64) g * n + i], 10);
         double x[16];
+        {
+            // X^aN * acc - acc, coefficient j = lane + 64 k: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap.
+            // Round 5: ALL 32 accumulator reads are requested before anything is computed, and the wrap's sign is applied
+            // as (v ^ m) - m with m = 0 / -1 from the index bit.  Round 4's select on a compare kept every element's
+            // condition in VCC across its own LDS read, so the compiler emitted read -> s_waitcnt lgkmcnt(0) -> select
+            // sixteen times in a row: sixteen LDS round trips per iteration and wavefront on the critical path.
+            int rv[16], av[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int j = lane + 64 * k;
-            // X^aN * acc, coefficient j: acc[(j - aN) mod 2N] with the sign of the negacyclic wrap -- index
-            // arithmetic and a select (branches per element would put every LDS read in its own basic block)
-            const int idx = (j - aN) & (2 * TF_N - 1);
-            const int v = acc[y][idx & (TF_N - 1)];
-            const int r = (idx & TF_N) ? -v : v;
-            const u32 diff = (u32) r - (u32) acc[y][j];
-            const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
-            x[k] = (double) d;
+            for (int k = 0; k < 16; k++) rv[k] = acc[y][(lane + 64 * k - aN) & (TF_N - 1)];
+#pragma unroll
+            for (int k = 0; k < 16; k++) av[k] = acc[y][lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int idx = (lane + 64 * k - aN) & (2 * TF_N - 1);
+                const int m = -((idx >> 10) & 1);
+                const u32 diff = (u32) ((rv[k] ^ m) - m) - (u32) av[k];
+                const int d = (int) (((diff + (u32) p.offset) >> shift) & (u32) p.mask_mod) - p.half_bg;
+                x[k] = (double) d;
+            }
         }
         fwave_ntt1024_l(x, buf[wv], p.ftw, twl, fc, lane);
         // The transformed digit goes to the own staging area (free after the transform); after the barrier
@@ -688,12 +717,14 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
                 ka[2 * k] = as_f64(v.x);
                 ka[2 * k + 1] = as_f64(v.y);
             }
+            // (the sixteen values of the other wavefront's digit requested together: one LDS round trip, not eight)
             const u64* ob = &buf[(wv + r) & 3][lane];
+            double xo[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const double xo = as_f64(ob[k * 64]);
-                x[k] += fp_mul(ka[k], xo, xo * fc.qi, fc);
-            }
+            for (int k = 0; k < 16; k++) xo[k] = as_f64(ob[k * 64]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] += fp_mul(ka[k], xo[k], xo[k] * fc.qi, fc);
         }
         __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
         fwave_intt1024_l(x, buf[wv], p.fitw, twl, p.fninv, p.fw1ninv, fc, lane);
