@@ -46,6 +46,55 @@ __device__ __forceinline__ void gst(u64* p, u64 v) { *p = v; }
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
 
+// A twiddle table seen through the CONSTANT address space.  hipcc turns a load with a wave-uniform address into a scalar
+// load only when it can prove that nothing in the kernel has written the memory before it; in a persistent kernel (a loop
+// with global stores in it) it cannot, and the "uniform" twiddles come back as vector loads whose s_waitcnt vmcnt(0) also
+// waits for every prefetch in flight.  The tables are written once, by the context, before any launch: constant it is.
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+struct ConstTw {
+    const u64x2_t __attribute__((address_space(4)))* p;
+    __device__ __forceinline__ ulonglong2 operator[](u32 i) const
+    {
+        const u64x2_t v = p[i];
+        return make_ulonglong2(v.x, v.y);
+    }
+};
+__device__ __forceinline__ ConstTw const_tw(const ulonglong2* t)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return ConstTw{(const u64x2_t __attribute__((address_space(4)))*) reinterpret_cast<const u64x2_t*>(t)};
+#pragma clang diagnostic pop
+}
+
+// scalar-cache reads of launch-constant tables from inside a persistent loop (see ConstTw)
+__device__ __forceinline__ int ld_const_i32(const int* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return *(const int __attribute__((address_space(4)))*) p;
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ Mod ld_const_mod(const Mod* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const u64 __attribute__((address_space(4)))* w = (const u64 __attribute__((address_space(4)))*) reinterpret_cast<const u64*>(p);
+#pragma clang diagnostic pop
+    static_assert(sizeof(Mod) == 56, "seven words");
+    Mod m;
+    m.q = w[0];
+    m.mu = w[1];
+    m.r_hi = w[2];
+    m.r_lo = w[3];
+    m.r64 = w[4];
+    m.qinv = w[5];
+    const u64 bf = w[6];
+    m.bit = (u32) bf;
+    m.fp = (u32) (bf >> 32);
+    return m;
+}
+
 // ------------------------------------------------------------------ FP64 path (arithmetic: fpmod.cuh)
 __device__ __forceinline__ void fp_ct_bfly(double& x, double& y, ulonglong2 w, const FC& c)
 {
@@ -553,7 +602,10 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
             const int c = L % CT, rb = L / CT;
             double y[RA];
             load_all(y, [&](int k) { return &src[(u64) (rb + 16 * k) * 256 + c]; }, g * RA);
-            fp_ct_radix<NSA>(y, tw, 1u, fc, CS::a_before, false);
+            // (SREG = inside the modulus loop of ntt_fwd_col_multi, a loop with stores in it: the wave-uniform twiddles
+            // of this round through the constant address space, or they come as vector loads -- see ConstTw)
+            if constexpr (SREG) fp_ct_radix<NSA>(y, const_tw(tw), 1u, fc, CS::a_before, false);
+            else fp_ct_radix<NSA>(y, tw, 1u, fc, CS::a_before, false);
 #pragma unroll
             for (int k = 0; k < RA; k++) lds[col_phys((rb + 16 * k) * CT + c)] = as_bits(y[k]);
         }
@@ -1213,40 +1265,115 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(xr[k]), fc);
         } else {
+            if constexpr (SPLIT) { // small launches (ks_row_mac_split shares its registers with the integer body): twiddles read where they are used
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = as_f64(xr[k]);
+                for (int k = 0; k < 16; k++) x[k] = as_f64(xr[k]);
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int half = 8 >> s;
+                for (int s = 0; s < 4; s++) {
+                    const int half = 8 >> s;
 #pragma unroll
-                for (int b = 0; b < (1 << s); b++) {
-                    const double w = twl[15 * 256 + ((1 << s) - 1 + b) * 16 + row];
-                    const ulonglong2 wp = make_ulonglong2(as_bits(w), as_bits(w * fc.qi));
+                    for (int b = 0; b < (1 << s); b++) {
+                        const double w = twl[15 * 256 + ((1 << s) - 1 + b) * 16 + row];
+                        const ulonglong2 wp = make_ulonglong2(as_bits(w), as_bits(w * fc.qi));
 #pragma unroll
-                    for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
+                        for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
+                for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
-            wave_lds_fence();
+                for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
+                wave_lds_fence();
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
-                x[2 * k] = as_f64(v.x);
-                x[2 * k + 1] = as_f64(v.y);
-            }
-            // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
+                for (int k = 0; k < 8; k++) {
+                    ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+                    x[2 * k] = as_f64(v.x);
+                    x[2 * k + 1] = as_f64(v.y);
+                }
+                // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int half = 8 >> s;
+                for (int s = 0; s < 4; s++) {
+                    const int half = 8 >> s;
 #pragma unroll
-                for (int b = 0; b < (1 << s); b++) {
-                    const double wd = twl[((1 << s) - 1 + b) * 256 + t];
-                    const ulonglong2 w = make_ulonglong2(as_bits(wd), as_bits(wd * fc.qi));
+                    for (int b = 0; b < (1 << s); b++) {
+                        const double wd = twl[((1 << s) - 1 + b) * 256 + t];
+                        const ulonglong2 w = make_ulonglong2(as_bits(wd), as_bits(wd * fc.qi));
 #pragma unroll
-                    for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+                        for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+                    }
+                }
+            } else {
+                // Round 5: the twiddles of a stage are REQUESTED ONE STAGE AHEAD of the butterflies that use them (those of the
+                // first two stages before the digit's coefficients are waited for) and pinned there with scheduling fences.
+                // Left to itself the compiler read each twiddle right in front of its butterflies: ds_read, s_waitcnt
+                // lgkmcnt(0), butterflies -- thirty exposed LDS round trips per digit at two waves per SIMD (the same find as in
+                // the blind rotate, profiles/r5d_c5/README.md).  All thirty at once do not fit: 236 registers are taken (64
+                // sums, 64 prefetched key values, the digit), a stage ahead costs at most 8 more doubles.  The indices are hidden
+                // from the optimiser: the twiddles do not depend on the digit and would be hoisted out of the loop for good.
+                int row_o = row, t_o = t;
+                asm volatile("" : "+v"(row_o), "+v"(t_o));
+                const double* twa = twl + 15 * 256 + row_o;
+                const double* twb = twl + t_o;
+                double wn[8], wc[8];
+                wc[0] = twa[0];
+                wn[0] = twa[16];
+                wn[1] = twa[32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = as_f64(xr[k]);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int half = 8 >> s;
+                    if (s > 0) {
+#pragma unroll
+                        for (int b = 0; b < (1 << s); b++) wc[b] = wn[b];
+                    }
+                    if (s < 3) { // next stage's twiddles (the first stage's successor was requested above)
+                        if (s > 0) {
+#pragma unroll
+                            for (int b = 0; b < (2 << s); b++) wn[b] = twa[((2 << s) - 1 + b) * 16];
+                        }
+                    } else {
+                        wn[0] = twb[0]; // first of the last four stages
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < (1 << s); b++) {
+                        const double w = wc[b];
+                        const ulonglong2 wp = make_ulonglong2(as_bits(w), as_bits(w * fc.qi));
+#pragma unroll
+                        for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
+#pragma unroll
+                for (int k = 0; k < 16; k++) lds[row_phys(row * 256 + i0 + 16 * k)] = as_bits(x[k]);
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[row_phys(row * 256 + 16 * i0 + 2 * k)]);
+                    x[2 * k] = as_f64(v.x);
+                    x[2 * k + 1] = as_f64(v.y);
+                }
+                // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int half = 8 >> s;
+#pragma unroll
+                    for (int b = 0; b < (1 << s); b++) wc[b] = wn[b];
+                    if (s < 3) {
+#pragma unroll
+                        for (int b = 0; b < (2 << s); b++) wn[b] = twb[((2 << s) - 1 + b) * 256];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < (1 << s); b++) {
+                        const double wd = wc[b];
+                        const ulonglong2 w = make_ulonglong2(as_bits(wd), as_bits(wd * fc.qi));
+#pragma unroll
+                        for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, fc);
+                    }
                 }
             }
             // (round 5) NO centred reduction here: x goes into the product as the "twiddle" operand, whose magnitude only
@@ -1850,14 +1977,16 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col_multi(NttArgs a)
     int done = 0; // executed iterations (parity of the twiddle buffer)
     for (int k = 0; k < rc; k++) {
         PolySel ps;
-        ps.mod = a.mod_offset + (a.mod_order ? a.mod_order[k] : k);
+        // (launch-constant tables read through the scalar cache: inside this loop plain loads of them are vector loads
+        // with an s_waitcnt vmcnt(0) each -- round 5, see ConstTw)
+        ps.mod = a.mod_offset + (a.mod_order ? ld_const_i32(a.mod_order + k) : k);
         ps.digit = digit;
         ps.item = item;
         ps.j = digit * rc + k;
         ps.in_off = 0;
         ps.out_off = (u64) item * a.out_item_stride + ((u64) ps.j << a.n_power);
         if (a.skip_identity && ps.mod == digit) continue;
-        const Mod md = a.mods[ps.mod];
+        const Mod md = ld_const_mod(a.mods + ps.mod);
         if (!md.fp) continue; // integer target moduli: ntt_fwd_col<S1, true> with only_int
         ulonglong2* tl = twl + ((S1 > 4) ? 256 * (done & 1) : 0);
         done++;

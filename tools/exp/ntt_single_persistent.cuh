@@ -7,56 +7,6 @@
 //   ntt_fwd_single_ps1  1024 threads, persistent, next limb's 16 coefficients prefetched (128 registers + 92 B scratch)
 #pragma once
 namespace hegpu {
-// (three things the persistent kernels need and the product does not)
-// A twiddle table seen through the CONSTANT address space.  hipcc turns a load with a wave-uniform address into a scalar
-// load only when it can prove that nothing in the kernel has written the memory before it; in a persistent kernel (a loop
-// with global stores in it) it cannot, and the "uniform" twiddles come back as vector loads whose s_waitcnt vmcnt(0) also
-// waits for every prefetch in flight.  The tables are written once, by the context, before any launch: constant it is.
-typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-struct ConstTw {
-    const u64x2_t __attribute__((address_space(4)))* p;
-    __device__ __forceinline__ ulonglong2 operator[](u32 i) const
-    {
-        const u64x2_t v = p[i];
-        return make_ulonglong2(v.x, v.y);
-    }
-};
-__device__ __forceinline__ ConstTw const_tw(const ulonglong2* t)
-{
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return ConstTw{(const u64x2_t __attribute__((address_space(4)))*) reinterpret_cast<const u64x2_t*>(t)};
-#pragma clang diagnostic pop
-}
-
-// scalar-cache reads of launch-constant tables from inside a persistent loop (see ConstTw)
-__device__ __forceinline__ int ld_const_i32(const int* p)
-{
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return *(const int __attribute__((address_space(4)))*) p;
-#pragma clang diagnostic pop
-}
-__device__ __forceinline__ Mod ld_const_mod(const Mod* p)
-{
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    const u64 __attribute__((address_space(4)))* w = (const u64 __attribute__((address_space(4)))*) reinterpret_cast<const u64*>(p);
-#pragma clang diagnostic pop
-    static_assert(sizeof(Mod) == 56, "seven words");
-    Mod m;
-    m.q = w[0];
-    m.mu = w[1];
-    m.r_hi = w[2];
-    m.r_lo = w[3];
-    m.r64 = w[4];
-    m.qinv = w[5];
-    const u64 bf = w[6];
-    m.bit = (u32) bf;
-    m.fp = (u32) (bf >> 32);
-    return m;
-}
-
 // select_poly with its two order tables read through the scalar cache
 __device__ __forceinline__ PolySel select_poly_const(const NttArgs& a, int poly)
 {
