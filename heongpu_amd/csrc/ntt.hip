@@ -146,7 +146,7 @@ __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], TW tw, u32 r
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-            const ulonglong2 w = tw[(root0 << s) + b];
+            const ulonglong2 w = NTT_ABLATE_TW(tw[(root0 << s) + b], root0, s);
 #pragma unroll
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglon
         const int half = 8 >> s;
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-            const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
+            const ulonglong2 w = NTT_ABLATE_TW(tb[((1 << s) - 1 + b) * 16], (u32) b, s);
 #pragma unroll
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }

@@ -28,8 +28,8 @@ __device__ __forceinline__ void gst(u64* p, u64 v)
 #define NTT_ABLATE_BFLY(x, y, w)
 #define NTT_ABLATE_FPBFLY(x, y, w)
 #endif
-#if NTT_EXP_MODE == 3
-#define NTT_ABLATE_TW(load, root0, s) make_ulonglong2(root0, s)
+#if NTT_EXP_MODE == 3 || NTT_EXP_MODE == 4 // 4: everything but the twiddle loads (values from registers: wrong results, same arithmetic)
+#define NTT_ABLATE_TW(load, root0, s) make_ulonglong2(0x4030000000000000ull + (root0) + (s), 0x3cb0000000000000ull)
 #else
 #define NTT_ABLATE_TW(load, root0, s) (load)
 #endif
