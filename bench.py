@@ -1107,7 +1107,7 @@ def sec_c5(torch, hg, prof):
         ok, _ = work.oracle_check(TCHK)
         dn, dok = work.decrypt_check()
         ab = prof_group(prof, "c5_tfhe_gates", g)
-        ab["blind_rotate"] = prof_group(prof, "c5_tfhe_gates", g, match=["k_tfhe_blind_rotate"])
+        ab["blind_rotate"] = prof_group(prof, "c5_tfhe_gates", g, match=["k_tfhe_blind_rotate_fp"])
         ab["blind_rotate"].pop("achieved_GBps", None)  # the live time is the whole gate's, not this kernel's
         e = {"workload": "TFHE STD128 NAND gate bootstrap (pre-computation, blind rotate n=512, sample extraction, key switch), "
                          "%d concurrent gates (%d distinct encrypted bit pairs), generated torus32 boot key (FP64 blind rotate)" % (S, TFHE_UNIQ),

@@ -7,7 +7,7 @@
 #                                      reads count at 1/2; calibrated in profiles/README.md)
 #   4 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES
 #   5 SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
-#   6 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE   (PROF_SKIP_LDS=1 skips 5 and 6)
+#   6 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE   (PROF_SKIP_LDS=1 skips 6)
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -25,8 +25,8 @@ CMD=("$@")
 pass fetch "FETCH_SIZE"
 pass write "WRITE_SIZE"
 pass sq1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES"
+pass sq2 "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"   # (always: SQ_BUSY_CYCLES gives short dispatches their cycles)
 if [ -z "${PROF_SKIP_LDS:-}" ]; then
-  pass sq2 "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
   pass sq3 "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 fi
 python3 - <<PY

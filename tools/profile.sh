@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every counter pass the bench line quotes (profiles/profile.json), on the GPU box:  tools/profile.sh <tag>
 # -> gpurun_out/<tag>/<workload>/{summary.txt, summary.json, kernel_stats.csv}, gpurun_out/<tag>/profile.json
-TAG=${1:-r4prof}
+TAG=${1:-r5prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 ARGS=""
