@@ -40,9 +40,10 @@ TFHE_BUDGETS = {
 
 
 def _usage(source, tmp_path):
+    """resource-usage remarks of every kernel of a source; the same compile leaves the device assembly in <source>.s"""
     src = os.path.join(ROOT, "heongpu_amd", "csrc", source)
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", src, "-o",
-                        str(tmp_path / (source + ".o")), "-Rpass-analysis=kernel-resource-usage"],
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", src,
+                        "-o", str(tmp_path / (source + ".s")), "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True, timeout=900, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
     usage, name = {}, None
@@ -71,3 +72,48 @@ def test_hot_kernels_keep_their_register_budgets(tmp_path, source, budgets):
         assert u.get("ScratchSize", 0) <= max_scratch, (hits[0], u)
         if key == "22k_tfhe_blind_rotate_fpE":
             assert u.get("LDS Size", 1 << 30) * 3 <= 160 * 1024, (hits[0], u)
+    _check_waits(str(tmp_path / (source + ".s")), source)
+
+
+# Round 5: two things that cost real time and are invisible in the source (profiles/r5c_c4, r5d_c5) -- hipcc
+# turns wave-uniform table reads inside a loop that contains global stores into VECTOR loads with an s_waitcnt vmcnt(0)
+# behind each, and it places LDS reads directly in front of their first use (read, s_waitcnt lgkmcnt(0), use -- one exposed
+# round trip per read).  The kernels below were rewritten against both; the counts pin the result (round-4 builds: 19
+# full vector-memory waits and 5 scalar loads in ntt_fwd_col_multi<8>'s body, 127 waits in the blind rotate).
+#   kernel (substring of the mangled name) -> (max `s_waitcnt vmcnt(0)`, min s_load, max s_waitcnt of any kind)
+WAIT_BUDGETS = {
+    "ntt.hip": {"17ntt_fwd_col_multiILi8EE": (13, 30, 90)},
+    "tfhe.hip": {"22k_tfhe_blind_rotate_fpE": (4, 8, 104)},
+}
+
+
+def _kernel_asm(path):
+    """{mangled kernel name: its lines} from a device assembly file (a kernel runs from its label to the next one)"""
+    out, name = {}, None
+    for line in open(path):
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", line)
+        if m:
+            name = m.group(1)
+            out[name] = []
+        elif line.startswith("\t.section") or line.startswith("\t.amdhsa_kernel") or line.startswith(".Lfunc_end"):
+            name = None
+        elif name:
+            out[name].append(line)
+    return out
+
+
+def _check_waits(asm_path, source):
+    budgets = WAIT_BUDGETS.get(source)
+    if not budgets:
+        return
+    kernels = _kernel_asm(asm_path)
+    for key, (max_vm0, min_sload, max_waits) in budgets.items():
+        hits = [n for n in kernels if key in n]
+        assert len(hits) == 1, (key, hits)
+        body = kernels[hits[0]]
+        vm0 = sum(1 for ln in body if "s_waitcnt" in ln and "vmcnt(0)" in ln)
+        sload = sum(1 for ln in body if "\ts_load_" in ln)
+        waits = sum(1 for ln in body if "\ts_waitcnt" in ln)
+        assert vm0 <= max_vm0, (hits[0], "s_waitcnt vmcnt(0)", vm0, "uniform tables read with vector loads again?")
+        assert sload >= min_sload, (hits[0], "s_load", sload)
+        assert waits <= max_waits, (hits[0], "s_waitcnt", waits, "reads placed in front of their uses again?")
