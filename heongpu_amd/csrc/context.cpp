@@ -539,6 +539,7 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     std::vector<ulonglong2> htw((size_t) cnt * n), hitw((size_t) cnt * n), hn(cnt), hw(cnt);
     const u64 rows = n / 256, perB = rows * 15 * 16; // re-laid entries per modulus
     std::vector<ulonglong2> htwB((size_t) cnt * perB), hitwB((size_t) cnt * perB);
+    std::vector<double> htwB8((size_t) cnt * perB, 0.0);
     // fp_on == false (option fp_ntt = 0) keeps every modulus on the integer butterflies
     for (int k = 0; k < cnt; k++) {
         const u64 q = mods[k];
@@ -575,6 +576,7 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
                         const u64 dst = k * perB + (c * 15 + ((1 << st) - 1 + b)) * 16 + j;
                         htwB[dst] = htw[k * n + src];
                         hitwB[dst] = hitw[k * n + src];
+                        if (hm[k].fp) htwB8[dst] = (double) fwd[k * n + src];
                     }
         const u64 w1n = host::mul_mod(inv[k * n + 1], ninv[k], q);
         if (hm[k].fp) {
@@ -609,6 +611,7 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
     if ((e = to_device(hitw, &p.itw)) != hipSuccess) return e;
     if ((e = to_device(htwB, &p.twB)) != hipSuccess) return e;
     if ((e = to_device(hitwB, &p.itwB)) != hipSuccess) return e;
+    if ((e = to_device(htwB8, &p.twB8)) != hipSuccess) return e;
     if ((e = to_device(hn, &p.ninv)) != hipSuccess) return e;
     return to_device(hw, &p.w1ninv);
 }
@@ -620,6 +623,7 @@ static void free_plan(NttPlan& p)
     if (p.itw) (void) hipFree(p.itw);
     if (p.twB) (void) hipFree(p.twB);
     if (p.itwB) (void) hipFree(p.itwB);
+    if (p.twB8) (void) hipFree(p.twB8);
     if (p.ninv) (void) hipFree(p.ninv);
     if (p.w1ninv) (void) hipFree(p.w1ninv);
     p = NttPlan();
@@ -869,6 +873,7 @@ NttArgs Context::ntt_args(int table_set) const
     a.itw = p.itw;
     a.twB = p.twB;
     a.itwB = p.itwB;
+    a.twB8 = p.twB8;
     a.ninv = p.ninv;
     a.w1ninv = p.w1ninv;
     a.n_power = n_power;

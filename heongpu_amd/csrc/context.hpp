@@ -30,6 +30,7 @@ struct NttPlan {
     ulonglong2* itw = nullptr;
     ulonglong2* twB = nullptr;  // row-pass last-four-stages layout (see ntt.hpp)
     ulonglong2* itwB = nullptr;
+    double* twB8 = nullptr;     // twB's layout as plain doubles (FP64 moduli; zeros elsewhere): 8 bytes per twiddle for the row pass
     ulonglong2* ninv = nullptr;
     ulonglong2* w1ninv = nullptr;
     int count = 0;

@@ -42,6 +42,7 @@ __device__ __forceinline__ void gst(u64* p, u64 v) { *p = v; }
 #define NTT_ABLATE_BFLY(x, y, w)
 #define NTT_ABLATE_FPBFLY(x, y, w)
 #define NTT_ABLATE_TW(load, root0, s) (load)
+#define NTT_FP_TW(t, i, c) ((t)[i])
 #endif
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return (x >= m) ? x - m : x; }
@@ -146,7 +147,7 @@ __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], TW tw, u32 r
         const int half = (1 << LOGR) >> (s + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-            const ulonglong2 w = NTT_ABLATE_TW(tw[(root0 << s) + b], root0, s);
+            const ulonglong2 w = NTT_ABLATE_TW(NTT_FP_TW(tw, (root0 << s) + b, c), root0, s);
 #pragma unroll
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
@@ -173,7 +174,31 @@ __device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglon
         const int half = 8 >> s;
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
-            const ulonglong2 w = NTT_ABLATE_TW(tb[((1 << s) - 1 + b) * 16], (u32) b, s);
+            const ulonglong2 w = NTT_ABLATE_TW(NTT_FP_TW(tb, ((1 << s) - 1 + b) * 16, c), (u32) b, s);
+#pragma unroll
+            for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fp_canon(x[k], c);
+}
+
+// the same from the plain-double table (NttArgs::twB8): companion recomputed as w * RN(1/q).  Bound: the values come
+// in centred (|x| <= q/2 (1 + 2^-40), the reduction that ends the first row round); with a recomputed companion a stage
+// takes b q to at most (1.375 b + 0.5) q (fpmod.cuh / ks_row_mac_fp: the companion's relative error 1.5 * 2^-52 times
+// |y w / q| <= b 2^50 adds 0.375 b to the quotient error), so four stages reach 5.22 q < 7.9 q <= 2^53; fp_canon takes that.
+__device__ __forceinline__ void fp_ct_radix16_tb8(double (&x)[16], const double* __restrict__ tb, const FC& c)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+        // (a fence per stage: left free, the scheduler requests all fifteen twiddles up front and the 1024-thread single
+        // pass -- 128 registers -- spills six of them)
+        if (s > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < (1 << s); b++) {
+            const double wd = tb[((1 << s) - 1 + b) * 16];
+            const ulonglong2 w = make_ulonglong2(as_bits(wd), as_bits(wd * c.qi));
 #pragma unroll
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
@@ -782,7 +807,7 @@ __device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel&
         x[2 * k] = as_f64(v.x);
         x[2 * k + 1] = as_f64(v.y);
     }
-    fp_ct_radix16_tb(x, a.twB + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), fc);
+    fp_ct_radix16_tb8(x, a.twB8 + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), fc);
     wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -967,7 +992,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
             x[2 * k] = as_f64(v.x);
             x[2 * k + 1] = as_f64(v.y);
         }
-        fp_ct_radix16_tb(x, tb, fc);
+        fp_ct_radix16_tb8(x, a.twB8 + ((u64) ps.mod * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0), fc);
 #pragma unroll
         for (int k = 0; k < 16; k++) r[k] = fp_to_u64(x[k]);
     } else {
@@ -1212,7 +1237,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
     const int row = t >> 4, i0 = t & 15;
     const u32 crow = tile * 16 + row;
-    const ulonglong2* __restrict__ tb = a.twB + ((u64) midx * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0);
+    const double* __restrict__ tb8 = a.twB8 + ((u64) midx * (15u << (a.n_power - 4))) + ((u64) crow * 15 * 16 + i0);
     const u64* __restrict__ pin = a.in + a.in_item_stride * item + ((u64) slot << a.n_power) + (u64) tile * 4096;
     const u64* __restrict__ pk = a.key + ((u64) midx << a.n_power) + (u64) tile * 4096 + row * 256 + i0;
     const u64 dig_off = (u64) a.rc << a.n_power;
@@ -1228,7 +1253,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     // estimate stays within 0.63 of the exact one, so |x| <= 4.1 q < 2^53 after four stages).
     double* twl = reinterpret_cast<double*>(twbuf); // [15 * 256 + 15 * 16]
 #pragma unroll
-    for (int k = 0; k < 15; k++) twl[k * 256 + t] = as_f64(tb[k * 16].x);
+    for (int k = 0; k < 15; k++) twl[k * 256 + t] = tb8[k * 16];
     if (i0 < 15) {
         // slot i0 = (1 << s) - 1 + b of local stage s
         const int s = (i0 >= 7) ? 3 : (i0 >= 3) ? 2 : (i0 >= 1) ? 1 : 0;

@@ -76,6 +76,11 @@ struct NttArgs {
     // stride there).  Entry = tw[(((N/256 + c)*16 + j) << s) + b].
     const ulonglong2* twB;
     const ulonglong2* itwB;
+    // plan: twB's layout as plain doubles for the FP64 moduli (zeros elsewhere).  The forward row stages of an FP64 limb
+    // read 15 lane-dependent twiddles per thread -- as (w, RN(w/q)) pairs 480 bytes next to 256 bytes of coefficients; the
+    // companion is one multiply (w * RN(1/q), as ks_row_mac_fp forms it), so the table need not carry it (round 5:
+    // tools/exp/ntt_exp5 bounded the gain at 4-7 % of the transform before the table was built)
+    const double* twB8;
     const ulonglong2* ninv;   // plan: (N^-1, companion)                    [mod]
     const ulonglong2* w1ninv; // plan: (itw[1]*N^-1, companion)             [mod]
     const int* mod_order;     // optional: modulus index = mod_order[i % mod_count]
@@ -192,6 +197,7 @@ struct KsMacArgs {
     const Mod* mods;
     const ulonglong2* tw;
     const ulonglong2* twB;
+    const double* twB8;     // as NttArgs::twB8 (the FP64 body parks plain doubles in LDS: half the bytes to fetch)
     const int* mod_order;   // modulus index of limb slot k (NULL: k)
     int n_power, digits, rc, key_limbs;
     u64 lazy_q_max;         // as NttArgs::lazy_q_max (the column pass that wrote `in` used the same bound)

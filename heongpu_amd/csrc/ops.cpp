@@ -118,7 +118,7 @@ static hipError_t keyswitch_ntt_mac(const Context& c, NttArgs a, const u64* key,
         KsMacArgs k{};
         k.in = ca.out; k.in_item_stride = a.out_item_stride; k.key = key;
         k.out = acc + (u64) b0 * acc_stride; k.out_item_stride = acc_stride;
-        k.mods = c.plan_qp.mods; k.tw = c.plan_qp.tw; k.twB = c.plan_qp.twB; k.mod_order = a.mod_order;
+        k.mods = c.plan_qp.mods; k.tw = c.plan_qp.tw; k.twB = c.plan_qp.twB; k.twB8 = c.plan_qp.twB8; k.mod_order = a.mod_order;
         k.lazy_q_max = a.lazy_q_max; k.n_power = c.n_power; k.digits = digits; k.rc = rc; k.key_limbs = c.Qp_size; k.skip_identity = skip_identity;
         k.ident = ident ? ident + (u64) b0 * ident_stride : nullptr; k.ident_item_stride = ident_stride;
         k.splits = splits;

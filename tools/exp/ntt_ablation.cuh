@@ -33,3 +33,19 @@ __device__ __forceinline__ void gst(u64* p, u64 v)
 #else
 #define NTT_ABLATE_TW(load, root0, s) (load)
 #endif
+
+// mode 5 (timing only): the FP64 twiddle tables read as if they held plain doubles (8 bytes per twiddle, consecutive
+// lanes consecutive), the companion recomputed -- what a compact table for the FP64 moduli would buy
+#if NTT_EXP_MODE == 5
+struct ConstTw;
+__device__ __forceinline__ ulonglong2 ntt_exp_tw8(const ulonglong2* t, unsigned i, const FC& c)
+{
+    const double w = reinterpret_cast<const double*>(t)[i];
+    const double wi = w * c.qi;
+    return make_ulonglong2((unsigned long long) __double_as_longlong(w), (unsigned long long) __double_as_longlong(wi));
+}
+template <typename T> __device__ __forceinline__ ulonglong2 ntt_exp_tw8(T t, unsigned i, const FC&) { return t[i]; }
+#define NTT_FP_TW(t, i, c) ntt_exp_tw8((t), (unsigned) (i), (c))
+#else
+#define NTT_FP_TW(t, i, c) ((t)[i])
+#endif

@@ -49,6 +49,12 @@ int main(int argc, char** argv)
     CK(hipMalloc((void**) &a.twB, mods * n * 16));
     CK(hipMalloc((void**) &a.itwB, mods * n * 16));
     CK(hipMemcpy((void*) a.twB, htw.data(), mods * n * 16, hipMemcpyHostToDevice));
+    CK(hipMalloc((void**) &a.twB8, mods * n * 8));
+    {
+        std::vector<double> h8(mods * n);
+        for (u64 i = 0; i < mods * n; i++) h8[i] = (double) (htw[i].x % hm[i / n].q);
+        CK(hipMemcpy((void*) a.twB8, h8.data(), mods * n * 8, hipMemcpyHostToDevice));
+    }
     CK(hipMemcpy((void*) a.itwB, htw.data(), mods * n * 16, hipMemcpyHostToDevice));
     CK(hipMalloc((void**) &a.ninv, mods * 16));
     CK(hipMalloc((void**) &a.w1ninv, mods * 16));
