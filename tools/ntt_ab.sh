@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two library builds under tools/ntt14_forms.py-style timing: tools/ntt_ab.sh <lib A> <lib B> <python script + args>
+# A/B of two library builds under a timing script (e.g. tools/ntt_deg.py): tools/ntt_ab.sh <lib A> <lib B> <python script + args>
 A=$1; B=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cp $R/heongpu_amd/lib/libhegpu.so /tmp/keep.so
