@@ -1925,14 +1925,8 @@ __device__ __forceinline__ void inv_single_body(const AR& ar, const NttArgs& a, 
     }
     __syncthreads();
     u64 unused[16];
-    // (round 5) the thread index of the second half is hidden from the optimiser: it computed the column part's LDS and
-    // store offsets at the top of the kernel, ahead of the row part, and -- at 128 registers for 1024 threads -- spilled a
-    // dozen of them to scratch and reloaded them here (48 to 148 bytes per lane, ~110 KiB of scratch traffic per 128 KiB limb)
-    int t2 = threadIdx.x;
-    asm volatile("" : "+v"(t2));
-    const int g2 = t2 >> 8, tt2 = t2 & 255;
-    if constexpr (EPI) inv_col_part<S1, AR, true, false, true>(ar, a, ps.mod, tt2, g2, a.out + ps.out_off + g2 * CT, limb, unused, epi, g2 * CT);
-    else inv_col_part<S1, AR, true>(ar, a, ps.mod, tt2, g2, a.out + ps.out_off + g2 * CT, limb, unused);
+    if constexpr (EPI) inv_col_part<S1, AR, true, false, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused, epi, g * CT);
+    else inv_col_part<S1, AR, true>(ar, a, ps.mod, tt, g, a.out + ps.out_off + g * CT, limb, unused);
 }
 
 template <int S1, bool EPI = false, bool TENSOR = false>
