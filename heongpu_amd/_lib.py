@@ -9,6 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhegpu.so")
+# TESTS ONLY: tests/audit/run_audit.py binds the INSTRUMENTED build of the same sources (tests/audit/Makefile: every FP64
+# operation checked against exact integer arithmetic).  Only that file name is accepted; nothing in the product sets it.
+if os.environ.get("HEGPU_AUDIT_LIB"):
+    if os.path.basename(os.environ["HEGPU_AUDIT_LIB"]) != "libhegpu_audit.so":
+        raise ImportError("HEGPU_AUDIT_LIB must name tests/audit/lib/libhegpu_audit.so")
+    LIB_PATH = os.environ["HEGPU_AUDIT_LIB"]
 
 u64 = ctypes.c_uint64
 u64p = ctypes.c_void_p  # device or host address passed as integer

@@ -25,6 +25,7 @@
 //  * wave-uniform twiddles (column pass, first round) are fetched through
 //    the scalar cache; the rest are 16-byte (w, w') pairs read as dwordx4.
 #include "ntt.hpp"
+#define HEGPU_FP_TU ntt // (names this file's table reader in the instrumented test build, see fpmod.cuh)
 #include "fpmod.cuh"
 
 namespace hegpu {
@@ -103,6 +104,8 @@ __device__ __forceinline__ void fp_ct_bfly(double& x, double& y, ulonglong2 w, c
     const double t = fp_mul(y, as_f64(w.x), as_f64(w.y), c);
     y = x - t;
     x = x + t;
+    FP_AUDIT_VAL(c, FPM_SUM, x);
+    FP_AUDIT_VAL(c, FPM_SUM, y);
 }
 // Where the centred reductions of the FP64 forward transform go (round 3).  A stage takes |x| <= b q to at most
 // (1.25 b + 0.5) q (fpmod.cuh, q < 2^50), and everything stays exact while |x| < 2^53 = 8 * 2^50: from b = 1/2 that is
@@ -140,6 +143,7 @@ __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], TW tw, u32 r
 {
 #pragma unroll
     for (int s = 0; s < LOGR; s++) {
+        FP_STAGE(c, 31 - __builtin_clz(root0) + s); // (audit build: global stage index; a reduction counts to the stage it precedes)
         if ((before >> s) & 1u) {
 #pragma unroll
             for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
@@ -152,6 +156,7 @@ __device__ __forceinline__ void fp_ct_radix(double (&x)[1 << LOGR], TW tw, u32 r
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
+    FP_STAGE(c, 31 - __builtin_clz(root0) + LOGR);
     if (at_end) {
 #pragma unroll
         for (int k = 0; k < (1 << LOGR); k++) x[k] = fp_reduce(x[k], c);
@@ -172,6 +177,7 @@ __device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglon
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
+        if (s > 0) FP_STAGE(c, (c).stage + 1); // (the caller's first row round left the index of this round's first stage)
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
             const ulonglong2 w = NTT_ABLATE_TW(NTT_FP_TW(tb, ((1 << s) - 1 + b) * 16, c), (u32) b, s);
@@ -179,6 +185,7 @@ __device__ __forceinline__ void fp_ct_radix16_tb(double (&x)[16], const ulonglon
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
+    FP_STAGE(c, (c).stage + 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = fp_canon(x[k], c);
 }
@@ -195,6 +202,7 @@ __device__ __forceinline__ void fp_ct_radix16_tb8(double (&x)[16], const double*
         // (a fence per stage: left free, the scheduler requests all fifteen twiddles up front and the 1024-thread single
         // pass -- 128 registers -- spills six of them)
         if (s > 0) __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) FP_STAGE(c, (c).stage + 1);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
             const double wd = tb[((1 << s) - 1 + b) * 16];
@@ -203,6 +211,7 @@ __device__ __forceinline__ void fp_ct_radix16_tb8(double (&x)[16], const double*
             for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
     }
+    FP_STAGE(c, (c).stage + 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = fp_canon(x[k], c);
 }
@@ -551,7 +560,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     // ~50 address registers, 154 VGPRs and three waves per SIMD at S1 = 8 -- measured 3 % faster than
     // recomputing them per iteration at four waves.)
     const int t = threadIdx.x;
-    const FC fc = make_fc(md.q);
+    const FC fc = make_fc(md.q, FP_SITE(DECOMP ? FPS_FWD_COL_DECOMP : FPS_FWD_COL, S1 - 4));
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + blockIdx.x * CT;
     u64* __restrict__ dst = a.out + ps.out_off + blockIdx.x * CT;
@@ -579,6 +588,7 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
     // basic block -- one memory latency -- each.
     auto load_all = [&](auto& y, auto addr, int si0) {
         constexpr int CNT = sizeof(y) / sizeof(y[0]);
+        FP_STAGE(fc, FP_STAGE_INPUT);
         if constexpr (SREG && !WIDE) {
             if (in_small) { // (uniform) the digit's own prime is at most 1/64 larger than this modulus: |y| <= 1.05 q
 #pragma unroll
@@ -611,6 +621,8 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
 #pragma unroll
             for (int k = 0; k < CNT; k++) y[k] = fp_reduce(y[k] - half_hm, fc);
         }
+#pragma unroll
+        for (int k = 0; k < CNT; k++) FP_AUDIT_VAL(fc, FPM_SUM, y[k]); // what enters the first stage
     };
 
     double x[16];
@@ -787,7 +799,7 @@ __device__ __forceinline__ void fwd_row_body(const NttArgs& a, const PolySel& ps
 __device__ __forceinline__ void fwd_row_body_fp(const NttArgs& a, const PolySel& ps, const Mod& md, u64* lds)
 {
     const int t = threadIdx.x;
-    const FC fc = make_fc(md.q);
+    const FC fc = make_fc(md.q, FP_SITE(FPS_FWD_ROW, a.n_power - 12));
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     u64* __restrict__ p = a.out + ps.out_off + (u64) blockIdx.x * 4096;
@@ -858,7 +870,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
     constexpr int G = 16 / RA;
     const int t = threadIdx.x, g = t >> 8, tt = t & 255;
     const QC qc = make_qc(md.q);
-    const FC fc = make_fc(md.q);
+    const FC fc = make_fc(md.q, FP_SITE(FPS_FWD_SINGLE, S1 - 4));
     const ulonglong2* __restrict__ tw = a.tw + ((u64) ps.mod << a.n_power);
     const u64* __restrict__ src = a.in + ps.in_off + g * CT;
     const int col = tt % CT, r1 = tt / CT;
@@ -880,6 +892,7 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
         }
         const u64 half_qP = a.half_on ? a.mods[a.half_src_mod].q : 0;
         if constexpr (FP) {
+            FP_STAGE(fc, FP_STAGE_INPUT);
             if (a.half_on) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) dv[k] = add_mod(dv[k], a.half, half_qP);
@@ -898,6 +911,8 @@ __device__ __forceinline__ void fwd_single_body(const NttArgs& a, const PolySel&
 #pragma unroll
                 for (int k = 0; k < 16; k++) dy[k] = fp_reduce(dy[k] - half_hm, fc);
             }
+#pragma unroll
+            for (int k = 0; k < 16; k++) FP_AUDIT_VAL(fc, FPM_SUM, dy[k]);
         } else {
             if (a.half_on) {
                 const u64 half_hm = a.half_mod[ps.mod];
@@ -1232,7 +1247,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
 {
     const int t = threadIdx.x;
     const int item = ki.item, tile = ki.tile, slot = ki.slot;
-    const FC fc = make_fc(md.q);
+    const FC fc = make_fc(md.q, FP_SITE(SPLIT ? FPS_KS_ROW_SPLIT : FPS_KS_ROW, a.n_power - 12));
     const int s1 = a.n_power - 8;
     const ulonglong2* __restrict__ tw = a.tw + ((u64) midx << a.n_power);
     const int row = t >> 4, i0 = t & 15;
@@ -1249,8 +1264,9 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     // available.  So they are parked in LDS once per workgroup: the 15 of the last four stages are
     // private to the lane (slot k at [k][t]), the 15 of the first four are shared by the 16 lanes of
     // a row ([k][row], written by lane i0 == k).  Only w is kept; its companion RN(w/q) is
-    // recomputed as w * RN(1/q) when the twiddle is used (one multiply per twiddle; the quotient
-    // estimate stays within 0.63 of the exact one, so |x| <= 4.1 q < 2^53 after four stages).
+    // recomputed as w * RN(1/q) when the twiddle is used (one multiply per twiddle; a stage then takes |x| <= b q
+    // to at most (1.375 b + 0.5) q: 0.5 -> 1.19, 2.13, 3.43, 5.22 q < 2^53 over the four stages of a round --
+    // tests/fp_model.py derives and searches these bounds, tests/test_gpu_fp_audit.py measures them on the device).
     double* twl = reinterpret_cast<double*>(twbuf); // [15 * 256 + 15 * 16]
 #pragma unroll
     for (int k = 0; k < 15; k++) twl[k * 256 + t] = tb8[k * 16];
@@ -1287,6 +1303,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
             kv1[k] = k1[16 * k];
         }
         if (ident) {
+            FP_STAGE(fc, FP_STAGE_INPUT);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fp_reduce(fp_from_u64(xr[k]), fc);
         } else {
@@ -1296,6 +1313,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int half = 8 >> s;
+                    FP_STAGE(fc, s1 + s);
 #pragma unroll
                     for (int b = 0; b < (1 << s); b++) {
                         const double w = twl[15 * 256 + ((1 << s) - 1 + b) * 16 + row];
@@ -1304,6 +1322,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
                         for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
                     }
                 }
+                FP_STAGE(fc, s1 + 4);
 #pragma unroll
                 for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
 #pragma unroll
@@ -1315,10 +1334,11 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
                     x[2 * k] = as_f64(v.x);
                     x[2 * k + 1] = as_f64(v.y);
                 }
-                // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
+                // last four stages; their output goes into the product un-reduced (|x| <= 5.22 q, see the product)
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int half = 8 >> s;
+                    FP_STAGE(fc, s1 + 4 + s);
 #pragma unroll
                     for (int b = 0; b < (1 << s); b++) {
                         const double wd = twl[((1 << s) - 1 + b) * 256 + t];
@@ -1349,6 +1369,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int half = 8 >> s;
+                    FP_STAGE(fc, s1 + s);
                     if (s > 0) {
 #pragma unroll
                         for (int b = 0; b < (1 << s); b++) wc[b] = wn[b];
@@ -1370,6 +1391,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
                         for (int j = 0; j < half; j++) fp_ct_bfly(x[b * 2 * half + j], x[b * 2 * half + j + half], wp, fc);
                     }
                 }
+                FP_STAGE(fc, s1 + 4);
 #pragma unroll
                 for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], fc);
 #pragma unroll
@@ -1381,10 +1403,11 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
                     x[2 * k] = as_f64(v.x);
                     x[2 * k + 1] = as_f64(v.y);
                 }
-                // last four stages; the centred reduction of fp_ct_radix (|x| <= q/2) is all the product needs
+                // last four stages; their output goes into the product un-reduced (|x| <= 5.22 q, see the product)
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int half = 8 >> s;
+                    FP_STAGE(fc, s1 + 4 + s);
 #pragma unroll
                     for (int b = 0; b < (1 << s); b++) wc[b] = wn[b];
                     if (s < 3) {
@@ -1426,11 +1449,16 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
             // every THIRD digit (round 4: x reduced to q / 2 first -- 48 instructions per digit and thread -- |t| <= 0.75 q,
             // re-centred every fourth: 24; now 0 + 32).
             const double xi = x[k] * fc.qi;
+            FP_STAGE(fc, FP_STAGE_PRODUCT);
             a0[k] += fp_mul(fp_from_u64(kv0[k]), x[k], xi, fc);
             a1[k] += fp_mul(fp_from_u64(kv1[k]), x[k], xi, fc);
+            FP_STAGE(fc, FP_STAGE_SUMS + since); // sums holding since + 1 products since they were last re-centred
+            FP_AUDIT_VAL(fc, FPM_SUM, a0[k]);
+            FP_AUDIT_VAL(fc, FPM_SUM, a1[k]);
         }
         if (++since == 3) {
             since = 0;
+            FP_STAGE(fc, FP_STAGE_SUMS + 3);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 a0[k] = fp_reduce(a0[k], fc);
@@ -1441,6 +1469,7 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     u64* po = (SPLIT ? const_cast<u64*>(pin) + dig_off * ki.d0 - (u64) tile * 4096
                      : a.out + a.out_item_stride * item + ((u64) slot << a.n_power)) +
               (u64) tile * 4096 + row * 256 + i0;
+    FP_STAGE(fc, FP_STAGE_OUT);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         po[16 * k] = fp_to_u64(fp_canon(a0[k], fc));
@@ -1512,6 +1541,7 @@ __device__ __forceinline__ void fp_gs_bfly(double& x, double& y, ulonglong2 w, c
     const double s = x + y, d = x - y;
     x = s;
     y = fp_mul(d, as_f64(w.x), as_f64(w.y), c);
+    FP_AUDIT_VAL(c, FPM_SUM, s);
 }
 
 struct ArInt {
@@ -1540,7 +1570,8 @@ struct ArInt {
 struct ArFp {
     typedef double T;
     FC fc;
-    __device__ __forceinline__ explicit ArFp(const Mod& md) : fc(make_fc(md.q)) {}
+    int s1; // log2 N - 8 (only the instrumented test build reads it: stage indices of its table)
+    __device__ __forceinline__ explicit ArFp(const Mod& md, int n_power) : fc(make_fc(md.q, FP_SITE(FPS_INV, n_power - 12))), s1(n_power - 8) {}
     __device__ __forceinline__ T from_canon(u64 v) const { return fp_from_u64(v); }
     __device__ __forceinline__ T from_bits(u64 v) const { return as_f64(v); }
     __device__ __forceinline__ u64 to_bits(T v) const { return as_bits(v); }
@@ -1558,6 +1589,7 @@ struct ArFp {
 #pragma unroll
         for (int s = LOGR - 1; s >= 0; s--) {
             const int half = (1 << LOGR) >> (s + 1);
+            FP_STAGE(fc, 31 - __builtin_clz(root0) + s); // (the forward stage this one inverts; a reduction counts to the stage it follows)
 #pragma unroll
             for (int b = 0; b < (1 << s); b++) {
                 const ulonglong2 w = tw[(root0 << s) + b];
@@ -1572,6 +1604,7 @@ struct ArFp {
 #pragma unroll
         for (int s = 3; s >= 0; s--) {
             const int half = 8 >> s;
+            FP_STAGE(fc, s1 + 4 + s);
 #pragma unroll
             for (int b = 0; b < (1 << s); b++) {
                 const ulonglong2 w = tb[((1 << s) - 1 + b) * 16];
@@ -1590,6 +1623,7 @@ struct ArFp {
 #pragma unroll
         for (int s = LOGR - 1; s >= 1; s--) {
             const int half = (1 << LOGR) >> (s + 1);
+            FP_STAGE(fc, s);
 #pragma unroll
             for (int b = 0; b < (1 << s); b++) {
                 const ulonglong2 w = tw[(1u << s) + b];
@@ -1599,6 +1633,7 @@ struct ArFp {
             if ((++done & 1) == 0) reduce_all(x);
         }
         constexpr int half = (1 << LOGR) >> 1;
+        FP_STAGE(fc, 0);
 #pragma unroll
         for (int j = 0; j < half; j++) {
             const double sum = x[j] + x[j + half], d = x[j] - x[j + half];
@@ -1854,7 +1889,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row(NttArgs a)
     const Mod md = a.mods[ps.mod];
     const u64* __restrict__ src = a.in + ps.in_off + (u64) blockIdx.x * 4096;
     u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
-    if (md.fp) inv_row_part<ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
+    if (md.fp) inv_row_part<ArFp, false>(ArFp(md, a.n_power), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
     else inv_row_part<ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds);
 }
 
@@ -1874,7 +1909,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_row_tensor(NttArgs a)
     int part;
     const u64* __restrict__ src = tensor_src(a, ps, part) + (u64) blockIdx.x * 4096;
     u64* __restrict__ dst = a.out + ps.out_off + (u64) blockIdx.x * 4096;
-    if (md.fp) inv_row_part<ArFp, false, true>(ArFp(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds, part);
+    if (md.fp) inv_row_part<ArFp, false, true>(ArFp(md, a.n_power), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds, part);
     else inv_row_part<ArInt, false, true>(ArInt(md), a, ps.mod, threadIdx.x, blockIdx.x * 16, src, dst, lds, part);
 }
 
@@ -1895,10 +1930,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_inv_col(NttArgs a)
         bool skip;
         inv_epi_setup(a, ps, epi, skip);
         if (skip) return;
-        if (md.fp) inv_col_part<S1, ArFp, false, false, true>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused, epi, blockIdx.x * CT);
+        if (md.fp) inv_col_part<S1, ArFp, false, false, true>(ArFp(md, a.n_power), a, ps.mod, threadIdx.x, 0, p, lds, unused, epi, blockIdx.x * CT);
         else inv_col_part<S1, ArInt, false, false, true>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused, epi, blockIdx.x * CT);
     } else {
-        if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
+        if (md.fp) inv_col_part<S1, ArFp, false>(ArFp(md, a.n_power), a, ps.mod, threadIdx.x, 0, p, lds, unused);
         else inv_col_part<S1, ArInt, false>(ArInt(md), a, ps.mod, threadIdx.x, 0, p, lds, unused);
     }
 }
@@ -1935,7 +1970,7 @@ __global__ __launch_bounds__(16 << S1, 4) void ntt_inv_single(NttArgs a)
     extern __shared__ __attribute__((aligned(16))) u64 limb[];
     const PolySel ps = select_poly(a, blockIdx.x);
     const Mod md = a.mods[ps.mod];
-    if (md.fp) inv_single_body<S1, EPI, TENSOR>(ArFp(md), a, ps, limb);
+    if (md.fp) inv_single_body<S1, EPI, TENSOR>(ArFp(md, a.n_power), a, ps, limb);
     else inv_single_body<S1, EPI, TENSOR>(ArInt(md), a, ps, limb);
 }
 
@@ -1975,7 +2010,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_fwd_col_multi(NttArgs a)
         // moduli only: with the integer inverse inlined as well the modulus loop below lost a wave per SIMD;
         // limbs of integer moduli get their column stages from ntt_inv_col (ntt_launch_inv_rows).
         const Mod im = a.mods[smod];
-        inv_col_part<S1, ArFp, false, true>(ArFp(im), a, smod, t, 0, const_cast<u64*>(src), lds, sreg);
+        inv_col_part<S1, ArFp, false, true>(ArFp(im, a.n_power), a, smod, t, 0, const_cast<u64*>(src), lds, sreg);
         __syncthreads(); // the exchange tile is free again
     } else if constexpr (NSA > 0) {
 #pragma unroll

@@ -19,6 +19,7 @@
 // results are identical to the reference's.
 #include "tfhe.hpp"
 #include <cstdlib>
+#define HEGPU_FP_TU tfhe // (names this file's table reader in the instrumented test build, see fpmod.cuh)
 #include "fpmod.cuh"
 #include "drbg.hpp"
 
@@ -351,12 +352,15 @@ __device__ __forceinline__ void f_ct(double& x, double& y, ulonglong2 w, const F
     const double t = fp_mul(y, as_f64(w.x), as_f64(w.y), c);
     y = x - t;
     x = x + t;
+    FP_AUDIT_VAL(c, FPM_SUM, x);
+    FP_AUDIT_VAL(c, FPM_SUM, y);
 }
 __device__ __forceinline__ void f_gs(double& x, double& y, ulonglong2 w, const FC& c)
 {
     const double s = x + y, d = x - y;
     x = s;
     y = fp_mul(d, as_f64(w.x), as_f64(w.y), c);
+    FP_AUDIT_VAL(c, FPM_SUM, s);
 }
 
 // Forward 1024-point NTT mod p' by one wavefront.  In: x[k] = element lane + 64k,
@@ -371,6 +375,7 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
+        FP_STAGE(c, s);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
             const ulonglong2 w = tw[(1 << s) + b];
@@ -387,6 +392,7 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
+        FP_STAGE(c, 4 + s);
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
             const ulonglong2 w = twl[((16 + b) << s) + bb];
@@ -403,12 +409,15 @@ __device__ __forceinline__ void fwave_ntt1024(double (&x)[16], u64* buf, const u
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const ulonglong2 w8 = twl[256 + 4 * lane + g];
+        FP_STAGE(c, 8);
         f_ct(x[4 * g + 0], x[4 * g + 2], w8, c);
         f_ct(x[4 * g + 1], x[4 * g + 3], w8, c);
         const ulonglong2 w9a = twl[512 + 8 * lane + 2 * g], w9b = twl[512 + 8 * lane + 2 * g + 1];
+        FP_STAGE(c, 9);
         f_ct(x[4 * g + 0], x[4 * g + 1], w9a, c);
         f_ct(x[4 * g + 2], x[4 * g + 3], w9b, c);
     }
+    FP_STAGE(c, 10);
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = fp_reduce(x[k], c);
     wave_fence();
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(64) void k_tfhe_prepare_bootkey_fp(const u64* __res
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = src[pi * TF_N + 16 * lane + k];
     wave_intt1024(x, buf, p.itw, p.ninv, p.w1ninv, c, lane);
-    const FC fc = make_fc(p.fprime);
+    const FC fc = make_fc(p.fprime, FP_SITE(FPS_TFHE_PREP, 0));
     double lo[16], hi[16];
     bool oob = false;
 #pragma unroll
@@ -494,6 +503,8 @@ __device__ __forceinline__ void f_ct_l(double& x, double& y, double w, const FC&
     const double t = fp_mul(y, w, w * c.qi, c);
     y = x - t;
     x = x + t;
+    FP_AUDIT_VAL(c, FPM_SUM, x);
+    FP_AUDIT_VAL(c, FPM_SUM, y);
 }
 // inverse butterfly with the FORWARD twiddle of the mirrored position: (x - y) * (-w) = (y - x) * w
 __device__ __forceinline__ void f_gs_l(double& x, double& y, double w, const FC& c)
@@ -501,6 +512,7 @@ __device__ __forceinline__ void f_gs_l(double& x, double& y, double w, const FC&
     const double s = x + y, d = y - x;
     x = s;
     y = fp_mul(d, w, w * c.qi, c);
+    FP_AUDIT_VAL(c, FPM_SUM, s);
 }
 // as fwave_ntt1024, lane-dependent twiddles from the re-laid LDS table
 __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const ulonglong2* __restrict__ tw,
@@ -509,6 +521,7 @@ __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
+        FP_STAGE(c, s);
 #pragma unroll
         for (int b = 0; b < (1 << s); b++) {
             const ulonglong2 w = tw[(1 << s) + b];
@@ -533,6 +546,7 @@ __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
+        FP_STAGE(c, 4 + s);
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
             const double w = wa[(1 << s) - 1 + bb];
@@ -554,8 +568,10 @@ __device__ __forceinline__ void fwave_ntt1024_l(double (&x)[16], u64* buf, const
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
+        FP_STAGE(c, 8);
         f_ct_l(x[4 * g + 0], x[4 * g + 2], w8[g], c);
         f_ct_l(x[4 * g + 1], x[4 * g + 3], w8[g], c);
+        FP_STAGE(c, 9);
         f_ct_l(x[4 * g + 0], x[4 * g + 1], w9[2 * g], c);
         f_ct_l(x[4 * g + 2], x[4 * g + 3], w9[2 * g + 1], c);
     }
@@ -584,8 +600,10 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
+        FP_STAGE(c, 10 + 9); // (instrumented build: the inverse stages are listed as 10 + s, next to the forward ones of the site)
         f_gs_l(x[4 * g + 0], x[4 * g + 1], w9[7 - 2 * g], c);
         f_gs_l(x[4 * g + 2], x[4 * g + 3], w9[6 - 2 * g], c);
+        FP_STAGE(c, 10 + 8);
         f_gs_l(x[4 * g + 0], x[4 * g + 2], w8[3 - g], c);
         f_gs_l(x[4 * g + 1], x[4 * g + 3], w8[3 - g], c);
     }
@@ -602,6 +620,7 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
 #pragma unroll
     for (int s = 3; s >= 0; s--) {
         const int half = 8 >> s;
+        FP_STAGE(c, 10 + 4 + s);
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
             // itw[((16 + b) << s) + bb] = -tw[((16 + 15 - b) << s) + ((1 << s) - 1 - bb)]
@@ -621,6 +640,7 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
 #pragma unroll
     for (int s = 3; s >= 1; s--) {
         const int half = 8 >> s;
+        FP_STAGE(c, 10 + s);
 #pragma unroll
         for (int bb = 0; bb < (1 << s); bb++) {
             const ulonglong2 w = itw[(1 << s) + bb];
@@ -628,6 +648,7 @@ __device__ __forceinline__ void fwave_intt1024_l(double (&x)[16], u64* buf, cons
             for (int j = 0; j < half; j++) f_gs(x[bb * 2 * half + j], x[bb * 2 * half + j + half], w, c);
         }
     }
+    FP_STAGE(c, 10);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const double s = x[j] + x[j + 8], d = x[j] - x[j + 8];
@@ -651,7 +672,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     for (int e = t; e < TF3_TW; e += TF_THREADS) twl[e] = as_f64(p.ftw[tf3_src(e)].x);
     const int g = blockIdx.x;
     const int n = p.n;
-    const FC fc = make_fc(p.fprime);
+    const FC fc = make_fc(p.fprime, FP_SITE(FPS_TFHE_BR, 0));
     {
         const int bN = 2 * TF_N - modswitch(in_b[g], 10);
         for (int j = t; j < TF_N; j += TF_THREADS) {
@@ -707,6 +728,7 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
         for (int k = 0; k < 16; k++) buf[wv][k * 64 + lane] = as_bits(x[k]);
         __syncthreads();
+        FP_STAGE(fc, FP_STAGE_PRODUCT);
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = fp_mul(ka[k], x[k], x[k] * fc.qi, fc);
 #pragma unroll
@@ -724,10 +746,18 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
             for (int k = 0; k < 16; k++) xo[k] = as_f64(ob[k * 64]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] += fp_mul(ka[k], xo[k], xo[k] * fc.qi, fc);
+            for (int k = 0; k < 16; k++) {
+                FP_STAGE(fc, FP_STAGE_PRODUCT);
+                x[k] += fp_mul(ka[k], xo[k], xo[k] * fc.qi, fc);
+                FP_STAGE(fc, FP_STAGE_SUMS + r - 1);
+                FP_AUDIT_VAL(fc, FPM_SUM, x[k]);
+            }
         }
         __syncthreads(); // all staging areas read: the inverse transform may use them as scratch
         fwave_intt1024_l(x, buf[wv], p.fitw, twl, p.fninv, p.fw1ninv, fc, lane);
+        FP_STAGE(fc, FP_STAGE_OUT);
+#pragma unroll
+        for (int k = 0; k < 16; k++) FP_AUDIT_VAL(fc, FPM_SUM, x[k]); // the convolution's coefficients themselves: |x| <= 2^37
 #pragma unroll
         for (int k = 0; k < 16; k++)
             atomicAdd(reinterpret_cast<u32*>(&acc[cc][lane + 64 * k]), f_low32(x[k]) << sh);

@@ -40,3 +40,41 @@ def backend_switches(**kw):
         opts[k[len("HEGPU_"):].lower()] = int(v)
     with hg.default_options(**opts):
         yield
+
+
+def extreme_limbs(c, primes, limb_ids, n, pattern, seed):
+    """[len(limb_ids)][n] residues at their extremes: 'max' every residue q - 1, 'alt' 0 / q - 1, 'alt3', 'spike' one
+    q - 1, 'half' q/2 and q/2 + 1, else seeded random.  Patterns ending in '_coeff' are built in the COEFFICIENT domain
+    and transformed on the device, so that the digits a key switch decomposes (after its inverse transform) are the
+    extremes."""
+    import torch
+    import heongpu_amd as hg
+    rows = []
+    for j, lid in enumerate(limb_ids):
+        q = primes[lid]
+        base = pattern.replace("_coeff", "")
+        if base == "max":
+            v = np.full(n, q - 1, dtype=np.uint64)
+        elif base == "alt":
+            v = np.zeros(n, dtype=np.uint64)
+            v[::2] = q - 1
+        elif base == "alt3":
+            v = np.full(n, q - 1, dtype=np.uint64)
+            v[::3] = 0
+        elif base == "spike":
+            v = np.zeros(n, dtype=np.uint64)
+            v[(seed * 7919 + 13 * j) % n] = q - 1
+        elif base == "half":
+            v = np.full(n, q // 2, dtype=np.uint64)
+            v[1::2] = q // 2 + 1
+        else:
+            v = ob.fill_poly(seed * 1000 + 17, lid, n, q)
+        rows.append(v)
+    x = np.concatenate(rows)
+    if pattern.endswith("_coeff"):
+        d = hg.to_device(x)
+        assert list(limb_ids) == list(range(len(limb_ids)))
+        c.ntt(d, d, False, len(limb_ids), len(limb_ids))
+        torch.cuda.synchronize()
+        x = hg.to_host(d)
+    return x

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import backend_switches, synth_ct, synth_key
+from helpers import backend_switches, extreme_limbs, synth_ct, synth_key
 
 pytestmark = pytest.mark.gpu
 
@@ -93,6 +93,39 @@ def test_c4_chain_multiply_relinearize_rotate(hg, oracle, torch, col_multi, batc
 
 
 # ------------------------------------------------------------------ fusions switched off
+@pytest.mark.parametrize("sw,batch,key_kind", [
+    (dict(), 8, "max"), (dict(), 8, "random"), (dict(), 2, "max"), (dict(HEGPU_FP_NTT=0), 8, "max"),
+    (dict(HEGPU_FUSED_ROW_MAC=0), 4, "max")],
+    ids=["default_batch8_key_max", "default_batch8_key_random", "default_batch2_split", "integer_butterflies", "unfused"])
+def test_c4_shape_key_switch_extreme_values(hg, oracle, torch, sw, batch, key_kind):
+    """The fused key switch at config C4's EXACT shape -- N = 2^16 (FpColSched<8>), {60, 50 x 15 | 60}, 16 digits: the
+    three-digit re-centring cadence of ks_row_mac_fp five times over -- with inputs at their extremes instead of
+    random ones: every residue q - 1, alternating 0 / q - 1, a single spike, q / 2, each in the NTT
+    domain and in the coefficient domain (so that the decomposed digits themselves are the extremes), against a key of
+    all q - 1 and a random one.  Eight ciphertexts take the kernels of the bench (ntt_fwd_col_multi<8> +
+    ks_row_mac_fp), two the small-launch form (ks_row_mac_split); the same under HEGPU_FP_NTT=0 (integer butterflies
+    on the same chain) and with the fusion off.  Canonical mult / add semantics: switchkey.cu:61-162.
+    (tests/test_gpu_fp_audit.py runs these inputs through the instrumented build and records the magnitudes.)"""
+    n = 65536
+    with backend_switches(**sw):
+        c, o, primes = _ckks(hg, oracle, n, [60] + [50] * 15, [60])
+    Q, Qp = 16, 17
+    pats = ["max", "alt", "spike", "max_coeff", "alt_coeff", "alt3_coeff", "half_coeff", "random"][:batch] if batch >= 4 \
+        else ["max_coeff", "alt_coeff"]
+    if key_kind == "max":
+        key = np.concatenate([np.full(n, primes[j] - 1, dtype=np.uint64) for _ in range(Q) for _c in range(2) for j in range(Qp)])
+    else:
+        key = synth_key(primes, Q, Qp, n, 3)
+    cts = [np.concatenate([extreme_limbs(c, primes, range(Q), n, pat, 31 * i + p) for p in range(3)]) for i, pat in enumerate(pats)]
+    d = hg.to_device(np.concatenate(cts))
+    c.ckks_relinearize_inplace(d, 3 * Q * n, hg.to_device(key), 0, len(cts), c.workspace(hg.OP_CKKS_RELIN, 0, len(cts)))
+    torch.cuda.synchronize()
+    got = hg.to_host(d).reshape(len(cts), -1)
+    for b, pat in enumerate(pats):
+        want = o.ckks_relinearize(cts[b].copy(), key, 0)
+        assert np.array_equal(got[b][:2 * Q * n], want[:2 * Q * n]), (pat, key_kind)
+
+
 _SWITCHES = [
     dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=1),  # forced: a small launch would pick the other forms
     dict(HEGPU_FUSED_ROW_MAC=1, HEGPU_SINGLE_PASS=0),
