@@ -52,7 +52,8 @@ LOG_P = [60]
 PAIRS_PER_GPU = 64      # config C4: 512 pairs over 8 GPUs
 GATES_PER_GPU = 1024    # config C5: 8192 gates over 8 GPUs
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-UNIQ = 4                # distinct seeded pairs, repeated to fill a batch
+UNIQ = 64               # distinct seeded pairs of the global batch (pair g has the inputs of index g % UNIQ): a rank's 64 pairs are
+#                         all different, every rank of an N-GPU run computes the same 64 -- what the cross-rank check compares
 TFHE_UNIQ = 64          # distinct seeded gate inputs
 SIMDS, LANES = 1024, 16  # 256 CUs x 4 SIMDs, 16 lanes each: a wave64 vector instruction holds its SIMD for 4 cycles
 NCCL_TIMEOUT_S = 60
@@ -94,6 +95,9 @@ def parse_args(argv=None):
                          "compact contract line")
     ap.add_argument("--compact-from", default=None,
                     help="no GPU work: read a detail file and print the compact contract line built from it")
+    ap.add_argument("--selftest-corrupt-rank", type=int, default=-1,
+                    help="testing: one bit of this rank's key replica is flipped after the broadcast: the line must say "
+                         "key_digest_equal / cross_rank_equal false and the run must fail")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: exercise launch, sharding, key replication and the max-over-ranks reduction on CPU")
     a = ap.parse_args(argv)
@@ -116,7 +120,28 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    # rank 0 touches this file when it has printed its line: a non-zero exit AFTER that is a failed check of a run that
+    # took place (a wrong replica, a mismatch) and must not be mistaken for a launch failure and retried in one process
+    import tempfile
+    fd, marker = tempfile.mkstemp(prefix="hegpu_bench_ran_")
+    os.close(fd)
+    os.unlink(marker)
+    env["HEGPU_BENCH_RAN_MARKER"] = marker
+    rc = subprocess.call(cmd, env=env)
+    if os.path.exists(marker):
+        os.unlink(marker)
+        if rc != 0:
+            raise SystemExit(rc)
+    return rc
+
+
+def mark_ran():
+    m = os.environ.get("HEGPU_BENCH_RAN_MARKER")
+    if m:
+        try:
+            open(m, "w").close()
+        except OSError:
+            pass
 
 
 # ------------------------------------------------------------------ distributed plumbing
@@ -154,6 +179,16 @@ class Dist:
         out = [self.torch.zeros(1, dtype=self.torch.float64) for _ in range(self.world)]
         self.dist.all_gather(out, self.torch.tensor([v], dtype=self.torch.float64))
         return [float(t.item()) for t in out]
+
+    def gather_i64(self, values):
+        """every rank's list of 64-bit values (bit patterns as Python ints), rank-major"""
+        vals = [v - (1 << 64) if v >> 63 else v for v in (int(x) & ((1 << 64) - 1) for x in values)]
+        if self.world == 1:
+            return [[v & ((1 << 64) - 1) for v in vals]]
+        own = self.torch.tensor(vals, dtype=self.torch.int64)
+        out = [self.torch.zeros_like(own) for _ in range(self.world)]
+        self.dist.all_gather(out, own)
+        return [[int(v) & ((1 << 64) - 1) for v in t.tolist()] for t in out]
 
     def _nccl_broadcast(self, tensors, dev, result):
         try:
@@ -227,6 +262,20 @@ def selftest_keys(torch, workload):
             (torch.arange(3000, dtype=torch.int64) % 251).to(torch.int32)]
 
 
+def selftest_outputs(torch, keys, slice_):
+    """stand-in "outputs" of a rank (CPU): unit g of its slice = a function of its input index g % 64 and of the rank's
+    own key replica -- so a broken replica shows in the outputs exactly as on the device.  Returns (digests, present)."""
+    start, count = slice_
+    dig, present = [0] * 64, [0] * 64
+    k = keys[0].reshape(-1).to(torch.int64)
+    for g in range(start, start + count):
+        u = g % 64
+        if not present[u]:
+            row = (k[:16384] * (2 * u + 1) + u).reshape(1, -1)
+            dig[u], present[u] = row_digests(torch, row)[0], 1
+    return dig, present
+
+
 def launcher_selftest(args):
     """What the multi-GPU paths do around the kernels, without a GPU.  Under a launcher (or self-launched): rendezvous,
     shard the global batch, replicate the key-shaped tensors from rank 0, reduce the elapsed time with MAX, gather
@@ -252,6 +301,11 @@ def launcher_selftest(args):
         for j in range(1, world):  # hegpu_broadcast_bytes on a fully connected node: a flat fan-out from device 0
             for a, b in zip(keys[0], keys[j]):
                 b.copy_(a)
+        if 0 <= args.selftest_corrupt_rank < world:
+            keys[args.selftest_corrupt_rank][0][12345 % keys[0][0].numel()] ^= 1
+        xc = cross_check([[digest64(torch, k) for k in ks] for ks in keys],
+                         *zip(*[selftest_outputs(torch, ks, slices_r) for ks, slices_r in
+                                zip(keys, [sharding.shard_range(args.batch * world, world, r) for r in range(world)])]))
         ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
         [t.start() for t in ths]
         [t.join() for t in ths]
@@ -259,8 +313,10 @@ def launcher_selftest(args):
         print(json.dumps({"launcher_selftest": True, "workload": args.workload, "n_gpus": world, "key_broadcast_ok": ok,
                           "replicated_tensors": len(refs), "max_elapsed_s": max(elapsed),
                           "global_batch": args.batch * world, "slices": slices,
+                          "key_digest_equal": xc["key_digest_equal"], "cross_rank_equal": xc["cross_rank_equal"],
+                          "distinct_inputs": xc["distinct_inputs"], "ranks_disagreeing_on_key": xc["ranks_disagreeing_on_key"],
                           "parallelism": "single process, one thread per device (fallback: launch failed)"}))
-        return 0 if ok else 1
+        return 0 if (ok and xc["key_digest_equal"] and xc["cross_rank_equal"]) else 1
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
     assert world == args.gpus, "world size %d != --gpus %d" % (world, args.gpus)
     d = Dist(torch, world, rank, "gloo")
@@ -269,7 +325,11 @@ def launcher_selftest(args):
     if world > 1:
         for k in keys:
             d.dist.broadcast(k, src=0)
-    ok = all(bool((k == r).all()) for k, r in zip(keys, refs))
+    if args.selftest_corrupt_rank == rank:
+        keys[0][12345 % keys[0].numel()] ^= 1
+    ok = all(bool((k == r).all()) for k, r in zip(keys, refs)) or args.selftest_corrupt_rank == rank
+    od, op = selftest_outputs(torch, keys, (start, count))
+    xc = cross_check(d.gather_i64([digest64(torch, k) for k in keys]), d.gather_i64(od), d.gather_i64(op))
     mx = d.max_float(0.001 * (rank + 1))
     d.gather_floats(count / (0.001 * (rank + 1)))
     slices = [[start, count]]
@@ -282,9 +342,61 @@ def launcher_selftest(args):
         print(json.dumps({"launcher_selftest": True, "workload": args.workload, "n_gpus": world, "key_broadcast_ok": ok,
                           "replicated_tensors": len(refs), "max_elapsed_s": mx,
                           "global_batch": args.batch * world, "slices": slices,
+                          "key_digest_equal": xc["key_digest_equal"], "cross_rank_equal": xc["cross_rank_equal"],
+                          "distinct_inputs": xc["distinct_inputs"], "ranks_disagreeing_on_key": xc["ranks_disagreeing_on_key"],
                           "parallelism": "one process per GPU (gloo control plane)"}))
-    d.close()
-    return 0 if ok else 1
+        mark_ran()
+    rc = 0 if (ok and xc["key_digest_equal"] and xc["cross_rank_equal"]) else 1
+    d.close(rc)
+    return rc
+
+
+# ------------------------------------------------------------------ what makes an N > 1 line prove itself
+_M64 = (1 << 64) - 1
+
+
+def _weights(torch, n, device, offset=0):
+    """n odd pseudo-random 64-bit weights (splitmix64 of the element index), as int64 bit patterns"""
+    from heongpu_amd import synth
+    idx = torch.arange(offset, offset + n, dtype=torch.int64, device=device)
+    return synth._splitmix64_t(torch, idx) | 1
+
+
+def digest64(torch, t, chunk=1 << 24):
+    """64-bit digest of a tensor: sum of x_i * w_i modulo 2^64 with odd pseudo-random w_i.  One changed element always
+    changes it (w_i is a unit modulo 2^64); computed where the tensor lives."""
+    x = t.reshape(-1)
+    if x.dtype != torch.int64:
+        x = x.to(torch.int64)
+    acc = 0
+    for off in range(0, x.numel(), chunk):
+        part = x[off:off + chunk]
+        acc = (acc + int((part * _weights(torch, part.numel(), part.device, off)).sum().item())) & _M64
+    return acc
+
+
+def row_digests(torch, rows):
+    """one digest per row of a 2-D integer tensor (the same weights for every row)"""
+    x = rows if rows.dtype == torch.int64 else rows.to(torch.int64)
+    w = _weights(torch, x.shape[1], x.device)
+    return [int((x[i] * w).sum().item()) & _M64 for i in range(x.shape[0])]
+
+
+def cross_check(key_digests, out_digests, out_present):
+    """Pure.  key_digests[r]: the digests of rank r's replicated tensors; out_digests[r][u] / out_present[r][u]: rank r's
+    output digest for distinct input u (0 / absent if its slice holds no item with that input).
+      key_digest_equal: every rank holds the bits rank 0 holds;
+      cross_rank_equal: whenever two ranks computed on the same input they produced the same output."""
+    key_ok = all(k == key_digests[0] for k in key_digests)
+    disagree, seen = [], 0
+    for u in range(len(out_digests[0])):
+        got = {out_digests[r][u] for r in range(len(out_digests)) if out_present[r][u]}
+        seen += 1 if got else 0
+        if len(got) > 1:
+            disagree.append(u)
+    return {"key_digest_equal": key_ok, "cross_rank_equal": not disagree, "distinct_inputs": seen,
+            "ranks_disagreeing_on_key": [r for r, k in enumerate(key_digests) if k != key_digests[0]],
+            "inputs_with_differing_outputs": disagree[:8]}
 
 
 # ------------------------------------------------------------------ timing helpers
@@ -400,10 +512,14 @@ class C4:
         if free_b < need + (1 << 30):
             raise SystemExit("bench.py: device %s has %.1f GiB free, the workload needs %.1f GiB"
                              % (dev, free_b / 2**30, need / 2**30))
-        self.uniq = min(B, UNIQ)
-        a = [synth.synth_ct_t(torch, self.primes, range(l), 2, n, 1 + 10 * u, dev) for u in range(self.uniq)]
-        b = [synth.synth_ct_t(torch, self.primes, range(l), 2, n, 2 + 10 * u, dev) for u in range(self.uniq)]
-        self.ct1, self.ct2 = tile_items(torch, a, B, first), tile_items(torch, b, B, first)
+        # pair g of the global batch has the inputs of distinct index g % UNIQ (seeds 1 + 10 u / 2 + 10 u)
+        need_u = sorted({(first + b) % UNIQ for b in range(B)})
+        self.uniq = len(need_u)
+        a = {u: synth.synth_ct_t(torch, self.primes, range(l), 2, n, 1 + 10 * u, dev) for u in need_u}
+        b = {u: synth.synth_ct_t(torch, self.primes, range(l), 2, n, 2 + 10 * u, dev) for u in need_u}
+        self.ct1 = torch.cat([a[(first + i) % UNIQ] for i in range(B)])
+        self.ct2 = torch.cat([b[(first + i) % UNIQ] for i in range(B)])
+        del a, b
         self.out = torch.empty(B * self.out_elems, dtype=torch.int64, device=dev)
         self.ws = ctx.workspace(hg.OP_CKKS_RELIN, 0, B, device=dev)
         self.key = torch.empty(2 * self.Q * self.Qp * n, dtype=torch.int64, device=dev)
@@ -426,7 +542,17 @@ class C4:
         c.ckks_relinearize_inplace(self.out, self.out_elems, self.key, 0, self.B, self.ws, stream=stream)
 
     def twins(self):
-        return twins_equal(self.torch, self.out, self.out_elems, self.B, self.uniq, self.first, used_elems=self.ct_elems)
+        return twins_equal(self.torch, self.out, self.out_elems, self.B, UNIQ, self.first, used_elems=self.ct_elems)
+
+    def output_digests(self):
+        """(digest, present) per distinct input index: the first item of this rank's slice that has it"""
+        d = row_digests(self.torch, self.out.view(self.B, self.out_elems)[:, :self.ct_elems])
+        dig, present = [0] * UNIQ, [0] * UNIQ
+        for b in range(self.B):
+            u = (self.first + b) % UNIQ
+            if not present[u]:
+                dig[u], present[u] = d[b], 1
+        return dig, present
 
     def describe(self, args, world):
         W, l = 8 * N, self.Q
@@ -438,12 +564,27 @@ class C4:
             "global_batch": args.batch * world, "algorithmic_bytes_per_op": (6 * l * l + 32 * l + 8) * W})
 
 
-def c4_host_inputs(primes, l, n, uniq):
-    """numpy copies of the distinct pairs of a batch (the CPU checker's input)"""
+def c4_host_inputs(primes, l, n, indices):
+    """numpy copies of the pairs with the given distinct indices (the CPU checker's input)"""
     from heongpu_amd import synth
-    a = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 1 + 10 * u) for u in range(uniq)])
-    b = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 2 + 10 * u) for u in range(uniq)])
+    a = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 1 + 10 * u) for u in indices])
+    b = np.concatenate([synth.synth_ct_np(primes, range(l), 2, n, 2 + 10 * u) for u in indices])
     return a, b
+
+
+def c4_oracle_item(hg, work, b):
+    """item b of this rank's slice against the CPU oracle (the checker): multiply + relinearize of its input pair"""
+    from heongpu_amd import synth
+    from oracle import binding as ob
+    u = (work.first + b) % UNIQ
+    l, n = work.Q, work.n
+    c1, c2 = c4_host_inputs(work.primes, l, n, [u])
+    key_h = synth.synth_key_np(work.primes, work.Q, work.Qp, n, 3)
+    o = ob.OracleContext(ob.CKKS, 16, work.primes, work.Q, 1)
+    want = o.ckks_multiply(c1, c2, 0)
+    o.ckks_relinearize(want, key_h, 0)
+    got = hg.to_host(work.out.view(work.B, work.out_elems)[b, :work.ct_elems])
+    return bool(np.array_equal(got, want[:work.ct_elems]))
 
 
 # ------------------------------------------------------------------ the C5 workload on one device
@@ -531,6 +672,20 @@ class C5:
         ga, gb = self.out_a.view(self.S, 512), self.out_b
         ok = bool(torch.equal(ga, ga[ref])) and bool(torch.equal(gb, gb[ref]))
         return self.S - len(first_pos), ok
+
+    def output_digests(self):
+        """(digest, present) per distinct input index: the first gate of this rank's slice that has it"""
+        torch = self.torch
+        rows = torch.cat([self.out_a.view(self.S, 512), self.out_b.view(self.S, 1)], dim=1)
+        first_pos = {}
+        for b, u in enumerate(self.idx):
+            first_pos.setdefault(int(u), b)
+        us = sorted(first_pos)
+        d = row_digests(torch, rows[torch.tensor([first_pos[u] for u in us], device=self.dev)])
+        dig, present = [0] * TFHE_UNIQ, [0] * TFHE_UNIQ
+        for u, v in zip(us, d):
+            dig[u], present[u] = v, 1
+        return dig, present
 
     def oracle_check(self, count):
         """the first `count` gates of this rank's slice against the CPU oracle (the checker; not timed here)"""
@@ -698,6 +853,7 @@ def emit(line, args):
         path = None
     sys.stdout.flush()
     print(compact_line(line, path), flush=True)
+    mark_ran()
 
 
 # ------------------------------------------------------------------ which path a command line takes (pure; CPU-testable)
@@ -797,6 +953,10 @@ def run_single_process(args, reason):
     for s in streams:
         s.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
+    if 0 < args.selftest_corrupt_rank < world:   # testing: a replica that arrived with one bit wrong
+        with torch.cuda.device(devs[args.selftest_corrupt_rank]):
+            works[args.selftest_corrupt_rank].replicated()[0].view(-1)[12345] ^= 1
+            torch.cuda.synchronize()
     bar = threading.Barrier(world)
     own, total = [0.0] * world, [0.0] * world
     errors = []
@@ -835,16 +995,38 @@ def run_single_process(args, reason):
     line["key_bytes"] = sum(t.numel() * t.element_size() for t in works[0].replicated())
     tw = [w.twins() for w in works]
     same_key = all(bool(torch.equal(a.to(w.dev), b)) for w in works[1:] for a, b in zip(works[0].replicated(), w.replicated()))
-    line["checked_items"] = {"twin_compared": sum(t[0] for t in tw), "twins_equal": all(t[1] for t in tw),
-                             "key_replicas_equal": same_key, "oracle_compared": 0,
+    # the same self-proof as the one-process-per-GPU tiers (run_rank): repeat, key digests, cross-device outputs
+    digs, repeat_ok, key_digs = [], True, []
+    for r, w in enumerate(works):
+        with torch.cuda.device(devs[r]), torch.cuda.stream(streams[r]):
+            d0 = w.output_digests()
+            w.step(streams[r].cuda_stream)
+            streams[r].synchronize()
+            repeat_ok &= w.output_digests()[0] == d0[0]
+            digs.append(d0)
+            key_digs.append([digest64(torch, t) for t in w.replicated()])
+    xc = cross_check(key_digs, [d[0] for d in digs], [d[1] for d in digs])
+    line["checked_items"] = {"distinct_inputs": xc["distinct_inputs"], "twin_compared": sum(t[0] for t in tw),
+                             "twins_equal": all(t[1] for t in tw), "repeat_equal": repeat_ok,
+                             "key_replicas_equal": same_key, "key_digest_equal": xc["key_digest_equal"],
+                             "cross_rank_equal": xc["cross_rank_equal"], "oracle_compared": 0,
                              "note": "multi-GPU run: the oracle comparison is part of the N=1 line"}
+    if args.workload == "c4" and not args.no_cpu_baseline:
+        got = []
+        for r, w in enumerate(works):
+            with torch.cuda.device(devs[r]):
+                got.append(c4_oracle_item(hg, w, r % w.B))
+        line["checked_items"].update(oracle_compared=len(got), oracle_equal=all(got),
+                                     note="one item per device against the CPU oracle; every other output through cross_rank_equal")
     dec_ok = True
     if hasattr(works[0], "decrypt_check"):
         dec = [w.decrypt_check() for w in works]
         dec_ok = all(d[1] for d in dec)
         line["checked_items"].update(decrypt_compared=sum(d[0] for d in dec), decrypt_equal=dec_ok)
     emit(line, args)
-    return 0 if (all(t[1] for t in tw) and same_key and dec_ok) else 1
+    chk = line["checked_items"]
+    return 0 if (all(t[1] for t in tw) and same_key and dec_ok and repeat_ok and chk["key_digest_equal"] and
+                 chk["cross_rank_equal"] and chk.get("oracle_equal", True)) else 1
 
 
 # ------------------------------------------------------------------ secondary workloads (N=1 only)
@@ -1233,6 +1415,8 @@ def run_rank(args):
     if rank == 0:
         work.make_keys()   # produced on the device (C4: 272 MiB; C5: 64 + 48 MiB)
     bcast_ms = dist.broadcast_keys(work.replicated(), dev)
+    if args.selftest_corrupt_rank == rank and world > 1:   # testing: a replica that arrived with one bit wrong
+        work.replicated()[0].view(-1)[12345] ^= 1
     stream = torch.cuda.current_stream().cuda_stream
     step = lambda: work.step(stream)
 
@@ -1252,6 +1436,18 @@ def run_rank(args):
     per_rank = dist.gather_floats(B * args.steps / own_elapsed)
     tw_n, tw_ok = work.twins()
     tw_all = dist.gather_floats(float(tw_n if tw_ok else -1))
+    # ---- the line proves itself: (a) the same step once more gives the same bits (determinism without twins: all inputs
+    # of a slice are distinct), (b) every rank holds the key bits rank 0 made, (c) ranks that computed on the same input
+    # produced the same output.  64-bit digests, gathered over gloo; a mismatch makes the run fail.
+    out_dig, out_present = work.output_digests()
+    repeat_ok = True
+    if not args.step_only:   # (counter passes: every dispatch belongs to a timed step)
+        step()
+        torch.cuda.synchronize()
+        repeat_ok = work.output_digests()[0] == out_dig
+    key_dig = [digest64(torch, t) for t in work.replicated()]
+    xc = cross_check(dist.gather_i64(key_dig), dist.gather_i64(out_dig), dist.gather_i64(out_present))
+    rep_all = dist.gather_floats(1.0 if repeat_ok else 0.0)
     dec_all = None
     if hasattr(work, "decrypt_check"):   # C5: every output decrypted with the secret key, on every rank
         dn, dok = work.decrypt_check()
@@ -1267,17 +1463,31 @@ def run_rank(args):
     if bcast_ms is not None:
         line["key_broadcast_ms"] = bcast_ms
         line["key_bytes"] = sum(t.numel() * t.element_size() for t in work.replicated())
-    line["checked_items"] = {"distinct_inputs": getattr(work, "uniq", TFHE_UNIQ), "twin_compared": int(sum(max(t, 0) for t in tw_all)),
-                             "twins_equal": all(t >= 0 for t in tw_all), "oracle_compared": 0}
+    line["checked_items"] = {"distinct_inputs": xc["distinct_inputs"], "twin_compared": int(sum(max(t, 0) for t in tw_all)),
+                             "twins_equal": all(t >= 0 for t in tw_all), "repeat_equal": all(v == 1.0 for v in rep_all),
+                             "key_digest_equal": xc["key_digest_equal"], "cross_rank_equal": xc["cross_rank_equal"],
+                             "oracle_compared": 0}
+    if not (xc["key_digest_equal"] and xc["cross_rank_equal"]):
+        line["checked_items"].update(ranks_disagreeing_on_key=xc["ranks_disagreeing_on_key"],
+                                     inputs_with_differing_outputs=xc["inputs_with_differing_outputs"])
     if dec_all is not None:
         line["checked_items"].update(decrypt_compared=int(sum(max(t, 0) for t in dec_all)), decrypt_equal=all(t >= 0 for t in dec_all))
 
     if args.step_only or not plan["full_line"]:
+        chk = line["checked_items"]
+        if world > 1 and args.workload == "c4" and not args.no_cpu_baseline and not args.step_only:
+            # one item per rank against the CPU oracle (rank r: the item of distinct index r of its slice) -- together with
+            # cross_rank_equal every rank's every output is tied to an oracle-checked one of the same input
+            ok_r = c4_oracle_item(hg, work, rank % B)
+            got = dist.gather_floats(1.0 if ok_r else 0.0)
+            chk.update(oracle_compared=len(got), oracle_equal=all(v == 1.0 for v in got),
+                       note="one item per rank against the CPU oracle; every other output through cross_rank_equal")
+        elif world > 1:
+            chk["note"] = "multi-GPU run: the oracle comparison is part of the N=1 line"
         if rank == 0:
-            if world > 1:
-                line["checked_items"]["note"] = "multi-GPU run: the oracle comparison is part of the N=1 line"
             emit(line, args)
-        rc = 0 if (line["checked_items"]["twins_equal"] and line["checked_items"].get("decrypt_equal", True)) else 1
+        rc = 0 if (chk["twins_equal"] and chk["repeat_equal"] and chk["key_digest_equal"] and chk["cross_rank_equal"] and
+                   chk.get("oracle_equal", True) and chk.get("decrypt_equal", True)) else 1
         dist.close(rc)
         return rc
 
@@ -1297,7 +1507,8 @@ def run_rank(args):
         emit(line, args)
         dist.close()
         chk = line["checked_items"]
-        return 0 if (chk["twins_equal"] and chk.get("oracle_equal", True) and chk.get("decrypt_equal", True)) else 1
+        return 0 if (chk["twins_equal"] and chk["repeat_equal"] and chk["key_digest_equal"] and chk["cross_rank_equal"] and
+                     chk.get("oracle_equal", True) and chk.get("decrypt_equal", True)) else 1
 
     ctx = work.ctx
     Q, Qp, n = ctx.Q_size, ctx.Q_prime_size, N
@@ -1397,7 +1608,7 @@ def run_rank(args):
         # exactly as the GPU's batch is), OpenMP over the pairs -- ~16 s on a 128-core host (2 x cores: 33 s, same rate:
         # the host's memory system, not its core count, bounds the restatement)
         sample = args.cpu_sample or max(cores, 2)
-        c1u, c2u = c4_host_inputs(primes, l, n, uniq)
+        c1u, c2u = c4_host_inputs(primes, l, n, range(uniq))
         key_h = synth.synth_key_np(primes, Q, Qp, n, 3)
         o3 = np.zeros(sample * out_elems, dtype=np.uint64)
         t0 = time.perf_counter()
@@ -1406,7 +1617,7 @@ def run_rank(args):
         cpu_s = time.perf_counter() - t0
         o3 = o3.reshape(sample, out_elems)[:, :ct_elems]
         equal = [bool(np.array_equal(o3[s], sample_gpu[(first + s) % uniq])) for s in range(sample)]
-        line["checked_items"]["oracle_compared"] = min(sample, B)
+        line["checked_items"]["oracle_compared"] = min(sample, uniq)   # DISTINCT (input, output) pairs verified by the CPU
         line["checked_items"]["oracle_equal"] = all(equal)
         line["checked_items"]["total"] = B  # every item of the timed batch: against the oracle's result for its input (directly for
         #                                      the first occurrence, through its twin otherwise)
@@ -1419,7 +1630,8 @@ def run_rank(args):
         }
     emit(line, args)
     dist.close()
-    ok = line["checked_items"]["twins_equal"] and line["checked_items"].get("oracle_equal", True)
+    chk = line["checked_items"]
+    ok = chk["twins_equal"] and chk["repeat_equal"] and chk["key_digest_equal"] and chk["cross_rank_equal"] and chk.get("oracle_equal", True)
     return 0 if ok else 1
 
 

@@ -225,3 +225,71 @@ def test_bench_c5_selftest_shards_gates_and_replicates_three_keys():
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["workload"] == "c5" and line["key_broadcast_ok"] and line["replicated_tensors"] == 3
         assert line["slices"] == [[0, 1024], [1024, 1024]] and line["global_batch"] == 2048 and where in line["parallelism"]
+
+
+def _selftest(extra, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launcher-selftest"] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_a_corrupted_key_replica_fails_the_multi_gpu_line():
+    """an N > 1 line must detect a wrong key replica.  Every rank digests each replicated key tensor
+    and its output per distinct input; the digests are gathered over gloo; rank 0 checks that every rank holds the bits
+    it made and that equal inputs gave equal outputs on every rank.  Here rank 1's replica has one bit flipped after
+    the broadcast (world 2, gloo, CPU stand-ins whose "outputs" depend on the rank's own replica as on the device):
+    the line says so, names the rank, the run exits non-zero -- and is NOT retried as a launch failure."""
+    r, line = _selftest(["--gpus", "2"])
+    assert r.returncode == 0 and line["key_digest_equal"] and line["cross_rank_equal"] and line["distinct_inputs"] == 64
+    r, line = _selftest(["--gpus", "2", "--selftest-corrupt-rank", "1"])
+    assert r.returncode != 0, r.stdout[-1500:]
+    assert line["key_digest_equal"] is False and line["cross_rank_equal"] is False and line["ranks_disagreeing_on_key"] == [1]
+    assert "one process per GPU" in line["parallelism"] and "single-process path" not in r.stderr
+    # the single-process tier (the launch of the ranks failing) runs the same check
+    r, line = _selftest(["--gpus", "3", "--force-launch-failure", "--selftest-corrupt-rank", "2"])
+    assert r.returncode != 0 and line["key_digest_equal"] is False and line["ranks_disagreeing_on_key"] == [2]
+    # C5: three replicated tensors
+    r, line = _selftest(["--gpus", "2", "--workload", "c5", "--selftest-corrupt-rank", "1"])
+    assert r.returncode != 0 and line["key_digest_equal"] is False
+
+
+def test_launcher_selftest_at_world_8():
+    """the driver's 8-GPU shape: eight ranks, 512 pairs in contiguous slices of 64, every rank's digests gathered"""
+    r, line = _selftest(["--gpus", "8"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert line["n_gpus"] == 8 and line["global_batch"] == 512 and line["slices"] == [[64 * i, 64] for i in range(8)]
+    assert line["key_digest_equal"] and line["cross_rank_equal"] and line["distinct_inputs"] == 64
+
+
+def test_cross_check_is_a_pure_function_of_the_digests():
+    import bench
+    keys = [[1, 2], [1, 2], [1, 2]]
+    outs = [[5, 6, 0], [5, 0, 7], [0, 6, 7]]
+    pres = [[1, 1, 0], [1, 0, 1], [0, 1, 1]]
+    x = bench.cross_check(keys, outs, pres)
+    assert x["key_digest_equal"] and x["cross_rank_equal"] and x["distinct_inputs"] == 3
+    x = bench.cross_check([[1, 2], [1, 3], [1, 2]], outs, pres)
+    assert not x["key_digest_equal"] and x["ranks_disagreeing_on_key"] == [1] and x["cross_rank_equal"]
+    outs[2][1] = 9
+    x = bench.cross_check(keys, outs, pres)
+    assert x["key_digest_equal"] and not x["cross_rank_equal"] and x["inputs_with_differing_outputs"] == [1]
+
+
+def test_digest64_sees_every_single_element_change():
+    import torch
+    import bench
+    t = (torch.arange(100000, dtype=torch.int64) * 2654435761) % 1000003
+    d0 = bench.digest64(torch, t, chunk=1 << 12)
+    assert d0 == bench.digest64(torch, t.clone()) and 0 <= d0 < 2 ** 64
+    for i in (0, 4095, 4096, 99999):
+        u = t.clone()
+        u[i] ^= 1
+        assert bench.digest64(torch, u, chunk=1 << 12) != d0
+    swapped = t.clone()
+    swapped[[3, 5]] = swapped[[5, 3]]
+    assert bench.digest64(torch, swapped) != d0     # position-dependent
+    assert bench.digest64(torch, t.to(torch.int32)) == bench.digest64(torch, t.to(torch.int32).to(torch.int64))
