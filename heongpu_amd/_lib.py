@@ -131,6 +131,7 @@ SIGNATURES = [
     ("hegpu_tfhe_prepared_format", c_int, [voidp, u64p, c_int]),
     ("hegpu_tfhe_gate_precompute", c_int, [voidp, c_int, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_bootstrapping", c_int, [voidp, voidp, voidp, u64p, voidp, voidp, c_int, voidp]),
+    ("hegpu_tfhe_status", c_int, [voidp, voidp]),
     ("hegpu_tfhe_key_switching", c_int, [voidp, voidp, voidp, voidp, voidp, voidp, voidp, c_int, voidp]),
     ("hegpu_tfhe_generate_secret_key", c_int, [voidp, voidp, voidp, voidp, voidp]),
     ("hegpu_tfhe_generate_bootstrapping_key", c_int,

@@ -655,6 +655,10 @@ class TfheContext:
         _check(self._lib.hegpu_tfhe_bootstrapping(self._h, _ptr(in_a), _ptr(in_b), _ptr(prepared_bk), _ptr(out_a),
                                                   _ptr(out_b), shape, stream if stream is not None else _stream()))
 
+    def status(self, stream=None):
+        """drains the stream; raises HEError(E_INVALID) if a bootstrapping call was handed a buffer that is no prepared key"""
+        _check(self._lib.hegpu_tfhe_status(self._h, stream if stream is not None else _stream()))
+
     def key_switching(self, in_a, in_b, out_a, out_b, ks_a, ks_b, shape, stream=None):
         _check(self._lib.hegpu_tfhe_key_switching(self._h, _ptr(in_a), _ptr(in_b), _ptr(out_a), _ptr(out_b),
                                                   _ptr(ks_a), _ptr(ks_b), shape,

@@ -1467,12 +1467,7 @@ uint64_t hegpu_tfhe_prime(const hegpu_tfhe_context* ctx) { return ctx ? ctx->p.m
 static int tfhe_need(hegpu_tfhe_context* ctx)
 {
     if (!ctx) return fail(HEGPU_E_INVALID, "null context");
-    if (ctx->uploaded) {
-        if (ctx->bad_key && __atomic_exchange_n(ctx->bad_key, 0, __ATOMIC_ACQ_REL))
-            return fail(HEGPU_E_INVALID, "an earlier bootstrapping call of this context was handed a buffer that is not a "
-                                         "prepared boot key (header word neither 0 nor 1): its outputs were not written");
-        return 0;
-    }
+    if (ctx->uploaded) return 0; // (the bad-key flag is NOT looked at here: hegpu_tfhe_status / the bootstrapping entries own it)
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
         (void) hipGetLastError();
@@ -1496,6 +1491,21 @@ static int tfhe_need(hegpu_tfhe_context* ctx)
     ctx->p.bad_key = ctx->bad_key;
     (void) hipGetDevice(&ctx->device);
     ctx->uploaded = true;
+    return 0;
+}
+// The blind rotate reads the prepared key's layout ON THE DEVICE; a buffer that is no prepared key makes the kernel set the
+// context's pinned flag and write nothing.  The flag is context-wide (not per stream) and is visible once the kernel that
+// set it has finished.  Who consumes it (round 5 let ANY later entry of the context consume it -- an unrelated
+// encrypt, or a nested call inside hegpu_tfhe_gate, reported and swallowed it):
+//   * hegpu_tfhe_status(ctx, stream): drains `stream`, returns HEGPU_E_INVALID if the flag is set and clears it -- the way
+//     to learn about a bad call AT that call (call + status), as the reference checks after each launch (util.cuh:47-55);
+//   * the entry of hegpu_tfhe_bootstrapping / _gate / _mux themselves, before they queue anything: a caller that never
+//     asks still hears about it at its next bootstrapping, and no gate is left half-queued.
+static int tfhe_take_bad_key(hegpu_tfhe_context* ctx)
+{
+    if (ctx->bad_key && __atomic_exchange_n(ctx->bad_key, 0, __ATOMIC_ACQ_REL))
+        return fail(HEGPU_E_INVALID, "a bootstrapping call of this context was handed a buffer that is not a prepared boot "
+                                     "key (header word neither 0 nor 1): its outputs were not written");
     return 0;
 }
 #define TFHE_NEED(ctx)        \
@@ -1576,11 +1586,19 @@ int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a
                    "hegpu_tfhe_gate_precompute");
 }
 
-int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
-                             const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
-                             hegpu_stream stream)
+int hegpu_tfhe_status(hegpu_tfhe_context* ctx, hegpu_stream stream)
 {
     TFHE_NEED(ctx);
+    hipError_t e = hipStreamSynchronize((hipStream_t) stream);
+    if (e != hipSuccess) return hip_ret(e, "hegpu_tfhe_status");
+    return tfhe_take_bad_key(ctx);
+}
+
+// (no look at the flag: the nested calls of hegpu_tfhe_gate / _mux)
+static int tfhe_bootstrapping_queue(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
+                                    const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
+                                    hegpu_stream stream)
+{
     if (shape <= 0) return 0;
     if (!prepared_boot_key) return fail(HEGPU_E_INVALID, "null prepared boot key");
     return hip_ret(tfhe_blind_rotate(ctx->p, in_a, in_b, (const u64*) prepared_boot_key, out_a, out_b,
@@ -1588,16 +1606,27 @@ int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const
                    "hegpu_tfhe_bootstrapping");
 }
 
+int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
+                             const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
+                             hegpu_stream stream)
+{
+    TFHE_NEED(ctx);
+    if ((r = tfhe_take_bad_key(ctx))) return r; // an earlier call's bad key, before anything is queued
+    return tfhe_bootstrapping_queue(ctx, in_a, in_b, prepared_boot_key, out_a, out_b, shape, stream);
+}
+
 int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
                              int32_t* out_b, const int32_t* ks_a, const int32_t* ks_b, int shape,
                              hegpu_stream stream)
 {
     TFHE_NEED(ctx);
-    // the split forms zero the outputs before any input is read (tfhe.hip): in and out must be distinct buffers
-    if (shape > 0 && in_a && in_b && out_a && out_b) {
-        const char *ia = (const char*) in_a, *ib = (const char*) in_b, *oa = (const char*) out_a, *ob = (const char*) out_b;
+    if (shape > 0) {
+        if (!in_a || !in_b || !out_a || !out_b || !ks_a || !ks_b) return fail(HEGPU_E_INVALID, "hegpu_tfhe_key_switching: null pointer");
+        // the split forms zero the outputs before any input is read (tfhe.hip): in and out must be distinct buffers
+        // (address ranges compared as integers: the pointers may belong to unrelated allocations)
+        const uintptr_t ia = (uintptr_t) in_a, ib = (uintptr_t) in_b, oa = (uintptr_t) out_a, ob = (uintptr_t) out_b;
         const size_t ia_n = (size_t) shape * ctx->p.k * ctx->p.N * 4, ib_n = (size_t) shape * 4, oa_n = (size_t) shape * ctx->p.n * 4;
-        auto hit = [](const char* a, size_t an, const char* b, size_t bn) { return a < b + bn && b < a + an; };
+        auto hit = [](uintptr_t a, size_t an, uintptr_t b, size_t bn) { return a < b + bn && b < a + an; };
         if (hit(ia, ia_n, oa, oa_n) || hit(ia, ia_n, ob, ib_n) || hit(ib, ib_n, oa, oa_n) || hit(ib, ib_n, ob, ib_n))
             return fail(HEGPU_E_INVALID, "hegpu_tfhe_key_switching: the output sample overlaps the input sample");
     }
@@ -1614,6 +1643,7 @@ int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, con
     const TfheDev& p = ctx->p;
     if (gate == HEGPU_GATE_NOT) // NOT needs no bootstrapping (tfhe/operator.cuh:640-686)
         return hegpu_tfhe_gate_precompute(ctx, gate, out_a, out_b, in1_a, in1_b, nullptr, nullptr, shape, stream);
+    if ((r = tfhe_take_bad_key(ctx))) return r; // an earlier call's bad key, before anything of this gate is queued
     const size_t need = ((size_t) p.n + (size_t) p.k * p.N + 2) * shape * sizeof(int32_t);
     if (!ws || ws_bytes < need) return fail(HEGPU_E_INVALID, "workspace too small");
     int32_t* t_a = (int32_t*) ws;
@@ -1621,7 +1651,7 @@ int hegpu_tfhe_gate(hegpu_tfhe_context* ctx, int gate, const int32_t* in1_a, con
     int32_t* e_a = t_b + shape;
     int32_t* e_b = e_a + (size_t) p.k * p.N * shape;
     if ((r = hegpu_tfhe_gate_precompute(ctx, gate, t_a, t_b, in1_a, in1_b, in2_a, in2_b, shape, stream))) return r;
-    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e_a, e_b, shape, stream))) return r;
+    if ((r = tfhe_bootstrapping_queue(ctx, t_a, t_b, prepared_boot_key, e_a, e_b, shape, stream))) return r;
     return hegpu_tfhe_key_switching(ctx, e_a, e_b, out_a, out_b, ks_a, ks_b, shape, stream);
 }
 
@@ -1696,13 +1726,14 @@ int hegpu_tfhe_mux(hegpu_tfhe_context* ctx, const int32_t* in1_a, const int32_t*
     int32_t* e1_b = e1_a + kN * shape;
     int32_t* e2_a = e1_b + shape;
     int32_t* e2_b = e2_a + kN * shape;
+    if ((r = tfhe_take_bad_key(ctx))) return r;
     // AND(c, in1) and AND(NOT c, in2), bootstrapped; OR of the two extracted samples; key switch
     if ((r = hegpu_tfhe_gate_precompute(ctx, HEGPU_GATE_AND, t_a, t_b, c_a, c_b, in1_a, in1_b, shape, stream))) return r;
-    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e1_a, e1_b, shape, stream))) return r;
+    if ((r = tfhe_bootstrapping_queue(ctx, t_a, t_b, prepared_boot_key, e1_a, e1_b, shape, stream))) return r;
     if ((r = hegpu_tfhe_gate_precompute(ctx, HEGPU_GATE_AND_FIRST_NOT, t_a, t_b, c_a, c_b, in2_a, in2_b, shape,
                                         stream)))
         return r;
-    if ((r = hegpu_tfhe_bootstrapping(ctx, t_a, t_b, prepared_boot_key, e2_a, e2_b, shape, stream))) return r;
+    if ((r = tfhe_bootstrapping_queue(ctx, t_a, t_b, prepared_boot_key, e2_a, e2_b, shape, stream))) return r;
     hipError_t e = tfhe_gate_pre(e1_a, e1_b, e1_a, e1_b, e2_a, e2_b, encode_to_torus32(1, 8), 1, 1, 1, (int) kN, shape,
                                  (hipStream_t) stream); // OR_pre_computation on the N-dimensional samples
     if (e != hipSuccess) return hip_ret(e, "hegpu_tfhe_mux");

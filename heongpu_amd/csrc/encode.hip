@@ -18,78 +18,171 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.i
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub_(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 
-// message [size] -> (message, 0) padded with zeros to `slots`; complex input: (re, im) pairs
-__global__ __launch_bounds__(EN_THREADS) void k_en_double_to_complex(const double* __restrict__ in, int size,
-                                                                     cplx* __restrict__ out, int complex_in)
-{
-    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    if (complex_in) out[idx] = idx < size ? ((const cplx*) in)[idx] : cplx{0.0, 0.0};
-    else out[idx] = {idx < size ? in[idx] : 0.0, 0.0};
-}
-__global__ __launch_bounds__(EN_THREADS) void k_en_complex_to_double(const cplx* __restrict__ in,
-                                                                     double* __restrict__ out, int complex_out)
-{
-    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    if (complex_out) ((cplx*) out)[idx] = in[idx];
-    else out[idx] = in[idx].re;
-}
+// ---- the special FFT (round 6: on the tile scheme of ntt.hip instead of one global-memory launch per stage).
+// slots <= 2^13 complex doubles (128 KiB) live in the LDS of ONE workgroup for all their stages: one launch, the
+// message conversion (double -> complex on the way in for encode, complex -> double on the way out for decode) in its
+// load / store.  Larger transforms (N = 2^15, 2^16) are cut as ntt.hip cuts a limb: the log2(slots) - 13 stages with
+// strides >= 2^13 run in a register pass over global memory (every access a coalesced 16-byte-per-lane segment), the 13
+// contiguous stages in LDS chunks of 2^13 -- two launches.  Two stages per exchange (radix-4 register rounds), one
+// barrier per round.  Every butterfly performs exactly the operations of the stage-per-launch form it replaces
+//   forward (decode):  u = a, v = b*w          -> (u + v, u - v)        (fftSpecial)
+//   inverse (encode):  u = a + b, v = (a-b)*w  -> (u, v), the stride-1 stage scaled by fix  (fftSpecialInv)
+// in the same order per element (no FMA contraction: -ffp-contract=off), so the result is bit-identical to the CPU
+// oracle's loop (oracle/o_encode.c) whatever the grouping.
+#define EN_LOG_CHUNK 13
+#define EN_FFT_THREADS 1024
 
-// One butterfly stage with block length len = 2*lenh; thread = one butterfly.
-// forward (decode):  u = a, v = b*w        -> (u + v, u - v)          (fftSpecial)
-// inverse (encode):  u = a + b, v = (a-b)*w -> (u, v), last stage scaled by fix (fftSpecialInv)
-template <bool INVERSE>
-__global__ __launch_bounds__(EN_THREADS) void k_en_fft_stage(cplx* __restrict__ v, const cplx* __restrict__ roots,
-                                                             int lenh, double fix, int last)
+struct EnIo {
+    const double* real_in; // encode: the message (nullptr: the transform reads `data`)
+    int in_size, in_complex;
+    double* real_out;      // decode: the message (nullptr: the transform writes `data`)
+    int out_complex;
+};
+__device__ __forceinline__ cplx en_load(const cplx* __restrict__ v, const EnIo& io, int e)
 {
-    const int t = blockIdx.x * EN_THREADS + threadIdx.x; // butterfly index
-    const int j = t & (lenh - 1), blk = t / lenh;
-    const int i0 = blk * 2 * lenh + j, i1 = i0 + lenh;
-    const cplx w = roots[lenh + j];
-    const cplx a = v[i0], b = v[i1];
-    cplx x, y;
+    if (!io.real_in) return v[e];
+    if (io.in_complex) return e < io.in_size ? reinterpret_cast<const cplx*>(io.real_in)[e] : cplx{0.0, 0.0};
+    return {e < io.in_size ? io.real_in[e] : 0.0, 0.0};
+}
+__device__ __forceinline__ void en_store(cplx* __restrict__ v, const EnIo& io, int e, cplx z)
+{
+    if (!io.real_out) v[e] = z;
+    else if (io.out_complex) reinterpret_cast<cplx*>(io.real_out)[e] = z;
+    else io.real_out[e] = z.re;
+}
+template <bool INVERSE>
+__device__ __forceinline__ void en_bfly(cplx& a, cplx& b, cplx w)
+{
     if (INVERSE) {
-        x = cadd(a, b);
-        y = cmul(csub_(a, b), w);
-        if (last) {
-            x = {x.re * fix, x.im * fix};
-            y = {y.re * fix, y.im * fix};
-        }
+        const cplx x = cadd(a, b), y = cmul(csub_(a, b), w);
+        a = x;
+        b = y;
     } else {
         const cplx bw = cmul(b, w);
-        x = cadd(a, bw);
-        y = csub_(a, bw);
+        const cplx x = cadd(a, bw), y = csub_(a, bw);
+        a = x;
+        b = y;
     }
-    v[i0] = x;
-    v[i1] = y;
 }
-
-hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st)
+// two stages (half-lengths L and 2L) on the four elements i + k L, i = blk * 4L + j, j < L
+template <bool INVERSE>
+__device__ __forceinline__ void en_radix4(cplx (&e)[4], const cplx* __restrict__ roots, int L, int j)
 {
-    const int slots = 1 << log_slots;
-    const int grid = (slots / 2 + EN_THREADS - 1) / EN_THREADS;
-    if (slots / 2 < EN_THREADS) return hipErrorInvalidValue;
-    if (!inverse) {
-        for (int lenh = 1; lenh < slots; lenh <<= 1)
-            hipLaunchKernelGGL(k_en_fft_stage<false>, dim3(grid), dim3(EN_THREADS), 0, st, (cplx*) data,
-                               (const cplx*) roots, lenh, 1.0, 0);
+    if (INVERSE) {
+        en_bfly<true>(e[0], e[2], roots[2 * L + j]);
+        en_bfly<true>(e[1], e[3], roots[2 * L + j + L]);
+        const cplx w = roots[L + j];
+        en_bfly<true>(e[0], e[1], w);
+        en_bfly<true>(e[2], e[3], w);
     } else {
-        for (int lenh = slots >> 1; lenh >= 1; lenh >>= 1)
-            hipLaunchKernelGGL(k_en_fft_stage<true>, dim3(grid), dim3(EN_THREADS), 0, st, (cplx*) data,
-                               (const cplx*) roots, lenh, fix, lenh == 1);
+        const cplx w = roots[L + j];
+        en_bfly<false>(e[0], e[1], w);
+        en_bfly<false>(e[2], e[3], w);
+        en_bfly<false>(e[0], e[2], roots[2 * L + j]);
+        en_bfly<false>(e[1], e[3], roots[2 * L + j + L]);
     }
-    return hipGetLastError();
 }
 
-hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, bool complex_in, hipStream_t st)
+// the contiguous stages (half-lengths 1 .. 2^(logch-1)) of chunk blockIdx.x, resident in LDS
+template <bool INVERSE>
+__global__ __launch_bounds__(EN_FFT_THREADS) void k_en_fft_chunk(cplx* __restrict__ v, const cplx* __restrict__ roots,
+                                                                 int logch, double fix, EnIo io)
 {
-    hipLaunchKernelGGL(k_en_double_to_complex, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, in, size, (cplx*) out,
-                       (int) complex_in);
-    return hipGetLastError();
+    extern __shared__ __attribute__((aligned(16))) unsigned char en_lds_raw[];
+    cplx* lds = reinterpret_cast<cplx*>(en_lds_raw);
+    const int CH = 1 << logch, t = threadIdx.x, T = blockDim.x;
+    const int base = blockIdx.x << logch;
+    for (int e = t; e < CH; e += T) lds[e] = en_load(v, io, base + e);
+    __syncthreads();
+    const bool odd = logch & 1;
+    if (INVERSE && odd) { // the single stage first: half-length CH / 2
+        const int L = CH >> 1;
+        for (int q = t; q < L; q += T) en_bfly<true>(lds[q], lds[q + L], roots[L + q]);
+        __syncthreads();
+    }
+    const int rounds = logch >> 1;
+    for (int r = 0; r < rounds; r++) {
+        // forward: (1,2), (4,8), ...; inverse: downwards, ending with (2,1)
+        const int s = INVERSE ? 2 * (rounds - 1 - r) : 2 * r;
+        const int L = 1 << s;
+        for (int q = t; q < (CH >> 2); q += T) {
+            const int j = q & (L - 1), i = ((q >> s) << (s + 2)) + j;
+            cplx e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = lds[i + k * L];
+            en_radix4<INVERSE>(e, roots, L, j);
+            if (INVERSE && L == 1) { // the stride-1 stage carries the scale (fftSpecialInv)
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[k] = {e[k].re * fix, e[k].im * fix};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) lds[i + k * L] = e[k];
+        }
+        __syncthreads();
+    }
+    if (!INVERSE && odd) {
+        const int L = CH >> 1;
+        for (int q = t; q < L; q += T) en_bfly<false>(lds[q], lds[q + L], roots[L + q]);
+        __syncthreads();
+    }
+    for (int e = t; e < CH; e += T) en_store(v, io, base + e, lds[e]);
 }
-hipError_t en_complex_to_double(const void* in, double* out, int slots, bool complex_out, hipStream_t st)
+
+// the REM = 1 or 2 stages whose half-lengths are >= 2^logch, in registers over global memory
+template <bool INVERSE, int REM>
+__global__ __launch_bounds__(EN_THREADS) void k_en_fft_outer(cplx* __restrict__ v, const cplx* __restrict__ roots, int logch,
+                                                             EnIo io)
 {
-    hipLaunchKernelGGL(k_en_complex_to_double, dim3(slots / EN_THREADS), dim3(EN_THREADS), 0, st, (const cplx*) in, out,
-                       (int) complex_out);
+    const int q = blockIdx.x * EN_THREADS + threadIdx.x;
+    const int L = 1 << logch;
+    if constexpr (REM == 2) {
+        const int j = q & (L - 1), i = ((q >> logch) << (logch + 2)) + j;
+        cplx e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = en_load(v, io, i + k * L);
+        en_radix4<INVERSE>(e, roots, L, j);
+#pragma unroll
+        for (int k = 0; k < 4; k++) en_store(v, io, i + k * L, e[k]);
+    } else {
+        const int j = q & (L - 1), i = ((q >> logch) << (logch + 1)) + j;
+        cplx a = en_load(v, io, i), b = en_load(v, io, i + L);
+        en_bfly<INVERSE>(a, b, roots[L + j]);
+        en_store(v, io, i, a);
+        en_store(v, io, i + L, b);
+    }
+}
+
+// `real_in` (encode) / `real_out` (decode): the message itself, converted in the first load / the last store of the
+// transform (k_en_double_to_complex / k_en_complex_to_double of rounds 1-5, reference encoder.cu:120 / :505)
+hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st,
+                          const double* real_in, int in_size, int in_complex, double* real_out, int out_complex)
+{
+    if (log_slots < 2 || log_slots > EN_LOG_CHUNK + 2) return hipErrorInvalidValue;
+    const int logch = log_slots < EN_LOG_CHUNK ? log_slots : EN_LOG_CHUNK, rem = log_slots - logch;
+    const int chunks = 1 << rem, ch = 1 << logch;
+    const int threads = (ch >> 2) < EN_FFT_THREADS ? (ch >> 2) : EN_FFT_THREADS;
+    const size_t lds_bytes = (size_t) ch * sizeof(cplx);
+    static const hipError_t a0 = hipFuncSetAttribute((const void*) k_en_fft_chunk<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int) (sizeof(cplx) << EN_LOG_CHUNK));
+    static const hipError_t a1 = hipFuncSetAttribute((const void*) k_en_fft_chunk<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int) (sizeof(cplx) << EN_LOG_CHUNK));
+    (void) a0;
+    (void) a1;
+    const EnIo plain{nullptr, 0, 0, nullptr, 0};
+    const EnIo in_io{real_in, in_size, in_complex, nullptr, 0}, out_io{nullptr, 0, 0, real_out, out_complex};
+    cplx* v = (cplx*) data;
+    const cplx* r = (const cplx*) roots;
+    const int outer_grid = ((1 << log_slots) >> (rem == 2 ? 2 : 1)) / EN_THREADS;
+    if (!inverse) {
+        // contiguous stages first, then the wide ones; the message leaves in the last store
+        hipLaunchKernelGGL(k_en_fft_chunk<false>, dim3(chunks), dim3(threads), lds_bytes, st, v, r, logch, 1.0, rem ? plain : out_io);
+        if (rem == 1) hipLaunchKernelGGL((k_en_fft_outer<false, 1>), dim3(outer_grid), dim3(EN_THREADS), 0, st, v, r, logch, out_io);
+        if (rem == 2) hipLaunchKernelGGL((k_en_fft_outer<false, 2>), dim3(outer_grid), dim3(EN_THREADS), 0, st, v, r, logch, out_io);
+    } else {
+        if (rem == 1) hipLaunchKernelGGL((k_en_fft_outer<true, 1>), dim3(outer_grid), dim3(EN_THREADS), 0, st, v, r, logch, in_io);
+        if (rem == 2) hipLaunchKernelGGL((k_en_fft_outer<true, 2>), dim3(outer_grid), dim3(EN_THREADS), 0, st, v, r, logch, in_io);
+        hipLaunchKernelGGL(k_en_fft_chunk<true>, dim3(chunks), dim3(threads), lds_bytes, st, v, r, logch, fix, rem ? plain : in_io);
+    }
     return hipGetLastError();
 }
 

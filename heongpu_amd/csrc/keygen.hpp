@@ -70,9 +70,11 @@ hipError_t kg_bfv_decode_gather(u64* message, const u64* in, const int* location
 // ---- CKKS encoder (encode.hip)
 // special FFT over `1 << log_slots` complex doubles in place; roots: the rotation-group-ordered
 // table; inverse: scaled by `fix`
-hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st);
-hipError_t en_double_to_complex(const double* in, int size, void* out, int slots, bool complex_in, hipStream_t st);
-hipError_t en_complex_to_double(const void* in, double* out, int slots, bool complex_out, hipStream_t st);
+// the special FFT over `data` (slots complex doubles); encode hands the message in (`real_in`: converted in the first
+// load), decode takes it out (`real_out`: converted in the last store)
+hipError_t en_special_fft(void* data, const void* roots, int log_slots, bool inverse, double fix, hipStream_t st,
+                          const double* real_in = nullptr, int in_size = 0, int in_complex = 0, double* real_out = nullptr,
+                          int out_complex = 0);
 // message == nullptr: the constant round(scale_or_value) everywhere
 hipError_t en_coeff_conversion(u64* plain, const double* message, int size, double scale_or_value, const Mod* mods,
                                int limbs, int n_power, hipStream_t st);

@@ -1044,9 +1044,9 @@ hipError_t op_ckks_encode(const Context& c, int mode, const double* message, int
     }
     if (message_size < 0 || message_size > slots) return hipErrorInvalidValue;
     void* cbuf = ws; // slots complex doubles = N words
-    TRY(en_double_to_complex(message, message_size, cbuf, slots, mode == 1, st));          // :120
     const double fix = scale / (double) slots;                                             // :127
-    TRY(en_special_fft(cbuf, c.d64("special_ifft_roots_table"), log2i(slots), true, fix, st));
+    // double -> complex (:120) in the transform's first load
+    TRY(en_special_fft(cbuf, c.d64("special_ifft_roots_table"), log2i(slots), true, fix, st, message, message_size, mode == 1));
     TRY(en_conversion(plain, cbuf, c.plan_qp.mods, Q, c.d32("reverse_order"), c.n_power, st)); // :138
     return ntt_launch(a, Q, false, st);                                                    // :153
 }
@@ -1071,8 +1071,8 @@ hipError_t op_ckks_decode(const Context& c, int mode, const u64* plain, int dept
     TRY(en_compose(cbuf, coeff, c.plan_qp.mods, c.d64("Mi_inv") + loc1, c.d64("Mi") + loc2,
                    c.d64("upper_half_threshold") + loc1, c.d64("decryption_modulus") + loc1, l, scale,
                    c.d32("reverse_order"), c.n_power, st));                                // :485
-    TRY(en_special_fft(cbuf, c.d64("special_fft_roots_table"), log2i(slots), false, 1.0, st)); // :502
-    return en_complex_to_double(cbuf, message, slots, mode == 1, st);                      // :505
+    // :502, complex -> double (:505) in the transform's last store
+    return en_special_fft(cbuf, c.d64("special_fft_roots_table"), log2i(slots), false, 1.0, st, nullptr, 0, 0, message, mode == 1);
 }
 
 hipError_t op_ckks_decrypt(const Context& c, const u64* ct, const u64* sk, int depth, u64* plain, hipStream_t st)

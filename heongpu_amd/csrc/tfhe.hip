@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_tfhe_prepare_bootkey(const u64* __restr
 __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tfhe_blind_rotate(const int* __restrict__ in_a,
                                                                   const int* __restrict__ in_b,
                                                                   const u64* __restrict__ bk, int* __restrict__ out_a,
-                                                                  int* __restrict__ out_b, TfheDev p, int encoded)
+                                                                  int* __restrict__ out_b, TfheDev p, int encoded, int shape)
 {
     if (bk[0] != 0) { // FP64-layout key: k_tfhe_blind_rotate_fp of the same call runs instead
         if (bk[0] != 1 && blockIdx.x == 0 && threadIdx.x == 0 && p.bad_key) *p.bad_key = 1; // neither layout: say so
@@ -231,8 +231,10 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) u64 buf[4][TF_BUF];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int y = wv >> 1, z = wv & 1;
-    const int g = blockIdx.x;
     const int n = p.n;
+    // gates in a grid-stride loop: the grid is capped (tfhe_blind_rotate), so a call whose key has the other layout pays
+    // for at most TFHE_INT_GRID_MAX workgroups that read one word and leave, not for one per gate
+    for (int g = blockIdx.x; g < shape; g += gridDim.x) {
     TQ c;
     c.q = p.mod.q;
     c.q4 = 4 * c.q;
@@ -333,6 +335,8 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = t; j < TF_N; j += TF_THREADS)
         out_a[(u64) g * TF_N + j] = (j < 1) ? acc[0][j] : (int) (0u - (u32) acc[0][TF_N - j]);
     if (t == 0) out_b[g] = acc[1][0];
+    __syncthreads(); // the accumulators are free for the next gate
+    }
 }
 
 // ------------------------------------------------------------------ FP64 blind rotate
@@ -1149,14 +1153,16 @@ hipError_t tfhe_prepare_bootkey(const TfheDev& p, const u64* src, u64* dst, u64 
 // Round 4 picked the kernel on the host from a per-pointer cache filled by a synchronous read -- not ordered behind the
 // caller's stream, stale after the buffer was overwritten or its address reused, and a mismatch was a silent return
 // (ADVICE r4, medium).  A header that is neither layout sets the context's pinned flag; its next entry reports it.
+#define TFHE_INT_GRID_MAX 2048
 hipError_t tfhe_blind_rotate(const TfheDev& p, const int* in_a, const int* in_b, const u64* bk_prepared, int* out_a,
                              int* out_b, int encoded, int shape, hipStream_t st)
 {
     if (shape <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_tfhe_blind_rotate_fp, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a, out_b,
                        p, encoded);
-    hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape), dim3(TF_THREADS), 0, st, in_a, in_b, bk_prepared, out_a, out_b, p,
-                       encoded);
+    // (two workgroups per CU are resident: 512 on the chip; 2048 keeps the tail of a large batch balanced)
+    hipLaunchKernelGGL(k_tfhe_blind_rotate, dim3(shape < TFHE_INT_GRID_MAX ? shape : TFHE_INT_GRID_MAX), dim3(TF_THREADS), 0, st,
+                       in_a, in_b, bk_prepared, out_a, out_b, p, encoded, shape);
     return hipGetLastError();
 }
 

@@ -493,8 +493,8 @@ int hegpu_tfhe_prepare_bootkey(hegpu_tfhe_context* ctx, const uint64_t* boot_key
  * rotate reads the header word on the device, in the order of the call's stream, so a buffer may be filled, copied
  * (hegpu_broadcast_bytes) or overwritten on that stream right before a gate call without any host synchronisation.
  * This call drains the device, then reads the word.  `refresh` is ignored (nothing is remembered since round 5).
- * A bootstrapping call that is handed a buffer whose header is neither layout writes no outputs; the NEXT call on the
- * context returns HEGPU_E_INVALID saying so (asynchronous error, like the runtime's own). */
+ * A bootstrapping call that is handed a buffer whose header is neither layout writes no outputs and raises the context's
+ * bad-key flag on the device: see hegpu_tfhe_status. */
 int hegpu_tfhe_prepared_format(hegpu_tfhe_context* ctx, const uint64_t* prepared, int refresh);
 /* tfhe_{nand,and,and_first_not,nor,or,xnor,xor}_pre_comp_kernel / tfhe_not_comp_kernel
  * (src/lib/kernel/bootstrapping.cu:378-660); in2_* ignored for NOT */
@@ -506,6 +506,15 @@ int hegpu_tfhe_gate_precompute(hegpu_tfhe_context* ctx, int gate, int32_t* out_a
 int hegpu_tfhe_bootstrapping(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b,
                              const uint64_t* prepared_boot_key, int32_t* out_a, int32_t* out_b, int shape,
                              hegpu_stream stream);
+/* The error check after a launch that the reference does with HEONGPU_CUDA_CHECK(cudaGetLastError())
+ * (src/include/heongpu/util/util.cuh:47-55), for the one error this backend can only find ON THE DEVICE: the layout of a
+ * prepared boot key is read by the blind-rotate kernel itself, in stream order; a buffer that is no prepared key (header word
+ * neither 0 nor 1) makes it write NO outputs and raise the context's bad-key flag.  hegpu_tfhe_status drains `stream`, then
+ * returns HEGPU_E_INVALID if the flag is up -- and clears it -- else 0: bootstrapping / gate / mux call + status = the
+ * error at the call that caused it.  The flag belongs to the context, not to a stream: with several streams on one
+ * context, drain them all before asking.  A caller that never asks hears about it at the entry of its NEXT
+ * hegpu_tfhe_bootstrapping / _gate / _mux (before anything of that call is queued); no other entry looks at the flag. */
+int hegpu_tfhe_status(hegpu_tfhe_context* ctx, hegpu_stream stream);
 /* HELogicOperator<TFHE>::key_switching (tfhe/operator.cu:272-294).  The output sample must not overlap the input
  * sample (HEGPU_E_INVALID): the forms that cut a gate's coefficient loop over several workgroups clear the outputs first. */
 int hegpu_tfhe_key_switching(hegpu_tfhe_context* ctx, const int32_t* in_a, const int32_t* in_b, int32_t* out_a,
