@@ -100,24 +100,58 @@ __global__ __launch_bounds__(EN_FFT_THREADS) void k_en_fft_chunk(cplx* __restric
         for (int q = t; q < L; q += T) en_bfly<true>(lds[q], lds[q + L], roots[L + q]);
         __syncthreads();
     }
+    // Radix-4 rounds.  The three twiddles of a butterfly group depend on (round, thread) only, not on the data: those of
+    // round r + 1 are REQUESTED BEFORE the barrier that ends round r, so their L2 latency (the table is 16 bytes per
+    // entry, far too large to park next to 128 KiB of data) runs under the exchange instead of in front of every round.
+    // EN_FFT_ITERS groups per thread and round (CH / 4 / threads <= 2).
     const int rounds = logch >> 1;
-    for (int r = 0; r < rounds; r++) {
-        // forward: (1,2), (4,8), ...; inverse: downwards, ending with (2,1)
-        const int s = INVERSE ? 2 * (rounds - 1 - r) : 2 * r;
-        const int L = 1 << s;
-        for (int q = t; q < (CH >> 2); q += T) {
-            const int j = q & (L - 1), i = ((q >> s) << (s + 2)) + j;
-            cplx e[4];
+    auto round_s = [&](int r) { return INVERSE ? 2 * (rounds - 1 - r) : 2 * r; }; // forward: (1,2), (4,8), ...; inverse: downwards to (2,1)
+    constexpr int ITERS = 2;
+    cplx tw[ITERS][3];
+    auto request = [&](int r) {
+        const int s = round_s(r), L = 1 << s;
 #pragma unroll
-            for (int k = 0; k < 4; k++) e[k] = lds[i + k * L];
-            en_radix4<INVERSE>(e, roots, L, j);
-            if (INVERSE && L == 1) { // the stride-1 stage carries the scale (fftSpecialInv)
-#pragma unroll
-                for (int k = 0; k < 4; k++) e[k] = {e[k].re * fix, e[k].im * fix};
+        for (int it = 0; it < ITERS; it++) {
+            const int q = t + it * T;
+            if (q < (CH >> 2)) {
+                const int j = q & (L - 1);
+                tw[it][0] = roots[L + j];
+                tw[it][1] = roots[2 * L + j];
+                tw[it][2] = roots[2 * L + j + L];
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) lds[i + k * L] = e[k];
         }
+    };
+    if (rounds > 0) request(0);
+    for (int r = 0; r < rounds; r++) {
+        const int s = round_s(r), L = 1 << s;
+        cplx e[ITERS][4];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int q = t + it * T;
+            if (q < (CH >> 2)) {
+                const int j = q & (L - 1), i = ((q >> s) << (s + 2)) + j;
+#pragma unroll
+                for (int k = 0; k < 4; k++) e[it][k] = lds[i + k * L];
+                if (INVERSE) {
+                    en_bfly<true>(e[it][0], e[it][2], tw[it][1]);
+                    en_bfly<true>(e[it][1], e[it][3], tw[it][2]);
+                    en_bfly<true>(e[it][0], e[it][1], tw[it][0]);
+                    en_bfly<true>(e[it][2], e[it][3], tw[it][0]);
+                    if (L == 1) { // the stride-1 stage carries the scale (fftSpecialInv)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) e[it][k] = {e[it][k].re * fix, e[it][k].im * fix};
+                    }
+                } else {
+                    en_bfly<false>(e[it][0], e[it][1], tw[it][0]);
+                    en_bfly<false>(e[it][2], e[it][3], tw[it][0]);
+                    en_bfly<false>(e[it][0], e[it][2], tw[it][1]);
+                    en_bfly<false>(e[it][1], e[it][3], tw[it][2]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) lds[i + k * L] = e[it][k];
+            }
+        }
+        if (r + 1 < rounds) request(r + 1);
         __syncthreads();
     }
     if (!INVERSE && odd) {
@@ -206,16 +240,17 @@ __global__ __launch_bounds__(EN_THREADS) void k_en_conversion(u64* __restrict__ 
                                                               const Mod* __restrict__ mods, int limbs,
                                                               const int* __restrict__ reverse_order, int n_power)
 {
-    const int idx = blockIdx.x * EN_THREADS + threadIdx.x; // slot
-    const cplx z = msg[reverse_order[idx]];
-    en_store_rns(plain, (u64) idx, z.re, mods, limbs, n_power);
-    en_store_rns(plain, (u64) idx + (1u << (n_power - 1)), z.im, mods, limbs, n_power);
+    // one thread per VALUE: coefficient v = the real part of slot v (v < N/2) or the imaginary part of slot v - N/2
+    const int v = blockIdx.x * EN_THREADS + threadIdx.x;
+    const int slots = 1 << (n_power - 1);
+    const double* z = reinterpret_cast<const double*>(msg + reverse_order[v & (slots - 1)]);
+    en_store_rns(plain, (u64) v, z[v >= slots ? 1 : 0], mods, limbs, n_power);
 }
 
 hipError_t en_conversion(u64* plain, const void* msg, const Mod* mods, int limbs, const int* reverse_order, int n_power,
                          hipStream_t st)
 {
-    hipLaunchKernelGGL(k_en_conversion, dim3((1u << (n_power - 1)) / EN_THREADS), dim3(EN_THREADS), 0, st, plain,
+    hipLaunchKernelGGL(k_en_conversion, dim3((1u << n_power) / EN_THREADS), dim3(EN_THREADS), 0, st, plain,
                        (const cplx*) msg, mods, limbs, reverse_order, n_power);
     return hipGetLastError();
 }
@@ -244,67 +279,104 @@ hipError_t en_coeff_conversion(u64* plain, const double* message, int size, doub
 // util/bigintegerarith.cuh): little-endian 64-bit words, at most EN_MAX_WORDS of them
 #define EN_MAX_WORDS 64
 
-__device__ __forceinline__ bool big_geq(const u64* a, const u64* b, int n)
+// LMAX: compile-time bound on the word count l, so that the accumulator lives in registers (every index below is static:
+// the word loops are fully unrolled with `k < l` guards).  Rounds 1-5 kept acc[64] in scratch memory and ran two values
+// per thread: 86 us at N = 2^14 -- more than the rest of a decode together.  The integers are the same whatever the
+// order of evaluation (each partial sum is brought below M, its canonical value), and the final conversion adds the words
+// in the reference's order.
+template <int LMAX>
+__device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, u64 at, const Mod* __restrict__ mods,
+                                                 const u64* __restrict__ Mi_inv, const u64* __restrict__ Mi,
+                                                 const u64* __restrict__ upper_half, const u64* __restrict__ M, int l,
+                                                 double inv_scale, int n_power)
 {
-    for (int k = n - 1; k >= 0; k--) {
-        if (a[k] != b[k]) return a[k] > b[k];
-    }
-    return true;
-}
-
-__device__ double en_compose_one(const u64* __restrict__ plain, u64 at, const Mod* __restrict__ mods,
-                                 const u64* __restrict__ Mi_inv, const u64* __restrict__ Mi,
-                                 const u64* __restrict__ upper_half, const u64* __restrict__ M, int l, double inv_scale,
-                                 int n_power)
-{
-    u64 acc[EN_MAX_WORDS];
-    for (int k = 0; k < l; k++) acc[k] = 0;
+    u64 acc[LMAX];
+#pragma unroll
+    for (int k = 0; k < LMAX; k++) acc[k] = 0;
     for (int i = 0; i < l; i++) {
         const u64 t = mul_barrett(plain[at + ((u64) i << n_power)], Mi_inv[i], mods[i]);
         // acc += Mi[i] * t  (l words; the sum stays below 2*M < 2^(64 l))
         const u64* mi = Mi + (u64) i * l;
         u64 carry = 0;
-        for (int k = 0; k < l; k++) {
-            u64 hi, lo;
-            mul64wide(mi[k], t, hi, lo);
-            const u64 s1 = lo + carry;
-            const u64 c1 = s1 < lo;
-            const u64 s2 = acc[k] + s1;
-            const u64 c2 = s2 < s1;
-            acc[k] = s2;
-            carry = hi + c1 + c2;
-        }
-        if (big_geq(acc, M, l)) {
-            u64 borrow = 0;
-            for (int k = 0; k < l; k++) {
-                const u64 d = acc[k] - M[k];
-                const u64 b1 = acc[k] < M[k];
-                const u64 d2 = d - borrow;
-                const u64 b2 = d < borrow;
-                acc[k] = d2;
-                borrow = b1 | b2;
+#pragma unroll
+        for (int k = 0; k < LMAX; k++) {
+            if (k < l) {
+                u64 hi, lo;
+                mul64wide(mi[k], t, hi, lo);
+                const u64 s1 = lo + carry;
+                const u64 c1 = s1 < lo;
+                const u64 s2 = acc[k] + s1;
+                const u64 c2 = s2 < s1;
+                acc[k] = s2;
+                carry = hi + c1 + c2;
             }
+        }
+        // acc >= M ?  (most significant differing word decides)
+        bool geq = true, decided = false;
+#pragma unroll
+        for (int k = LMAX - 1; k >= 0; k--) {
+            if (k < l && !decided && acc[k] != M[k]) {
+                geq = acc[k] > M[k];
+                decided = true;
+            }
+        }
+        if (geq) {
+            u64 borrow = 0;
+#pragma unroll
+            for (int k = 0; k < LMAX; k++) {
+                if (k < l) {
+                    const u64 m = M[k];
+                    const u64 d = acc[k] - m;
+                    const u64 b1 = acc[k] < m;
+                    const u64 d2 = d - borrow;
+                    const u64 b2 = d < borrow;
+                    acc[k] = d2;
+                    borrow = b1 | b2;
+                }
+            }
+        }
+    }
+    bool upper = true, decided = false;
+#pragma unroll
+    for (int k = LMAX - 1; k >= 0; k--) {
+        if (k < l && !decided && acc[k] != upper_half[k]) {
+            upper = acc[k] > upper_half[k];
+            decided = true;
         }
     }
     const double two64 = 18446744073709551616.0;
     double result = 0.0, w = inv_scale;
-    if (big_geq(acc, upper_half, l)) {
+    if (upper) {
         // negative value: word-wise difference to M, exactly as the reference accumulates it
-        for (int j = 0; j < l; j++, w *= two64) {
-            if (acc[j] > M[j]) {
-                const u64 diff = acc[j] - M[j];
-                result += diff ? (double) diff * w : 0.0;
-            } else {
-                const u64 diff = M[j] - acc[j];
-                result -= diff ? (double) diff * w : 0.0;
+#pragma unroll
+        for (int j = 0; j < LMAX; j++) {
+            if (j < l) {
+                const u64 m = M[j];
+                if (acc[j] > m) {
+                    const u64 diff = acc[j] - m;
+                    result += diff ? (double) diff * w : 0.0;
+                } else {
+                    const u64 diff = m - acc[j];
+                    result -= diff ? (double) diff * w : 0.0;
+                }
+                w *= two64;
             }
         }
     } else {
-        for (int j = 0; j < l; j++, w *= two64) result += acc[j] ? (double) acc[j] * w : 0.0;
+#pragma unroll
+        for (int j = 0; j < LMAX; j++) {
+            if (j < l) {
+                result += acc[j] ? (double) acc[j] * w : 0.0;
+                w *= two64;
+            }
+        }
     }
     return result;
 }
 
+// one thread per VALUE (coefficient v of the plaintext: the real part of slot v for v < N/2, the imaginary part of slot
+// v - N/2 otherwise): N threads instead of N/2 chains twice as long
+template <int LMAX>
 __global__ __launch_bounds__(EN_THREADS) void k_en_compose(cplx* __restrict__ msg, const u64* __restrict__ plain,
                                                            const Mod* __restrict__ mods, const u64* __restrict__ Mi_inv,
                                                            const u64* __restrict__ Mi,
@@ -312,13 +384,12 @@ __global__ __launch_bounds__(EN_THREADS) void k_en_compose(cplx* __restrict__ ms
                                                            const u64* __restrict__ M, int l, double scale,
                                                            const int* __restrict__ reverse_order, int n_power)
 {
-    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
+    const int v = blockIdx.x * EN_THREADS + threadIdx.x;
+    const int slots = 1 << (n_power - 1), slot = v & (slots - 1);
     const double inv_scale = 1.0 / scale;
-    cplx z;
-    z.re = en_compose_one(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, inv_scale, n_power);
-    z.im = en_compose_one(plain, (u64) idx + (1u << (n_power - 1)), mods, Mi_inv, Mi, upper_half, M, l, inv_scale,
-                          n_power);
-    msg[reverse_order[idx]] = z;
+    const double r = en_compose_one<LMAX>(plain, (u64) v, mods, Mi_inv, Mi, upper_half, M, l, inv_scale, n_power);
+    double* out = reinterpret_cast<double*>(msg + reverse_order[slot]);
+    out[v >= slots ? 1 : 0] = r;
 }
 
 hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
@@ -326,12 +397,18 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
                       hipStream_t st)
 {
     if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_en_compose, dim3((1u << (n_power - 1)) / EN_THREADS), dim3(EN_THREADS), 0, st, (cplx*) msg,
-                       plain, mods, Mi_inv, Mi, upper_half, M, l, scale, reverse_order, n_power);
+    const dim3 grid((1u << n_power) / EN_THREADS), block(EN_THREADS);
+#define EN_COMPOSE(LM) hipLaunchKernelGGL(k_en_compose<LM>, grid, block, 0, st, (cplx*) msg, plain, mods, Mi_inv, Mi, upper_half, M, l, scale, reverse_order, n_power)
+    if (l <= 8) EN_COMPOSE(8);
+    else if (l <= 16) EN_COMPOSE(16);
+    else if (l <= 32) EN_COMPOSE(32);
+    else EN_COMPOSE(EN_MAX_WORDS);
+#undef EN_COMPOSE
     return hipGetLastError();
 }
 
 // decode_kernel_coeff_ckks_compose (encoding.cu:387-464): one real value per coefficient
+template <int LMAX>
 __global__ __launch_bounds__(EN_THREADS) void k_en_coeff_compose(double* __restrict__ message,
                                                                  const u64* __restrict__ plain,
                                                                  const Mod* __restrict__ mods,
@@ -342,15 +419,20 @@ __global__ __launch_bounds__(EN_THREADS) void k_en_coeff_compose(double* __restr
                                                                  int n_power)
 {
     const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    message[idx] = en_compose_one(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, 1.0 / scale, n_power);
+    message[idx] = en_compose_one<LMAX>(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, 1.0 / scale, n_power);
 }
 
 hipError_t en_coeff_compose(double* message, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
                             const u64* upper_half, const u64* M, int l, double scale, int n_power, hipStream_t st)
 {
     if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_en_coeff_compose, dim3((1u << n_power) / EN_THREADS), dim3(EN_THREADS), 0, st, message, plain,
-                       mods, Mi_inv, Mi, upper_half, M, l, scale, n_power);
+    const dim3 grid((1u << n_power) / EN_THREADS), block(EN_THREADS);
+#define EN_COMPOSE(LM) hipLaunchKernelGGL(k_en_coeff_compose<LM>, grid, block, 0, st, message, plain, mods, Mi_inv, Mi, upper_half, M, l, scale, n_power)
+    if (l <= 8) EN_COMPOSE(8);
+    else if (l <= 16) EN_COMPOSE(16);
+    else if (l <= 32) EN_COMPOSE(32);
+    else EN_COMPOSE(EN_MAX_WORDS);
+#undef EN_COMPOSE
     return hipGetLastError();
 }
 
