@@ -279,6 +279,9 @@ hipError_t en_coeff_conversion(u64* plain, const double* message, int size, doub
 // util/bigintegerarith.cuh): little-endian 64-bit words, at most EN_MAX_WORDS of them
 #define EN_MAX_WORDS 64
 
+// one wavefront per workgroup: a thread is one long dependent chain -- l mul_barrett + l x l multiply-accumulate words --
+// so the launch is spread over as many CUs as it has wavefronts (N = 2^14: 256 workgroups, one per CU)
+#define EN_COMPOSE_THREADS 64
 // LMAX: compile-time bound on the word count l, so that the accumulator lives in registers (every index below is static:
 // the word loops are fully unrolled with `k < l` guards).  Rounds 1-5 kept acc[64] in scratch memory and ran two values
 // per thread: 86 us at N = 2^14 -- more than the rest of a decode together.  The integers are the same whatever the
@@ -288,13 +291,20 @@ template <int LMAX>
 __device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, u64 at, const Mod* __restrict__ mods,
                                                  const u64* __restrict__ Mi_inv, const u64* __restrict__ Mi,
                                                  const u64* __restrict__ upper_half, const u64* __restrict__ M, int l,
-                                                 double inv_scale, int n_power)
+                                                 double inv_scale, int n_power, u64* tl)
 {
+    // The l residues of the value are requested TOGETHER (unrolled, independent loads) and their products with Mi_inv parked
+    // in the thread's own column of `tl` -- inside the word loop below each would cost a full memory latency per limb
+    // (measured: 26 us of a 28 us kernel at N = 2^14).  A thread reads back only what it wrote itself: no barrier.
+#pragma unroll
+    for (int k = 0; k < LMAX; k++) {
+        if (k < l) tl[k * EN_COMPOSE_THREADS + threadIdx.x] = mul_barrett(plain[at + ((u64) k << n_power)], Mi_inv[k], mods[k]);
+    }
     u64 acc[LMAX];
 #pragma unroll
     for (int k = 0; k < LMAX; k++) acc[k] = 0;
     for (int i = 0; i < l; i++) {
-        const u64 t = mul_barrett(plain[at + ((u64) i << n_power)], Mi_inv[i], mods[i]);
+        const u64 t = tl[i * EN_COMPOSE_THREADS + threadIdx.x];
         // acc += Mi[i] * t  (l words; the sum stays below 2*M < 2^(64 l))
         const u64* mi = Mi + (u64) i * l;
         u64 carry = 0;
@@ -376,18 +386,20 @@ __device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, 
 
 // one thread per VALUE (coefficient v of the plaintext: the real part of slot v for v < N/2, the imaginary part of slot
 // v - N/2 otherwise): N threads instead of N/2 chains twice as long
+// (one wavefront per workgroup, see EN_COMPOSE_THREADS)
 template <int LMAX>
-__global__ __launch_bounds__(EN_THREADS) void k_en_compose(cplx* __restrict__ msg, const u64* __restrict__ plain,
+__global__ __launch_bounds__(EN_COMPOSE_THREADS) void k_en_compose(cplx* __restrict__ msg, const u64* __restrict__ plain,
                                                            const Mod* __restrict__ mods, const u64* __restrict__ Mi_inv,
                                                            const u64* __restrict__ Mi,
                                                            const u64* __restrict__ upper_half,
                                                            const u64* __restrict__ M, int l, double scale,
                                                            const int* __restrict__ reverse_order, int n_power)
 {
-    const int v = blockIdx.x * EN_THREADS + threadIdx.x;
+    const int v = blockIdx.x * EN_COMPOSE_THREADS + threadIdx.x;
     const int slots = 1 << (n_power - 1), slot = v & (slots - 1);
     const double inv_scale = 1.0 / scale;
-    const double r = en_compose_one<LMAX>(plain, (u64) v, mods, Mi_inv, Mi, upper_half, M, l, inv_scale, n_power);
+    __shared__ u64 tl[LMAX * EN_COMPOSE_THREADS];
+    const double r = en_compose_one<LMAX>(plain, (u64) v, mods, Mi_inv, Mi, upper_half, M, l, inv_scale, n_power, tl);
     double* out = reinterpret_cast<double*>(msg + reverse_order[slot]);
     out[v >= slots ? 1 : 0] = r;
 }
@@ -397,7 +409,7 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
                       hipStream_t st)
 {
     if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
-    const dim3 grid((1u << n_power) / EN_THREADS), block(EN_THREADS);
+    const dim3 grid((1u << n_power) / EN_COMPOSE_THREADS), block(EN_COMPOSE_THREADS);
 #define EN_COMPOSE(LM) hipLaunchKernelGGL(k_en_compose<LM>, grid, block, 0, st, (cplx*) msg, plain, mods, Mi_inv, Mi, upper_half, M, l, scale, reverse_order, n_power)
     if (l <= 8) EN_COMPOSE(8);
     else if (l <= 16) EN_COMPOSE(16);
@@ -409,7 +421,7 @@ hipError_t en_compose(void* msg, const u64* plain, const Mod* mods, const u64* M
 
 // decode_kernel_coeff_ckks_compose (encoding.cu:387-464): one real value per coefficient
 template <int LMAX>
-__global__ __launch_bounds__(EN_THREADS) void k_en_coeff_compose(double* __restrict__ message,
+__global__ __launch_bounds__(EN_COMPOSE_THREADS) void k_en_coeff_compose(double* __restrict__ message,
                                                                  const u64* __restrict__ plain,
                                                                  const Mod* __restrict__ mods,
                                                                  const u64* __restrict__ Mi_inv,
@@ -418,15 +430,16 @@ __global__ __launch_bounds__(EN_THREADS) void k_en_coeff_compose(double* __restr
                                                                  const u64* __restrict__ M, int l, double scale,
                                                                  int n_power)
 {
-    const int idx = blockIdx.x * EN_THREADS + threadIdx.x;
-    message[idx] = en_compose_one<LMAX>(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, 1.0 / scale, n_power);
+    const int idx = blockIdx.x * EN_COMPOSE_THREADS + threadIdx.x;
+    __shared__ u64 tl[LMAX * EN_COMPOSE_THREADS];
+    message[idx] = en_compose_one<LMAX>(plain, (u64) idx, mods, Mi_inv, Mi, upper_half, M, l, 1.0 / scale, n_power, tl);
 }
 
 hipError_t en_coeff_compose(double* message, const u64* plain, const Mod* mods, const u64* Mi_inv, const u64* Mi,
                             const u64* upper_half, const u64* M, int l, double scale, int n_power, hipStream_t st)
 {
     if (l > EN_MAX_WORDS) return hipErrorInvalidValue;
-    const dim3 grid((1u << n_power) / EN_THREADS), block(EN_THREADS);
+    const dim3 grid((1u << n_power) / EN_COMPOSE_THREADS), block(EN_COMPOSE_THREADS);
 #define EN_COMPOSE(LM) hipLaunchKernelGGL(k_en_coeff_compose<LM>, grid, block, 0, st, message, plain, mods, Mi_inv, Mi, upper_half, M, l, scale, n_power)
     if (l <= 8) EN_COMPOSE(8);
     else if (l <= 16) EN_COMPOSE(16);
