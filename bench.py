@@ -472,7 +472,11 @@ def prof_group(prof, workload, live_ms, match=None, algorithmic_bytes=None):
     insts = sum(per(v, "valu_wave_insts") for v in ks.values())
     busy = sum(v.get("valu_busy", 0.0) * per(v, "cycles") for v in ks.values())
     copy = prof.get("copy_ceiling_GBps") or 5230.0
+    # share of the group's cycles that are not a counter of the dispatch but duration x an assumed clock (short dispatches,
+    # tools/prof_all.sh `cycles_estimated`): the issue fractions of such a group are estimates and say so
+    est = sum(per(v, "cycles") for v in ks.values() if v.get("cycles_estimated"))
     fp = {"dir": prof.get("dir"), "workload": workload, "kernels": sorted(ks), "ms": ms, "sclk_GHz": cyc / (ms * 1e-3) / 1e9 if ms else None,
+          "cycles_estimated_share": est / cyc if cyc else None,
           "hbm_bytes": by, "lane_instructions": insts * 64,
           "valu_busy": busy / cyc if cyc else None,
           "frac_of_issue_ceiling": insts * 4 / SIMDS / cyc if cyc else None,

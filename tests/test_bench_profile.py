@@ -35,6 +35,12 @@ def test_profile_json_is_complete_and_tracked():
             ghz = e["cycles"] / (e["ms"] * 1e-3) / 1e9
             assert 1.2 <= ghz <= 2.6, (w, k, ghz, e.get("cycles_source"))
             assert e.get("cycles_source"), (w, k)
+            # a clock the heuristic ASSUMED passes the range check by construction -- such kernels must say so
+            # (schema v3: cycles_estimated), and the kernels the line's roofline rests on must be measured ones
+            if "v3" in prof.get("schema", ""):
+                assert e.get("cycles_estimated") == e["cycles_source"].startswith("ESTIMATED"), (w, k)
+                if w in ("c4_step", "ntt_pair", "c5_tfhe_gates") and e["ms"] >= 0.1:
+                    assert e["cycles_estimated"] is False, (w, k)
             for f in ("valu_busy", "frac_of_issue_ceiling"):
                 assert e.get(f) is None or 0.0 <= e[f] <= 1.6, (w, k, f, e[f])  # (simple 32-bit ops issue faster than one per 4 cycles: BEHZ > 1)
 

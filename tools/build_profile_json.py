@@ -12,7 +12,7 @@ import sys
 
 def main():
     desc, outp = sys.argv[1], sys.argv[2]
-    res = {"dir": desc, "schema": "profile.json v2 (tools/build_profile_json.py): cycles of dispatches < 0.1 ms from SQ_BUSY_CYCLES, not the counter window", "workloads": {},
+    res = {"dir": desc, "schema": "profile.json v3 (tools/build_profile_json.py): cycles of dispatches < 0.1 ms from SQ_BUSY_CYCLES over the device's shader-engine count, not the counter window; cycles_estimated marks kernels whose cycles are duration x an assumed clock", "workloads": {},
            "how": "tools/prof_all.sh: rocprofv3 --kernel-trace [--stats | --pmc <one counter set>] -- python bench.py "
                   "--profile-workload NAME --reps R; FETCH_SIZE, WRITE_SIZE and three SQ sets each in a pass of its own; "
                   "hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: wide coalesced reads count at 1/2, profiles/README.md)"}
@@ -51,7 +51,7 @@ def main():
                 continue
             w["kernels"][name] = {
                 "per_batch": int(n // batches), "ms": e["ms"], "cycles": e.get("cycles", e.get("cycles_sq1")), "GHz": e.get("GHz"),
-                "cycles_source": e.get("cycles_source"),
+                "cycles_source": e.get("cycles_source"), "cycles_estimated": bool(e.get("cycles_estimated", False)),
                 "hbm_bytes": e.get("hbm_bytes", 0.0), "valu_wave_insts": e.get("SQ_INSTS_VALU", 0.0),
                 "valu_busy": e.get("valu_busy"), "frac_of_issue_ceiling": e.get("frac_of_issue_ceiling"),
                 "waves": e.get("SQ_WAVES"), "waves_resident_per_simd": e.get("waves_resident_per_simd"),

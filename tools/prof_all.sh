@@ -10,6 +10,8 @@
 #   6 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE   (PROF_SKIP_LDS=1 skips 6)
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+# shader engines of the device (SQ_BUSY_CYCLES sums one counter per engine): read, not assumed
+SES=$(rocminfo 2>/dev/null | awk '/Shader Engines:/ {if ($3 > m) m = $3} END {print m + 0}'); [ "$SES" -gt 0 ] 2>/dev/null || SES=32
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p0 -o x -- "$@" > $OUT/run_stats.txt 2>&1
 find $OUT/p0 -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
@@ -75,7 +77,7 @@ for key, e in res.items():
         # SQ_BUSY_CYCLES sums the busy cycles of the 32 shader engines' SQs; per engine it is the kernel's own span on that
         # engine (no launch window around it, unlike GRBM_GUI_ACTIVE): the clock it implies over the dispatch's duration
         e["sq_busy_over_gui"] = e["SQ_BUSY_CYCLES"] / e["cycles_sq2"]
-        e["GHz_sq_busy"] = e["SQ_BUSY_CYCLES"] / 32 / e["seconds_sq2"] / 1e9
+        e["GHz_sq_busy"] = e["SQ_BUSY_CYCLES"] / $SES / e["seconds_sq2"] / 1e9
 # Cycles of a dispatch.  GRBM_GUI_ACTIVE / 8 is the counter window, which for a dispatch of a few microseconds is several
 # times wider than the dispatch ("clocks" of 2.6 - 6.9 GHz).  Dispatches of >= 0.1 ms keep it (window
 # error < 3 %); shorter ones take SQ_BUSY_CYCLES / 32 engines scaled to this pass's duration when the launch is big enough to
@@ -89,12 +91,16 @@ for key, e in res.items():
     if "SQ_INSTS_VALU" in e and e.get("cycles_sq1"):
         e["ms"] = e["seconds_sq1"] * 1e3
         e["GHz_gui_window"] = e["cycles_sq1"] / e["seconds_sq1"] / 1e9
+        # cycles_estimated: the cycles are NOT a counter of this dispatch but duration x a clock taken from elsewhere -- every
+        # fraction divided by them (valu_busy, frac_of_issue_ceiling, waves_resident) is an estimate and is marked as one
         if e["ms"] >= SHORT_MS:
-            e["cycles"], e["cycles_source"] = e["cycles_sq1"], "GRBM_GUI_ACTIVE / 8"
+            e["cycles"], e["cycles_source"], e["cycles_estimated"] = e["cycles_sq1"], "GRBM_GUI_ACTIVE / 8", False
         elif "GHz_sq_busy" in e and e.get("SQ_WAVES", 0) >= 1024:
-            e["cycles"], e["cycles_source"] = e["GHz_sq_busy"] * 1e9 * e["seconds_sq1"], "SQ_BUSY_CYCLES / 32 (own pass), scaled to this pass's duration"
+            e["cycles"], e["cycles_source"] = e["GHz_sq_busy"] * 1e9 * e["seconds_sq1"], "SQ_BUSY_CYCLES / $SES engines (own pass), scaled to this pass's duration"
+            e["cycles_estimated"] = False
         else:
-            e["cycles"], e["cycles_source"] = ref_clk * 1e9 * e["seconds_sq1"], "duration x %.2f GHz (median of the workload's short kernels)" % ref_clk
+            e["cycles"], e["cycles_source"] = ref_clk * 1e9 * e["seconds_sq1"], "ESTIMATED: duration x %.2f GHz (median of the workload's short kernels)" % ref_clk
+            e["cycles_estimated"] = True
         e["GHz"] = e["cycles"] / e["seconds_sq1"] / 1e9
         e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / e["cycles"]
         e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / max(e["SQ_WAVES"], 1)
@@ -114,7 +120,7 @@ with open(f"{out}/summary.txt", "w") as f:
     f.write("command: $*\n")
     for key, e in sorted(res.items(), key=lambda kv: -kv[1].get("ms", 0) * kv[1].get("dispatches", 1)):
         f.write("%s  x%d\n" % (key, e.get("dispatches", 0)))
-        if "cycles_source" in e: f.write("    %-30s %s\n" % ("cycles from", e["cycles_source"]))
+        if "cycles_source" in e: f.write("    %-30s %s%s\n" % ("cycles from", e["cycles_source"], "  (fractions below are estimates)" if e.get("cycles_estimated") else ""))
         for c in ("ms", "GHz", "GHz_gui_window", "GHz_sq_busy", "hbm_bytes", "hbm_GBps", "valu_busy", "frac_of_issue_ceiling", "valu_insts_per_wave", "SQ_WAVES",
                   "waves_resident_per_simd", "wait_any_frac_of_wave_cycles", "lds_busy", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT"):
             if c in e: f.write("    %-30s %16.4f\n" % (c, e[c]))
