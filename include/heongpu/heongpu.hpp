@@ -2008,14 +2008,18 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     template <typename T> void encode(Plaintext<S>& plain, const HostVector<T>& message, double scale,
                                       const ExecutionOptions& o = ExecutionOptions())
     {
-        // through a pageable copy: a small pageable upload goes through the runtime's staging buffer at once, while a
-        // pinned source takes the DMA engine's start-up time (benchmark_ckks.cpp encode, N = 4096: 78 against 150 us)
-        encode_from(plain, std::vector<T>(message.begin(), message.end()), scale, o);
+        // Round 6: NO copy at all.  hipHostMalloc memory is mapped into the device's address space, and since round 6 the
+        // special FFT converts the message in its first load (encode.hip: en_load): the transform reads the 8 N / 2 bytes
+        // straight out of the pinned vector over the host link.  (Rounds 2-5 went through a pageable copy -- 78 us against
+        // 150 us for a DMA copy of the pinned source at N = 4096; the upload was ~16 us of a 0.09 ms call.)
+        encode_from(plain, message, scale, o, encoding::SLOT, true);
     }
-    // decoded straight into the pinned vector: the device-to-host copy is a DMA transfer, no pageable staging
+    // decoded straight into the pinned vector: the transform's last store writes the message there, no copy (same-box
+    // A/B against the DMA copy of rounds 2-5, benchmark_ckks.cpp decode: N = 2^12..2^15 0.060 / 0.074 / 0.108 / 0.197 ms against
+    // 0.071 / 0.100 / 0.130 / 0.224 -- profiles/r6_experiments/encode_decode_mapped_ab.txt)
     template <typename T> void decode(HostVector<T>& message, Plaintext<S>& plain, const ExecutionOptions& o = ExecutionOptions())
     {
-        decode_to(message, plain, o);
+        decode_to(message, plain, o, true);
     }
     void encode(Plaintext<S>& plain, const std::vector<double>& message, double scale,
                 const ExecutionOptions& o = ExecutionOptions(), encoding type = encoding::SLOT)
@@ -2030,8 +2034,9 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     }
 
   private:
+    // `mapped`: the vector lives in pinned, device-visible memory (HostVector): the kernels read it where it is
     template <typename A> void encode_from(Plaintext<S>& plain, const std::vector<double, A>& message, double scale,
-                                           const ExecutionOptions& o, encoding type = encoding::SLOT)
+                                           const ExecutionOptions& o, encoding type = encoding::SLOT, bool mapped = false)
     {
         detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         check_scale(scale);
@@ -2039,35 +2044,39 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
             throw std::invalid_argument("Vector size can not be higher than slot count!");        // :74
         if (type != encoding::SLOT && message.size() > (size_t) context_->n)
             throw std::invalid_argument("Vector size can not be higher than polynomial degree!"); // :80
-        DeviceVector<Data64> msg(message.size() ? message.size() : 1, o.stream_);
-        if (!message.empty())
+        mapped = mapped && !message.empty();
+        DeviceVector<Data64> msg(mapped ? 1 : (message.size() ? message.size() : 1), o.stream_);
+        if (!mapped && !message.empty())
             detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(double),
                                        hipMemcpyHostToDevice, o.stream_));
+        const double* src = mapped ? message.data() : (const double*) msg.data();
         DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
         if (type == encoding::SLOT) {
             DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_ENCODE, 0), o.stream_);
-            detail::check(hegpu_ckks_encode(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
+            detail::check(hegpu_ckks_encode(context_->handle(), src, (int) message.size(), scale,
                                             (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
         } else {
-            detail::check(hegpu_ckks_encode_coeff(context_->handle(), (const double*) msg.data(), (int) message.size(),
+            detail::check(hegpu_ckks_encode_coeff(context_->handle(), src, (int) message.size(),
                                                   scale, (uint64_t*) out.data(), o.stream_));
         }
-        finish(plain, std::move(out), scale, type, o);
+        finish(plain, std::move(out), scale, type, o); // (synchronises: the caller may change `message` afterwards)
     }
     template <typename A> void encode_from(Plaintext<S>& plain, const std::vector<Complex64, A>& message, double scale,
-                                           const ExecutionOptions& o)
+                                           const ExecutionOptions& o, encoding = encoding::SLOT, bool mapped = false)
     {
         detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         check_scale(scale);
         if ((int) message.size() > slot_count())
             throw std::invalid_argument("Vector size can not be higher than slot count!");
-        DeviceVector<Data64> msg(message.size() ? 2 * message.size() : 1, o.stream_);
-        if (!message.empty())
+        mapped = mapped && !message.empty();
+        DeviceVector<Data64> msg(mapped ? 1 : (message.size() ? 2 * message.size() : 1), o.stream_);
+        if (!mapped && !message.empty())
             detail::hip(hipMemcpyAsync(msg.data(), message.data(), message.size() * sizeof(Complex64),
                                        hipMemcpyHostToDevice, o.stream_));
+        const double* src = mapped ? (const double*) message.data() : (const double*) msg.data();
         DeviceVector<Data64> out((size_t) context_->Q_size * context_->n, o.stream_);
         DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_ENCODE, 0), o.stream_);
-        detail::check(hegpu_ckks_encode_complex(context_->handle(), (const double*) msg.data(), (int) message.size(), scale,
+        detail::check(hegpu_ckks_encode_complex(context_->handle(), src, (int) message.size(), scale,
                                                 (uint64_t*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
         finish(plain, std::move(out), scale, encoding::SLOT, o);
     }
@@ -2099,33 +2108,37 @@ template <> class HEEncoder<Scheme::CKKS> { // host/ckks/encoder.cuh: N/2 comple
     }
 
   private:
-    template <typename A> void decode_to(std::vector<double, A>& message, Plaintext<S>& plain, const ExecutionOptions& o)
+    template <typename A> void decode_to(std::vector<double, A>& message, Plaintext<S>& plain, const ExecutionOptions& o,
+                                         bool mapped = false)
     {
         detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         const bool coeff = plain.encoding_ == encoding::COEFFICIENT; // encoder.cuh:383
         const size_t count = coeff ? (size_t) context_->n : (size_t) slot_count();
-        DeviceVector<Data64> out(count, o.stream_);
+        message.resize(count);
+        DeviceVector<Data64> out(mapped ? 1 : count, o.stream_);
         DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_DECODE, plain.depth_), o.stream_);
         detail::check((coeff ? hegpu_ckks_decode_coeff : hegpu_ckks_decode)(
-            context_->handle(), (const uint64_t*) plain.data(), plain.depth_, plain.scale_, (double*) out.data(),
-            ws.data(), ws.size() * sizeof(Data64), o.stream_));
-        message.resize(count);
-        detail::hip(hipMemcpyAsync(message.data(), out.data(), count * sizeof(double), hipMemcpyDeviceToHost, o.stream_));
+            context_->handle(), (const uint64_t*) plain.data(), plain.depth_, plain.scale_,
+            mapped ? message.data() : (double*) out.data(), ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        if (!mapped)
+            detail::hip(hipMemcpyAsync(message.data(), out.data(), count * sizeof(double), hipMemcpyDeviceToHost, o.stream_));
         detail::hip(hipStreamSynchronize(o.stream_));
     }
-    template <typename A> void decode_to(std::vector<Complex64, A>& message, Plaintext<S>& plain, const ExecutionOptions& o)
+    template <typename A> void decode_to(std::vector<Complex64, A>& message, Plaintext<S>& plain, const ExecutionOptions& o,
+                                         bool mapped = false)
     {
         detail::OpScope storage_scope(o); // storage manager: stage HOST-stored operands, place the results
         if (plain.encoding_ == encoding::COEFFICIENT)
             throw std::invalid_argument("Coefficient encoded CKKS plaintext can not be decoded to complex slots."); // :438
-        DeviceVector<Data64> out((size_t) 2 * slot_count(), o.stream_);
+        message.resize(slot_count());
+        DeviceVector<Data64> out(mapped ? 1 : (size_t) 2 * slot_count(), o.stream_);
         DeviceVector<Data64> ws(ws_words(HEGPU_OP_CKKS_DECODE, plain.depth_), o.stream_);
         detail::check(hegpu_ckks_decode_complex(context_->handle(), (const uint64_t*) plain.data(), plain.depth_,
-                                                plain.scale_, (double*) out.data(), ws.data(),
-                                                ws.size() * sizeof(Data64), o.stream_));
-        message.resize(slot_count());
-        detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(Complex64), hipMemcpyDeviceToHost,
-                                   o.stream_));
+                                                plain.scale_, mapped ? (double*) message.data() : (double*) out.data(),
+                                                ws.data(), ws.size() * sizeof(Data64), o.stream_));
+        if (!mapped)
+            detail::hip(hipMemcpyAsync(message.data(), out.data(), message.size() * sizeof(Complex64), hipMemcpyDeviceToHost,
+                                       o.stream_));
         detail::hip(hipStreamSynchronize(o.stream_));
     }
 
