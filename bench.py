@@ -1482,6 +1482,8 @@ def run_rank(args):
         if world > 1 and args.workload == "c4" and not args.no_cpu_baseline and not args.step_only:
             # one item per rank against the CPU oracle (rank r: the item of distinct index r of its slice) -- together with
             # cross_rank_equal every rank's every output is tied to an oracle-checked one of the same input
+            # (the ranks share the host: each takes its share of the cores for the checker -- set before the oracle loads)
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or world) // world)))
             ok_r = c4_oracle_item(hg, work, rank % B)
             got = dist.gather_floats(1.0 if ok_r else 0.0)
             chk.update(oracle_compared=len(got), oracle_equal=all(v == 1.0 for v in got),
