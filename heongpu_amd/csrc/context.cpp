@@ -546,7 +546,10 @@ static hipError_t build_plan(NttPlan& p, const vec& mods, const vec& fwd, const 
         hm[k] = make_mod(q);
         // moduli below 2^50: forward transform in FP64 (ntt.hip), the forward
         // tables hold (double(w), RN(w/q)) instead of (w, Shoup companion)
-        hm[k].fp = (fp_on && hm[k].bit <= 50) ? 1 : 0;
+        // (THE place that admits a modulus to the FP64 path: every exactness bound of fpmod.cuh / ntt.hip is stated for
+        // q < 2^50 -- 8 q <= 2^53 -- and machine-checked for it: tests/fp_model.py, tests/test_gpu_fp_audit.py)
+        static_assert(FP_MAX_MODULUS_BITS == 50, "the bounds in fpmod.cuh, ntt.hip and tests/fp_model.py are derived for q < 2^50");
+        hm[k].fp = (fp_on && hm[k].bit <= FP_MAX_MODULUS_BITS && (q >> FP_MAX_MODULUS_BITS) == 0) ? 1 : 0;
         for (u64 j = 0; j < n; j++) {
             const u64 w = fwd[k * n + j], iw = inv[k * n + j];
             if (hm[k].fp) {

@@ -16,6 +16,10 @@
 
 namespace hegpu {
 
+// moduli of at most this many bits run on the exact FP64 arithmetic of fpmod.cuh (Mod::fp, set in context.cpp)
+#define FP_MAX_MODULUS_BITS 50
+
+
 typedef unsigned long long u64;
 typedef unsigned int u32;
 

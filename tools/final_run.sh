@@ -21,4 +21,9 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 SOAK_REPS=40 python tools/soak.py > $O/soak.txt 2>&1; tail -1 $O/soak.txt
 for g in 8192 1024 8; do python tools/tfhe_bench.py --gates $g 2>&1 | grep -E "NAND|blind|key_sw"; done > $O/tfhe_bench.txt; cat $O/tfhe_bench.txt
 python tools/exp/overlap_free.py 20 2>&1 | grep -v amdgpu.ids > $O/overlap_free.txt
+# the big GPU test files under four sets of forced options (the environment seeds the defaults of every context created)
+(for SET in "HEGPU_FP_NTT=0" "HEGPU_FUSED_ROW_MAC=1 HEGPU_COL_MULTI=1 HEGPU_DIGIT_SPLIT=0" "HEGPU_SINGLE_PASS=1 HEGPU_FUSED_ROW_MAC=0" \
+            "HEGPU_FUSED_MODDOWN=0 HEGPU_NTT_GALOIS=0 HEGPU_FUSE_INVERSE=0 HEGPU_FUSED_TENSOR=0"; do
+   echo "== $SET"; env $SET python -m pytest tests/test_gpu_parity.py tests/test_gpu_kernels.py tests/test_gpu_edges.py tests/test_gpu_keygen.py tests/test_gpu_encode.py \
+       -m gpu -q --deselect tests/test_gpu_edges.py::test_options_change_the_launches_not_the_result 2>&1 | tail -2; done) > $O/switch_soak.txt 2>&1; grep -E "==|passed|failed" $O/switch_soak.txt
 tail -c 3700 $O/bench_compact_line.json
