@@ -657,7 +657,13 @@ __device__ __forceinline__ void fwd_col_body_fp(const NttArgs& a, const PolySel&
         fp_ct_radix<4>(x, tw, (u32) (RA + r1), fc, CS::b_before, CS::b_at_end);
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(u64) (16 * r1 + k) * 256 + col] = as_bits(x[k]);
+    for (int k = 0; k < 16; k++) {
+        // Round 6: the multi-modulus kernel (SREG) only runs on launches of >= 2048 source tiles -- gigabytes of digits that
+        // the row pass reads back from HBM long after: written with the non-temporal hint they do not push the twiddles and
+        // the source tiles out of L2 (C4 step, same-box A/B: 8.11 -> 8.00 ms; profiles/r6_experiments/README.md)
+        if constexpr (SREG) __builtin_nontemporal_store(as_bits(x[k]), &dst[(u64) (16 * r1 + k) * 256 + col]);
+        else dst[(u64) (16 * r1 + k) * 256 + col] = as_bits(x[k]);
+    }
 }
 
 template <int S1, bool DECOMP>
@@ -1293,7 +1299,12 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
         const u64* px = ident ? a.ident + a.ident_item_stride * item + ((u64) i << a.n_power) + (u64) tile * 4096 : p;
         u64 xr[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) xr[k] = px[row * 256 + i0 + 16 * k];
+        for (int k = 0; k < 16; k++) {
+            // (large-launch form: the digits are read exactly once -- non-temporal; the key tile next to them is what the
+            // ciphertexts of a group share through L2.  With the stores below: 8.16 -> 8.03 ms per C4 step, same-box A/B)
+            if constexpr (!SPLIT) xr[k] = __builtin_nontemporal_load(&px[row * 256 + i0 + 16 * k]);
+            else xr[k] = px[row * 256 + i0 + 16 * k];
+        }
         const u64* k0 = pk + key_off2 * i;
         const u64* k1 = k0 + key_off1;
         u64 kv0[16], kv1[16];
@@ -1472,8 +1483,13 @@ __device__ __forceinline__ void ks_row_mac_fp_body(const KsMacArgs& a, const KsI
     FP_STAGE(fc, FP_STAGE_OUT);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        po[16 * k] = fp_to_u64(fp_canon(a0[k], fc));
-        po[dig_off + 16 * k] = fp_to_u64(fp_canon(a1[k], fc));
+        if constexpr (!SPLIT) {
+            __builtin_nontemporal_store(fp_to_u64(fp_canon(a0[k], fc)), &po[16 * k]);
+            __builtin_nontemporal_store(fp_to_u64(fp_canon(a1[k], fc)), &po[dig_off + 16 * k]);
+        } else {
+            po[16 * k] = fp_to_u64(fp_canon(a0[k], fc));
+            po[dig_off + 16 * k] = fp_to_u64(fp_canon(a1[k], fc));
+        }
     }
 }
 
