@@ -300,12 +300,20 @@ __device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, 
     for (int k = 0; k < LMAX; k++) {
         if (k < l) tl[k * EN_COMPOSE_THREADS + threadIdx.x] = mul_barrett(plain[at + ((u64) k << n_power)], Mi_inv[k], mods[k]);
     }
-    u64 acc[LMAX];
+    // Round 6: the l terms are summed WITHOUT a comparison / subtraction after each (the reference brings every partial sum
+    // below M: l compares + up to l subtractions of l words each, 40 % of the instructions at l = 9).  The sum is below
+    // l M < 2^(64 l + 6): one more word (`top`).  Its quotient by M is floor(sum_i t_i / q_i) -- sum_i t_i M / q_i over M -- which
+    // a double-precision sum of the l fractions gives to within one (absolute error below l 2^-51: wrong only when the true
+    // sum sits that close to an integer, and then by exactly one); ONE multiply-subtract of ke M and one correction (add M
+    // back if the difference went negative, subtract M once more if it is still >= M) leave the canonical value in [0, M) --
+    // the same integer the reference's chain of reductions ends with.
+    u64 acc[LMAX], top = 0;
 #pragma unroll
     for (int k = 0; k < LMAX; k++) acc[k] = 0;
+    double tf = 0.0;
     for (int i = 0; i < l; i++) {
         const u64 t = tl[i * EN_COMPOSE_THREADS + threadIdx.x];
-        // acc += Mi[i] * t  (l words; the sum stays below 2*M < 2^(64 l))
+        tf += (double) t * (1.0 / (double) mods[i].q);
         const u64* mi = Mi + (u64) i * l;
         u64 carry = 0;
 #pragma unroll
@@ -321,8 +329,28 @@ __device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, 
                 carry = hi + c1 + c2;
             }
         }
-        // acc >= M ?  (most significant differing word decides)
-        bool geq = true, decided = false;
+        top += carry;
+    }
+    {
+        const u64 ke = (u64) tf; // <= l
+        u64 borrow = 0, mcarry = 0;
+#pragma unroll
+        for (int k = 0; k < LMAX; k++) {
+            if (k < l) {
+                u64 hi, lo;
+                mul64wide(M[k], ke, hi, lo);
+                const u64 sub = lo + mcarry; // word k of ke M
+                mcarry = hi + (sub < lo);
+                const u64 d = acc[k] - sub;
+                const u64 b1 = acc[k] < sub;
+                const u64 d2 = d - borrow;
+                const u64 b2 = d < borrow;
+                acc[k] = d2;
+                borrow = b1 | b2;
+            }
+        }
+        top = top - mcarry - borrow; // 0, or all ones when ke was one too large
+        bool geq = true, decided = false; // acc >= M ?  (most significant differing word decides)
 #pragma unroll
         for (int k = LMAX - 1; k >= 0; k--) {
             if (k < l && !decided && acc[k] != M[k]) {
@@ -330,18 +358,28 @@ __device__ __forceinline__ double en_compose_one(const u64* __restrict__ plain, 
                 decided = true;
             }
         }
-        if (geq) {
-            u64 borrow = 0;
+        const bool negative = top != 0;
+        if (negative || geq) { // acc += M  or  acc -= M
+            u64 c = 0;
 #pragma unroll
             for (int k = 0; k < LMAX; k++) {
                 if (k < l) {
                     const u64 m = M[k];
-                    const u64 d = acc[k] - m;
-                    const u64 b1 = acc[k] < m;
-                    const u64 d2 = d - borrow;
-                    const u64 b2 = d < borrow;
-                    acc[k] = d2;
-                    borrow = b1 | b2;
+                    if (negative) {
+                        const u64 s1 = acc[k] + m;
+                        const u64 c1 = s1 < m;
+                        const u64 s2 = s1 + c;
+                        const u64 c2 = s2 < s1;
+                        acc[k] = s2;
+                        c = c1 | c2;
+                    } else {
+                        const u64 d = acc[k] - m;
+                        const u64 b1 = acc[k] < m;
+                        const u64 d2 = d - c;
+                        const u64 b2 = d < c;
+                        acc[k] = d2;
+                        c = b1 | b2;
+                    }
                 }
             }
         }
